@@ -1,0 +1,193 @@
+"""Golden-vector generator: runs the REAL reference (/root/reference, imported unmodified through
+``stubs.py``) on the cases of ``oracle/casegen.py`` and writes ``tests/golden/*.npz``.
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container (the reference never travels to the GPU box):
+
+    python -m oracle.refharness.gen_golden            # regenerates every fixture
+
+``FUMI.evaluate`` (fumi/models/fumi.py:115-196) is run byte-for-byte unmodified inside
+``torch.autograd.graph.allow_mutation_on_saved_tensors()``: on torch>=2 the in-place
+``hyper_params -=`` at :168 otherwise trips the saved-tensor version check at :172.
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import casegen as cg                      # noqa: E402
+from oracle.refharness import stubs                   # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _args(T, first_order=False, n_way=5):
+    return SimpleNamespace(device=torch.device("cpu"), num_train_adapt_steps=T, num_test_adapt_steps=T,
+                           step_size=cg.ALPHA, first_order=first_order, num_ways=n_way, batch_size=1)
+
+
+def _grad_entries(prefix, named_params, full):
+    out = {}
+    for name, p in named_params:
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        out[f"{prefix}.{name}.digest"] = cg.digest(g)
+        if full or g.numel() <= 70000:
+            out[f"{prefix}.{name}"] = g.detach().numpy().copy()
+    return out
+
+
+def gen_fumi(ref_fumi, name, c):
+    torch.manual_seed(0)
+    seed = sum(ord(ch) for ch in name)
+    ep = cg.make_episodes(seed, c["B"], c["N"], c["K"], c["Q"], c["D"], c["Dt"], blocked=c["blocked"])
+    theta, phi = cg.make_fumi_params(seed, c["D"], c["hid"], c["Dt"], c["Ht"])
+    model = ref_fumi.FUMI(n_way=c["N"], im_emb_dim=c["D"], im_hid_dim=c["hid"], text_encoder="BERT",
+                          text_emb_dim=c["Dt"], text_hid_dim=c["Ht"], dropout_rate=0.0,
+                          norm_hypernet=c["tanh"], init_bias=c["init_bias"])
+    sd = cg.fumi_state_dict(theta, phi)
+    extra = {}
+    if c["init_bias"]:
+        # keep the reference's own initialiser output for the hypernet head (hypernet_init.py live path)
+        extra["init_head_weight"] = model.hyper_net[2].weight.detach().numpy().copy()
+        extra["init_head_bias"] = model.hyper_net[2].bias.detach().numpy().copy()
+        sd["hyper_net.2.weight"] = model.hyper_net[2].weight.detach().clone()
+        sd["hyper_net.2.bias"] = model.hyper_net[2].bias.detach().clone()
+    model.load_state_dict(sd)
+    opt = torch.optim.Adam(model.parameters(), lr=3e-5, weight_decay=5e-4)   # utils.py:280-283 defaults
+
+    calls = []
+    orig = model.im_forward
+
+    def rec(im, p, h):
+        o = orig(im, p, h)
+        calls.append(o.detach().clone())
+        return o
+    model.im_forward = rec
+
+    with torch.autograd.graph.allow_mutation_on_saved_tensors():
+        loss, acc, preds, tgt = model.evaluate(_args(c["T"], n_way=c["N"]), cg.to_batch(ep), opt, "train")
+    T = c["T"]
+    logits_q = torch.stack([calls[b * (T + 1) + T] for b in range(c["B"])])
+    out = dict(loss=np.float64(loss), acc=np.float64(acc), preds=preds.numpy().astype(np.int64),
+               logits_q=logits_q.numpy(), seed=np.int64(seed),
+               in_digest=cg.digest(torch.cat([ep["x_s"].reshape(-1), ep["x_q"].reshape(-1), ep["text_s"].reshape(-1)])),
+               **extra)
+    out.update(_grad_entries("grad", model.named_parameters(), full=False))
+    for n, p in model.named_parameters():
+        out[f"post.{n}.digest"] = cg.digest(p)
+    # eval-mode call on the post-step parameters (task="test", fumi.py:126-127,154): loss/acc/preds only
+    calls.clear()
+    with torch.autograd.graph.allow_mutation_on_saved_tensors():
+        l2, a2, p2, _ = model.evaluate(_args(c["T"], n_way=c["N"]), cg.to_batch(ep), None, "test")
+    out.update(test_loss=np.float64(l2), test_acc=np.float64(a2), test_preds=p2.numpy().astype(np.int64))
+    np.savez(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={float(loss):.6f} acc={float(acc):.4f}")
+
+
+def gen_maml(ref_maml, name, c):
+    seed = sum(ord(ch) for ch in name)
+    ep = cg.make_episodes(seed, c["B"], c["N"], c["K"], c["Q"], c["D"], 8)
+    p = cg.make_maml_params(seed, c["D"], c["hid"], c["N"])
+    model = ref_maml.PureImageNetwork(im_embed_dim=c["D"], n_way=c["N"], hidden_dims=c["hid"])
+    model.load_state_dict(cg.maml_state_dict(p))
+    opt = torch.optim.Adam(model.parameters(), lr=3e-5, weight_decay=5e-4)
+    outs = []
+    hook = model.register_forward_hook(lambda m, i, o: outs.append(o.detach().clone()))
+    loss, acc = ref_maml.evaluate(_args(c["T"], c["first_order"], c["N"]), model, cg.to_batch(ep), opt, "train")
+    hook.remove()
+    T = c["T"]
+    logits_q = torch.stack([outs[b * (T + 1) + T] for b in range(c["B"])])
+    out = dict(loss=np.float64(loss), acc=np.float64(acc), logits_q=logits_q.numpy(), seed=np.int64(seed),
+               preds=logits_q.max(-1)[1].numpy(),
+               in_digest=cg.digest(torch.cat([ep["x_s"].reshape(-1), ep["x_q"].reshape(-1)])))
+    out.update(_grad_entries("grad", model.named_parameters(), full=False))
+    np.savez(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={float(loss):.6f} acc={float(acc):.4f}")
+
+
+def gen_am3(ref_am3, name, c):
+    seed = sum(ord(ch) for ch in name)
+    ep = cg.make_episodes(seed, c["B"], c["N"], c["K"], c["Q"], c["D"], c["Dt"])
+    w = cg.make_am3_params(seed, c["D"], c["Dt"], c["Ht"], c["P"])
+    model = ref_am3.AM3(im_encoder="precomputed", im_emb_dim=c["D"], text_encoder="BERT", text_emb_dim=c["Dt"],
+                        text_hid_dim=c["Ht"], prototype_dim=c["P"], dropout=0.0, lamda_fixed=c["lamda_fixed"])
+    model.load_state_dict(cg.am3_state_dict(w))
+    opt = torch.optim.Adam(model.parameters(), lr=3e-5, weight_decay=5e-4)
+    loss, acc, f1, prec, rec, avg_lam = model.evaluate(cg.to_batch(ep), opt, None, c["N"], torch.device("cpu"), "train")
+    out = dict(loss=np.float64(loss), acc=np.float64(acc), f1=np.float64(f1), prec=np.float64(prec),
+               rec=np.float64(rec), avg_lamda=np.float64(avg_lam), seed=np.int64(seed),
+               in_digest=cg.digest(torch.cat([ep["x_s"].reshape(-1), ep["x_q"].reshape(-1), ep["text_s"].reshape(-1)])))
+    out.update(_grad_entries("grad", model.named_parameters(), full=False))
+    # test-mode call on the post-step parameters: 11-tuple incl. preds and per-support lamda (am3.py:202-209)
+    with torch.no_grad():
+        r = model.evaluate(cg.to_batch(ep), None, None, c["N"], torch.device("cpu"), "test")
+    out.update(test_loss=np.float64(r[0]), test_acc=np.float64(r[1]), test_preds=np.asarray(r[6]).astype(np.int64),
+               test_lamda_s=np.asarray(r[10]), test_avg_lamda=np.float64(r[5]))
+    for n, p in model.named_parameters():
+        out[f"post.{n}.digest"] = cg.digest(p)
+    np.savez(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={float(loss):.6f} acc={float(acc):.4f} lam={float(avg_lam):.4f}")
+
+
+class _FakeKV:
+    """Stand-in for a gensim KeyedVectors table (tiny vocabulary; the real one needs a download)."""
+
+    def __init__(self, words, dim, seed):
+        rs = np.random.RandomState(seed)
+        self.vector_size = dim
+        self.key_to_index = {w: i for i, w in enumerate(words)}
+        self._v = rs.standard_normal((len(words), dim)).astype(np.float32)
+
+    def __getitem__(self, w):
+        return self._v[self.key_to_index[w]]
+
+
+def gen_wordemb(ref_common):
+    """WordEmbedding (common.py:8-41) mean and max pooling incl. rows with a single non-PAD token."""
+    dim, L = 12, 9
+    known = [f"w{i}" for i in range(30)]
+    dictionary = {"PAD": 0}
+    for i in range(40):                       # w30..w39 are OOV -> np.random rows (a fixture, not a formula)
+        dictionary[f"w{i}"] = i + 1
+    kv = _FakeKV(known, dim, 5)
+    stubs.install()
+    import gensim.downloader as api
+    api.load = lambda name: kv
+    ref_common.api = api
+    np.random.seed(11)
+    rs = np.random.RandomState(3)
+    tokens = np.zeros((2, 7, L), dtype=np.int64)
+    for b in range(2):
+        for s in range(7):
+            ln = 1 if s == 0 else rs.randint(1, L + 1)
+            tokens[b, s, :ln] = rs.randint(1, 41, size=ln)
+    out = dict(tokens=tokens, pad=np.int64(0))
+    for mode in ("mean", "max"):
+        np.random.seed(11)
+        we = ref_common.WordEmbedding("glove", mode, dictionary)
+        out["table"] = we.embed.weight.detach().numpy().copy()
+        out[mode] = we(torch.from_numpy(tokens)).detach().numpy()
+    np.savez(os.path.join(OUT, "wordemb.npz"), **out)
+    print("wordemb: table", out["table"].shape)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref_fumi, ref_maml, ref_am3, ref_utils, ref_common = stubs.import_reference()
+    torch.set_num_threads(1)                  # deterministic summation order for the fixtures
+    for name, c in cg.FUMI_CASES.items():
+        gen_fumi(ref_fumi, name, c)
+    for name, c in cg.MAML_CASES.items():
+        gen_maml(ref_maml, name, c)
+    for name, c in cg.AM3_CASES.items():
+        gen_am3(ref_am3, name, c)
+    gen_wordemb(ref_common)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+"""CPU suite: the oracle restatement (oracle/fumi_ref.py) against golden vectors produced by the REAL
+reference (oracle/refharness/gen_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import casegen as cg
+from oracle import fumi_ref as R
+from helpers import load_golden, case_seed, assert_close_max, check_grad
+
+TOL = 2e-5          # fp32 round-off between two orderings of the same math, relative to max|.|
+
+
+def _leaf(ts):
+    return [t.clone().requires_grad_(True) for t in ts]
+
+
+@pytest.mark.parametrize("name", list(cg.FUMI_CASES))
+def test_fumi_oracle_matches_reference(name):
+    c, gold = cg.FUMI_CASES[name], load_golden(name)
+    seed = case_seed(name)
+    assert int(gold["seed"]) == seed
+    ep = cg.make_episodes(seed, c["B"], c["N"], c["K"], c["Q"], c["D"], c["Dt"], blocked=c["blocked"])
+    d = cg.digest(torch.cat([ep["x_s"].reshape(-1), ep["x_q"].reshape(-1), ep["text_s"].reshape(-1)]))
+    np.testing.assert_array_equal(d[3:], gold["in_digest"][3:])        # regenerated inputs == generator's inputs
+    np.testing.assert_allclose(d[:3], gold["in_digest"][:3], rtol=1e-12)
+    theta, phi = cg.make_fumi_params(seed, c["D"], c["hid"], c["Dt"], c["Ht"])
+    if c["init_bias"]:
+        W, b = torch.from_numpy(gold["init_head_weight"]), torch.from_numpy(gold["init_head_bias"])
+        assert float(W.abs().max()) == 0.0                       # hypernet_init.py:150 (adjust_weights=False)
+        assert abs(float(b.norm()) - 2 ** 0.5) < 1e-5            # normc row of norm gain('relu')
+        phi[2], phi[3] = W, b
+    theta, phi = _leaf(theta), _leaf(phi)
+    out = R.fumi_meta_step(theta, phi, ep["text_s"], ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"],
+                           c["N"], c["T"], cg.ALPHA, c["tanh"])
+    assert_close_max(out["logits"], gold["logits_q"], TOL, "logits")
+    assert abs(float(out["loss"]) - float(gold["loss"])) <= TOL * max(1.0, abs(float(gold["loss"])))
+    assert np.array_equal(out["preds"].numpy(), gold["preds"])   # integer predictions: bit-exact
+    assert abs(float(out["acc"]) - float(gold["acc"])) < 1e-6
+    names = [f"im_net.linear{i}.{k}" for i in range(len(c["hid"])) for k in ("weight", "bias")]
+    for n, g in zip(names, out["g_theta"]):
+        check_grad(gold, "grad." + n, g, 5e-5)
+    for n, g in zip(["hyper_net.0.weight", "hyper_net.0.bias", "hyper_net.2.weight", "hyper_net.2.bias"], out["g_phi"]):
+        check_grad(gold, "grad." + n, g, 5e-5)
+
+
+@pytest.mark.parametrize("name", list(cg.MAML_CASES))
+def test_maml_oracle_matches_reference(name):
+    c, gold = cg.MAML_CASES[name], load_golden(name)
+    seed = case_seed(name)
+    ep = cg.make_episodes(seed, c["B"], c["N"], c["K"], c["Q"], c["D"], 8)
+    p = _leaf(cg.make_maml_params(seed, c["D"], c["hid"], c["N"]))
+    out = R.maml_meta_step(p, ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], c["T"], cg.ALPHA, c["first_order"])
+    assert_close_max(out["logits"], gold["logits_q"], TOL, "logits")
+    assert abs(float(out["loss"]) - float(gold["loss"])) <= TOL * max(1.0, abs(float(gold["loss"])))
+    assert np.array_equal(out["preds"].numpy(), gold["preds"])
+    names = [f"net.lin_{i}.{k}" for i in range(len(c["hid"])) for k in ("weight", "bias")]
+    names += ["net.lin_final.weight", "net.lin_final.bias"]
+    for n, g in zip(names, out["g_params"]):
+        check_grad(gold, "grad." + n, g, 5e-5)
+
+
+@pytest.mark.parametrize("name", list(cg.AM3_CASES))
+def test_am3_oracle_matches_reference(name):
+    c, gold = cg.AM3_CASES[name], load_golden(name)
+    seed = case_seed(name)
+    ep = cg.make_episodes(seed, c["B"], c["N"], c["K"], c["Q"], c["D"], c["Dt"])
+    w = {k: v.clone().requires_grad_(True) for k, v in cg.make_am3_params(seed, c["D"], c["Dt"], c["Ht"], c["P"]).items()}
+    out = R.am3_step(w, ep["text_s"], ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], c["N"], c["lamda_fixed"])
+    assert abs(float(out["loss"]) - float(gold["loss"])) <= TOL * max(1.0, abs(float(gold["loss"])))
+    assert abs(float(out["acc"]) - float(gold["acc"])) < 1e-6
+    assert abs(float(out["avg_lamda"]) - float(gold["avg_lamda"])) < 1e-5
+    sd_names = {"Wi": "image_encoder.weight", "bi": "image_encoder.bias", "G0": "g.0.weight", "g0": "g.0.bias",
+                "G1": "g.3.weight", "g1": "g.3.bias", "H0": "h.0.weight", "h0": "h.0.bias",
+                "H1": "h.3.weight", "h1": "h.3.bias"}
+    for k, g in out["grads"].items():
+        if float(np.abs(gold["grad." + sd_names[k] + ".digest"][:3]).max()) == 0.0:
+            assert float(g.abs().max()) == 0.0
+            continue
+        check_grad(gold, "grad." + sd_names[k], g, 5e-5)
+
+
+def test_word_embedding_oracle_matches_reference():
+    gold = load_golden("wordemb")
+    table = torch.from_numpy(gold["table"]).float()
+    tokens = torch.from_numpy(gold["tokens"])
+    for mode in ("mean", "max"):
+        out = R.word_embedding_pool(tokens, table, int(gold["pad"]), mode)
+        assert_close_max(out, gold[mode], 1e-6, mode)
