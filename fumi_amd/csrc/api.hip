@@ -1,0 +1,245 @@
+// C-ABI entry points (include/fumi_hip.h): workspace management and the orchestration of one meta-step.
+#include "common.h"
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_hip_err[512] = "";
+
+void fumi_set_hip_error(hipError_t e, const char* where) {
+    snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
+}
+
+int ws_reserve(fumi_ws* ws, size_t bytes) {
+    ws->off = 0;
+    if (bytes <= ws->cap) return FUMI_OK;
+    // growth happens only on the first call of a new shape: synchronise, free, allocate 25 % headroom
+    HIP_TRY(hipDeviceSynchronize());
+    if (ws->base) HIP_TRY(hipFree(ws->base));
+    ws->base = nullptr; ws->cap = 0;
+    size_t want = bytes + bytes / 4 + (1u << 20);
+    hipError_t e = hipMalloc((void**)&ws->base, want);
+    if (e != hipSuccess) { fumi_set_hip_error(e, "hipMalloc(workspace)"); ws->base = nullptr; return FUMI_ENOMEM; }
+    ws->cap = want;
+    return FUMI_OK;
+}
+
+extern "C" {
+
+int fumi_hip_version(void) { return 100; }
+
+const char* fumi_hip_strerror(int code) {
+    switch (code) {
+        case FUMI_OK: return "ok";
+        case FUMI_EINVAL: return "invalid argument";
+        case FUMI_ENOMEM: return "workspace allocation failed";
+        case FUMI_EHIP: return "HIP runtime error";
+        case FUMI_ENOTSUP: return "not supported by this build";
+        default: return "unknown error";
+    }
+}
+
+const char* fumi_hip_last_hip_error(void) { return g_hip_err; }
+
+int fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out) {
+    if (!out) return FUMI_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(device));
+    fumi_ws* ws = new fumi_ws();
+    ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr;
+    if (hipMalloc((void**)&ws->status, 256) != hipSuccess) { delete ws; return FUMI_ENOMEM; }
+    if (hipHostMalloc((void**)&ws->status_host, 256, hipHostMallocDefault) != hipSuccess) { (void)hipFree(ws->status); delete ws; return FUMI_ENOMEM; }
+    HIP_TRY(hipMemset(ws->status, 0, 256));
+    if (bytes_hint) {
+        int rc = ws_reserve(ws, bytes_hint);
+        if (rc) { fumi_hip_workspace_destroy(ws); return rc; }
+    }
+    *out = ws;
+    return FUMI_OK;
+}
+
+void fumi_hip_workspace_destroy(fumi_ws_t* ws) {
+    if (!ws) return;
+    (void)hipSetDevice(ws->device);
+    (void)hipDeviceSynchronize();
+    if (ws->base) (void)hipFree(ws->base);
+    if (ws->status) (void)hipFree(ws->status);
+    if (ws->status_host) (void)hipHostFree(ws->status_host);
+    delete ws;
+}
+
+size_t fumi_hip_workspace_bytes(const fumi_ws_t* ws) { return ws ? ws->cap : 0; }
+
+int fumi_hip_read_status(fumi_ws_t* ws, fumi_stream_t stream, int* status_out) {
+    if (!ws || !status_out) return FUMI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(ws->status_host, ws->status, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemsetAsync(ws->status, 0, sizeof(int), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *status_out = *ws->status_host;
+    return FUMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// FuMI
+// ------------------------------------------------------------------------------------------------------------
+int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int D, int n_hidden, const int* hid, int Dt, int Ht,
+        int T, float alpha, int tanh_head, int need_grad, float grad_scale,
+        const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
+        const float* cls_text, const float* text_s,
+        const float* const* theta, const float* const* phi,
+        float* logits_q, int64_t* preds_q, float* loss_b, float* acc_b,
+        float* const* g_theta, float* const* g_phi) {
+    if (!ws || !hid || !theta || !phi || !x_s || !y_s || !x_q || !y_q || !logits_q || !preds_q || !loss_b || !acc_b)
+        return FUMI_EINVAL;
+    if (!cls_text && !text_s) return FUMI_EINVAL;
+    if (n_hidden < 1 || n_hidden > FUMI_MAX_HIDDEN || B < 1 || N < 1 || S < 1 || Qn < 1 || D < 1 || Dt < 1 || Ht < 1 || T < 0)
+        return FUMI_EINVAL;
+    if (need_grad && (!g_theta || !g_phi)) return FUMI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ws->device));
+
+    EpisodeProblem p;
+    memset(&p, 0, sizeof(p));
+    p.B = B; p.N = N; p.S = S; p.Qn = Qn; p.D = D; p.L = n_hidden; p.T = T; p.alpha = alpha;
+    p.need_grad = need_grad ? 1 : 0; p.second_order = 1; p.grad_scale = grad_scale;
+    for (int i = 0; i < n_hidden; ++i) {
+        if (hid[i] < 1 || !theta[2 * i] || !theta[2 * i + 1]) return FUMI_EINVAL;
+        p.h[i] = hid[i]; p.W[i] = theta[2 * i]; p.b[i] = theta[2 * i + 1];
+        if (need_grad) { if (!g_theta[2 * i] || !g_theta[2 * i + 1]) return FUMI_EINVAL; p.gW[i] = g_theta[2 * i]; p.gb[i] = g_theta[2 * i + 1]; }
+    }
+    for (int i = 0; i < 4; ++i) if (!phi[i] || (need_grad && !g_phi[i])) return FUMI_EINVAL;
+    const int H = hid[n_hidden - 1], R = B * N, H1 = H + 1;
+    p.x_s = x_s; p.y_s = y_s; p.x_q = x_q; p.y_q = y_q;
+    p.logits_q = logits_q; p.preds_q = preds_q; p.loss_b = loss_b; p.acc_b = acc_b;
+
+    size_t bytes = episode_workspace_bytes(p);
+    bytes += ws_align((size_t)R * Dt * 4) + 2 * ws_align((size_t)R * Ht * 4) + 3 * ws_align((size_t)R * H1 * 4);
+    int rc = ws_reserve(ws, bytes);
+    if (rc) return rc;
+    float* c = ws_f(ws, (size_t)R * Dt);
+    float* u = ws_f(ws, (size_t)R * Ht);
+    float* ub = ws_f(ws, (size_t)R * Ht);
+    float* h = ws_f(ws, (size_t)R * H1);
+    float* hbar = ws_f(ws, (size_t)R * H1);
+    float* hpb = ws_f(ws, (size_t)R * H1);
+
+    // class text rows (fumi.py:207-210), then the hypernetwork (fumi.py:70-86,104-113)
+    const float* ctext = cls_text;
+    if (!ctext) {
+        if ((rc = launch_class_text_select(st, B, N, S, Dt, text_s, y_s, c, ws->status))) return rc;
+        ctext = c;
+    }
+    GemmArgs g = gemm_args(R, Ht, Dt, ctext, Dt, phi[0], Dt, u, Ht);
+    g.bias = phi[1]; g.act = 1;
+    if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+    g = gemm_args(R, H1, Ht, u, Ht, phi[2], Ht, h, H1);
+    g.bias = phi[3]; g.act = tanh_head ? 2 : 0;
+    if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+
+    p.head = h; p.head_bar = hbar;
+    if ((rc = run_episodes(ws, st, p))) return rc;
+    if (!need_grad) return FUMI_OK;
+
+    // hypernetwork backward: rows are (episode, class) pairs, weights are shared
+    const float* hp = hbar;
+    if (tanh_head) { if ((rc = launch_tanh_bwd(st, (long)R * H1, h, hbar, hpb))) return rc; hp = hpb; }
+    g = gemm_args(H1, Ht, R, hp, H1, u, Ht, g_phi[2], Ht);           // gA1 = hp^T u
+    g.alpha = grad_scale;
+    if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+    if ((rc = launch_colsum(st, hp, R, H1, H1, grad_scale, g_phi[3]))) return rc;
+    g = gemm_args(R, Ht, H1, hp, H1, phi[2], Ht, ub, Ht);            // ubar = (hp A1) * relu'(u)
+    if ((rc = launch_gemm(st, g, 0, 1))) return rc;
+    if ((rc = launch_relu_mask_mul(st, (long)R * Ht, u, ub))) return rc;
+    g = gemm_args(Ht, Dt, R, ub, Ht, ctext, Dt, g_phi[0], Dt);       // gA0 = ubar^T c
+    g.alpha = grad_scale;
+    if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+    if ((rc = launch_colsum(st, ub, R, Ht, Ht, grad_scale, g_phi[1]))) return rc;
+    return FUMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// MAML
+// ------------------------------------------------------------------------------------------------------------
+int fumi_hip_maml_step(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int D, int n_hidden, const int* hid,
+        int T, float alpha, int first_order, int need_grad, float grad_scale,
+        const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
+        const float* const* params,
+        float* logits_q, int64_t* preds_q, float* loss_b, float* acc_b,
+        float* const* g_params) {
+    if (!ws || !params || !x_s || !y_s || !x_q || !y_q || !logits_q || !preds_q || !loss_b || !acc_b) return FUMI_EINVAL;
+    if (n_hidden == 0) return FUMI_ENOTSUP;      // hidden_dims=None (a bare linear head on the embeddings)
+    if (!hid || n_hidden < 0 || n_hidden > FUMI_MAX_HIDDEN || B < 1 || N < 1 || S < 1 || Qn < 1 || D < 1 || T < 0) return FUMI_EINVAL;
+    if (need_grad && !g_params) return FUMI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ws->device));
+
+    EpisodeProblem p;
+    memset(&p, 0, sizeof(p));
+    p.B = B; p.N = N; p.S = S; p.Qn = Qn; p.D = D; p.L = n_hidden; p.T = T; p.alpha = alpha;
+    p.need_grad = need_grad ? 1 : 0; p.second_order = first_order ? 0 : 1; p.grad_scale = grad_scale;
+    for (int i = 0; i < n_hidden; ++i) {
+        if (hid[i] < 1 || !params[2 * i] || !params[2 * i + 1]) return FUMI_EINVAL;
+        p.h[i] = hid[i]; p.W[i] = params[2 * i]; p.b[i] = params[2 * i + 1];
+        if (need_grad) { if (!g_params[2 * i] || !g_params[2 * i + 1]) return FUMI_EINVAL; p.gW[i] = g_params[2 * i]; p.gb[i] = g_params[2 * i + 1]; }
+    }
+    const float* Wf = params[2 * n_hidden]; const float* bf = params[2 * n_hidden + 1];
+    if (!Wf || !bf || (need_grad && (!g_params[2 * n_hidden] || !g_params[2 * n_hidden + 1]))) return FUMI_EINVAL;
+    const int H = hid[n_hidden - 1], H1 = H + 1;
+    p.x_s = x_s; p.y_s = y_s; p.x_q = x_q; p.y_q = y_q;
+    p.logits_q = logits_q; p.preds_q = preds_q; p.loss_b = loss_b; p.acc_b = acc_b;
+
+    size_t bytes = episode_workspace_bytes(p) + 2 * ws_align((size_t)B * N * H1 * 4);
+    int rc = ws_reserve(ws, bytes);
+    if (rc) return rc;
+    float* head = ws_f(ws, (size_t)B * N * H1);
+    float* hbar = ws_f(ws, (size_t)B * N * H1);
+    if ((rc = launch_broadcast_head(st, B, N, H, Wf, bf, head))) return rc;
+    p.head = head; p.head_bar = hbar;
+    if ((rc = run_episodes(ws, st, p))) return rc;
+    if (!need_grad) return FUMI_OK;
+    return launch_split_head_grad(st, B, N, H, hbar, grad_scale, g_params[2 * n_hidden], g_params[2 * n_hidden + 1]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// finer-grained ops
+// ------------------------------------------------------------------------------------------------------------
+int fumi_hip_class_text_select(fumi_ws_t* ws, fumi_stream_t stream, int B, int N, int S, int Dt,
+        const float* text_s, const int64_t* y_s, float* out) {
+    if (!ws || !text_s || !y_s || !out || B < 1 || N < 1 || S < 1 || Dt < 1) return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(ws->device));
+    return launch_class_text_select((hipStream_t)stream, B, N, S, Dt, text_s, y_s, out, ws->status);
+}
+
+int fumi_hip_linear_fwd(fumi_ws_t* ws, fumi_stream_t stream, int M, int N, int K,
+        const float* x, const float* W, const float* b, int act, float* y) {
+    if (!ws || !x || !W || !y || M < 1 || N < 1 || K < 1 || act < 0 || act > 2) return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(ws->device));
+    GemmArgs g = gemm_args(M, N, K, x, K, W, K, y, N);
+    g.bias = b; g.act = act;
+    return launch_gemm((hipStream_t)stream, g, 0, 0);
+}
+
+int fumi_hip_linear_bwd_data(fumi_ws_t* ws, fumi_stream_t stream, int M, int N, int K,
+        const float* dy, const float* W, float* dx) {
+    if (!ws || !dy || !W || !dx || M < 1 || N < 1 || K < 1) return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(ws->device));
+    GemmArgs g = gemm_args(M, K, N, dy, N, W, K, dx, K);             // dx[M,K] = dy[M,N] W[N,K]
+    return launch_gemm((hipStream_t)stream, g, 0, 1);
+}
+
+int fumi_hip_linear_bwd_weight(fumi_ws_t* ws, fumi_stream_t stream, int M, int N, int K,
+        const float* dy, const float* x, float* dW, float* db) {
+    if (!ws || !dy || !x || !dW || M < 1 || N < 1 || K < 1) return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(ws->device));
+    GemmArgs g = gemm_args(N, K, M, dy, N, x, K, dW, K);             // dW[N,K] = dy^T x
+    int rc = launch_gemm((hipStream_t)stream, g, 1, 1);
+    if (rc || !db) return rc;
+    return launch_colsum((hipStream_t)stream, dy, M, N, N, 1.f, db);
+}
+
+}  // extern "C"

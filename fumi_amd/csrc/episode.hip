@@ -1,0 +1,646 @@
+// Episode engine: the MAML inner loop of FuMI / MAML with a hand-written forward tape and second-order reverse sweep.
+//
+// Replaces, for B episodes at once (citations into /root/reference):
+//   fumi/models/fumi.py:159-185   im_params / inner loop / query forward / CE / argmax
+//   fumi/models/maml.py:162-183   same without the hypernetwork
+//   torchmeta gradient_update_parameters (requirements.txt:10)  p <- p - alpha * grad, graph kept
+//   fumi/models/fumi.py:190-192   the second-order part of outer_loss.backward()
+//
+// Algebra (verified against autograd in fp64 by oracle/manual_sweep.py + tests/test_manual_sweep.py):
+//   layer 0 is never materialised per episode.  With dz0_t the support pre-activation gradient of layer 0 at step t,
+//       W0_t = W0 - alpha * D_t^T Xs,  D_t = sum_{tau<t} dz0_tau [S,h0],  b0_t = b0 - alpha * colsum(D_t)
+//       z0_t(X) = A0(X) - alpha * G(X) D_t + b0_t,     A0 = X W0^T,  G = X Xs^T
+//   so X is touched only by the shared GEMMs (gemm.hip): forward  A0|G = X [W0;Xs]^T, backward gW0 = Abar0^T X.
+//   Everything else is per-episode work on [S|Qn, h] matrices that stay L2-resident:
+//       adapt   (1 workgroup / episode)       T inner steps on the support set, tape kept when a gradient is needed
+//       query   (1 workgroup / 32 query rows) forward with (theta_T, h_T), CE/argmax, first-order backward, partial slabs
+//       reverse (1 workgroup / episode)       sums the slabs, then walks the tape backwards (second order)
+//   Small products run on v_mfma_f32_16x16x4_f32 straight from memory (wg_mm in common.h).
+#include "common.h"
+
+namespace {
+
+constexpr int QR = 32;                 // query rows per workgroup
+constexpr int MAXL = FUMI_MAX_HIDDEN;
+
+struct EpiBuf {
+    float *A0s, *A0q, *Gss, *Gqs;              // [B,S,h0] [B,Qn,h0] [B,S,S] [B,Qn,S]
+    float *D, *cs;                             // [B,S,h0] [B,h0]
+    float *bcur[MAXL], *bh;                    // i>=1: [B,h_i];  [B,N]
+    float *Wslot[MAXL], *Whslot;               // i>=1: [B,nslot,h_i*h_{i-1}];  [B,nslot,N*H]
+    float *ta[MAXL], *tdz[MAXL], *tp, *te;     // tape: [B,ntape,S*h_i] ..., [B,ntape,S*N]
+    float *lg;                                 // [B,S*N] support logits scratch
+    float *aq[MAXL], *zq[MAXL], *lbar, *qcs;   // query: [B,Qn,h_i] x2, [B,Qn,N], [B,ntile,h0]
+    float *pW[MAXL], *pb[MAXL], *pWh, *pbh, *pb0, *pD, *ploss, *pcorr;   // per-tile partial slabs
+    float *Wb[MAXL], *bb[MAXL], *Whb, *bhb, *b0b, *Db;                   // adjoint state per episode
+    float *abar[MAXL], *X0, *X1, *eb, *lb;     // reverse scratch
+    float *A0bar_s, *A0bar_q;                  // [B,S,h0] [B,Qn,h0]
+    int nslot, ntape, ntile, maxh;
+};
+
+struct EpiDims {
+    int B, N, S, Qn, L, T, H;
+    int h[MAXL];
+    float alpha;
+    int need_grad, second_order, taped;
+};
+
+struct EpiParams {                             // meta-parameters of the hidden layers (device pointers)
+    const float* W[MAXL];
+    const float* b[MAXL];
+};
+
+__device__ __forceinline__ int label(const int64_t* y, long i, int N, int* status) {
+    long v = y[i];
+    if (v < 0 || v >= N) { atomicOr(status, FUMI_ST_LABEL_RANGE); v = 0; }
+    return (int)v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// adapt: T inner SGD steps on the support set of one episode
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void adapt_kernel(EpiDims d, EpiBuf w, EpiParams prm, const int64_t* y_s,
+                                                     const float* head, int* status) {
+    const float* const* Wm = prm.W;
+    const float* const* bm = prm.b;
+    const float* b0 = prm.b[0];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int S = d.S, N = d.N, L = d.L, H = d.H, h0 = d.h[0];
+    const float alpha = d.alpha;
+    const int64_t* ys = y_s + (long)b * S;
+    float* D = w.D + (long)b * S * h0;
+    float* cs = w.cs + (long)b * h0;
+    float* bh = w.bh + (long)b * N;
+    const float* A0s = w.A0s + (long)b * S * h0;
+    const float* Gss = w.Gss + (long)b * S * S;
+    float* lg = w.lg + (long)b * S * N;
+
+    // ---- initial fast weights: copies of the meta-parameters (slot 0) and of this episode's head
+    for (int i = tid; i < S * h0; i += nt) D[i] = 0.f;
+    for (int i = 1; i < L; ++i) {
+        const long sz = (long)d.h[i] * d.h[i - 1];
+        float* dst = w.Wslot[i] + (long)b * w.nslot * sz;
+        for (long j = tid; j < sz; j += nt) dst[j] = Wm[i][j];
+        float* bd = w.bcur[i] + (long)b * d.h[i];
+        for (int j = tid; j < d.h[i]; j += nt) bd[j] = bm[i][j];
+    }
+    {
+        float* dst = w.Whslot + (long)b * w.nslot * N * H;
+        const float* hb = head + (long)b * N * (H + 1);
+        for (int j = tid; j < N * H; j += nt) dst[j] = hb[(j / H) * (H + 1) + (j % H)];
+        for (int j = tid; j < N; j += nt) bh[j] = hb[j * (H + 1) + H];
+    }
+    __syncthreads();
+
+    for (int t = 0; t < d.T; ++t) {
+        const int slot = d.taped ? t : 0, nslot = d.taped ? t + 1 : 0, tp = d.taped ? t : 0;
+        float* a[MAXL]; float* dz[MAXL]; const float* Wc[MAXL]; float* Wn[MAXL];
+        for (int i = 0; i < L; ++i) {
+            a[i] = w.ta[i] + ((long)b * w.ntape + tp) * S * d.h[i];
+            dz[i] = w.tdz[i] + ((long)b * w.ntape + tp) * S * d.h[i];
+            if (i >= 1) {
+                const long sz = (long)d.h[i] * d.h[i - 1];
+                Wc[i] = w.Wslot[i] + ((long)b * w.nslot + slot) * sz;
+                Wn[i] = w.Wslot[i] + ((long)b * w.nslot + nslot) * sz;
+            }
+        }
+        const float* Whc = w.Whslot + ((long)b * w.nslot + slot) * N * H;
+        float* Whn = w.Whslot + ((long)b * w.nslot + nslot) * N * H;
+        float* p = w.tp + ((long)b * w.ntape + tp) * S * N;
+        float* e = w.te + ((long)b * w.ntape + tp) * S * N;
+
+        // 1. layer 0 through the low-rank form
+        wg_colsum(S, h0, D, h0, [&](int n, float s) { cs[n] = s; });
+        __syncthreads();
+        wg_mm(S, h0, S, Gss, S, 1, D, h0, 1, [&](int m, int n, float acc) {
+            const float z = A0s[(long)m * h0 + n] - alpha * acc + (b0[n] - alpha * cs[n]);
+            a[0][(long)m * h0 + n] = z > 0.f ? z : 0.f;
+        });
+        __syncthreads();
+        // 2. deeper layers with the episode's fast weights
+        for (int i = 1; i < L; ++i) {
+            const int hi = d.h[i], hp = d.h[i - 1];
+            const float* bi = w.bcur[i] + (long)b * hi;
+            float* ai = a[i];
+            wg_mm(S, hi, hp, a[i - 1], hp, 1, Wc[i], 1, hp, [&](int m, int n, float acc) {
+                const float z = acc + bi[n];
+                ai[(long)m * hi + n] = z > 0.f ? z : 0.f;
+            });
+            __syncthreads();
+        }
+        // 3. head logits, softmax, e = (p - onehot)/S
+        wg_mm(S, N, H, a[L - 1], H, 1, Whc, 1, H, [&](int m, int n, float acc) { lg[m * N + n] = acc + bh[n]; });
+        __syncthreads();
+        for (int s = tid; s < S; s += nt) {
+            const int y = label(ys, s, N, status);
+            float mx = lg[s * N];
+            for (int n = 1; n < N; ++n) mx = fmaxf(mx, lg[s * N + n]);
+            float sum = 0.f;
+            for (int n = 0; n < N; ++n) sum += expf(lg[s * N + n] - mx);
+            const float inv = 1.f / sum;
+            for (int n = 0; n < N; ++n) {
+                const float pv = expf(lg[s * N + n] - mx) * inv;
+                p[s * N + n] = pv;
+                e[s * N + n] = (pv - (n == y ? 1.f : 0.f)) / (float)S;
+            }
+        }
+        __syncthreads();
+        // 4. backward through the head: dz_{L-1} = (e Wh) * relu'   (before Wh may be overwritten in place)
+        {
+            float* dzl = dz[L - 1]; const float* al = a[L - 1];
+            wg_mm(S, H, N, e, N, 1, Whc, H, 1, [&](int m, int n, float acc) {
+                dzl[(long)m * H + n] = al[(long)m * H + n] > 0.f ? acc : 0.f;
+            });
+        }
+        __syncthreads();
+        // head update: Wh <- Wh - alpha e^T a,  bh <- bh - alpha colsum(e)
+        wg_mm(N, H, S, e, 1, N, a[L - 1], H, 1, [&](int m, int n, float acc) {
+            Whn[m * H + n] = Whc[m * H + n] - alpha * acc;
+        });
+        wg_colsum(S, N, e, N, [&](int n, float s) { bh[n] -= alpha * s; });
+        // 5. hidden layers, top down
+        for (int i = L - 1; i >= 1; --i) {
+            const int hi = d.h[i], hp = d.h[i - 1];
+            float* dzp = dz[i - 1]; const float* ap = a[i - 1];
+            wg_mm(S, hp, hi, dz[i], hi, 1, Wc[i], hp, 1, [&](int m, int n, float acc) {
+                dzp[(long)m * hp + n] = ap[(long)m * hp + n] > 0.f ? acc : 0.f;
+            });
+            __syncthreads();
+            const float* Wci = Wc[i]; float* Wni = Wn[i];
+            wg_mm(hi, hp, S, dz[i], 1, hi, a[i - 1], hp, 1, [&](int m, int n, float acc) {
+                Wni[(long)m * hp + n] = Wci[(long)m * hp + n] - alpha * acc;
+            });
+            float* bi = w.bcur[i] + (long)b * hi;
+            wg_colsum(S, hi, dz[i], hi, [&](int n, float s) { bi[n] -= alpha * s; });
+        }
+        if (L == 1) __syncthreads();
+        // 6. layer 0: only the low-rank factor moves
+        for (int i = tid; i < S * h0; i += nt) D[i] += dz[0][i];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// query: forward with the adapted weights, loss / argmax, first-order backward of the query loss (partial slabs)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const float* const b0, const int64_t* y_q,
+                                                    float* logits_q, int64_t* preds_q, int* status) {
+    const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    const int S = d.S, N = d.N, L = d.L, H = d.H, h0 = d.h[0], Qn = d.Qn;
+    const int r0 = tile * QR, nr = min(QR, Qn - r0);
+    const float alpha = d.alpha;
+    const int slot = d.taped ? d.T : 0;
+    const float* D = w.D + (long)b * S * h0;
+    float* cs = w.qcs + ((long)b * w.ntile + tile) * h0;
+    const float* A0q = w.A0q + ((long)b * Qn + r0) * h0;
+    const float* Gqs = w.Gqs + ((long)b * Qn + r0) * S;
+    const float* bh = w.bh + (long)b * N;
+    const float* Whc = w.Whslot + ((long)b * w.nslot + slot) * N * H;
+    float* lq = logits_q + ((long)b * Qn + r0) * N;
+    float* lbar = w.lbar + ((long)b * Qn + r0) * N;
+    const int64_t* yq = y_q + (long)b * Qn + r0;
+    float* a[MAXL]; float* z[MAXL]; const float* Wc[MAXL];
+    for (int i = 0; i < L; ++i) {
+        a[i] = w.aq[i] + ((long)b * Qn + r0) * d.h[i];
+        z[i] = w.zq[i] + ((long)b * Qn + r0) * d.h[i];
+        if (i >= 1) Wc[i] = w.Wslot[i] + ((long)b * w.nslot + slot) * (long)d.h[i] * d.h[i - 1];
+    }
+
+    wg_colsum(S, h0, D, h0, [&](int n, float s) { cs[n] = s; });
+    __syncthreads();
+    wg_mm(nr, h0, S, Gqs, S, 1, D, h0, 1, [&](int m, int n, float acc) {
+        const float v = A0q[(long)m * h0 + n] - alpha * acc + (b0[n] - alpha * cs[n]);
+        a[0][(long)m * h0 + n] = v > 0.f ? v : 0.f;
+    });
+    __syncthreads();
+    for (int i = 1; i < L; ++i) {
+        const int hi = d.h[i], hp = d.h[i - 1];
+        const float* bi = w.bcur[i] + (long)b * hi;
+        float* ai = a[i];
+        wg_mm(nr, hi, hp, a[i - 1], hp, 1, Wc[i], 1, hp, [&](int m, int n, float acc) {
+            const float v = acc + bi[n];
+            ai[(long)m * hi + n] = v > 0.f ? v : 0.f;
+        });
+        __syncthreads();
+    }
+    wg_mm(nr, N, H, a[L - 1], H, 1, Whc, 1, H, [&](int m, int n, float acc) { lq[m * N + n] = acc + bh[n]; });
+    __syncthreads();
+
+    // per row: log-softmax loss, first arg-max (torch.max semantics, fumi.py:180), lbar = (p - onehot)/Qn
+    __shared__ float s_loss[QR];
+    __shared__ float s_corr[QR];
+    for (int m = tid; m < nr; m += nt) {
+        const int y = label(yq, m, N, status);
+        float mx = lq[m * N]; int arg = 0;
+        for (int n = 1; n < N; ++n) { const float v = lq[m * N + n]; if (v > mx) { mx = v; arg = n; } }
+        float sum = 0.f;
+        for (int n = 0; n < N; ++n) sum += expf(lq[m * N + n] - mx);
+        const float lse = mx + logf(sum), inv = 1.f / sum;
+        s_loss[m] = lse - lq[m * N + y];
+        s_corr[m] = (arg == y) ? 1.f : 0.f;
+        preds_q[(long)b * Qn + r0 + m] = arg;
+        for (int n = 0; n < N; ++n)
+            lbar[m * N + n] = (expf(lq[m * N + n] - mx) * inv - (n == y ? 1.f : 0.f)) / (float)Qn;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float ls = 0.f, cs_ = 0.f;
+        for (int m = 0; m < nr; ++m) { ls += s_loss[m]; cs_ += s_corr[m]; }
+        w.ploss[(long)b * w.ntile + tile] = ls;
+        w.pcorr[(long)b * w.ntile + tile] = cs_;
+    }
+    if (!d.need_grad) return;
+
+    // ---- backward of the query loss w.r.t. (theta_T, h_T): partial sums over this tile's rows
+    const long pt = (long)b * w.ntile + tile;
+    {
+        float* pWh = w.pWh + pt * N * H;
+        wg_mm(N, H, nr, lbar, 1, N, a[L - 1], H, 1, [&](int m, int n, float acc) { pWh[m * H + n] = acc; });
+        float* pbh = w.pbh + pt * N;
+        wg_colsum(nr, N, lbar, N, [&](int n, float s) { pbh[n] = s; });
+        float* zl = z[L - 1]; const float* al = a[L - 1];
+        wg_mm(nr, H, N, lbar, N, 1, Whc, H, 1, [&](int m, int n, float acc) {
+            zl[(long)m * H + n] = al[(long)m * H + n] > 0.f ? acc : 0.f;
+        });
+    }
+    __syncthreads();
+    for (int i = L - 1; i >= 1; --i) {
+        const int hi = d.h[i], hp = d.h[i - 1];
+        float* pWi = w.pW[i] + pt * (long)hi * hp;
+        wg_mm(hi, hp, nr, z[i], 1, hi, a[i - 1], hp, 1, [&](int m, int n, float acc) { pWi[(long)m * hp + n] = acc; });
+        float* pbi = w.pb[i] + pt * hi;
+        wg_colsum(nr, hi, z[i], hi, [&](int n, float s) { pbi[n] = s; });
+        float* zp = z[i - 1]; const float* ap = a[i - 1];
+        wg_mm(nr, hp, hi, z[i], hi, 1, Wc[i], hp, 1, [&](int m, int n, float acc) {
+            zp[(long)m * hp + n] = ap[(long)m * hp + n] > 0.f ? acc : 0.f;
+        });
+        __syncthreads();
+    }
+    // layer 0: Abar0 rows of the query set, b0bar, and the adjoint of the low-rank factor D_T
+    float* A0bq = w.A0bar_q + ((long)b * Qn + r0) * h0;
+    for (int i = tid; i < nr * h0; i += nt) A0bq[i] = z[0][i];
+    float* pb0 = w.pb0 + pt * h0;
+    wg_colsum(nr, h0, z[0], h0, [&](int n, float s) { pb0[n] = s; });
+    __syncthreads();
+    float* pD = w.pD + pt * (long)S * h0;
+    wg_mm(S, h0, nr, Gqs, 1, S, z[0], h0, 1, [&](int m, int n, float acc) {
+        pD[(long)m * h0 + n] = -alpha * (acc + pb0[n]);
+    });
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// reverse: sum the query slabs, then the second-order sweep back through the T inner steps
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void reverse_kernel(EpiDims d, EpiBuf w, float* loss_b, float* acc_b, float* head_bar) {
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int S = d.S, N = d.N, L = d.L, H = d.H, h0 = d.h[0];
+    const float alpha = d.alpha;
+    const int ntile = w.ntile;
+
+    if (tid == 0) {
+        float ls = 0.f, cr = 0.f;
+        for (int t = 0; t < ntile; ++t) { ls += w.ploss[(long)b * ntile + t]; cr += w.pcorr[(long)b * ntile + t]; }
+        loss_b[b] = ls / (float)d.Qn;
+        acc_b[b] = cr / (float)d.Qn;
+    }
+    if (!d.need_grad) return;
+
+    float* Wb[MAXL]; float* bb[MAXL];
+    float* Whb = w.Whb + (long)b * N * H;
+    float* bhb = w.bhb + (long)b * N;
+    float* b0b = w.b0b + (long)b * h0;
+    float* Db = w.Db + (long)b * S * h0;
+    float* A0bs = w.A0bar_s + (long)b * S * h0;
+    auto sum_tiles = [&](float* dst, const float* src, long sz) {
+        for (long i = tid; i < sz; i += nt) {
+            float s = 0.f;
+            for (int t = 0; t < ntile; ++t) s += src[((long)b * ntile + t) * sz + i];
+            dst[i] = s;
+        }
+    };
+    for (int i = 1; i < L; ++i) {
+        const long sz = (long)d.h[i] * d.h[i - 1];
+        Wb[i] = w.Wb[i] + (long)b * sz;
+        bb[i] = w.bb[i] + (long)b * d.h[i];
+        sum_tiles(Wb[i], w.pW[i], sz);
+        sum_tiles(bb[i], w.pb[i], d.h[i]);
+    }
+    sum_tiles(Whb, w.pWh, (long)N * H);
+    sum_tiles(bhb, w.pbh, N);
+    sum_tiles(b0b, w.pb0, h0);
+    sum_tiles(Db, w.pD, (long)S * h0);
+    for (int i = tid; i < S * h0; i += nt) A0bs[i] = 0.f;
+    __syncthreads();
+
+    if (d.second_order) {
+        const float* Gss = w.Gss + (long)b * S * S;
+        float* cs = w.cs + (long)b * h0;
+        float* eb = w.eb + (long)b * S * N;
+        float* lb = w.lb + (long)b * S * N;
+        float* X[2] = {w.X0 + (long)b * S * w.maxh, w.X1 + (long)b * S * w.maxh};
+        for (int t = d.T - 1; t >= 0; --t) {
+            const float* a[MAXL]; const float* dz[MAXL]; const float* Wc[MAXL]; float* ab[MAXL];
+            for (int i = 0; i < L; ++i) {
+                a[i] = w.ta[i] + ((long)b * w.ntape + t) * S * d.h[i];
+                dz[i] = w.tdz[i] + ((long)b * w.ntape + t) * S * d.h[i];
+                ab[i] = w.abar[i] + (long)b * S * d.h[i];
+                if (i >= 1) Wc[i] = w.Wslot[i] + ((long)b * w.nslot + t) * (long)d.h[i] * d.h[i - 1];
+            }
+            const float* Whc = w.Whslot + ((long)b * w.nslot + t) * N * H;
+            const float* p = w.tp + ((long)b * w.ntape + t) * S * N;
+            const float* e = w.te + ((long)b * w.ntape + t) * S * N;
+
+            // abar_i = 0 ; dab = Dbar * relu'(z0)          (dz0bar = adjoint of D_{t+1})
+            for (int i = 0; i < L; ++i)
+                for (int j = tid; j < S * d.h[i]; j += nt) ab[i][j] = 0.f;
+            int cur = 0;
+            for (int j = tid; j < S * h0; j += nt) X[0][j] = a[0][j] > 0.f ? Db[j] : 0.f;
+            __syncthreads();
+            // ---- reverse of the backward pass, bottom up
+            for (int i = 1; i < L; ++i) {
+                const int hi = d.h[i], hp = d.h[i - 1];
+                const float* dab = X[cur]; float* nxt = X[cur ^ 1];
+                const float* bbi = bb[i]; const float* Wbi = Wb[i]; const float* ai = a[i];
+                // dzbar_i = dab W_i^T - alpha bbar_i - alpha a_{i-1} Wbar_i^T ; next dab = dzbar_i * relu'(z_i)
+                wg_mm(S, hi, hp, dab, hp, 1, Wc[i], 1, hp, [&](int m, int n, float acc) {
+                    nxt[(long)m * hi + n] = acc - alpha * bbi[n];
+                });
+                wg_mm(S, hi, hp, a[i - 1], hp, 1, Wbi, 1, hp, [&](int m, int n, float acc) {      // same thread, same (m,n)
+                    const float v = nxt[(long)m * hi + n] - alpha * acc;
+                    nxt[(long)m * hi + n] = ai[(long)m * hi + n] > 0.f ? v : 0.f;
+                });
+                // abar_{i-1} += dz_i (-alpha Wbar_i)
+                float* abp = ab[i - 1];
+                wg_mm(S, hp, hi, dz[i], hi, 1, Wbi, hp, 1, [&](int m, int n, float acc) {
+                    abp[(long)m * hp + n] -= alpha * acc;
+                });
+                __syncthreads();
+                // Wbar_i += dz_i^T dab
+                float* Wbw = Wb[i];
+                wg_mm(hi, hp, S, dz[i], 1, hi, dab, hp, 1, [&](int m, int n, float acc) { Wbw[(long)m * hp + n] += acc; });
+                __syncthreads();
+                cur ^= 1;
+            }
+            {   // head: ebar = dab Wh^T - alpha bhbar - alpha a Whbar^T ; abar += e (-alpha Whbar) ; Whbar += e^T dab
+                const float* dab = X[cur];
+                wg_mm(S, N, H, dab, H, 1, Whc, 1, H, [&](int m, int n, float acc) { eb[m * N + n] = acc - alpha * bhb[n]; });
+                wg_mm(S, N, H, a[L - 1], H, 1, Whb, 1, H, [&](int m, int n, float acc) { eb[m * N + n] -= alpha * acc; });
+                float* abl = ab[L - 1];
+                wg_mm(S, H, N, e, N, 1, Whb, H, 1, [&](int m, int n, float acc) { abl[(long)m * H + n] -= alpha * acc; });
+                __syncthreads();
+                wg_mm(N, H, S, e, 1, N, dab, H, 1, [&](int m, int n, float acc) { Whb[m * H + n] += acc; });
+                // softmax-CE second derivative: lbar = p * (pbar - <p,pbar>),  pbar = ebar / S
+                for (int s = tid; s < S; s += nt) {
+                    float dot = 0.f;
+                    for (int n = 0; n < N; ++n) dot += p[s * N + n] * eb[s * N + n];
+                    for (int n = 0; n < N; ++n) lb[s * N + n] = p[s * N + n] * (eb[s * N + n] - dot) / (float)S;
+                }
+                __syncthreads();
+                // ---- reverse of the forward pass
+                wg_mm(S, H, N, lb, N, 1, Whc, H, 1, [&](int m, int n, float acc) { abl[(long)m * H + n] += acc; });
+                wg_mm(N, H, S, lb, 1, N, a[L - 1], H, 1, [&](int m, int n, float acc) { Whb[m * H + n] += acc; });
+                wg_colsum(S, N, lb, N, [&](int n, float s) { bhb[n] += s; });
+                __syncthreads();
+            }
+            for (int i = L - 1; i >= 1; --i) {
+                const int hi = d.h[i], hp = d.h[i - 1];
+                float* zb = ab[i];
+                for (int j = tid; j < S * hi; j += nt) zb[j] = a[i][j] > 0.f ? zb[j] : 0.f;
+                __syncthreads();
+                float* abp = ab[i - 1]; float* Wbw = Wb[i]; float* bbw = bb[i];
+                wg_mm(S, hp, hi, zb, hi, 1, Wc[i], hp, 1, [&](int m, int n, float acc) { abp[(long)m * hp + n] += acc; });
+                wg_mm(hi, hp, S, zb, 1, hi, a[i - 1], hp, 1, [&](int m, int n, float acc) { Wbw[(long)m * hp + n] += acc; });
+                wg_colsum(S, hi, zb, hi, [&](int n, float s) { bbw[n] += s; });
+                __syncthreads();
+            }
+            // layer 0: z0bar -> Abar0 rows of the support set, b0bar, Dbar
+            float* z0b = ab[0];
+            for (int j = tid; j < S * h0; j += nt) {
+                const float v = a[0][j] > 0.f ? z0b[j] : 0.f;
+                z0b[j] = v;
+                A0bs[j] += v;
+            }
+            __syncthreads();
+            wg_colsum(S, h0, z0b, h0, [&](int n, float s) { cs[n] = s; b0b[n] += s; });
+            __syncthreads();
+            wg_mm(S, h0, S, Gss, S, 1, z0b, h0, 1, [&](int m, int n, float acc) {
+                Db[(long)m * h0 + n] -= alpha * (acc + cs[n]);
+            });
+            __syncthreads();
+        }
+    }
+    // d loss_b / d head_b = [Whbar | bhbar]
+    float* hb = head_bar + (long)b * N * (H + 1);
+    for (int j = tid; j < N * H; j += nt) hb[(j / H) * (H + 1) + (j % H)] = Whb[j];
+    for (int j = tid; j < N; j += nt) hb[j * (H + 1) + H] = bhb[j];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------------------
+__global__ void class_text_select_kernel(int N, int S, int Dt, const float* text_s, const int64_t* y_s, float* out,
+                                         int* status) {
+    // one wave per (episode, class): ballot for the FIRST support row of the class (fumi.py:207-210), then row copy
+    const int b = blockIdx.y, n = blockIdx.x, lane = threadIdx.x;
+    const int64_t* ys = y_s + (long)b * S;
+    int first = S;
+    for (int s0 = 0; s0 < S && first == S; s0 += 64) {
+        const int s = s0 + lane;
+        const bool hit = s < S && ys[s] == n;
+        const unsigned long long m = __ballot(hit);
+        if (m) first = s0 + __ffsll((long long)m) - 1;
+    }
+    float* o = out + ((long)b * N + n) * Dt;
+    if (first == S) {
+        if (lane == 0) atomicOr(status, FUMI_ST_CLASS_MISSING);
+        for (int j = lane; j < Dt; j += 64) o[j] = __builtin_nanf("");
+        return;
+    }
+    const float* src = text_s + ((long)b * S + first) * Dt;
+    for (int j = lane; j < Dt; j += 64) o[j] = src[j];
+}
+
+__global__ void broadcast_head_kernel(int N, int H, const float* Wf, const float* bf, float* head) {
+    float* hb = head + (long)blockIdx.x * N * (H + 1);
+    for (int j = threadIdx.x; j < N * (H + 1); j += blockDim.x) {
+        const int n = j / (H + 1), c = j % (H + 1);
+        hb[j] = c < H ? Wf[n * H + c] : bf[n];
+    }
+}
+
+__global__ void tanh_bwd_kernel(long n, const float* h, const float* hbar, float* out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = hbar[i] * (1.f - h[i] * h[i]);
+}
+
+__global__ void relu_mask_mul_kernel(long n, const float* u, float* g) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        g[i] = u[i] > 0.f ? g[i] : 0.f;
+}
+
+__global__ void split_head_grad_kernel(int B, int N, int H, const float* head_bar, float scale, float* gW, float* gb) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N * (H + 1)) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += head_bar[(long)b * N * (H + 1) + j];
+    const int n = j / (H + 1), c = j % (H + 1);
+    if (c < H) gW[n * H + c] = scale * s; else gb[n] = scale * s;
+}
+
+inline int blocks_for(long n) { long b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
+
+struct Carver {      // computes the layout twice: once to size the workspace, once to hand out pointers
+    fumi_ws* ws; size_t bytes;
+    float* take(size_t n) {
+        bytes += ws_align(n * sizeof(float));
+        return ws ? ws_f(ws, n) : nullptr;
+    }
+};
+
+void carve(Carver& c, const EpisodeProblem& p, EpiBuf& w) {
+    const size_t B = p.B, S = p.S, Qn = p.Qn, N = p.N, L = p.L, h0 = p.h[0], H = p.h[L - 1];
+    const bool taped = p.need_grad && p.second_order && p.T > 0;
+    w.nslot = taped ? p.T + 1 : 1;
+    w.ntape = taped ? p.T : 1;
+    w.ntile = (p.Qn + QR - 1) / QR;
+    int maxh = 0;
+    for (int i = 0; i < p.L; ++i) maxh = p.h[i] > maxh ? p.h[i] : maxh;
+    w.maxh = maxh;
+    const size_t nt = w.ntile;
+    w.A0s = c.take(B * S * h0); w.A0q = c.take(B * Qn * h0); w.Gss = c.take(B * S * S); w.Gqs = c.take(B * Qn * S);
+    w.D = c.take(B * S * h0); w.cs = c.take(B * h0);
+    w.bh = c.take(B * N); w.Whslot = c.take(B * w.nslot * N * H);
+    w.tp = c.take(B * w.ntape * S * N); w.te = c.take(B * w.ntape * S * N);
+    w.lg = c.take(B * S * N);
+    w.lbar = c.take(B * Qn * N); w.qcs = c.take(B * nt * h0);
+    w.ploss = c.take(B * nt); w.pcorr = c.take(B * nt);
+    for (size_t i = 0; i < L; ++i) {
+        const size_t hi = p.h[i], hp = i ? p.h[i - 1] : 0;
+        w.ta[i] = c.take(B * w.ntape * S * hi); w.tdz[i] = c.take(B * w.ntape * S * hi);
+        w.aq[i] = c.take(B * Qn * hi); w.zq[i] = c.take(B * Qn * hi);
+        if (i >= 1) { w.bcur[i] = c.take(B * hi); w.Wslot[i] = c.take(B * w.nslot * hi * hp); }
+        else { w.bcur[i] = nullptr; w.Wslot[i] = nullptr; }
+    }
+    if (p.need_grad) {
+        w.pWh = c.take(B * nt * N * H); w.pbh = c.take(B * nt * N); w.pb0 = c.take(B * nt * h0); w.pD = c.take(B * nt * S * h0);
+        w.Whb = c.take(B * N * H); w.bhb = c.take(B * N); w.b0b = c.take(B * h0); w.Db = c.take(B * S * h0);
+        w.X0 = c.take(B * S * maxh); w.X1 = c.take(B * S * maxh); w.eb = c.take(B * S * N); w.lb = c.take(B * S * N);
+        w.A0bar_s = c.take(B * S * h0); w.A0bar_q = c.take(B * Qn * h0);
+        for (size_t i = 0; i < L; ++i) {
+            const size_t hi = p.h[i], hp = i ? p.h[i - 1] : 0;
+            w.abar[i] = c.take(B * S * hi);
+            if (i >= 1) {
+                w.pW[i] = c.take(B * nt * hi * hp); w.pb[i] = c.take(B * nt * hi);
+                w.Wb[i] = c.take(B * hi * hp); w.bb[i] = c.take(B * hi);
+            } else { w.pW[i] = w.pb[i] = w.Wb[i] = w.bb[i] = nullptr; }
+        }
+    }
+}
+
+constexpr int GW0_KCHUNK = 1024;     // contraction rows per split of gW0 = Abar0^T X (multiple of the GEMM's BK)
+
+}  // namespace
+
+size_t episode_workspace_bytes(const EpisodeProblem& p) {
+    Carver c{nullptr, 0};
+    EpiBuf w;
+    carve(c, p, w);
+    if (p.need_grad) {
+        const size_t ns = (size_t)((long)p.B * p.S + GW0_KCHUNK - 1) / GW0_KCHUNK + ((long)p.B * p.Qn + GW0_KCHUNK - 1) / GW0_KCHUNK;
+        c.bytes += ws_align(ns * p.h[0] * (size_t)p.D * sizeof(float));
+    }
+    return c.bytes;
+}
+
+int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
+    if (p.L < 1 || p.L > MAXL || p.B < 1 || p.N < 1 || p.S < 1 || p.Qn < 1 || p.D < 1 || p.T < 0) return FUMI_EINVAL;
+    for (int i = 0; i < p.L; ++i) if (p.h[i] < 1) return FUMI_EINVAL;
+    EpiBuf w;
+    Carver c{ws, 0};
+    carve(c, p, w);
+    EpiDims d;
+    d.B = p.B; d.N = p.N; d.S = p.S; d.Qn = p.Qn; d.L = p.L; d.T = p.T; d.H = p.h[p.L - 1];
+    for (int i = 0; i < MAXL; ++i) d.h[i] = i < p.L ? p.h[i] : 0;
+    d.alpha = p.alpha; d.need_grad = p.need_grad; d.second_order = p.second_order;
+    d.taped = (p.need_grad && p.second_order && p.T > 0) ? 1 : 0;
+    const int h0 = p.h[0];
+    int rc;
+
+    // ---- shared GEMM 1: A0 = X W0^T (support and query rows), G = X Xs^T (batched per episode)
+    {
+        GemmArgs g = gemm_args(p.B * p.S, h0, p.D, p.x_s, p.D, p.W[0], p.D, w.A0s, h0);
+        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+        g = gemm_args(p.B * p.Qn, h0, p.D, p.x_q, p.D, p.W[0], p.D, w.A0q, h0);
+        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+        g = gemm_args(p.S, p.S, p.D, p.x_s, p.D, p.x_s, p.D, w.Gss, p.S);
+        g.nbatch = p.B; g.sA = (long)p.S * p.D; g.sB = (long)p.S * p.D; g.sC = (long)p.S * p.S;
+        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+        g = gemm_args(p.Qn, p.S, p.D, p.x_q, p.D, p.x_s, p.D, w.Gqs, p.S);
+        g.nbatch = p.B; g.sA = (long)p.Qn * p.D; g.sB = (long)p.S * p.D; g.sC = (long)p.Qn * p.S;
+        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+    }
+    // ---- per-episode phases
+    EpiParams prm;
+    for (int i = 0; i < MAXL; ++i) { prm.W[i] = i < p.L ? p.W[i] : nullptr; prm.b[i] = i < p.L ? p.b[i] : nullptr; }
+    hipLaunchKernelGGL(adapt_kernel, dim3(p.B), dim3(1024), 0, st, d, w, prm, p.y_s, p.head, ws->status);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(query_kernel, dim3(w.ntile, p.B), dim3(512), 0, st, d, w, p.b[0], p.y_q, p.logits_q, p.preds_q,
+                       ws->status);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(reverse_kernel, dim3(p.B), dim3(1024), 0, st, d, w, p.loss_b, p.acc_b, p.head_bar);
+    LAUNCH_CHECK();
+    if (!p.need_grad) return FUMI_OK;
+
+    // ---- meta-gradients of the hidden layers: sums over episodes
+    for (int i = 1; i < p.L; ++i) {
+        const long sz = (long)p.h[i] * p.h[i - 1];
+        if ((rc = launch_reduce_slabs(st, w.Wb[i], p.B, sz, sz, p.grad_scale, p.gW[i]))) return rc;
+        if ((rc = launch_reduce_slabs(st, w.bb[i], p.B, p.h[i], p.h[i], p.grad_scale, p.gb[i]))) return rc;
+    }
+    if ((rc = launch_reduce_slabs(st, w.b0b, p.B, h0, h0, p.grad_scale, p.gb[0]))) return rc;
+    // ---- shared GEMM 2: gW0 = Abar0^T X, contraction over all rows of all episodes, split into slabs
+    {
+        const long Ks = (long)p.B * p.S, Kq = (long)p.B * p.Qn;
+        const int ns = d.second_order ? (int)((Ks + GW0_KCHUNK - 1) / GW0_KCHUNK) : 0;
+        const int nq = (int)((Kq + GW0_KCHUNK - 1) / GW0_KCHUNK);
+        const long slab = (long)h0 * p.D;
+        float* slabs = ws_f(ws, (size_t)(ns + nq) * slab);
+        if (ns) {
+            GemmArgs g = gemm_args(h0, p.D, (int)Ks, w.A0bar_s, h0, p.x_s, p.D, slabs, p.D);
+            g.kchunk = GW0_KCHUNK; g.nsplit = ns; g.sCsplit = slab;
+            if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+        }
+        GemmArgs g = gemm_args(h0, p.D, (int)Kq, w.A0bar_q, h0, p.x_q, p.D, slabs + (long)ns * slab, p.D);
+        g.kchunk = GW0_KCHUNK; g.nsplit = nq; g.sCsplit = slab;
+        if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+        if ((rc = launch_reduce_slabs(st, slabs, ns + nq, slab, slab, p.grad_scale, p.gW[0]))) return rc;
+    }
+    return FUMI_OK;
+}
+
+int launch_class_text_select(hipStream_t st, int B, int N, int S, int Dt, const float* text_s, const int64_t* y_s,
+                             float* out, int* status) {
+    hipLaunchKernelGGL(class_text_select_kernel, dim3(N, B), dim3(64), 0, st, N, S, Dt, text_s, y_s, out, status);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+int launch_broadcast_head(hipStream_t st, int B, int N, int H, const float* Wf, const float* bf, float* head) {
+    hipLaunchKernelGGL(broadcast_head_kernel, dim3(B), dim3(256), 0, st, N, H, Wf, bf, head);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+int launch_tanh_bwd(hipStream_t st, long n, const float* h, const float* hbar, float* out) {
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, st, n, h, hbar, out);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+int launch_relu_mask_mul(hipStream_t st, long n, const float* u, float* g) {
+    hipLaunchKernelGGL(relu_mask_mul_kernel, dim3(blocks_for(n)), dim3(256), 0, st, n, u, g);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+int launch_split_head_grad(hipStream_t st, int B, int N, int H, const float* head_bar, float scale, float* gW, float* gb) {
+    hipLaunchKernelGGL(split_head_grad_kernel, dim3((N * (H + 1) + 255) / 256), dim3(256), 0, st, B, N, H, head_bar, scale, gW, gb);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}

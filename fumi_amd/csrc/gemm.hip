@@ -1,0 +1,203 @@
+// Dense fp32 GEMM family on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 256 FLOP/clk/CU).
+//
+// Used for every shared-weight contraction of the hot path (ATen mm/addmm + their backward in the reference:
+// torchmeta MetaLinear.forward via fumi/models/fumi.py:215, autograd AddmmBackward/MmBackward via :165-176,192):
+//   * A0|G  = X [W0;Xs]^T   (layer-0 pre-activations + support Gram matrix, see episode.hip)
+//   * gW0   = Abar0^T X     (layer-0 meta-gradient, split over the contraction, slabs summed by reduce_slabs)
+//   * the hypernetwork / AM3 encoder linears and their backward
+//
+// Tiling: BM x BN = 64 x 64 output tile per 256-thread workgroup (4 waves as 2 x 2, one 32x32 accumulator each),
+// BK = 32 contraction slab, double-buffered in LDS, next slab prefetched to registers while the MFMAs run.
+// LDS images (both conflict-free for the fragment reads, see MI355X_MICROARCH LDS table):
+//   k-contiguous operand  -> T[row][BK+4]: a lane reads 4 consecutive k as one ds_read_b128 (row stride 144 B puts
+//                            16 consecutive rows on 16 distinct 4-bank slots); MFMA step 4c+j of a slab contracts
+//                            k = 8c + 4*(lane>>5) + j  -- any partition of the slab's k works if A and B agree.
+//   m/n-contiguous operand-> T[k][BM]    : a lane reads T[k][col0 + (lane&31)] (consecutive lanes, consecutive banks).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int KC_LD = BK + 4;     // row stride (floats) of a k-contiguous LDS image
+constexpr int TILE_F = 64 * KC_LD; // floats reserved per operand image (>= 32*64 for the other layout)
+
+// global -> registers for one operand tile (64 rows/cols x 32 k), 2 float4 per thread
+template <int LAYOUT>
+__device__ __forceinline__ void load_tile(f32x4 (&r)[2], const float* __restrict__ P, long ld, int row0, int rows,
+                                          int k0, int kend, bool vec) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int f = tid + 256 * j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (LAYOUT == 0) {                       // P(row,k) = P[row*ld + k]
+            const int row = row0 + (f >> 3), k = k0 + ((f & 7) << 2);
+            if (row < rows) {
+                const float* p = P + (long)row * ld + k;
+                if (vec && k + 3 < kend) v = *(const f32x4*)p;
+                else {
+                    if (k < kend) v[0] = p[0];
+                    if (k + 1 < kend) v[1] = p[1];
+                    if (k + 2 < kend) v[2] = p[2];
+                    if (k + 3 < kend) v[3] = p[3];
+                }
+            }
+        } else {                                 // P(row,k) = P[k*ld + row]
+            const int k = k0 + (f >> 4), row = row0 + ((f & 15) << 2);
+            if (k < kend) {
+                const float* p = P + (long)k * ld + row;
+                if (vec && row + 3 < rows) v = *(const f32x4*)p;
+                else {
+                    if (row < rows) v[0] = p[0];
+                    if (row + 1 < rows) v[1] = p[1];
+                    if (row + 2 < rows) v[2] = p[2];
+                    if (row + 3 < rows) v[3] = p[3];
+                }
+            }
+        }
+        r[j] = v;
+    }
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ void store_tile(const f32x4 (&r)[2], float* T) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int f = tid + 256 * j;
+        if (LAYOUT == 0) *(f32x4*)(T + (f >> 3) * KC_LD + ((f & 7) << 2)) = r[j];
+        else             *(f32x4*)(T + (f >> 4) * 64 + ((f & 15) << 2)) = r[j];
+    }
+}
+
+template <int AL, int BL>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int avec, int bvec) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][TILE_F];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int zb = blockIdx.z / g.nsplit, zs = blockIdx.z % g.nsplit;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = zs * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const float* A = g.A + (long)zb * g.sA;
+    const float* B = g.B + (long)zb * g.sB;
+    float* C = g.C + (long)zb * g.sC + (long)zs * g.sCsplit;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    f32x4 ra[2], rb[2];
+    const int nslab = (kend - kbeg + BK - 1) / BK;
+    if (nslab > 0) {
+        load_tile<AL>(ra, A, g.lda, m0, g.M, kbeg, kend, avec);
+        load_tile<BL>(rb, B, g.ldb, n0, g.N, kbeg, kend, bvec);
+        store_tile<AL>(ra, lds[0][0]);
+        store_tile<BL>(rb, lds[0][1]);
+    }
+    __syncthreads();
+    const int li = lane & 31, kh = lane >> 5;
+    for (int s = 0; s < nslab; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nslab) {
+            load_tile<AL>(ra, A, g.lda, m0, g.M, kbeg + (s + 1) * BK, kend, avec);
+            load_tile<BL>(rb, B, g.ldb, n0, g.N, kbeg + (s + 1) * BK, kend, bvec);
+        }
+        const float* TA = lds[cur][0];
+        const float* TB = lds[cur][1];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 av, bv;
+            if (AL == 0) av = *(const f32x4*)(TA + (wm * 32 + li) * KC_LD + 8 * c + 4 * kh);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[j] = TA[(8 * c + 4 * kh + j) * 64 + wm * 32 + li];
+            }
+            if (BL == 0) bv = *(const f32x4*)(TB + (wn * 32 + li) * KC_LD + 8 * c + 4 * kh);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = TB[(8 * c + 4 * kh + j) * 64 + wn * 32 + li];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+        }
+        if (s + 1 < nslab) {
+            store_tile<AL>(ra, lds[cur ^ 1][0]);
+            store_tile<BL>(rb, lds[cur ^ 1][1]);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31 of the wave's 32x32 tile
+    const int n = n0 + wn * 32 + li;
+    if (n < g.N) {
+        const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (m < g.M) {
+                float v = g.alpha * acc[r] + bias;
+                if (g.act == 1) v = v > 0.f ? v : 0.f;
+                else if (g.act == 2) v = tanhf(v);
+                float* c = C + (long)m * g.ldc + n;
+                if (g.accumulate) v += *c;
+                *c = v;
+            }
+        }
+    }
+}
+
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, long stride, long n, float scale,
+                                    float* __restrict__ out) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nslab; ++k) s += slabs[k * stride + i];
+        out[i] = scale * s;
+    }
+}
+
+__global__ void colsum_kernel(const float* __restrict__ X, int M, int N, long ld, float scale, float* __restrict__ out) {
+    // one wave-column-group per block: blockDim = (64, 4); each y-slice sums a strided subset of rows
+    __shared__ float part[4][64];
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    float s = 0.f;
+    if (n < N) for (int m = threadIdx.y; m < M; m += 4) s += X[(long)m * ld + n];
+    part[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && n < N) out[n] = scale * (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+int launch_gemm(hipStream_t st, const GemmArgs& g, int AL, int BL) {
+    if (g.M <= 0 || g.N <= 0) return FUMI_OK;
+    if (g.K < 0 || g.nsplit < 1 || g.nbatch < 1 || !g.A || !g.B || !g.C) return FUMI_EINVAL;
+    // float4 path needs every float4 to be 16-byte aligned and never to straddle a tile bound
+    const bool avec = aligned16(g.A) && g.lda % 4 == 0 && g.sA % 4 == 0 && (AL == 0 ? (g.kchunk % 4 == 0) : true);
+    const bool bvec = aligned16(g.B) && g.ldb % 4 == 0 && g.sB % 4 == 0 && (BL == 0 ? (g.kchunk % 4 == 0) : true);
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.nbatch * g.nsplit), block(256);
+    if (AL == 0 && BL == 0) hipLaunchKernelGGL((gemm_kernel<0, 0>), grid, block, 0, st, g, avec, bvec);
+    else if (AL == 0 && BL == 1) hipLaunchKernelGGL((gemm_kernel<0, 1>), grid, block, 0, st, g, avec, bvec);
+    else if (AL == 1 && BL == 0) hipLaunchKernelGGL((gemm_kernel<1, 0>), grid, block, 0, st, g, avec, bvec);
+    else hipLaunchKernelGGL((gemm_kernel<1, 1>), grid, block, 0, st, g, avec, bvec);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+int launch_reduce_slabs(hipStream_t st, const float* slabs, int nslab, long stride, long n, float scale, float* out) {
+    if (n <= 0) return FUMI_OK;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, nslab, stride, n, scale, out);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+int launch_colsum(hipStream_t st, const float* X, int M, int N, long ld, float scale, float* out) {
+    if (N <= 0) return FUMI_OK;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(64, 4), 0, st, X, M, N, ld, scale, out);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}

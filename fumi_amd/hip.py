@@ -1,0 +1,342 @@
+"""ctypes binding of ``include/fumi_hip.h`` (the gfx950 engine, ``fumi_amd/lib/libfumi_hip.so``).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every tensor is handed to the
+library as a raw device pointer.  There is NO CPU fallback: if the library is missing, or a tensor
+is not on a GPU, these functions raise.
+"""
+import ctypes
+import os
+import threading
+from ctypes import c_int, c_int64, c_float, c_void_p, c_size_t, c_char_p, POINTER
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfumi_hip.so")
+
+# every symbol include/fumi_hip.h declares (tests/test_abi.py checks the shared object exports them all)
+SYMBOLS = [
+    "fumi_hip_version", "fumi_hip_strerror", "fumi_hip_last_hip_error",
+    "fumi_hip_workspace_create", "fumi_hip_workspace_destroy", "fumi_hip_workspace_bytes", "fumi_hip_read_status",
+    "fumi_hip_fumi_step", "fumi_hip_maml_step", "fumi_hip_am3_step",
+    "fumi_hip_glove_bag", "fumi_hip_class_text_select",
+    "fumi_hip_linear_fwd", "fumi_hip_linear_bwd_data", "fumi_hip_linear_bwd_weight",
+]
+
+ST_LABEL_RANGE, ST_CLASS_MISSING = 1, 2
+
+_lib = None
+_lock = threading.Lock()
+
+
+class FumiHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared object once.  Fails loudly when it has not been built (``python __graft_entry__.py``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise FumiHipError(
+                f"{LIB_PATH} is missing: the MI355X engine has no CPU fallback. Build it with "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).")
+        L = ctypes.CDLL(LIB_PATH)
+        L.fumi_hip_version.restype = c_int
+        L.fumi_hip_strerror.restype = c_char_p
+        L.fumi_hip_strerror.argtypes = [c_int]
+        L.fumi_hip_last_hip_error.restype = c_char_p
+        L.fumi_hip_workspace_create.argtypes = [c_int, c_size_t, POINTER(c_void_p)]
+        L.fumi_hip_workspace_destroy.argtypes = [c_void_p]
+        L.fumi_hip_workspace_destroy.restype = None
+        L.fumi_hip_workspace_bytes.argtypes = [c_void_p]
+        L.fumi_hip_workspace_bytes.restype = c_size_t
+        L.fumi_hip_read_status.argtypes = [c_void_p, c_void_p, POINTER(c_int)]
+        PP = POINTER(c_void_p)
+        L.fumi_hip_fumi_step.argtypes = (
+            [c_void_p, c_void_p] + [c_int] * 6 + [POINTER(c_int), c_int, c_int, c_int, c_float, c_int, c_int, c_float]
+            + [c_void_p] * 6 + [PP, PP] + [c_void_p] * 4 + [PP, PP])
+        L.fumi_hip_maml_step.argtypes = (
+            [c_void_p, c_void_p] + [c_int] * 6 + [POINTER(c_int), c_int, c_float, c_int, c_int, c_float]
+            + [c_void_p] * 4 + [PP] + [c_void_p] * 4 + [PP])
+        L.fumi_hip_am3_step.argtypes = (
+            [c_void_p, c_void_p] + [c_int] * 10 + [c_float] + [c_void_p] * 5 + [PP] + [c_void_p] * 4 + [PP])
+        L.fumi_hip_glove_bag.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int, c_int,
+                                         c_int, c_void_p]
+        L.fumi_hip_class_text_select.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p] * 3
+        L.fumi_hip_linear_fwd.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 3 + [c_int, c_void_p]
+        L.fumi_hip_linear_bwd_data.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 3
+        L.fumi_hip_linear_bwd_weight.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 4
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        L = lib()
+        msg = L.fumi_hip_strerror(rc).decode()
+        if rc == -3:
+            msg += ": " + L.fumi_hip_last_hip_error().decode()
+        raise FumiHipError(f"{what} failed: {msg} ({rc})")
+
+
+def _dev(t):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise FumiHipError("the MI355X engine needs GPU tensors (there is no CPU path); got "
+                           f"{getattr(t, 'device', type(t))}")
+    return t.device
+
+
+def _f32(t, name):
+    _dev(t)
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise FumiHipError(f"{name}: expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return c_void_p(t.data_ptr())
+
+
+def _i64(t, name):
+    _dev(t)
+    if t.dtype != torch.int64 or not t.is_contiguous():
+        raise FumiHipError(f"{name}: expected a contiguous int64 tensor, got {t.dtype}")
+    return c_void_p(t.data_ptr())
+
+
+def _parr(tensors, name):
+    arr = (c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = _f32(t, f"{name}[{i}]").value
+    return arr
+
+
+def _stream(device):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Workspace:
+    """One per (process, device).  Owns the engine's scratch slab; not re-entrant."""
+
+    _per_device = {}
+
+    def __init__(self, device, bytes_hint=0):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise FumiHipError("the MI355X engine has no CPU path")
+        self.device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+        h = c_void_p()
+        with torch.cuda.device(self.device):
+            _check(lib().fumi_hip_workspace_create(self.device.index, bytes_hint, ctypes.byref(h)), "workspace_create")
+        self._h = h
+
+    @classmethod
+    def get(cls, device):
+        device = torch.device(device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        ws = cls._per_device.get(idx)
+        if ws is None:
+            ws = cls._per_device[idx] = Workspace(torch.device("cuda", idx))
+        return ws
+
+    @property
+    def handle(self):
+        return self._h
+
+    def bytes(self):
+        return int(lib().fumi_hip_workspace_bytes(self._h))
+
+    def read_status(self):
+        """Synchronises the current stream; returns and clears the device status bits."""
+        st = c_int(0)
+        _check(lib().fumi_hip_read_status(self._h, _stream(self.device), ctypes.byref(st)), "read_status")
+        return st.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().fumi_hip_workspace_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def raise_on_status(status):
+    if status & ST_CLASS_MISSING:
+        raise IndexError("a class has no support sample (the reference raises IndexError at fumi/models/fumi.py:209)")
+    if status & ST_LABEL_RANGE:
+        raise IndexError("label / token id out of range")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def fumi_step(ws, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head, *, cls_text=None, text_s=None,
+              need_grad=True, grad_scale=None, g_theta=None, g_phi=None):
+    """One FuMI meta-step over B episodes (fumi/models/fumi.py:146-192).  Returns a dict of GPU tensors."""
+    dev = _dev(x_s)
+    B, S, D = x_s.shape
+    Qn = x_q.shape[1]
+    n_hidden = len(theta) // 2
+    hid = [int(theta[2 * i].shape[0]) for i in range(n_hidden)]
+    Ht, Dt = int(phi[0].shape[0]), int(phi[0].shape[1])
+    N = int((cls_text.shape[1]) if cls_text is not None else 0) or None
+    if N is None:
+        raise FumiHipError("fumi_step: pass n_way through cls_text=[B,N,Dt] or use fumi_step_select")
+    return _fumi_step(ws, dev, B, N, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head,
+                      cls_text, text_s, need_grad, grad_scale, g_theta, g_phi)
+
+
+def fumi_step_select(ws, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head, *,
+                     need_grad=True, grad_scale=None, g_theta=None, g_phi=None):
+    """Same, selecting the per-class text rows from text_s [B,S,Dt] on the device (fumi.py:207-210)."""
+    dev = _dev(x_s)
+    B, S, D = x_s.shape
+    Qn = x_q.shape[1]
+    n_hidden = len(theta) // 2
+    hid = [int(theta[2 * i].shape[0]) for i in range(n_hidden)]
+    Ht, Dt = int(phi[0].shape[0]), int(phi[0].shape[1])
+    return _fumi_step(ws, dev, B, n_way, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head,
+                      None, text_s, need_grad, grad_scale, g_theta, g_phi)
+
+
+def _fumi_step(ws, dev, B, N, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head,
+               cls_text, text_s, need_grad, grad_scale, g_theta, g_phi):
+    L = lib()
+    logits = torch.empty(B, Qn, N, device=dev, dtype=torch.float32)
+    preds = torch.empty(B, Qn, device=dev, dtype=torch.int64)
+    loss_b = torch.empty(B, device=dev, dtype=torch.float32)
+    acc_b = torch.empty(B, device=dev, dtype=torch.float32)
+    if need_grad:
+        if g_theta is None:
+            g_theta = [torch.empty_like(t) for t in theta]
+        if g_phi is None:
+            g_phi = [torch.empty_like(t) for t in phi]
+    if grad_scale is None:
+        grad_scale = 1.0 / B
+    hid_arr = (c_int * len(hid))(*hid)
+    rc = L.fumi_hip_fumi_step(
+        ws.handle, _stream(dev), B, N, S, Qn, D, len(hid), hid_arr, Dt, Ht, int(T), float(alpha), int(bool(tanh_head)),
+        int(bool(need_grad)), float(grad_scale),
+        _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"),
+        _f32(cls_text, "cls_text") if cls_text is not None else None,
+        _f32(text_s, "text_s") if text_s is not None else None,
+        _parr(theta, "theta"), _parr(phi, "phi"),
+        _f32(logits, "logits"), _i64(preds, "preds"), _f32(loss_b, "loss_b"), _f32(acc_b, "acc_b"),
+        _parr(g_theta, "g_theta") if need_grad else None, _parr(g_phi, "g_phi") if need_grad else None)
+    _check(rc, "fumi_hip_fumi_step")
+    return dict(logits=logits, preds=preds, loss_b=loss_b, acc_b=acc_b, g_theta=g_theta, g_phi=g_phi)
+
+
+def maml_step(ws, x_s, y_s, x_q, y_q, params, T, alpha, first_order=False, *, need_grad=True, grad_scale=None,
+              g_params=None):
+    """One MAML meta-step (fumi/models/maml.py:156-191).  params = hidden (W,b)* then lin_final W [N,H], b [N]."""
+    dev = _dev(x_s)
+    L = lib()
+    B, S, D = x_s.shape
+    Qn = x_q.shape[1]
+    n_hidden = len(params) // 2 - 1
+    hid = [int(params[2 * i].shape[0]) for i in range(n_hidden)]
+    N = int(params[-2].shape[0])
+    logits = torch.empty(B, Qn, N, device=dev, dtype=torch.float32)
+    preds = torch.empty(B, Qn, device=dev, dtype=torch.int64)
+    loss_b = torch.empty(B, device=dev, dtype=torch.float32)
+    acc_b = torch.empty(B, device=dev, dtype=torch.float32)
+    if need_grad and g_params is None:
+        g_params = [torch.empty_like(t) for t in params]
+    if grad_scale is None:
+        grad_scale = 1.0 / B
+    hid_arr = (c_int * max(1, len(hid)))(*hid)
+    rc = L.fumi_hip_maml_step(
+        ws.handle, _stream(dev), B, N, S, Qn, D, n_hidden, hid_arr, int(T), float(alpha), int(bool(first_order)),
+        int(bool(need_grad)), float(grad_scale),
+        _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"), _parr(params, "params"),
+        _f32(logits, "logits"), _i64(preds, "preds"), _f32(loss_b, "loss_b"), _f32(acc_b, "acc_b"),
+        _parr(g_params, "g_params") if need_grad else None)
+    _check(rc, "fumi_hip_maml_step")
+    return dict(logits=logits, preds=preds, loss_b=loss_b, acc_b=acc_b, g_params=g_params)
+
+
+AM3_KEYS = ["Wi", "bi", "G0", "g0", "G1", "g1", "H0", "h0", "H1", "h1"]
+
+
+def am3_step(ws, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed=None, *, need_grad=True, grad_scale=1.0, g_w=None):
+    """One AM3 step (fumi/models/am3.py:160-200).  w: list of the 10 tensors in AM3_KEYS order."""
+    dev = _dev(x_s)
+    L = lib()
+    B, S, D = x_s.shape
+    Qn = x_q.shape[1]
+    P, Ht, Dt = int(w[0].shape[0]), int(w[2].shape[0]), int(w[2].shape[1])
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    correct = torch.empty(1, device=dev, dtype=torch.float32)
+    preds = torch.empty(B, Qn, device=dev, dtype=torch.int64)
+    lam = torch.empty(B, S, device=dev, dtype=torch.float32)
+    if need_grad and g_w is None:
+        g_w = [torch.empty_like(t) for t in w]
+    lf = -1 if lamda_fixed is None else int(lamda_fixed)
+    rc = L.fumi_hip_am3_step(
+        ws.handle, _stream(dev), B, n_way, S, Qn, D, Dt, Ht, P, lf, int(bool(need_grad)), float(grad_scale),
+        _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"), _f32(text_s, "text_s"),
+        _parr(w, "w"), _f32(loss, "loss"), _i64(preds, "preds"), _f32(lam, "lamda_s"), _f32(correct, "correct"),
+        _parr(g_w, "g_w") if need_grad else None)
+    _check(rc, "fumi_hip_am3_step")
+    return dict(loss=loss, preds=preds, lamda_s=lam, correct=correct, grads=g_w)
+
+
+def glove_bag(ws, tokens, table, pad_id, mode="mean"):
+    """WordEmbedding.forward (fumi/models/common.py:23-41): tokens [..., L] int64 -> [..., E]."""
+    if mode not in ("mean", "max"):
+        raise NameError(f"{mode} pooling strat not defined")           # common.py:41
+    dev = _dev(tokens)
+    Lseq = tokens.shape[-1]
+    R = tokens.numel() // Lseq
+    V, E = table.shape
+    out = torch.empty(*tokens.shape[:-1], E, device=dev, dtype=torch.float32)
+    rc = lib().fumi_hip_glove_bag(ws.handle, _stream(dev), _i64(tokens, "tokens"), R, Lseq, int(pad_id),
+                                  _f32(table, "table"), V, E, 0 if mode == "mean" else 1, _f32(out, "out"))
+    _check(rc, "fumi_hip_glove_bag")
+    return out
+
+
+def class_text_select(ws, text_s, y_s, n_way):
+    dev = _dev(text_s)
+    B, S, Dt = text_s.shape
+    out = torch.empty(B, n_way, Dt, device=dev, dtype=torch.float32)
+    rc = lib().fumi_hip_class_text_select(ws.handle, _stream(dev), B, n_way, S, Dt, _f32(text_s, "text_s"),
+                                          _i64(y_s, "y_s"), _f32(out, "out"))
+    _check(rc, "fumi_hip_class_text_select")
+    return out
+
+
+def linear_fwd(ws, x, W, b=None, act=0):
+    dev = _dev(x)
+    M, K = x.shape
+    N = W.shape[0]
+    y = torch.empty(M, N, device=dev, dtype=torch.float32)
+    rc = lib().fumi_hip_linear_fwd(ws.handle, _stream(dev), M, N, K, _f32(x, "x"), _f32(W, "W"),
+                                   _f32(b, "b") if b is not None else None, int(act), _f32(y, "y"))
+    _check(rc, "fumi_hip_linear_fwd")
+    return y
+
+
+def linear_bwd_data(ws, dy, W):
+    dev = _dev(dy)
+    M, N = dy.shape
+    K = W.shape[1]
+    dx = torch.empty(M, K, device=dev, dtype=torch.float32)
+    _check(lib().fumi_hip_linear_bwd_data(ws.handle, _stream(dev), M, N, K, _f32(dy, "dy"), _f32(W, "W"), _f32(dx, "dx")),
+           "fumi_hip_linear_bwd_data")
+    return dx
+
+
+def linear_bwd_weight(ws, dy, x):
+    dev = _dev(dy)
+    M, N = dy.shape
+    K = x.shape[1]
+    dW = torch.empty(N, K, device=dev, dtype=torch.float32)
+    db = torch.empty(N, device=dev, dtype=torch.float32)
+    _check(lib().fumi_hip_linear_bwd_weight(ws.handle, _stream(dev), M, N, K, _f32(dy, "dy"), _f32(x, "x"),
+                                            _f32(dW, "dW"), _f32(db, "db")), "fumi_hip_linear_bwd_weight")
+    return dW, db

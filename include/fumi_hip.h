@@ -1,0 +1,122 @@
+/*
+ * fumi_hip.h -- C ABI of the MI355X (gfx950) episodic meta-training engine.
+ *
+ * The reference (s-a-malik/fumi) has no FFI: its seam is a Python API.  This ABI is what replaces the
+ * arithmetic the reference obtains from torch autograd + torchmeta *inside* these Python entry points
+ * (citations into /root/reference):
+ *
+ *   fumi_hip_fumi_step   <- FUMI.evaluate                 fumi/models/fumi.py:115-196
+ *                           (+ get_hyper_params :198-212, im_forward :214-218, hyper_net :70-86,104-113)
+ *   fumi_hip_maml_step   <- maml.evaluate                 fumi/models/maml.py:134-193 (PureImageNetwork :15-33)
+ *   fumi_hip_am3_step    <- AM3.evaluate / forward        fumi/models/am3.py:90-126,128-212
+ *                           (+ get_prototypes / prototypical_loss / get_preds  fumi/utils/utils.py:302-402)
+ *   fumi_hip_glove_bag   <- WordEmbedding.forward         fumi/models/common.py:23-41
+ *   fumi_hip_class_text_select <- the per-class "first support row" loop  fumi/models/fumi.py:207-210
+ *   fumi_hip_linear_*    <- torchmeta MetaLinear.forward / autograd AddmmBackward (requirements.txt:10)
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer borrowed for the call (owned by the caller, e.g. a torch tensor);
+ *     row-major, contiguous; fp32 values, int64 labels/tokens (the dtypes the reference's tensors have).
+ *   - `theta`, `phi`, `g_theta`, `g_phi`, `hid` are HOST arrays (of device pointers / ints).
+ *   - `stream` is a hipStream_t (NULL = the null stream).  All work is enqueued asynchronously on it; no call
+ *     synchronises the device except workspace growth and fumi_hip_read_status.
+ *   - return value: 0 on success, a negative FUMI_E* code otherwise; fumi_hip_strerror() names it.
+ *   - one workspace per (process, device); a workspace is not re-entrant.
+ *   - gradients are written (not accumulated) as  grad_scale * SUM over the call's episodes of d(loss_b)/d(param);
+ *     pass grad_scale = 1/B for the reference's mean loss on one GPU, 1/B_global before an all-reduce(sum).
+ */
+#ifndef FUMI_HIP_H
+#define FUMI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fumi_ws fumi_ws_t;
+typedef void* fumi_stream_t;          /* hipStream_t */
+
+#define FUMI_OK            0
+#define FUMI_EINVAL      (-1)         /* bad argument (shape, NULL pointer, unsupported size) */
+#define FUMI_ENOMEM      (-2)         /* workspace allocation failed */
+#define FUMI_EHIP        (-3)         /* a HIP runtime call or kernel launch failed (see fumi_hip_last_hip_error) */
+#define FUMI_ENOTSUP     (-4)         /* valid request this build does not implement */
+
+/* device-side status bits (fumi_hip_read_status) -- the reference raises IndexError in both situations */
+#define FUMI_ST_LABEL_RANGE   1       /* a label outside [0, N) */
+#define FUMI_ST_CLASS_MISSING 2       /* a class without a support sample (fumi.py:209 would raise) */
+
+#define FUMI_MAX_HIDDEN 8
+
+int          fumi_hip_version(void);
+const char*  fumi_hip_strerror(int code);
+const char*  fumi_hip_last_hip_error(void);
+
+int   fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out);
+void  fumi_hip_workspace_destroy(fumi_ws_t* ws);
+size_t fumi_hip_workspace_bytes(const fumi_ws_t* ws);
+/* Copies the device status word to the host (synchronises `stream`) and clears it. */
+int   fumi_hip_read_status(fumi_ws_t* ws, fumi_stream_t stream, int* status_out);
+
+/* ---- FuMI meta-step (replaces fumi/models/fumi.py:146-192 for B episodes) ------------------------------------
+ * theta   : 2*n_hidden pointers  W_i [hid[i], hid[i-1]] (hid[-1] = D), b_i [hid[i]]   (im_net.linear{i}.*)
+ * phi     : 4 pointers           A0 [Ht,Dt], a0 [Ht], A1 [H+1,Ht], a1 [H+1]           (hyper_net.0.*, hyper_net.2.*)
+ * cls_text: [B,N,Dt] per-class text encodings, or NULL to select them from text_s [B,S,Dt] (first support row of
+ *           each class, fumi.py:207-210)
+ * outputs : logits_q [B,Qn,N], preds_q [B,Qn] (first arg-max), loss_b [B] (query CE), acc_b [B];
+ *           g_theta/g_phi (same shapes as theta/phi) only when need_grad != 0.
+ * second-order outer gradient always (fumi.py:176 hard-codes first_order=False). */
+int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int D, int n_hidden, const int* hid, int Dt, int Ht,
+        int T, float alpha, int tanh_head, int need_grad, float grad_scale,
+        const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
+        const float* cls_text, const float* text_s,
+        const float* const* theta, const float* const* phi,
+        float* logits_q, int64_t* preds_q, float* loss_b, float* acc_b,
+        float* const* g_theta, float* const* g_phi);
+
+/* ---- MAML meta-step (replaces fumi/models/maml.py:156-191) ---------------------------------------------------
+ * params: 2*n_hidden + 2 pointers: hidden layers as above, then lin_final W [N,H], b [N].  n_hidden >= 1. */
+int fumi_hip_maml_step(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int D, int n_hidden, const int* hid,
+        int T, float alpha, int first_order, int need_grad, float grad_scale,
+        const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
+        const float* const* params,
+        float* logits_q, int64_t* preds_q, float* loss_b, float* acc_b,
+        float* const* g_params);
+
+/* ---- AM3 step (replaces am3.py:160-200 + utils.py:302-402, dropout 0) -----------------------------------------
+ * w: 10 pointers  Wi [P,D], bi [P], G0 [Ht,Dt], g0 [Ht], G1 [P,Ht], g1 [P], H0 [Ht,P], h0 [Ht], H1 [1,Ht], h1 [1]
+ * lamda_fixed: -1 = learned, 0 or 1 = fixed (am3.py:174-179).
+ * outputs: loss [1] (mean over B*Qn), preds_q [B,Qn] (first arg-min of the distances), lamda_s [B,S],
+ *          correct [1] (number of correct query predictions, float); g_w (10 pointers) when need_grad. */
+int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int D, int Dt, int Ht, int P, int lamda_fixed, int need_grad, float grad_scale,
+        const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q, const float* text_s,
+        const float* const* w,
+        float* loss, int64_t* preds_q, float* lamda_s, float* correct,
+        float* const* g_w);
+
+/* ---- finer-grained ops (unit parity tests; building blocks of the steps) --------------------------------------- */
+/* out[r,:] = mean (mode 0: sum / #non-PAD tokens) or max (mode 1: over ALL L positions) of table[tok[r,l],:]. */
+int fumi_hip_glove_bag(fumi_ws_t* ws, fumi_stream_t stream, const int64_t* tok, int R, int L, int64_t pad_id,
+        const float* table, int V, int E, int mode, float* out);
+/* out[b,n,:] = text_s[b, first s with y_s[b,s]==n, :] */
+int fumi_hip_class_text_select(fumi_ws_t* ws, fumi_stream_t stream, int B, int N, int S, int Dt,
+        const float* text_s, const int64_t* y_s, float* out);
+/* y[M,N] = act(x[M,K] W[N,K]^T + b[N]);  act: 0 none, 1 relu, 2 tanh.  b may be NULL. */
+int fumi_hip_linear_fwd(fumi_ws_t* ws, fumi_stream_t stream, int M, int N, int K,
+        const float* x, const float* W, const float* b, int act, float* y);
+/* dx[M,K] = dy[M,N] W[N,K] */
+int fumi_hip_linear_bwd_data(fumi_ws_t* ws, fumi_stream_t stream, int M, int N, int K,
+        const float* dy, const float* W, float* dx);
+/* dW[N,K] = dy[M,N]^T x[M,K];  db[N] = colsum(dy) (db may be NULL) */
+int fumi_hip_linear_bwd_weight(fumi_ws_t* ws, fumi_stream_t stream, int M, int N, int K,
+        const float* dy, const float* x, float* dW, float* db);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FUMI_HIP_H */
