@@ -1,0 +1,218 @@
+"""Benchmark of the FuMI meta-training step on MI355X (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one meta-batch through ``FUMI.evaluate(task='train')``: GloVe embedding bag -> class text select ->
+hypernetwork -> T inner SGD steps on the support set -> query loss -> second-order meta-gradients ->
+[all-reduce over ranks] -> Adam step (the reference defaults: lr 3e-5, coupled weight decay 5e-4), on synthetic
+episodes of the reference's batch layout that are already resident in HBM when the timed region starts.
+Workload (configs[1]): 5-way 5-shot, 32 query/class, D=2048 ResNet-152-style embeddings, im_hid_dim [256,64],
+GloVe-300 token text (L=128, V=20000, mean pooling), text_hid 256, 1 inner step, 32 episodes per GPU (weak scaling:
+the global meta-batch is 32*N episodes sharded as contiguous blocks, one RCCL all-reduce of the flat gradient).
+
+Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (A0q = Xq W0^T on the fp32 MFMA), timed with
+HIP events on the launch stream inside the timed region; ``cpu_baseline`` is the oracle restatement of the reference
+path timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CFG = dict(N=5, K=5, Q=32, D=2048, hid=[256, 64], E=300, L=128, V=20000, Ht=256, T=1, B_per_gpu=32, alpha=0.01)
+PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+NBATCH = 4                            # distinct pre-generated meta-batches cycled through the steps
+
+
+def make_batches(B, dev, seed0, nbatch=NBATCH):
+    """Synthetic meta-batches in the reference loader's layout, generated on the device."""
+    c = CFG
+    S, Qn = c["N"] * c["K"], c["N"] * c["Q"]
+    out = []
+    for i in range(nbatch):
+        g = torch.Generator(device=dev).manual_seed(seed0 + i)
+        cg_ = torch.Generator().manual_seed(seed0 + i)
+        y_s = torch.stack([torch.arange(c["N"]).repeat_interleave(c["K"])[torch.randperm(S, generator=cg_)] for _ in range(B)])
+        y_q = torch.stack([torch.arange(c["N"]).repeat_interleave(c["Q"])[torch.randperm(Qn, generator=cg_)] for _ in range(B)])
+        lens = torch.randint(8, c["L"] + 1, (B, c["N"]), generator=cg_)
+        tok = torch.randint(1, c["V"], (B, c["N"], c["L"]), generator=cg_)
+        tok = tok * (torch.arange(c["L"])[None, None, :] < lens[..., None])              # PAD (=0) after the length
+        text_s = torch.gather(tok, 1, y_s[..., None].expand(-1, -1, c["L"]))             # same text for a class's shots
+        text_q = torch.gather(tok, 1, y_q[..., None].expand(-1, -1, c["L"]))
+        x_s = torch.randn(B, S, c["D"], device=dev, generator=g)
+        x_q = torch.randn(B, Qn, c["D"], device=dev, generator=g)
+        idx_s = torch.arange(B * S, device=dev).view(B, S)
+        idx_q = torch.arange(B * Qn, device=dev).view(B, Qn)
+        out.append({'train': ([idx_s, text_s.to(dev), x_s], y_s.to(dev)),
+                    'test': ([idx_q, text_q.to(dev), x_q], y_q.to(dev))})
+    return out
+
+
+def make_model(dev, seed=123):
+    from fumi_amd.models.fumi import FUMI
+    from fumi_amd.models import common
+    c = CFG
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed)
+    vecs = (torch.rand(c["V"], c["E"], generator=g) * 2 - 1).numpy()           # stands in for glove-wiki-gigaword-300
+    words = [f"w{i}" for i in range(c["V"])]
+    common.register_word_vectors("glove", common.ArrayKeyedVectors(words, vecs))
+    dictionary = {"PAD": 0}
+    dictionary.update({w: i for i, w in enumerate(words) if i > 0})
+    model = FUMI(n_way=c["N"], im_emb_dim=c["D"], im_hid_dim=c["hid"], text_encoder="glove", text_emb_dim=c["E"],
+                 text_hid_dim=c["Ht"], dropout_rate=0.0, dictionary=dictionary, pooling_strat="mean",
+                 norm_hypernet=False)
+    return model.to(dev), model.text_encoder.embed.weight.detach().cpu().clone()
+
+
+def flops_dominant(B):
+    c = CFG
+    return 2.0 * B * c["N"] * c["Q"] * c["D"] * c["hid"][0]                   # A0q = Xq[B*Qn, D] W0[h0, D]^T
+
+
+def flops_step_algorithmic(B):
+    """F_ep(T) = S T (4u0 + 9 sum u_i + 9 u_head) + Qn (2u0 + 3 sum u_i + 3 u_head) + hypernet."""
+    c = CFG
+    S, Qn, N = c["N"] * c["K"], c["N"] * c["Q"], c["N"]
+    u0 = 2 * c["D"] * c["hid"][0]
+    ui = sum(2 * c["hid"][i - 1] * c["hid"][i] for i in range(1, len(c["hid"])))
+    uh = 2 * c["hid"][-1] * N
+    hyper = 3 * N * 2 * (c["E"] * c["Ht"] + c["Ht"] * (c["hid"][-1] + 1))
+    return B * (S * c["T"] * (4 * u0 + 9 * ui + 9 * uh) + Qn * (2 * u0 + 3 * ui + 3 * uh) + hyper)
+
+
+def cpu_baseline(table, budget_s=12.0):
+    """The oracle restatement of the reference path (oracle/fumi_ref.py, eager PyTorch CPU, per-episode Python loop,
+    autograd.grad(create_graph=True)) on this box's host cores: GloVe pooling + meta-step + Adam step per meta-batch."""
+    from oracle import fumi_ref as R
+    from oracle import casegen as cg
+    c = CFG
+    B = c["B_per_gpu"]
+    theta, phi = cg.make_fumi_params(5, c["D"], c["hid"], c["E"], c["Ht"])
+    params = [t.clone().requires_grad_(True) for t in theta + phi]
+    opt = torch.optim.Adam(params, lr=3e-5, weight_decay=5e-4)
+    batches = make_batches(B, torch.device("cpu"), 900, nbatch=2)
+
+    def step(bt):
+        (_, tok, x_s), y_s = bt['train']
+        (_, _, x_q), y_q = bt['test']
+        text = R.word_embedding_pool(tok, table, 0, "mean")
+        out = R.fumi_meta_step(params[:len(theta)], params[len(theta):], text, x_s, y_s, x_q, y_q, c["N"], c["T"],
+                               c["alpha"], False)
+        for p, g in zip(params, out["g_theta"] + out["g_phi"]):
+            p.grad = g
+        opt.step()
+        return out
+    step(batches[0])                                                          # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step(batches[n % 2])
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 200:
+            break
+    return dict(value=round(n * B / el, 2), unit="episodes/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} meta-batches of {B} episodes ({el:.1f} s) of the same workload through oracle/fumi_ref.py "
+                       f"(eager PyTorch CPU, {os.cpu_count()} logical CPUs visible)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-phase-timing", action="store_true", help="do not record HIP events around the library's phases")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    import torch.distributed as dist
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from fumi_amd import hip
+    from fumi_amd.utils import utils as U
+    c = CFG
+    Bg = c["B_per_gpu"] * world
+    model, table = make_model(dev)
+    args = SimpleNamespace(device=dev, num_train_adapt_steps=c["T"], num_test_adapt_steps=c["T"], step_size=c["alpha"],
+                           first_order=False, optim="adam", lr=3e-5, weight_decay=5e-4, momentum=0.9,
+                           batch_size=Bg, num_ways=c["N"])
+    opt = U.init_optim(args, model)
+    batches = make_batches(Bg, dev, 1000)                                     # same global meta-batches on every rank
+    ws = hip.Workspace.get(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        model.evaluate(args, batches[i % NBATCH], opt, "train")
+    hip.raise_on_status(ws.read_status())
+    if not a.no_phase_timing:
+        ws.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(a.steps):
+        last = model.evaluate(args, batches[i % NBATCH], opt, "train")
+    barrier()
+    el = time.perf_counter() - t0
+    prof = ws.profile() if not a.no_phase_timing else {}
+    ws.set_profiling(False)
+    t = torch.tensor([el], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+
+    if rank == 0:
+        ms = el / a.steps * 1e3
+        out = {
+            "metric": "episodes/sec (5-way 5-shot FuMI)", "value": round(Bg * a.steps / el, 2), "unit": "episodes/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "FuMI 5-way 5-shot, 32 query/class, ResNet-152-style 2048-d embeddings, im_hid [256,64], "
+                                   "GloVe-300 token text (L=128, V=20000, mean pool), text_hid 256, 1 inner step, "
+                                   "second-order meta-gradient + Adam step; BASELINE.json configs[1]",
+                       "episodes_per_gpu": c["B_per_gpu"], "global_meta_batch": Bg,
+                       "parallelism": f"episode-sharded x{world}, 1 all-reduce of the flat gradient"},
+            "final_loss": float(last[0]), "final_acc": float(last[1]),
+            "step_tflops_algorithmic": round(flops_step_algorithmic(c["B_per_gpu"]) / (ms * 1e-3) / 1e12, 3),
+        }
+        if "gemm_A0q" in prof:
+            tot, n = prof["gemm_A0q"]
+            dur = tot / n * 1e-3
+            ach = flops_dominant(c["B_per_gpu"]) / dur / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                               "kernel": "gemm_kernel<0,0> (A0q = Xq W0^T, M=5120 N=256 K=2048, fp32 MFMA 32x32x2)",
+                               "avg_us": round(dur * 1e6, 2), "launches": n}
+            out["phase_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items()}
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(table)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,22 @@ void fumi_set_hip_error(hipError_t e, const char* where) {
     snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
 }
 
+static hipEvent_t prof_event(fumi_ws* ws) {
+    if (!ws->pool->empty()) { hipEvent_t e = ws->pool->back(); ws->pool->pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+ProfScope::ProfScope(fumi_ws* w, hipStream_t s, int phase) : ws(w), st(s), b(nullptr), on(w && w->profiling) {
+    if (!on) return;
+    hipEvent_t a = prof_event(ws);
+    b = prof_event(ws);
+    (void)hipEventRecord(a, st);
+    ws->recs->push_back(ProfRec{phase, a, b});
+}
+ProfScope::~ProfScope() { if (on) (void)hipEventRecord(b, st); }
+
 int ws_reserve(fumi_ws* ws, size_t bytes) {
     ws->off = 0;
     if (bytes <= ws->cap) return FUMI_OK;
@@ -49,6 +65,7 @@ int fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out) {
     HIP_TRY(hipSetDevice(device));
     fumi_ws* ws = new fumi_ws();
     ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr;
+    ws->profiling = 0; ws->recs = new std::vector<ProfRec>(); ws->pool = new std::vector<hipEvent_t>();
     if (hipMalloc((void**)&ws->status, 256) != hipSuccess) { delete ws; return FUMI_ENOMEM; }
     if (hipHostMalloc((void**)&ws->status_host, 256, hipHostMallocDefault) != hipSuccess) { (void)hipFree(ws->status); delete ws; return FUMI_ENOMEM; }
     HIP_TRY(hipMemset(ws->status, 0, 256));
@@ -67,10 +84,44 @@ void fumi_hip_workspace_destroy(fumi_ws_t* ws) {
     if (ws->base) (void)hipFree(ws->base);
     if (ws->status) (void)hipFree(ws->status);
     if (ws->status_host) (void)hipHostFree(ws->status_host);
+    for (auto& r : *ws->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : *ws->pool) (void)hipEventDestroy(e);
+    delete ws->recs; delete ws->pool;
     delete ws;
 }
 
 size_t fumi_hip_workspace_bytes(const fumi_ws_t* ws) { return ws ? ws->cap : 0; }
+
+int fumi_hip_set_profiling(fumi_ws_t* ws, int on) {
+    if (!ws) return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(ws->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (auto& r : *ws->recs) { ws->pool->push_back(r.a); ws->pool->push_back(r.b); }
+    ws->recs->clear();
+    ws->profiling = on ? 1 : 0;
+    return FUMI_OK;
+}
+
+int fumi_hip_get_profile(fumi_ws_t* ws, int phase, double* total_ms, int* count) {
+    if (!ws || !total_ms || !count || phase < 0 || phase >= FUMI_PH_COUNT) return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(ws->device));
+    HIP_TRY(hipDeviceSynchronize());
+    double tot = 0.0; int n = 0;
+    for (auto& r : *ws->recs) {
+        if (r.phase != phase) continue;
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        tot += ms; ++n;
+    }
+    *total_ms = tot; *count = n;
+    return FUMI_OK;
+}
+
+const char* fumi_hip_phase_name(int phase) {
+    static const char* names[FUMI_PH_COUNT] = {"class_text_select", "hyper_fwd", "gemm_A0s", "gemm_A0q", "gram",
+        "adapt", "query", "reverse", "reduce", "gemm_gW0", "hyper_bwd", "am3_head"};
+    return (phase >= 0 && phase < FUMI_PH_COUNT) ? names[phase] : "?";
+}
 
 int fumi_hip_read_status(fumi_ws_t* ws, fumi_stream_t stream, int* status_out) {
     if (!ws || !status_out) return FUMI_EINVAL;
@@ -130,21 +181,27 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
     // class text rows (fumi.py:207-210), then the hypernetwork (fumi.py:70-86,104-113)
     const float* ctext = cls_text;
     if (!ctext) {
+        ProfScope ps(ws, st, FUMI_PH_SELECT);
         if ((rc = launch_class_text_select(st, B, N, S, Dt, text_s, y_s, c, ws->status))) return rc;
         ctext = c;
     }
-    GemmArgs g = gemm_args(R, Ht, Dt, ctext, Dt, phi[0], Dt, u, Ht);
-    g.bias = phi[1]; g.act = 1;
-    if ((rc = launch_gemm(st, g, 0, 0))) return rc;
-    g = gemm_args(R, H1, Ht, u, Ht, phi[2], Ht, h, H1);
-    g.bias = phi[3]; g.act = tanh_head ? 2 : 0;
-    if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+    GemmArgs g;
+    {
+        ProfScope ps(ws, st, FUMI_PH_HYPER_FWD);
+        g = gemm_args(R, Ht, Dt, ctext, Dt, phi[0], Dt, u, Ht);
+        g.bias = phi[1]; g.act = 1;
+        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+        g = gemm_args(R, H1, Ht, u, Ht, phi[2], Ht, h, H1);
+        g.bias = phi[3]; g.act = tanh_head ? 2 : 0;
+        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+    }
 
     p.head = h; p.head_bar = hbar;
     if ((rc = run_episodes(ws, st, p))) return rc;
     if (!need_grad) return FUMI_OK;
 
     // hypernetwork backward: rows are (episode, class) pairs, weights are shared
+    ProfScope ps(ws, st, FUMI_PH_HYPER_BWD);
     const float* hp = hbar;
     if (tanh_head) { if ((rc = launch_tanh_bwd(st, (long)R * H1, h, hbar, hpb))) return rc; hp = hpb; }
     g = gemm_args(H1, Ht, R, hp, H1, u, Ht, g_phi[2], Ht);           // gA1 = hp^T u

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <vector>
 #include "../../include/fumi_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -12,6 +13,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ------------------------------------------------------------------------------------------------------------
 // workspace: one hipMalloc'd slab, carved per call by a bump allocator (all sizes known on the host).
 // ------------------------------------------------------------------------------------------------------------
+struct ProfRec { int phase; hipEvent_t a, b; };
 struct fumi_ws {
     int device;
     char* base;
@@ -19,6 +21,16 @@ struct fumi_ws {
     size_t off;          // bump pointer (bytes), reset at the start of each step
     int* status;         // device status word (own small allocation)
     int* status_host;    // pinned
+    int profiling;       // record HIP events around each phase (bench only)
+    std::vector<ProfRec>* recs;
+    std::vector<hipEvent_t>* pool;
+};
+
+// RAII phase timer: two hipEventRecords on the caller's stream when profiling is on, nothing otherwise
+struct ProfScope {
+    fumi_ws* ws; hipStream_t st; hipEvent_t b; bool on;
+    ProfScope(fumi_ws* w, hipStream_t s, int phase);
+    ~ProfScope();
 };
 
 void fumi_set_hip_error(hipError_t e, const char* where);

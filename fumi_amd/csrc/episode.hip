@@ -569,9 +569,10 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     // ---- shared GEMM 1: A0 = X W0^T (support and query rows), G = X Xs^T (batched per episode)
     {
         GemmArgs g = gemm_args(p.B * p.S, h0, p.D, p.x_s, p.D, p.W[0], p.D, w.A0s, h0);
-        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+        { ProfScope ps(ws, st, FUMI_PH_GEMM_A0S); if ((rc = launch_gemm(st, g, 0, 0))) return rc; }
         g = gemm_args(p.B * p.Qn, h0, p.D, p.x_q, p.D, p.W[0], p.D, w.A0q, h0);
-        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+        { ProfScope ps(ws, st, FUMI_PH_GEMM_A0Q); if ((rc = launch_gemm(st, g, 0, 0))) return rc; }
+        ProfScope ps(ws, st, FUMI_PH_GRAM);
         g = gemm_args(p.S, p.S, p.D, p.x_s, p.D, p.x_s, p.D, w.Gss, p.S);
         g.nbatch = p.B; g.sA = (long)p.S * p.D; g.sB = (long)p.S * p.D; g.sC = (long)p.S * p.S;
         if ((rc = launch_gemm(st, g, 0, 0))) return rc;
@@ -582,22 +583,35 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     // ---- per-episode phases
     EpiParams prm;
     for (int i = 0; i < MAXL; ++i) { prm.W[i] = i < p.L ? p.W[i] : nullptr; prm.b[i] = i < p.L ? p.b[i] : nullptr; }
-    hipLaunchKernelGGL(adapt_kernel, dim3(p.B), dim3(1024), 0, st, d, w, prm, p.y_s, p.head, ws->status);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(query_kernel, dim3(w.ntile, p.B), dim3(512), 0, st, d, w, p.b[0], p.y_q, p.logits_q, p.preds_q,
-                       ws->status);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(reverse_kernel, dim3(p.B), dim3(1024), 0, st, d, w, p.loss_b, p.acc_b, p.head_bar);
-    LAUNCH_CHECK();
+    {
+        ProfScope ps(ws, st, FUMI_PH_ADAPT);
+        hipLaunchKernelGGL(adapt_kernel, dim3(p.B), dim3(1024), 0, st, d, w, prm, p.y_s, p.head, ws->status);
+        LAUNCH_CHECK();
+    }
+    {
+        ProfScope ps(ws, st, FUMI_PH_QUERY);
+        hipLaunchKernelGGL(query_kernel, dim3(w.ntile, p.B), dim3(512), 0, st, d, w, p.b[0], p.y_q, p.logits_q, p.preds_q,
+                           ws->status);
+        LAUNCH_CHECK();
+    }
+    {
+        ProfScope ps(ws, st, FUMI_PH_REVERSE);
+        hipLaunchKernelGGL(reverse_kernel, dim3(p.B), dim3(1024), 0, st, d, w, p.loss_b, p.acc_b, p.head_bar);
+        LAUNCH_CHECK();
+    }
     if (!p.need_grad) return FUMI_OK;
 
     // ---- meta-gradients of the hidden layers: sums over episodes
-    for (int i = 1; i < p.L; ++i) {
-        const long sz = (long)p.h[i] * p.h[i - 1];
-        if ((rc = launch_reduce_slabs(st, w.Wb[i], p.B, sz, sz, p.grad_scale, p.gW[i]))) return rc;
-        if ((rc = launch_reduce_slabs(st, w.bb[i], p.B, p.h[i], p.h[i], p.grad_scale, p.gb[i]))) return rc;
+    {
+        ProfScope pr(ws, st, FUMI_PH_REDUCE);
+        for (int i = 1; i < p.L; ++i) {
+            const long sz = (long)p.h[i] * p.h[i - 1];
+            if ((rc = launch_reduce_slabs(st, w.Wb[i], p.B, sz, sz, p.grad_scale, p.gW[i]))) return rc;
+            if ((rc = launch_reduce_slabs(st, w.bb[i], p.B, p.h[i], p.h[i], p.grad_scale, p.gb[i]))) return rc;
+        }
+        if ((rc = launch_reduce_slabs(st, w.b0b, p.B, h0, h0, p.grad_scale, p.gb[0]))) return rc;
     }
-    if ((rc = launch_reduce_slabs(st, w.b0b, p.B, h0, h0, p.grad_scale, p.gb[0]))) return rc;
+    ProfScope pg(ws, st, FUMI_PH_GEMM_GW0);
     // ---- shared GEMM 2: gW0 = Abar0^T X, contraction over all rows of all episodes, split into slabs
     {
         const long Ks = (long)p.B * p.S, Kq = (long)p.B * p.Qn;

@@ -1,0 +1,64 @@
+"""Synthetic episodic loader with the reference loader's batch contract (fumi/dataset/data.py:571-581 + torchmeta
+collate):
+
+    batch = {'train': ([idx i64 [B,S], text f32 [B,S,Dt] | i64 [B,S,L], im f32 [B,S,D]], targets i64 [B,S]),
+             'test' : same with Qn = N * num_shots_test rows}
+
+The iNat-Anim files (Zenodo JSON + HDF5 embeddings, BERT/GloVe downloads) cannot be fetched here, so
+``--dataset synthetic`` draws a learnable task instead: class prototypes mu_c ~ N(0, I_D), images x = mu_c + 2 eps,
+class text = P mu_c + 0.5 eps with a fixed random P [Dt, D] (the text is identical for all samples of a class, like
+data.py:543-549).  Deterministic in (seed, split, batch index); every rank regenerates the SAME meta-batch."""
+import numpy as np
+import torch
+
+
+class SyntheticEpisodes:
+    def __init__(self, n_classes, D, Dt, N, K, Q, batch_size, seed, split, tokens=None, length=None):
+        rs = np.random.RandomState(seed * 7 + {"train": 0, "val": 1, "test": 2}[split])
+        self.mu = rs.standard_normal((n_classes, D)).astype(np.float32)
+        proj = np.random.RandomState(seed + 99).standard_normal((Dt if tokens is None else 16, D)).astype(np.float32) / np.sqrt(D)
+        self.N, self.K, self.Q, self.B, self.D = N, K, Q, batch_size, D
+        self.tokens = tokens
+        if tokens is None:
+            self.text = (self.mu @ proj.T + 0.5 * rs.standard_normal((n_classes, Dt))).astype(np.float32)
+        else:
+            V, L, pad = tokens
+            self.text = np.full((n_classes, L), pad, dtype=np.int64)
+            for c in range(n_classes):
+                ln = rs.randint(4, L + 1)
+                self.text[c, :ln] = rs.randint(1, V, size=ln)
+        self.seed, self.split, self.length = seed, split, length
+
+    def batch(self, index):
+        rs = np.random.RandomState((self.seed * 1000003 + index * 31 + len(self.split)) % (2 ** 31))
+        B, N, K, Q = self.B, self.N, self.K, self.Q
+        S, Qn = N * K, N * Q
+        cls = np.stack([rs.choice(len(self.mu), N, replace=False) for _ in range(B)])          # [B,N]
+        y_s = np.stack([rs.permutation(np.repeat(np.arange(N), K)) for _ in range(B)])
+        y_q = np.stack([rs.permutation(np.repeat(np.arange(N), Q)) for _ in range(B)])
+        cs, cq = np.take_along_axis(cls, y_s, 1), np.take_along_axis(cls, y_q, 1)
+        x_s = self.mu[cs] + 2.0 * rs.standard_normal((B, S, self.D)).astype(np.float32)
+        x_q = self.mu[cq] + 2.0 * rs.standard_normal((B, Qn, self.D)).astype(np.float32)
+        t = torch.from_numpy
+        return {'train': ([t(cs.astype(np.int64)), t(self.text[cs]), t(x_s.astype(np.float32))], t(y_s.astype(np.int64))),
+                'test': ([t(cq.astype(np.int64)), t(self.text[cq]), t(x_q.astype(np.float32))], t(y_q.astype(np.int64)))}
+
+    def __iter__(self):
+        i = 0
+        while self.length is None or i < self.length:
+            yield self.batch(i)
+            i += 1
+
+
+def get_synthetic(args):
+    """(train_loader, val_loader, test_loader, dictionary) like fumi/dataset/data.py:25-86."""
+    tokens, dictionary = None, None
+    if args.text_encoder in ("glove", "w2v"):
+        V, L = args.synthetic_vocab, args.synthetic_seq_len
+        tokens = (V, L, 0)
+        dictionary = {"PAD": 0}
+        dictionary.update({f"tok{i}": i for i in range(1, V)})
+    mk = lambda split, q: SyntheticEpisodes(args.synthetic_classes, args.im_emb_dim, args.text_emb_dim, args.num_ways,
+                                            args.num_shots, q, args.batch_size, args.seed, split, tokens)
+    q_eval = int(100 / args.num_ways)                      # data.py:163-166,180-183
+    return mk("train", args.num_shots_test), mk("val", q_eval), mk("test", q_eval), dictionary

@@ -1,0 +1,54 @@
+"""The compute engine behind the model classes.  There is exactly one implementation, the HIP library
+(``fumi_amd/hip.py`` -> ``lib/libfumi_hip.so``); it raises when the library is missing or a tensor is not on a GPU.
+The indirection exists so host-side plumbing (loops, flags, checkpoints, sharding) can be unit-tested: tests may
+install a checker engine with ``set_engine`` -- product code never does."""
+import torch
+
+from . import hip
+
+_ENGINE = None
+
+
+class HipEngine:
+    name = "hip-gfx950"
+
+    def _ws(self, t):
+        return hip.Workspace.get(t.device if isinstance(t, torch.Tensor) and t.is_cuda else hip._dev(t))
+
+    def fumi_step(self, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head, need_grad, grad_scale,
+                  g_theta=None, g_phi=None):
+        return hip.fumi_step_select(self._ws(x_s), n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head,
+                                    need_grad=need_grad, grad_scale=grad_scale, g_theta=g_theta, g_phi=g_phi)
+
+    def maml_step(self, x_s, y_s, x_q, y_q, params, T, alpha, first_order, need_grad, grad_scale, g_params=None):
+        return hip.maml_step(self._ws(x_s), x_s, y_s, x_q, y_q, params, T, alpha, first_order, need_grad=need_grad,
+                             grad_scale=grad_scale, g_params=g_params)
+
+    def am3_step(self, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad, grad_scale, g_w=None):
+        return hip.am3_step(self._ws(x_s), x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad=need_grad,
+                            grad_scale=grad_scale, g_w=g_w)
+
+    def glove_bag(self, tokens, table, pad_id, mode):
+        return hip.glove_bag(self._ws(tokens), tokens, table, pad_id, mode)
+
+    def linear(self, x, W, b=None, act=0):
+        return hip.linear_fwd(self._ws(x), x.contiguous(), W.contiguous(), b, act)
+
+    def check(self, device):
+        """Synchronising validity check of the last calls (labels in range, every class has a support sample)."""
+        hip.raise_on_status(hip.Workspace.get(device).read_status())
+
+
+def get_engine():
+    global _ENGINE
+    if _ENGINE is None:
+        hip.lib()                      # fail loudly here if the shared object has not been built
+        _ENGINE = HipEngine()
+    return _ENGINE
+
+
+def set_engine(engine):
+    """Test hook (tests/ only)."""
+    global _ENGINE
+    old, _ENGINE = _ENGINE, engine
+    return old

@@ -1,0 +1,25 @@
+"""One flat fp32 buffer [all trainable gradients | sum loss | sum acc]: the engine writes gradients straight into
+views of it, a single all-reduce covers everything (fumi_amd/dist.py), and ``.grad`` of every parameter is a view."""
+import torch
+
+
+class FlatGrads:
+    def __init__(self, params, extra=2):
+        self.params = list(params)
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n + extra, device=dev, dtype=torch.float32)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.tail = self.flat[off:]
+
+    def matches(self, params):
+        params = list(params)
+        return (len(params) == len(self.params) and all(a is b for a, b in zip(params, self.params))
+                and self.flat.device == params[0].device)
+
+    def attach(self):
+        for p, v in zip(self.params, self.views):
+            p.grad = v

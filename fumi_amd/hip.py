@@ -18,12 +18,14 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfumi_hip.so")
 SYMBOLS = [
     "fumi_hip_version", "fumi_hip_strerror", "fumi_hip_last_hip_error",
     "fumi_hip_workspace_create", "fumi_hip_workspace_destroy", "fumi_hip_workspace_bytes", "fumi_hip_read_status",
+    "fumi_hip_set_profiling", "fumi_hip_get_profile", "fumi_hip_phase_name",
     "fumi_hip_fumi_step", "fumi_hip_maml_step", "fumi_hip_am3_step",
     "fumi_hip_glove_bag", "fumi_hip_class_text_select",
     "fumi_hip_linear_fwd", "fumi_hip_linear_bwd_data", "fumi_hip_linear_bwd_weight",
 ]
 
 ST_LABEL_RANGE, ST_CLASS_MISSING = 1, 2
+N_PHASES = 12
 
 _lib = None
 _lock = threading.Lock()
@@ -56,6 +58,10 @@ def lib():
         L.fumi_hip_workspace_bytes.argtypes = [c_void_p]
         L.fumi_hip_workspace_bytes.restype = c_size_t
         L.fumi_hip_read_status.argtypes = [c_void_p, c_void_p, POINTER(c_int)]
+        L.fumi_hip_set_profiling.argtypes = [c_void_p, c_int]
+        L.fumi_hip_get_profile.argtypes = [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int)]
+        L.fumi_hip_phase_name.argtypes = [c_int]
+        L.fumi_hip_phase_name.restype = c_char_p
         PP = POINTER(c_void_p)
         L.fumi_hip_fumi_step.argtypes = (
             [c_void_p, c_void_p] + [c_int] * 6 + [POINTER(c_int), c_int, c_int, c_int, c_float, c_int, c_int, c_float]
@@ -152,6 +158,21 @@ class Workspace:
         st = c_int(0)
         _check(lib().fumi_hip_read_status(self._h, _stream(self.device), ctypes.byref(st)), "read_status")
         return st.value
+
+    def set_profiling(self, on):
+        """HIP-event timing of every phase inside the library (bench.py); switching it clears the records."""
+        _check(lib().fumi_hip_set_profiling(self._h, int(bool(on))), "set_profiling")
+
+    def profile(self):
+        """{phase name: (total ms, launches)} since profiling was switched on (synchronises the device)."""
+        out = {}
+        L = lib()
+        for ph in range(N_PHASES):
+            ms, n = ctypes.c_double(0), c_int(0)
+            _check(L.fumi_hip_get_profile(self._h, ph, ctypes.byref(ms), ctypes.byref(n)), "get_profile")
+            if n.value:
+                out[L.fumi_hip_phase_name(ph).decode()] = (ms.value, n.value)
+        return out
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

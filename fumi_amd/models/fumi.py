@@ -1,0 +1,251 @@
+"""FuMI: text-conditioned hypernetwork head + MAML inner loop -- host-side mirror of fumi/models/fumi.py.
+
+Same class name, constructor keywords, attributes (``im_net``, ``hyper_net``, ``text_encoder``), ``state_dict`` keys
+and method signatures as the reference (fumi/models/fumi.py:18-218); same ``training_run`` / ``test_loop``
+(:220-326).  What differs is where the arithmetic happens: ``evaluate`` does not build an autograd graph, it hands
+the parameter tensors of the whole meta-batch to the MI355X engine (one C-ABI call, csrc/api.hip) which returns the
+query logits / predictions / losses and the second-order meta-gradients, then performs the (optionally sharded)
+gradient reduction and the optimizer step.
+"""
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import dist as fdist
+from .. import engine as _engine
+from ..flatgrad import FlatGrads
+from ..meta import MetaLinear, MetaSequential
+from ..utils import utils as utils
+from ..utils.average_meter import AverageMeter
+from ..utils.hypernet_init import hyper_weight_layer_init
+from ..utils.wandb_compat import wandb
+from .common import RNN, RnnHid, WordEmbedding
+
+try:
+    from tqdm import tqdm
+except Exception:          # pragma: no cover
+    def tqdm(x=None, **k):
+        return x
+
+
+class FUMI(nn.Module):
+    def __init__(self, n_way=5, im_emb_dim=2048, im_hid_dim=[64], text_encoder="BERT", text_emb_dim=300,
+                 text_hid_dim=1024, dropout_rate=0.0, dictionary=None, pooling_strat="mean", init_all_layers=False,
+                 norm_hypernet=True, fine_tune=False, init_bias=False):
+        super().__init__()
+        self.n_way = n_way
+        self.im_emb_dim = im_emb_dim
+        self.im_hid_dim = list(im_hid_dim)
+        self.text_encoder_type = text_encoder
+        self.text_emb_dim = text_emb_dim
+        self.text_hid_dim = text_hid_dim
+        self.dropout_rate = dropout_rate
+        self.dictionary = dictionary
+        self.pooling_strat = pooling_strat
+        self.norm_hypernet = norm_hypernet
+        self.fine_tune = fine_tune
+        self.init_bias = init_bias
+        self.init_all_layers = init_all_layers
+
+        # text encoder (fumi.py:47-63)
+        if text_encoder in ("BERT", "precomputed"):
+            self.text_encoder = nn.Identity()
+        elif text_encoder in ("w2v", "glove"):
+            self.text_encoder = WordEmbedding(text_encoder, pooling_strat, dictionary)
+            self.text_emb_dim = self.text_encoder.embedding_dim
+        elif text_encoder == "rand":
+            self.text_encoder = nn.Linear(self.text_emb_dim, self.text_emb_dim)
+        elif text_encoder == "RNN":
+            self.text_encoder = RNN("glove", pooling_strat, dictionary, self.text_emb_dim)
+        elif text_encoder == "RNNhid":
+            self.text_encoder = RnnHid("glove", pooling_strat, dictionary, self.text_emb_dim)
+        else:
+            raise NameError(f"{text_encoder} not allowed as text encoder")
+        if not fine_tune:
+            for p in self.text_encoder.parameters():
+                p.requires_grad = False
+        if init_all_layers:
+            raise NotImplementedError("Entire model hypernet initialisation removed")
+        if len(self.im_hid_dim) < 1:
+            raise IndexError("im_hid_dim needs at least one hidden layer (the reference indexes im_hid_dim[-1])")
+
+        # hypernetwork: Linear . ReLU . Linear(H+1) [. Tanh]  (fumi.py:70-86,104-107)
+        head = nn.Linear(self.text_hid_dim, self.im_hid_dim[-1] + 1)
+        if init_bias:
+            head = hyper_weight_layer_init('relu', 'normc', self.text_hid_dim, self.im_hid_dim[-1] + 1, 1, False,
+                                           adjust_weights=False, adjust_bias=True, use_film=False)(head)
+        layers = [nn.Linear(self.text_emb_dim, self.text_hid_dim), nn.ReLU(), head]
+        if norm_hypernet:
+            layers.append(nn.Tanh())
+        self.hyper_net = nn.Sequential(*layers)
+
+        # adapted image network: (MetaLinear, ReLU[, Dropout])*  (fumi.py:89-100)
+        im = OrderedDict()
+        d = im_emb_dim
+        for i, h in enumerate(self.im_hid_dim):
+            im[f'linear{i}'] = MetaLinear(d, h)
+            im[f'relu{i}'] = nn.ReLU()
+            if dropout_rate > 0:
+                im[f'dropout{i}'] = nn.Dropout(dropout_rate)
+            d = h
+        self.im_net = MetaSequential(im)
+        self._flat = None
+
+    # ---- parameter views handed to the engine --------------------------------------------------------------------
+    def _theta(self):
+        out = []
+        for i in range(len(self.im_hid_dim)):
+            lin = getattr(self.im_net, f'linear{i}')
+            out += [lin.weight, lin.bias]
+        return out
+
+    def _phi(self):
+        return [self.hyper_net[0].weight, self.hyper_net[0].bias, self.hyper_net[2].weight, self.hyper_net[2].bias]
+
+    def _flat_grads(self):
+        params = self._theta() + self._phi()
+        if self._flat is None or not self._flat.matches(params):
+            self._flat = FlatGrads(params, extra=2)
+        return self._flat
+
+    # ---- reference surface ----------------------------------------------------------------------------------------
+    def forward(self, text_embed):
+        """Hyper-network forward (text -> [.., H+1] head rows), inference helper on the engine's linear op."""
+        eng = _engine.get_engine()
+        lead = text_embed.shape[:-1]
+        x = text_embed.reshape(-1, text_embed.shape[-1]).contiguous()
+        A0, a0, A1, a1 = [p.detach() for p in self._phi()]
+        u = eng.linear(x, A0, a0, act=1)
+        h = eng.linear(u, A1, a1, act=2 if self.norm_hypernet else 0)
+        return h.reshape(*lead, h.shape[-1])
+
+    def _encode_text(self, text, device):
+        """text_encoder applied to a whole meta-batch [B,S,*] (fumi.py:199-204 per task)."""
+        if self.text_encoder_type == "rand":
+            B, S = text.shape[:2]
+            return (2 * torch.rand(B, S, self.text_emb_dim) - 1).to(device)          # CPU RNG like the reference
+        if self.text_encoder_type in ("BERT", "precomputed"):
+            return text.to(torch.float32).contiguous()
+        return self.text_encoder(text)
+
+    def get_hyper_params(self, text, targets, device, attn_mask=None):
+        """Per-class head rows [N, H+1] for ONE task (fumi.py:198-212)."""
+        from .. import hip
+        enc = self._encode_text(text.unsqueeze(0), device)
+        c = hip.class_text_select(hip.Workspace.get(enc.device), enc.contiguous(), targets.unsqueeze(0).contiguous(), self.n_way)
+        return self(c[0])
+
+    def im_forward(self, im_embeds, im_params, hyper_params):
+        """logits [rows, N] = im_net(x; params) @ h[:, :-1].T + h[:, -1]  (fumi.py:214-218); inference helper."""
+        eng = _engine.get_engine()
+        x = im_embeds.contiguous()
+        names = [f'linear{i}' for i in range(len(self.im_hid_dim))]
+        for n in names:
+            x = eng.linear(x, im_params[n + '.weight'].detach().contiguous(), im_params[n + '.bias'].detach().contiguous(), act=1)
+        h = hyper_params.detach()
+        return eng.linear(x, h[:, :-1].contiguous(), h[:, -1].contiguous(), act=0)
+
+    def evaluate(self, args, batch, optimizer, task="train"):
+        """One meta-batch (fumi.py:115-196).  Returns (loss np scalar, acc np scalar, preds float [B,Qn], targets)."""
+        train = task == "train"
+        if train:
+            self.train()
+            self.zero_grad()
+        else:
+            self.eval()
+        if train and self.dropout_rate > 0:
+            raise NotImplementedError("inner-loop dropout (fumi.py:93-99) is not implemented by the MI355X engine; "
+                                      "run with --dropout 0 (the parity configuration)")
+        dev = args.device
+        (_, s_text, s_im), s_y = batch['train']
+        (_, q_text, q_im), q_y = batch['test']
+        B = s_im.shape[0]
+        lo, hi = fdist.shard(B)
+        to = lambda t: t[lo:hi].to(dev).contiguous()
+        x_s, x_q, y_s, y_q = to(s_im).float(), to(q_im).float(), to(s_y), to(q_y)
+        text_s = self._encode_text(to(s_text), dev)
+        T = args.num_train_adapt_steps if train else args.num_test_adapt_steps
+
+        eng = _engine.get_engine()
+        theta = [p.detach() for p in self._theta()]
+        phi = [p.detach() for p in self._phi()]
+        fg = self._flat_grads() if train else None
+        nth = len(theta)
+        out = eng.fumi_step(self.n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, args.step_size, self.norm_hypernet,
+                            need_grad=train, grad_scale=1.0 / B,
+                            g_theta=fg.views[:nth] if train else None, g_phi=fg.views[nth:] if train else None)
+        # [.. grads .. | sum loss / B | sum acc / B] -> one all-reduce(sum) -> global means on every rank
+        if train:
+            tail = fg.tail
+        else:
+            tail = torch.empty(2, device=x_s.device, dtype=torch.float32)
+        torch.stack([out["loss_b"].sum(), out["acc_b"].sum()], out=tail)
+        tail.mul_(1.0 / B)
+        fdist.all_reduce_sum_(fg.flat if train else tail)
+        if train:
+            optimizer.zero_grad()
+            fg.attach()
+            optimizer.step()
+        preds = out["preds"]
+        if fdist.world()[1] > 1 and not train:
+            preds = fdist.all_gather_rows(preds)
+        stats = tail.detach().cpu().numpy()                      # the one host sync of the step (fumi.py:195)
+        test_preds = preds.to(torch.float32) if preds.shape[0] == B else None
+        return stats[0], stats[1], test_preds, q_y.to(dev)
+
+
+def training_run(args, model, optimizer, train_loader, val_loader, max_test_batches):
+    """FuMI training loop (fumi.py:220-299): initial validation, per-batch logging, periodic validation +
+    checkpoint, early stopping, best checkpoint reloaded at the end."""
+    best_loss, best_acc, _, _ = test_loop(args, model, val_loader, max_test_batches)
+    print(f"\ninitial loss: {best_loss}, acc: {best_acc}")
+    best_batch_idx = 0
+    opt, scheduler = optimizer if type(optimizer) == tuple else (optimizer, None)
+    try:
+        for batch_idx, batch in enumerate(train_loader):
+            train_loss, train_acc, _, _ = model.evaluate(args=args, batch=batch, optimizer=opt, task="train")
+            wandb.log({"train/acc": train_acc, "train/loss": train_loss,
+                       "num_episodes": (batch_idx + 1) * args.batch_size}, step=batch_idx)
+            if batch_idx % args.eval_freq == 0 and batch_idx != 0:
+                val_loss, val_acc, _, _ = test_loop(args, model, val_loader, max_test_batches)
+                is_best = val_loss < best_loss
+                if is_best:
+                    best_loss, best_batch_idx = val_loss, batch_idx
+                wandb.log({"val/acc": val_acc, "val/loss": val_loss}, step=batch_idx)
+                utils.save_checkpoint({"batch_idx": batch_idx, "state_dict": model.state_dict(), "best_loss": best_loss,
+                                       "optimizer": opt.state_dict(), "args": vars(args)}, is_best)
+                print(f"\nBatch {batch_idx + 1}/{args.epochs}: \ntrain/loss: {train_loss}, train/acc: {train_acc}"
+                      f"\nval/loss: {val_loss}, val/acc: {val_acc}")
+            # the reference's off-by-one is kept: epochs+1 batches are processed (fumi.py:288)
+            if (batch_idx > args.epochs - 1) or (args.patience > 0 and batch_idx - best_batch_idx > args.patience):
+                break
+    except KeyboardInterrupt:
+        pass
+    best_file = os.path.join(wandb.run.dir, "best.pth.tar")
+    if os.path.exists(best_file):
+        model, _ = utils.load_checkpoint(model, opt, args.device, best_file)
+    return model
+
+
+def test_loop(args, model, test_loader, max_num_batches):
+    """Validation / test loop (fumi.py:302-326).  Like the reference it consumes max_num_batches + 1 batches (the
+    break is tested after the batch is processed)."""
+    avg_test_acc, avg_test_loss = AverageMeter(), AverageMeter()
+    test_preds, test_targets = [], []
+    for batch_idx, batch in enumerate(test_loader):
+        test_loss, test_acc, preds, target = model.evaluate(args=args, batch=batch, optimizer=None, task="test")
+        avg_test_acc.update(test_acc)
+        avg_test_loss.update(test_loss)
+        test_preds.append(preds)
+        test_targets.append(target)
+        if batch_idx > max_num_batches - 1:
+            break
+    return avg_test_loss.avg, avg_test_acc.avg, test_preds, test_targets
+
+
+def get_accuracy(logits, targets):
+    """fumi.py:329-331"""
+    _, predictions = torch.max(logits, dim=-1)
+    return torch.mean(predictions.eq(targets).float())

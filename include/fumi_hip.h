@@ -60,6 +60,26 @@ size_t fumi_hip_workspace_bytes(const fumi_ws_t* ws);
 /* Copies the device status word to the host (synchronises `stream`) and clears it. */
 int   fumi_hip_read_status(fumi_ws_t* ws, fumi_stream_t stream, int* status_out);
 
+/* ---- in-library phase timing (HIP events recorded on the caller's stream around each phase) ---------------------
+ * Used by bench.py to time the dominant kernel live inside the timed region.  Off by default (no events recorded). */
+#define FUMI_PH_SELECT     0   /* class text select                                   */
+#define FUMI_PH_HYPER_FWD  1   /* hypernetwork forward (2 GEMMs)                       */
+#define FUMI_PH_GEMM_A0S   2   /* A0s = Xs W0^T                                        */
+#define FUMI_PH_GEMM_A0Q   3   /* A0q = Xq W0^T   <- dominant kernel of the FuMI step  */
+#define FUMI_PH_GRAM       4   /* Gss, Gqs (batched X Xs^T)                            */
+#define FUMI_PH_ADAPT      5   /* inner loop                                           */
+#define FUMI_PH_QUERY      6   /* query forward/backward                               */
+#define FUMI_PH_REVERSE    7   /* second-order reverse sweep                           */
+#define FUMI_PH_REDUCE     8   /* sums over episodes                                   */
+#define FUMI_PH_GEMM_GW0   9   /* gW0 = Abar0^T X (split-K GEMMs + slab reduce)        */
+#define FUMI_PH_HYPER_BWD 10   /* hypernetwork backward                                */
+#define FUMI_PH_AM3       11   /* AM3 fused head kernels                               */
+#define FUMI_PH_COUNT     12
+int          fumi_hip_set_profiling(fumi_ws_t* ws, int on);          /* also clears the records */
+/* Synchronises the device; total elapsed ms and number of records of `phase` since profiling was switched on. */
+int          fumi_hip_get_profile(fumi_ws_t* ws, int phase, double* total_ms, int* count);
+const char*  fumi_hip_phase_name(int phase);
+
 /* ---- FuMI meta-step (replaces fumi/models/fumi.py:146-192 for B episodes) ------------------------------------
  * theta   : 2*n_hidden pointers  W_i [hid[i], hid[i-1]] (hid[-1] = D), b_i [hid[i]]   (im_net.linear{i}.*)
  * phi     : 4 pointers           A0 [Ht,Dt], a0 [Ht], A1 [H+1,Ht], a1 [H+1]           (hyper_net.0.*, hyper_net.2.*)
