@@ -1,8 +1,271 @@
-// AM3 step -- placeholder until the prototype kernels land (the symbol is part of the ABI).
+// AM3 step: prototypical network with text-gated convex combination (no inner loop).
+//
+// Replaces AM3.forward / AM3.evaluate (fumi/models/am3.py:90-126,160-200, dropout 0) and the head math of
+// fumi/utils/utils.py: get_num_samples :379-387, get_prototypes :331-376, prototypical_loss :390-402, get_preds :302-328.
+//
+// Shared-weight linears (image encoder on B*(S+Qn) rows, g / h text MLPs on B*S rows) and their backward run on the
+// GEMM family (gemm.hip).  The per-episode head is one fused kernel (am3_head_kernel, 1 workgroup / episode):
+//   * per-class prototype sums as wavefront-level segmented reductions: one wave per class, lanes over the prototype
+//     dim, the class test is wave-uniform (no scatter atomics, unlike the reference's scatter_add_)
+//   * squared distances query x class with one wave per query row (lanes over P, shuffle reduction), softmax-CE over
+//     the N classes, first arg-min, and the backward to every embedding in the same pass (per-wave slabs in LDS for the
+//     prototype adjoints: deterministic, no float atomics)
 #include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// LDS layout (floats): ip[N*P] tp[N*P] pr[N*P] pb[nw][N*P] lamc[N] cnt[N] lbar[N] wl[nw] wc[nw]
+__global__ __launch_bounds__(256) void am3_head_kernel(int N, int S, int Qn, int P, int lamda_fixed, int need_grad,
+                                                       float dscale,
+                                                       const float* __restrict__ im_s, const float* __restrict__ tx,
+                                                       float* __restrict__ lam_s, const int64_t* __restrict__ y_s,
+                                                       const float* __restrict__ im_q, const int64_t* __restrict__ y_q,
+                                                       int64_t* __restrict__ preds, float* __restrict__ loss_b,
+                                                       float* __restrict__ corr_b,
+                                                       float* __restrict__ im_s_bar, float* __restrict__ tx_bar,
+                                                       float* __restrict__ zl_bar, float* __restrict__ im_q_bar,
+                                                       int* status) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int NP = N * P;
+    float* ip = sm; float* tp = ip + NP; float* pr = tp + NP; float* pb = pr + NP;
+    float* lamc = pb + nw * NP; float* cnt = lamc + N; float* lbar = cnt + N; float* wl = lbar + N; float* wc = wl + nw;
+    im_s += (long)b * S * P; tx += (long)b * S * P; lam_s += (long)b * S; y_s += (long)b * S;
+    im_q += (long)b * Qn * P; y_q += (long)b * Qn; preds += (long)b * Qn;
+
+    if (lamda_fixed >= 0) for (int s = tid; s < S; s += blockDim.x) lam_s[s] = (float)lamda_fixed;   // am3.py:174-177
+    __syncthreads();
+    // ---- prototypes: wave per class, lanes over P; count clamped to >= 1 (utils.py:353-355)
+    for (int c = wave; c < N; c += nw) {
+        float n = 0.f, ls = 0.f;
+        for (int s = 0; s < S; ++s) {
+            const long y = y_s[s];
+            if (y < 0 || y >= N) { if (lane == 0) atomicOr(status, FUMI_ST_LABEL_RANGE); continue; }
+            if (y == c) { n += 1.f; ls += lam_s[s]; }
+        }
+        const float nn = fmaxf(n, 1.f);
+        for (int j = lane; j < P; j += 64) {
+            float si = 0.f, st = 0.f;
+            for (int s = 0; s < S; ++s)
+                if (y_s[s] == c) { si += im_s[(long)s * P + j]; st += tx[(long)s * P + j]; }
+            si /= nn; st /= nn;
+            const float lc = ls / nn;
+            ip[c * P + j] = si; tp[c * P + j] = st;
+            pr[c * P + j] = lc * si + (1.f - lc) * st;
+        }
+        if (lane == 0) { lamc[c] = ls / nn; cnt[c] = nn; }
+    }
+    for (int i = tid; i < nw * NP; i += blockDim.x) pb[i] = 0.f;
+    __syncthreads();
+
+    // ---- queries: wave per row; d[c] = |proto_c - x|^2 ; CE over -d ; first arg-min ; backward
+    float lsum = 0.f, csum = 0.f;
+    float* mypb = pb + wave * NP;
+    for (int q = wave; q < Qn; q += nw) {
+        long yq = y_q[q];
+        if (yq < 0 || yq >= N) { if (lane == 0) atomicOr(status, FUMI_ST_LABEL_RANGE); yq = 0; }
+        // pass 1: distances (kept for the <= 64 classes handled per register group; general N re-computes)
+        float dmin = INFINITY; int amin = 0; float mx = -INFINITY;
+        for (int c = 0; c < N; ++c) {
+            float v = 0.f;
+            for (int j = lane; j < P; j += 64) { const float df = pr[c * P + j] - im_q[(long)q * P + j]; v += df * df; }
+            v = wave_sum(v);
+            if (v < dmin) { dmin = v; amin = c; }
+            mx = fmaxf(mx, -v);
+        }
+        float se = 0.f, dy = 0.f;
+        for (int c = 0; c < N; ++c) {
+            float v = 0.f;
+            for (int j = lane; j < P; j += 64) { const float df = pr[c * P + j] - im_q[(long)q * P + j]; v += df * df; }
+            v = wave_sum(v);
+            se += expf(-v - mx);
+            if (c == yq) dy = v;
+        }
+        const float lse = mx + logf(se);
+        lsum += lse + dy;                                   // -log softmax(-d)[y] = lse - (-d_y)
+        csum += (amin == yq) ? 1.f : 0.f;
+        if (lane == 0) preds[q] = amin;
+        if (need_grad) {
+            // dbar[c] = dL/dd[c] = -(p_c - onehot_c) * dscale ;  xbar = sum_c dbar[c] * (-2)(proto_c - x) ;  pbar_c += dbar[c]*2(proto_c - x)
+            for (int j0 = 0; j0 < P; j0 += 64) {
+                const int j = j0 + lane;
+                float xb = 0.f;
+                const float x = j < P ? im_q[(long)q * P + j] : 0.f;
+                for (int c = 0; c < N; ++c) {
+                    float v = 0.f;
+                    for (int jj = lane; jj < P; jj += 64) { const float df = pr[c * P + jj] - im_q[(long)q * P + jj]; v += df * df; }
+                    v = wave_sum(v);
+                    const float pc = expf(-v - lse);
+                    const float db = -(pc - (c == yq ? 1.f : 0.f)) * dscale;
+                    if (j < P) {
+                        const float df2 = 2.f * (pr[c * P + j] - x);
+                        xb -= db * df2;
+                        mypb[c * P + j] += db * df2;
+                    }
+                }
+                if (j < P) im_q_bar[((long)b * Qn + q) * P + j] = xb;
+            }
+        }
+    }
+    if (lane == 0) { wl[wave] = lsum; wc[wave] = csum; }
+    __syncthreads();
+    if (tid == 0) {
+        float l = 0.f, c = 0.f;
+        for (int w = 0; w < nw; ++w) { l += wl[w]; c += wc[w]; }
+        loss_b[b] = l * dscale;
+        corr_b[b] = c;
+    }
+    if (!need_grad) return;
+    // ---- prototype adjoints -> per-sample gradients (utils.py:358-375 reversed)
+    for (int i = tid; i < NP; i += blockDim.x) {
+        float s = 0.f;
+        for (int w = 0; w < nw; ++w) s += pb[w * NP + i];
+        pb[i] = s;                                          // slab 0 now holds pbar (only element i of slab 0 is touched by thread i)
+    }
+    __syncthreads();
+    for (int c = wave; c < N; c += nw) {
+        float v = 0.f;
+        for (int j = lane; j < P; j += 64) v += pb[c * P + j] * (ip[c * P + j] - tp[c * P + j]);
+        v = wave_sum(v);
+        if (lane == 0) lbar[c] = v;
+    }
+    __syncthreads();
+    im_s_bar += (long)b * S * P; tx_bar += (long)b * S * P; zl_bar += (long)b * S;
+    for (int i = tid; i < S * P; i += blockDim.x) {
+        const int s = i / P, j = i % P;
+        long c = y_s[s];
+        if (c < 0 || c >= N) { im_s_bar[i] = 0.f; tx_bar[i] = 0.f; continue; }
+        const float g = pb[c * P + j] / cnt[c];
+        im_s_bar[i] = lamc[c] * g;
+        tx_bar[i] = (1.f - lamc[c]) * g;
+    }
+    for (int s = tid; s < S; s += blockDim.x) {
+        long c = y_s[s];
+        float z = 0.f;
+        if (lamda_fixed < 0 && c >= 0 && c < N) { const float l = lam_s[s]; z = lbar[c] / cnt[c] * l * (1.f - l); }
+        zl_bar[s] = z;
+    }
+}
+
+}  // namespace
+
 extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
         int B, int N, int S, int Qn, int D, int Dt, int Ht, int P, int lamda_fixed, int need_grad, float grad_scale,
         const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q, const float* text_s,
         const float* const* w, float* loss, int64_t* preds_q, float* lamda_s, float* correct, float* const* g_w) {
-    return FUMI_ENOTSUP;
+    if (!ws || !x_s || !y_s || !x_q || !y_q || !text_s || !w || !loss || !preds_q || !lamda_s || !correct) return FUMI_EINVAL;
+    if (B < 1 || N < 1 || S < 1 || Qn < 1 || D < 1 || Dt < 1 || Ht < 1 || P < 1 || lamda_fixed < -1 || lamda_fixed > 1) return FUMI_EINVAL;
+    for (int i = 0; i < 10; ++i) if (!w[i] || (need_grad && (!g_w || !g_w[i]))) return FUMI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ws->device));
+    const float *Wi = w[0], *bi = w[1], *G0 = w[2], *g0 = w[3], *G1 = w[4], *g1 = w[5], *H0 = w[6], *h0 = w[7], *H1 = w[8], *h1 = w[9];
+    const long Rs = (long)B * S, Rq = (long)B * Qn;
+    const int nwaves = 4;
+    const size_t lds = ((size_t)(3 + nwaves) * N * P + 3 * N + 2 * nwaves) * sizeof(float);
+    if (lds > 160 * 1024) return FUMI_ENOTSUP;
+    const int KCH = 1024;
+    const int ns = (int)((Rs + KCH - 1) / KCH), nq = (int)((Rq + KCH - 1) / KCH);
+
+    size_t bytes = 0;
+    auto A = [&](size_t n) { bytes += ws_align(n * sizeof(float)); };
+    A((Rs + Rq) * P); A(Rs * Ht); A(Rs * P); A(Rs * Ht); A(2 * B);
+    if (need_grad) { A((Rs + Rq) * P); A(Rs * P); A(Rs); A(Rs * Ht); A(Rs * Ht); A((size_t)(ns + nq) * P * D); }
+    int rc = ws_reserve(ws, bytes);
+    if (rc) return rc;
+    float* im = ws_f(ws, (Rs + Rq) * P);          // [support rows | query rows]
+    float* t1 = ws_f(ws, Rs * Ht);
+    float* tx = ws_f(ws, Rs * P);
+    float* l1 = ws_f(ws, Rs * Ht);
+    float* lc = ws_f(ws, 2 * B);                  // per-episode loss | correct
+    float* imq = im + Rs * P;
+
+    GemmArgs g;
+    {
+        ProfScope ps(ws, st, FUMI_PH_GEMM_A0S);
+        g = gemm_args((int)Rs, P, D, x_s, D, Wi, D, im, P); g.bias = bi;
+        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+    }
+    {
+        ProfScope ps(ws, st, FUMI_PH_GEMM_A0Q);
+        g = gemm_args((int)Rq, P, D, x_q, D, Wi, D, imq, P); g.bias = bi;
+        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+    }
+    {
+        ProfScope ps(ws, st, FUMI_PH_HYPER_FWD);
+        g = gemm_args((int)Rs, Ht, Dt, text_s, Dt, G0, Dt, t1, Ht); g.bias = g0; g.act = 1;
+        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+        g = gemm_args((int)Rs, P, Ht, t1, Ht, G1, Ht, tx, P); g.bias = g1;
+        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+        if (lamda_fixed < 0) {
+            g = gemm_args((int)Rs, Ht, P, tx, P, H0, P, l1, Ht); g.bias = h0; g.act = 1;
+            if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+            g = gemm_args((int)Rs, 1, Ht, l1, Ht, H1, Ht, lamda_s, 1); g.bias = h1; g.act = 3;
+            if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+        }
+    }
+    float *imb = nullptr, *txb = nullptr, *zlb = nullptr, *l1b = nullptr, *t1b = nullptr, *slabs = nullptr;
+    if (need_grad) {
+        imb = ws_f(ws, (Rs + Rq) * P); txb = ws_f(ws, Rs * P); zlb = ws_f(ws, Rs);
+        l1b = ws_f(ws, Rs * Ht); t1b = ws_f(ws, Rs * Ht); slabs = ws_f(ws, (size_t)(ns + nq) * P * D);
+    }
+    {
+        ProfScope ps(ws, st, FUMI_PH_AM3);
+        const float dscale = grad_scale / (float)Qn;
+        hipLaunchKernelGGL(am3_head_kernel, dim3(B), dim3(64 * nwaves), lds, st, N, S, Qn, P, lamda_fixed, need_grad ? 1 : 0,
+                           dscale, im, tx, lamda_s, y_s, imq, y_q, preds_q, lc, lc + B, imb, txb, zlb,
+                           imb ? imb + Rs * P : nullptr, ws->status);
+        LAUNCH_CHECK();
+        if ((rc = launch_reduce_slabs(st, lc, B, 1, 1, 1.f, loss))) return rc;
+        if ((rc = launch_reduce_slabs(st, lc + B, B, 1, 1, 1.f, correct))) return rc;
+    }
+    if (!need_grad) return FUMI_OK;
+
+    ProfScope pb(ws, st, FUMI_PH_HYPER_BWD);
+    if (lamda_fixed < 0) {
+        // h network: lam = sigmoid(l1 H1^T + h1), l1 = relu(tx H0^T + h0)
+        g = gemm_args(1, Ht, (int)Rs, zlb, 1, l1, Ht, g_w[8], Ht);                     // gH1 = zlbar^T l1
+        if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+        if ((rc = launch_colsum(st, zlb, (int)Rs, 1, 1, 1.f, g_w[9]))) return rc;
+        g = gemm_args((int)Rs, Ht, 1, zlb, 1, H1, Ht, l1b, Ht);                        // l1bar = zlbar H1, masked
+        if ((rc = launch_gemm(st, g, 0, 1))) return rc;
+        if ((rc = launch_relu_mask_mul(st, Rs * Ht, l1, l1b))) return rc;
+        g = gemm_args(Ht, P, (int)Rs, l1b, Ht, tx, P, g_w[6], P);                      // gH0 = l1bar^T tx
+        if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+        if ((rc = launch_colsum(st, l1b, (int)Rs, Ht, Ht, 1.f, g_w[7]))) return rc;
+        g = gemm_args((int)Rs, P, Ht, l1b, Ht, H0, P, txb, P); g.accumulate = 1;       // txbar += l1bar H0
+        if ((rc = launch_gemm(st, g, 0, 1))) return rc;
+    } else {
+        HIP_TRY(hipMemsetAsync(g_w[6], 0, (size_t)Ht * P * 4, st)); HIP_TRY(hipMemsetAsync(g_w[7], 0, (size_t)Ht * 4, st));
+        HIP_TRY(hipMemsetAsync(g_w[8], 0, (size_t)Ht * 4, st)); HIP_TRY(hipMemsetAsync(g_w[9], 0, 4, st));
+    }
+    // g network: tx = t1 G1^T + g1, t1 = relu(text G0^T + g0)
+    g = gemm_args(P, Ht, (int)Rs, txb, P, t1, Ht, g_w[4], Ht);                         // gG1 = txbar^T t1
+    if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+    if ((rc = launch_colsum(st, txb, (int)Rs, P, P, 1.f, g_w[5]))) return rc;
+    g = gemm_args((int)Rs, Ht, P, txb, P, G1, Ht, t1b, Ht);                            // t1bar = txbar G1, masked
+    if ((rc = launch_gemm(st, g, 0, 1))) return rc;
+    if ((rc = launch_relu_mask_mul(st, Rs * Ht, t1, t1b))) return rc;
+    g = gemm_args(Ht, Dt, (int)Rs, t1b, Ht, text_s, Dt, g_w[2], Dt);                   // gG0 = t1bar^T text
+    if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+    if ((rc = launch_colsum(st, t1b, (int)Rs, Ht, Ht, 1.f, g_w[3]))) return rc;
+    // image encoder: gWi = imbar_s^T Xs + imbar_q^T Xq (split over the contraction), gbi = colsum(imbar)
+    {
+        ProfScope pg(ws, st, FUMI_PH_GEMM_GW0);
+        const long slab = (long)P * D;
+        g = gemm_args(P, D, (int)Rs, imb, P, x_s, D, slabs, D);
+        g.kchunk = KCH; g.nsplit = ns; g.sCsplit = slab;
+        if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+        g = gemm_args(P, D, (int)Rq, imb + Rs * P, P, x_q, D, slabs + (long)ns * slab, D);
+        g.kchunk = KCH; g.nsplit = nq; g.sCsplit = slab;
+        if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+        if ((rc = launch_reduce_slabs(st, slabs, ns + nq, slab, slab, 1.f, g_w[0]))) return rc;
+        if ((rc = launch_colsum(st, imb, (int)(Rs + Rq), P, P, 1.f, g_w[1]))) return rc;
+    }
+    return FUMI_OK;
 }

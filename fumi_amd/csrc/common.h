@@ -71,7 +71,7 @@ struct GemmArgs {
     const float* B; long ldb; long sB;
     float* C; long ldc; long sC; long sCsplit;
     const float* bias;     // [N] or NULL
-    int act;               // 0 none, 1 relu, 2 tanh
+    int act;               // 0 none, 1 relu, 2 tanh, 3 sigmoid
     float alpha;
     int accumulate;        // C += result
 };

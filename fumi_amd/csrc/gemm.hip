@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int avec, int bve
                 float v = g.alpha * acc[r] + bias;
                 if (g.act == 1) v = v > 0.f ? v : 0.f;
                 else if (g.act == 2) v = tanhf(v);
+                else if (g.act == 3) v = 1.f / (1.f + expf(-v));
                 float* c = C + (long)m * g.ldc + n;
                 if (g.accumulate) v += *c;
                 *c = v;

@@ -283,7 +283,7 @@ def maml_step(ws, x_s, y_s, x_q, y_q, params, T, alpha, first_order=False, *, ne
 AM3_KEYS = ["Wi", "bi", "G0", "g0", "G1", "g1", "H0", "h0", "H1", "h1"]
 
 
-def am3_step(ws, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed=None, *, need_grad=True, grad_scale=1.0, g_w=None):
+def am3_step(ws, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed=None, *, need_grad=True, grad_scale=None, g_w=None):
     """One AM3 step (fumi/models/am3.py:160-200).  w: list of the 10 tensors in AM3_KEYS order."""
     dev = _dev(x_s)
     L = lib()
@@ -297,6 +297,8 @@ def am3_step(ws, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed=None, *, need
     if need_grad and g_w is None:
         g_w = [torch.empty_like(t) for t in w]
     lf = -1 if lamda_fixed is None else int(lamda_fixed)
+    if grad_scale is None:
+        grad_scale = 1.0 / B
     rc = L.fumi_hip_am3_step(
         ws.handle, _stream(dev), B, n_way, S, Qn, D, Dt, Ht, P, lf, int(bool(need_grad)), float(grad_scale),
         _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"), _f32(text_s, "text_s"),

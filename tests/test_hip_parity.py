@@ -242,3 +242,43 @@ def test_engine_rejects_cpu_tensors(dev, ws):
     from fumi_amd import hip
     with pytest.raises(hip.FumiHipError):
         hip.linear_fwd(ws, torch.zeros(2, 2), torch.zeros(2, 2))
+
+
+@pytest.mark.parametrize("name", list(cg.AM3_CASES))
+def test_am3_step_matches_reference(name, dev, ws):
+    from fumi_amd import hip
+    c, gold = cg.AM3_CASES[name], load_golden(name)
+    seed = case_seed(name)
+    ep = cg.make_episodes(seed, c["B"], c["N"], c["K"], c["Q"], c["D"], c["Dt"])
+    w = cg.make_am3_params(seed, c["D"], c["Dt"], c["Ht"], c["P"])
+    wl = [w[k] for k in hip.AM3_KEYS]
+    out = hip.am3_step(ws, _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev),
+                       _g(ep["text_s"], dev), [_g(t, dev) for t in wl], c["N"], c["lamda_fixed"])
+    assert ws.read_status() == 0
+    wr = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    ref = R.am3_step(wr, ep["text_s"], ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], c["N"], c["lamda_fixed"])
+    assert abs(float(out["loss"]) - float(gold["loss"])) <= LOGIT_TOL * max(1.0, abs(float(gold["loss"])))
+    nq = c["B"] * c["N"] * c["Q"]
+    assert abs(float(out["correct"]) / nq - float(gold["acc"])) < 1e-6
+    # integer predictions: bit-exact where the two nearest prototypes are not within round-off of each other
+    d2 = ref["dist"].transpose(1, 2).topk(2, dim=-1, largest=False)[0]
+    mask = (d2[..., 1] - d2[..., 0]) > 1e-4 * d2[..., 1].abs().clamp_min(1.0)
+    assert float(mask.float().mean()) > 0.95
+    assert torch.equal(out["preds"].cpu()[mask], ref["preds"][mask])
+    assert rel_to_max(out["lamda_s"].cpu(), ref["lamda_s"]) <= 1e-5
+    assert abs(float(out["lamda_s"].mean()) - float(gold["avg_lamda"])) < 1e-5
+    sd = {"Wi": "image_encoder.weight", "bi": "image_encoder.bias", "G0": "g.0.weight", "g0": "g.0.bias",
+          "G1": "g.3.weight", "g1": "g.3.bias", "H0": "h.0.weight", "h0": "h.0.bias", "H1": "h.3.weight", "h1": "h.3.bias"}
+    _check_grads([sd[k] for k in hip.AM3_KEYS], out["grads"], gold, [ref["grads"][k] for k in hip.AM3_KEYS])
+
+
+def test_am3_eval_mode_matches_train_forward(dev, ws):
+    from fumi_amd import hip
+    c = cg.AM3_CASES["am3_lam"]
+    ep = cg.make_episodes(3, c["B"], c["N"], c["K"], c["Q"], c["D"], c["Dt"])
+    wl = [_g(cg.make_am3_params(3, c["D"], c["Dt"], c["Ht"], c["P"])[k], dev) for k in hip.AM3_KEYS]
+    args = (ws, _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev), _g(ep["text_s"], dev), wl, c["N"], None)
+    a = hip.am3_step(*args, need_grad=True)
+    la, pa = float(a["loss"]), a["preds"].clone()
+    b = hip.am3_step(*args, need_grad=False)
+    assert abs(la - float(b["loss"])) < 1e-6 and torch.equal(pa, b["preds"])
