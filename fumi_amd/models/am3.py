@@ -1,0 +1,197 @@
+"""AM3: prototypical network with a text-gated convex combination -- host-side mirror of fumi/models/am3.py.
+
+Same constructor keywords, attributes (``image_encoder``, ``text_encoder``, ``g``, ``h``), ``state_dict`` keys
+(``image_encoder.*``, ``g.{0,3}.*``, ``h.{0,3}.*``) and ``evaluate`` return tuples (am3.py:16-212).  The arithmetic of a
+step (encoders, per-class prototypes, squared distances, CE, arg-min, backward) is one call of the MI355X engine
+(csrc/am3.hip); precision / recall / F1 are computed from the integer predictions on the host like the reference does
+with sklearn (utils.py:319-326)."""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import dist as fdist
+from .. import engine as _engine
+from ..flatgrad import FlatGrads
+from ..utils import utils as utils
+from ..utils.average_meter import AverageMeter
+from ..utils.wandb_compat import wandb
+from .common import RNN, RnnHid, WordEmbedding
+
+
+class AM3(nn.Module):
+    def __init__(self, im_encoder, im_emb_dim, text_encoder, text_emb_dim=300, text_hid_dim=300, prototype_dim=512,
+                 dropout=0.7, fine_tune=False, dictionary=None, pooling_strat="mean", lamda_fixed=None):
+        super().__init__()
+        self.im_emb_dim = im_emb_dim
+        self.text_encoder_type = text_encoder
+        self.text_emb_dim = text_emb_dim
+        self.text_hid_dim = text_hid_dim
+        self.prototype_dim = prototype_dim
+        self.dropout = dropout
+        self.fine_tune = fine_tune
+        self.dictionary = dictionary
+        self.pooling_strat = pooling_strat
+        self.lamda_fixed = lamda_fixed
+
+        if im_encoder in ("precomputed", "resnet"):            # "resnet" is the same Linear in the reference (am3.py:44-46)
+            self.image_encoder = nn.Linear(im_emb_dim, prototype_dim)
+        else:
+            raise NameError(f"{im_encoder} not allowed as image encoder")
+        if text_encoder in ("BERT", "precomputed"):
+            self.text_encoder = nn.Identity()
+        elif text_encoder in ("w2v", "glove"):
+            self.text_encoder = WordEmbedding(text_encoder, pooling_strat, dictionary)
+            self.text_emb_dim = self.text_encoder.embedding_dim
+        elif text_encoder == "RNN":
+            self.text_encoder = RNN("glove", pooling_strat, dictionary, self.text_emb_dim)
+        elif text_encoder == "RNNhid":
+            self.text_encoder = RnnHid("glove", pooling_strat, dictionary, self.text_emb_dim)
+        elif text_encoder == "rand":
+            self.text_encoder = nn.Linear(self.text_emb_dim, self.text_emb_dim)
+        else:
+            raise NameError(f"{text_encoder} not allowed as text encoder")
+        if not fine_tune:
+            print("Not fine tuning embeddings")
+            for p in self.text_encoder.parameters():
+                p.requires_grad = False
+        self.g = nn.Sequential(nn.Linear(self.text_emb_dim, text_hid_dim), nn.ReLU(), nn.Dropout(p=dropout),
+                               nn.Linear(text_hid_dim, prototype_dim))
+        self.h = nn.Sequential(nn.Linear(prototype_dim, text_hid_dim), nn.ReLU(), nn.Dropout(p=dropout),
+                               nn.Linear(text_hid_dim, 1))
+        self._flat = None
+
+    def _w(self):
+        return [self.image_encoder.weight, self.image_encoder.bias, self.g[0].weight, self.g[0].bias, self.g[3].weight,
+                self.g[3].bias, self.h[0].weight, self.h[0].bias, self.h[3].weight, self.h[3].bias]
+
+    def _flat_grads(self):
+        params = self._w()
+        if self._flat is None or not self._flat.matches(params):
+            self._flat = FlatGrads(params, extra=3)
+        return self._flat
+
+    def _encode_text(self, text):
+        if self.text_encoder_type in ("BERT", "precomputed"):
+            return text.to(torch.float32).contiguous()
+        if self.text_encoder_type == "rand":
+            raise NotImplementedError("text_encoder='rand' draws the text prototypes at random inside the step "
+                                      "(am3.py:118-121); it is excluded from the parity path")
+        return self.text_encoder(text)
+
+    def forward(self, inputs, im_only=False):
+        """Inference helper (am3.py:90-126): prototype-space embeddings through the engine's linear op."""
+        eng = _engine.get_engine()
+        idx, text, im = inputs
+        w = [p.detach() for p in self._w()]
+        lead = im.shape[:-1]
+        im_emb = eng.linear(im.reshape(-1, im.shape[-1]).contiguous(), w[0], w[1]).reshape(*lead, -1)
+        if im_only:
+            return im_emb
+        enc = self._encode_text(text)
+        t = eng.linear(eng.linear(enc.reshape(-1, enc.shape[-1]).contiguous(), w[2], w[3], act=1), w[4], w[5])
+        lam = eng.linear(eng.linear(t, w[6], w[7], act=1), w[8], w[9], act=3)
+        return im_emb, t.reshape(*lead, -1), lam.reshape(*lead, 1)
+
+    def evaluate(self, batch, optimizer, scheduler, num_ways, device, task="train"):
+        """One meta-batch (am3.py:128-212): 6-tuple for train/val, 11-tuple for test."""
+        train = task == "train"
+        if train:
+            self.train()
+        else:
+            self.eval()
+        if train and self.dropout > 0:
+            raise NotImplementedError("dropout inside g/h (am3.py:82,88) is not implemented by the MI355X engine; "
+                                      "run with --dropout 0 (the parity configuration)")
+        (s_idx, s_text, s_im), s_y = batch['train']
+        (q_idx, _, q_im), q_y = batch['test']
+        B, Qn = q_im.shape[0], q_im.shape[1]
+        lo, hi = fdist.shard(B)
+        to = lambda t: t[lo:hi].to(device).contiguous()
+        x_s, x_q, y_s, y_q = to(s_im).float(), to(q_im).float(), to(s_y), to(q_y)
+        text = self._encode_text(to(s_text))
+        need_grad = train and torch.is_grad_enabled()
+        fg = self._flat_grads() if need_grad else None
+        out = _engine.get_engine().am3_step(x_s, y_s, x_q, y_q, text, [p.detach() for p in self._w()], num_ways,
+                                            self.lamda_fixed, need_grad=need_grad, grad_scale=1.0 / B,
+                                            g_w=fg.views if need_grad else None)
+        tail = fg.tail if need_grad else torch.empty(3, device=x_s.device, dtype=torch.float32)
+        torch.stack([out["loss"].reshape(()), out["correct"].reshape(()) / (B * Qn),
+                     out["lamda_s"].sum() / (B * out["lamda_s"].shape[1])], out=tail)
+        fdist.all_reduce_sum_(fg.flat if need_grad else tail)
+        if need_grad:
+            optimizer.zero_grad()
+            fg.attach()
+            if self.lamda_fixed in (0, 1):
+                # h is not part of the graph when lamda is overridden (am3.py:174-177): the reference leaves its .grad
+                # None, so the optimizer (and its weight decay) skips those tensors
+                for p in self.h.parameters():
+                    p.grad = None
+            optimizer.step()
+            if scheduler:
+                scheduler.step()
+        preds = fdist.all_gather_rows(out["preds"])
+        lam_s = fdist.all_gather_rows(out["lamda_s"])
+        stats = tail.detach().cpu().numpy()
+        preds_np = preds.detach().cpu().numpy()
+        targets_np = q_y.detach().cpu().numpy()
+        acc, f1, prec, rec = utils.macro_metrics(targets_np, preds_np)
+        if task == "test":
+            return (stats[0], acc, f1, prec, rec, stats[2], preds_np, q_y.to(device), q_idx.detach().cpu().numpy(),
+                    s_idx.detach().cpu().numpy(), lam_s.detach().cpu().numpy())
+        return stats[0], acc, f1, prec, rec, stats[2]
+
+
+def training_run(args, model, optimizer, train_loader, val_loader, max_test_batches):
+    """am3.py:215-305 (validates at batch 0 too, unlike FuMI/MAML; reloads the best checkpoint at the end)."""
+    best_loss, best_acc = test_loop(args, model, val_loader, max_test_batches)[:2]
+    print(f"\ninitial loss: {best_loss}, acc: {best_acc}")
+    best_batch_idx = 0
+    opt, scheduler = optimizer if type(optimizer) == tuple else (optimizer, None)
+    try:
+        for batch_idx, batch in enumerate(train_loader):
+            tl, ta, tf1, tp, tr, tlam = model.evaluate(batch=batch, optimizer=opt, scheduler=scheduler,
+                                                       num_ways=args.num_ways, device=args.device, task="train")
+            wandb.log({"train/acc": ta, "train/f1": tf1, "train/prec": tp, "train/rec": tr, "train/loss": tl,
+                       "train/avg_lamda": tlam, "num_episodes": (batch_idx + 1) * args.batch_size}, step=batch_idx)
+            if batch_idx % args.eval_freq == 0:
+                r = test_loop(args, model, val_loader, max_test_batches)
+                val_loss, val_acc, val_f1, val_prec, val_rec, val_lamda = r[:6]
+                is_best = val_loss < best_loss
+                if is_best:
+                    best_loss, best_batch_idx = val_loss, batch_idx
+                wandb.log({"val/acc": val_acc, "val/f1": val_f1, "val/prec": val_prec, "val/rec": val_rec,
+                           "val/loss": val_loss, "val/avg_lamda": val_lamda}, step=batch_idx)
+                utils.save_checkpoint({"batch_idx": batch_idx, "state_dict": model.state_dict(), "best_loss": best_loss,
+                                       "optimizer": opt.state_dict(), "args": vars(args)}, is_best)
+                print(f"\nBatch {batch_idx + 1}/{args.epochs}: \ntrain/loss: {tl}, train/acc: {ta}, train/avg_lamda: {tlam}"
+                      f"\nval/loss: {val_loss}, val/acc: {val_acc}, val/avg_lamda: {val_lamda}")
+            if (batch_idx > args.epochs - 1) or (args.patience > 0 and batch_idx - best_batch_idx > args.patience):
+                break
+    except KeyboardInterrupt:
+        pass
+    best_file = os.path.join(wandb.run.dir, "best.pth.tar")
+    if os.path.exists(best_file):
+        model, _ = utils.load_checkpoint(model, opt, args.device, best_file)
+    return model
+
+
+def test_loop(args, model, test_dataloader, max_num_batches):
+    """am3.py:308-367: 11-tuple of averages + flattened per-query / per-support records (max_num_batches + 1 batches)."""
+    m_acc, m_f1, m_prec, m_rec, m_loss, m_lam = (AverageMeter() for _ in range(6))
+    test_preds, test_trues, query_idx, support_idx, support_lamdas = [], [], [], [], []
+    for batch_idx, batch in enumerate(test_dataloader):
+        with torch.no_grad():
+            (loss, acc, f1, prec, rec, lamda, preds, trues, query, support, support_lamda) = model.evaluate(
+                batch=batch, optimizer=None, scheduler=None, num_ways=args.num_ways, device=args.device, task="test")
+        m_acc.update(acc); m_f1.update(f1); m_prec.update(prec); m_rec.update(rec); m_loss.update(loss); m_lam.update(lamda)
+        test_preds += preds.tolist()
+        test_trues += trues.tolist()
+        query_idx += query.tolist()
+        support_idx += support.tolist()
+        support_lamdas += support_lamda.tolist()
+        if batch_idx > max_num_batches - 1:
+            break
+    return (m_loss.avg, m_acc.avg, m_f1.avg, m_prec.avg, m_rec.avg, m_lam.avg, test_preds, test_trues, query_idx,
+            support_idx, support_lamdas)

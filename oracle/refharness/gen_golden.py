@@ -176,6 +176,32 @@ def gen_wordemb(ref_common):
     print("wordemb: table", out["table"].shape)
 
 
+def gen_surface(ref_fumi, ref_maml, ref_am3, ref_utils):
+    """The drop-in surface: every CLI flag's default/type (utils.py:19-229) and the state_dict keys/shapes of the three
+    models at the CLI defaults -> tests/golden/surface.json."""
+    import json
+    p = ref_utils.parser()
+    flags = {}
+    for a in p._actions:
+        if not a.option_strings or a.dest == "help":
+            continue
+        flags[a.dest] = dict(flag=a.option_strings[0], default=a.default,
+                             type=(a.type.__name__ if a.type else None), nargs=a.nargs,
+                             choices=list(a.choices) if a.choices else None,
+                             store_true=type(a).__name__ == "_StoreTrueAction")
+    d = p.parse_args([])
+    f = ref_fumi.FUMI(n_way=d.num_ways, im_emb_dim=d.im_emb_dim, im_hid_dim=d.im_hid_dim, text_encoder="BERT",
+                      text_emb_dim=d.text_emb_dim, text_hid_dim=d.text_hid_dim, dropout_rate=d.dropout,
+                      norm_hypernet=d.norm_hypernet)
+    m = ref_maml.PureImageNetwork(im_embed_dim=d.im_emb_dim, n_way=d.num_ways, hidden_dims=d.im_hid_dim)
+    a3 = ref_am3.AM3(im_encoder=d.im_encoder, im_emb_dim=d.im_emb_dim, text_encoder="BERT", text_emb_dim=d.text_emb_dim,
+                     text_hid_dim=d.text_hid_dim, prototype_dim=d.prototype_dim, dropout=d.dropout)
+    sd = lambda mod: {k: list(v.shape) for k, v in mod.state_dict().items()}
+    json.dump(dict(flags=flags, fumi=sd(f), maml=sd(m), am3=sd(a3)), open(os.path.join(OUT, "surface.json"), "w"),
+              indent=1, sort_keys=True)
+    print("surface:", len(flags), "flags")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_fumi, ref_maml, ref_am3, ref_utils, ref_common = stubs.import_reference()
@@ -187,6 +213,7 @@ def main():
     for name, c in cg.AM3_CASES.items():
         gen_am3(ref_am3, name, c)
     gen_wordemb(ref_common)
+    gen_surface(ref_fumi, ref_maml, ref_am3, ref_utils)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,53 @@
+"""A checker engine for the CPU suite: same interface as fumi_amd.engine.HipEngine, arithmetic from the oracle
+(oracle/fumi_ref.py).  Lives under tests/ and is installed with fumi_amd.engine.set_engine only by tests: it lets the
+host-side plumbing (evaluate, loops, sharding, CLI, checkpoints) run in the GPU-less container."""
+import torch
+import torch.nn.functional as F
+
+from oracle import fumi_ref as R
+
+
+class OracleEngine:
+    name = "oracle-cpu (tests only)"
+
+    def fumi_step(self, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head, need_grad, grad_scale,
+                  g_theta=None, g_phi=None):
+        B = x_s.shape[0]
+        th = [t.detach().clone().requires_grad_(True) for t in theta]
+        ph = [t.detach().clone().requires_grad_(True) for t in phi]
+        out = R.fumi_meta_step(th, ph, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha, tanh_head, need_grad=need_grad)
+        if need_grad:
+            for dst, g in zip(list(g_theta) + list(g_phi), out["g_theta"] + out["g_phi"]):
+                dst.copy_(g * (B * grad_scale))               # oracle returns mean-loss grads = (1/B) sum_b
+        return dict(logits=out["logits"], preds=out["preds"], loss_b=out["loss_b"], acc_b=out["acc_b"])
+
+    def maml_step(self, x_s, y_s, x_q, y_q, params, T, alpha, first_order, need_grad, grad_scale, g_params=None):
+        B = x_s.shape[0]
+        p = [t.detach().clone().requires_grad_(True) for t in params]
+        out = R.maml_meta_step(p, x_s, y_s, x_q, y_q, T, alpha, first_order, need_grad=need_grad)
+        if need_grad:
+            for dst, g in zip(g_params, out["g_params"]):
+                dst.copy_(g * (B * grad_scale))
+        return dict(logits=out["logits"], preds=out["preds"], loss_b=out["loss_b"], acc_b=out["acc_b"])
+
+    def am3_step(self, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad, grad_scale, g_w=None):
+        from fumi_amd.hip import AM3_KEYS
+        B, Qn = x_q.shape[0], x_q.shape[1]
+        wd = {k: t.detach().clone().requires_grad_(True) for k, t in zip(AM3_KEYS, w)}
+        out = R.am3_step(wd, text_s, x_s, y_s, x_q, y_q, n_way, lamda_fixed, need_grad=need_grad)
+        if need_grad:
+            for dst, k in zip(g_w, AM3_KEYS):
+                dst.copy_(out["grads"][k] * (B * grad_scale))
+        correct = out["preds"].eq(y_q).float().sum().reshape(1)
+        return dict(loss=(out["loss"] * (B * grad_scale)).reshape(1), preds=out["preds"], lamda_s=out["lamda_s"],
+                    correct=correct)
+
+    def glove_bag(self, tokens, table, pad_id, mode):
+        return R.word_embedding_pool(tokens, table, pad_id, mode)
+
+    def linear(self, x, W, b=None, act=0):
+        y = F.linear(x, W, b)
+        return [y, torch.relu(y), torch.tanh(y), torch.sigmoid(y)][act]
+
+    def check(self, device):
+        pass

@@ -1,0 +1,106 @@
+"""CPU suite: episode sharding over 2 ranks (gloo) gives the same step as one process on the same meta-batch --
+the N>1 path of bench.py / main.py (fumi_amd/dist.py), with the oracle standing in for the GPU engine."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(kind):
+    from oracle import casegen as cg
+    from fumi_amd.models.fumi import FUMI
+    from fumi_amd.models import maml
+    from fumi_amd.models.am3 import AM3
+    c = dict(B=4, N=5, K=2, Q=3, D=48, hid=[24, 12], Dt=16, Ht=12, P=10)
+    ep = cg.make_episodes(11, c["B"], c["N"], c["K"], c["Q"], c["D"], c["Dt"])
+    if kind == "fumi":
+        theta, phi = cg.make_fumi_params(11, c["D"], c["hid"], c["Dt"], c["Ht"])
+        m = FUMI(n_way=c["N"], im_emb_dim=c["D"], im_hid_dim=c["hid"], text_encoder="BERT", text_emb_dim=c["Dt"],
+                 text_hid_dim=c["Ht"], norm_hypernet=True)
+        m.load_state_dict(cg.fumi_state_dict(theta, phi))
+    elif kind == "maml":
+        m = maml.PureImageNetwork(im_embed_dim=c["D"], n_way=c["N"], hidden_dims=c["hid"])
+        m.load_state_dict(cg.maml_state_dict(cg.make_maml_params(11, c["D"], c["hid"], c["N"])))
+    else:
+        m = AM3("precomputed", c["D"], "BERT", text_emb_dim=c["Dt"], text_hid_dim=c["Ht"], prototype_dim=c["P"], dropout=0.0)
+        m.load_state_dict(cg.am3_state_dict(cg.make_am3_params(11, c["D"], c["Dt"], c["Ht"], c["P"])))
+    return c, ep, m
+
+
+def _step(kind, c, ep, m):
+    from types import SimpleNamespace
+    from oracle import casegen as cg
+    from fumi_amd.models import maml
+    args = SimpleNamespace(device=torch.device("cpu"), num_train_adapt_steps=2, num_test_adapt_steps=2,
+                           step_size=cg.ALPHA, first_order=False, num_ways=c["N"], batch_size=c["B"])
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4)
+    if kind == "fumi":
+        tr = m.evaluate(args, cg.to_batch(ep), opt, "train")[:2]
+        te = m.evaluate(args, cg.to_batch(ep), None, "test")
+        extra = te[2].numpy()
+    elif kind == "maml":
+        tr = maml.evaluate(args, m, cg.to_batch(ep), opt, "train")
+        te = maml.evaluate(args, m, cg.to_batch(ep), None, "test")
+        extra = np.zeros(1)
+    else:
+        tr = m.evaluate(cg.to_batch(ep), opt, None, c["N"], torch.device("cpu"), "train")[:2]
+        te = m.evaluate(cg.to_batch(ep), None, None, c["N"], torch.device("cpu"), "test")
+        extra = np.asarray(te[6])
+    params = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).numpy()
+    return np.array([float(tr[0]), float(tr[1]), float(te[0]), float(te[1])]), params, extra
+
+
+def _worker(rank, world, port, kind, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    from fumi_amd import engine
+    from oracle_engine import OracleEngine
+    engine.set_engine(OracleEngine())
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c, ep, m = _build(kind)
+    stats, params, extra = _step(kind, c, ep, m)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), stats=stats, params=params, extra=extra)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["fumi", "maml", "am3"])
+def test_two_rank_sharded_step_equals_single_process(kind, tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fumi_amd import engine
+    from oracle_engine import OracleEngine
+    old = engine.set_engine(OracleEngine())
+    try:
+        c, ep, m = _build(kind)
+        ref_stats, ref_params, ref_extra = _step(kind, c, ep, m)
+    finally:
+        engine.set_engine(old)
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    np.testing.assert_array_equal(r0["params"], r1["params"])            # replicas stay bit-identical
+    np.testing.assert_allclose(r0["params"], ref_params, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(r0["stats"], ref_stats, rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(r0["stats"], r1["stats"])
+    np.testing.assert_array_equal(r0["extra"], ref_extra)                  # gathered test-time predictions, full batch
+
+
+def test_uneven_shard_is_refused():
+    from fumi_amd import dist as fdist
+    assert fdist.shard(7) == (0, 7)
