@@ -256,7 +256,7 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     if ((rc = launch_colsum(st, t1b, (int)Rs, Ht, Ht, 1.f, g_w[3]))) return rc;
     // image encoder: gWi = imbar_s^T Xs + imbar_q^T Xq (split over the contraction), gbi = colsum(imbar)
     {
-        ProfScope pg(ws, st, FUMI_PH_GEMM_GW0);
+        ProfScope pg(ws, st, FUMI_PH_XPANEL_BWD);
         const long slab = (long)P * D;
         g = gemm_args(P, D, (int)Rs, imb, P, x_s, D, slabs, D);
         g.kchunk = KCH; g.nsplit = ns; g.sCsplit = slab;

@@ -118,8 +118,8 @@ int fumi_hip_get_profile(fumi_ws_t* ws, int phase, double* total_ms, int* count)
 }
 
 const char* fumi_hip_phase_name(int phase) {
-    static const char* names[FUMI_PH_COUNT] = {"class_text_select", "hyper_fwd", "gemm_A0s", "gemm_A0q", "gram",
-        "adapt", "query", "reverse", "reduce", "gemm_gW0", "hyper_bwd", "am3_head"};
+    static const char* names[FUMI_PH_COUNT] = {"class_text_select", "hyper_fwd", "enc_gemm_s", "enc_gemm_q", "xpanel_fwd",
+        "adapt", "query", "reverse", "reduce", "xpanel_bwd", "hyper_bwd", "am3_head"};
     return (phase >= 0 && phase < FUMI_PH_COUNT) ? names[phase] : "?";
 }
 
@@ -270,6 +270,30 @@ int fumi_hip_class_text_select(fumi_ws_t* ws, fumi_stream_t stream, int B, int N
     if (!ws || !text_s || !y_s || !out || B < 1 || N < 1 || S < 1 || Dt < 1) return FUMI_EINVAL;
     HIP_TRY(hipSetDevice(ws->device));
     return launch_class_text_select((hipStream_t)stream, B, N, S, Dt, text_s, y_s, out, ws->status);
+}
+
+int fumi_hip_xpanel_fwd(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int Qn, int D, int h0,
+        const float* x_s, const float* x_q, const float* W0, float* A0, float* G) {
+    if (!ws || !x_s || !x_q || !W0 || !A0 || !G || B < 1 || S < 1 || Qn < 1 || D < 1 || h0 < 1) return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(ws->device));
+    ProfScope ps(ws, (hipStream_t)stream, FUMI_PH_XPANEL_FWD);
+    return launch_xpanel_fwd((hipStream_t)stream, B, S, Qn, D, h0, x_s, x_q, W0, A0, G);
+}
+
+int fumi_hip_xpanel_bwd(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int Qn, int D, int h0,
+        const float* x_s, const float* x_q, const float* Abar, float scale, float* gW0) {
+    if (!ws || !x_s || !x_q || !Abar || !gW0 || B < 1 || S < 1 || Qn < 1 || D < 1 || h0 < 1) return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(ws->device));
+    hipStream_t st = (hipStream_t)stream;
+    int kc;
+    const int ns = xpanel_bwd_nsplit(B, S, Qn, D, h0, &kc);
+    const long slab = (long)h0 * D;
+    int rc = ws_reserve(ws, ws_align((size_t)ns * slab * 4));
+    if (rc) return rc;
+    float* slabs = ws_f(ws, (size_t)ns * slab);
+    ProfScope ps(ws, st, FUMI_PH_XPANEL_BWD);
+    if ((rc = launch_xpanel_bwd(st, B, S, Qn, D, h0, x_s, x_q, Abar, slabs, kc, ns))) return rc;
+    return launch_reduce_slabs(st, slabs, ns, slab, slab, scale, gW0);
 }
 
 int fumi_hip_linear_fwd(fumi_ws_t* ws, fumi_stream_t stream, int M, int N, int K,

@@ -90,6 +90,15 @@ int launch_reduce_slabs(hipStream_t st, const float* slabs, int nslab, long stri
 int launch_colsum(hipStream_t st, const float* X, int M, int N, long ld, float scale, float* out);
 
 // ------------------------------------------------------------------------------------------------------------
+// the two shared passes over the wide inputs (xpanel.hip)
+// ------------------------------------------------------------------------------------------------------------
+int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
+                      const float* W0, float* A0 /*[B,S+Qn,h0]*/, float* G /*[B,S+Qn,S]*/);
+int xpanel_bwd_nsplit(int B, int S, int Qn, int D, int h0, int* kchunk_out);
+int launch_xpanel_bwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
+                      const float* Abar /*[B,S+Qn,h0]*/, float* slabs /*[nsplit,h0,D]*/, int kchunk, int nsplit);
+
+// ------------------------------------------------------------------------------------------------------------
 // episode engine (episode.hip): inner-loop adaptation, query pass, second-order reverse sweep
 // ------------------------------------------------------------------------------------------------------------
 struct EpisodeProblem {

@@ -24,7 +24,7 @@ constexpr int QR = 32;                 // query rows per workgroup
 constexpr int MAXL = FUMI_MAX_HIDDEN;
 
 struct EpiBuf {
-    float *A0s, *A0q, *Gss, *Gqs;              // [B,S,h0] [B,Qn,h0] [B,S,S] [B,Qn,S]
+    float *A0, *G;                             // [B,R,h0] [B,R,S], R = S+Qn, support rows first (xpanel.hip)
     float *D, *cs;                             // [B,S,h0] [B,h0]
     float *bcur[MAXL], *bh;                    // i>=1: [B,h_i];  [B,N]
     float *Wslot[MAXL], *Whslot;               // i>=1: [B,nslot,h_i*h_{i-1}];  [B,nslot,N*H]
@@ -34,7 +34,7 @@ struct EpiBuf {
     float *pW[MAXL], *pb[MAXL], *pWh, *pbh, *pb0, *pD, *ploss, *pcorr;   // per-tile partial slabs
     float *Wb[MAXL], *bb[MAXL], *Whb, *bhb, *b0b, *Db;                   // adjoint state per episode
     float *abar[MAXL], *X0, *X1, *eb, *lb;     // reverse scratch
-    float *A0bar_s, *A0bar_q;                  // [B,S,h0] [B,Qn,h0]
+    float *A0bar;                              // [B,R,h0] adjoint of A0 (support rows: sum over inner steps)
     int nslot, ntape, ntile, maxh;
 };
 
@@ -71,8 +71,8 @@ __global__ __launch_bounds__(1024) void adapt_kernel(EpiDims d, EpiBuf w, EpiPar
     float* D = w.D + (long)b * S * h0;
     float* cs = w.cs + (long)b * h0;
     float* bh = w.bh + (long)b * N;
-    const float* A0s = w.A0s + (long)b * S * h0;
-    const float* Gss = w.Gss + (long)b * S * S;
+    const float* A0s = w.A0 + (long)b * (S + d.Qn) * h0;
+    const float* Gss = w.G + (long)b * (S + d.Qn) * S;
     float* lg = w.lg + (long)b * S * N;
 
     // ---- initial fast weights: copies of the meta-parameters (slot 0) and of this episode's head
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
     const int slot = d.taped ? d.T : 0;
     const float* D = w.D + (long)b * S * h0;
     float* cs = w.qcs + ((long)b * w.ntile + tile) * h0;
-    const float* A0q = w.A0q + ((long)b * Qn + r0) * h0;
-    const float* Gqs = w.Gqs + ((long)b * Qn + r0) * S;
+    const float* A0q = w.A0 + ((long)b * (S + Qn) + S + r0) * h0;
+    const float* Gqs = w.G + ((long)b * (S + Qn) + S + r0) * S;
     const float* bh = w.bh + (long)b * N;
     const float* Whc = w.Whslot + ((long)b * w.nslot + slot) * N * H;
     float* lq = logits_q + ((long)b * Qn + r0) * N;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
         __syncthreads();
     }
     // layer 0: Abar0 rows of the query set, b0bar, and the adjoint of the low-rank factor D_T
-    float* A0bq = w.A0bar_q + ((long)b * Qn + r0) * h0;
+    float* A0bq = w.A0bar + ((long)b * (S + Qn) + S + r0) * h0;
     for (int i = tid; i < nr * h0; i += nt) A0bq[i] = z[0][i];
     float* pb0 = w.pb0 + pt * h0;
     wg_colsum(nr, h0, z[0], h0, [&](int n, float s) { pb0[n] = s; });
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(1024) void reverse_kernel(EpiDims d, EpiBuf w, floa
     float* bhb = w.bhb + (long)b * N;
     float* b0b = w.b0b + (long)b * h0;
     float* Db = w.Db + (long)b * S * h0;
-    float* A0bs = w.A0bar_s + (long)b * S * h0;
+    float* A0bs = w.A0bar + (long)b * (S + d.Qn) * h0;
     auto sum_tiles = [&](float* dst, const float* src, long sz) {
         for (long i = tid; i < sz; i += nt) {
             float s = 0.f;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(1024) void reverse_kernel(EpiDims d, EpiBuf w, floa
     __syncthreads();
 
     if (d.second_order) {
-        const float* Gss = w.Gss + (long)b * S * S;
+        const float* Gss = w.G + (long)b * (S + d.Qn) * S;
         float* cs = w.cs + (long)b * h0;
         float* eb = w.eb + (long)b * S * N;
         float* lb = w.lb + (long)b * S * N;
@@ -507,7 +507,7 @@ void carve(Carver& c, const EpisodeProblem& p, EpiBuf& w) {
     for (int i = 0; i < p.L; ++i) maxh = p.h[i] > maxh ? p.h[i] : maxh;
     w.maxh = maxh;
     const size_t nt = w.ntile;
-    w.A0s = c.take(B * S * h0); w.A0q = c.take(B * Qn * h0); w.Gss = c.take(B * S * S); w.Gqs = c.take(B * Qn * S);
+    w.A0 = c.take(B * (S + Qn) * h0); w.G = c.take(B * (S + Qn) * S);
     w.D = c.take(B * S * h0); w.cs = c.take(B * h0);
     w.bh = c.take(B * N); w.Whslot = c.take(B * w.nslot * N * H);
     w.tp = c.take(B * w.ntape * S * N); w.te = c.take(B * w.ntape * S * N);
@@ -525,7 +525,7 @@ void carve(Carver& c, const EpisodeProblem& p, EpiBuf& w) {
         w.pWh = c.take(B * nt * N * H); w.pbh = c.take(B * nt * N); w.pb0 = c.take(B * nt * h0); w.pD = c.take(B * nt * S * h0);
         w.Whb = c.take(B * N * H); w.bhb = c.take(B * N); w.b0b = c.take(B * h0); w.Db = c.take(B * S * h0);
         w.X0 = c.take(B * S * maxh); w.X1 = c.take(B * S * maxh); w.eb = c.take(B * S * N); w.lb = c.take(B * S * N);
-        w.A0bar_s = c.take(B * S * h0); w.A0bar_q = c.take(B * Qn * h0);
+        w.A0bar = c.take(B * (S + Qn) * h0);
         for (size_t i = 0; i < L; ++i) {
             const size_t hi = p.h[i], hp = i ? p.h[i - 1] : 0;
             w.abar[i] = c.take(B * S * hi);
@@ -537,7 +537,6 @@ void carve(Carver& c, const EpisodeProblem& p, EpiBuf& w) {
     }
 }
 
-constexpr int GW0_KCHUNK = 1024;     // contraction rows per split of gW0 = Abar0^T X (multiple of the GEMM's BK)
 
 }  // namespace
 
@@ -546,7 +545,8 @@ size_t episode_workspace_bytes(const EpisodeProblem& p) {
     EpiBuf w;
     carve(c, p, w);
     if (p.need_grad) {
-        const size_t ns = (size_t)((long)p.B * p.S + GW0_KCHUNK - 1) / GW0_KCHUNK + ((long)p.B * p.Qn + GW0_KCHUNK - 1) / GW0_KCHUNK;
+        int kc;
+        const size_t ns = (size_t)xpanel_bwd_nsplit(p.B, p.S, p.Qn, p.D, p.h[0], &kc);
         c.bytes += ws_align(ns * p.h[0] * (size_t)p.D * sizeof(float));
     }
     return c.bytes;
@@ -566,19 +566,10 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     const int h0 = p.h[0];
     int rc;
 
-    // ---- shared GEMM 1: A0 = X W0^T (support and query rows), G = X Xs^T (batched per episode)
+    // ---- shared pass 1 over X: [A0 | G] = [Xs;Xq] [W0;Xs]^T for every episode, one launch (xpanel.hip)
     {
-        GemmArgs g = gemm_args(p.B * p.S, h0, p.D, p.x_s, p.D, p.W[0], p.D, w.A0s, h0);
-        { ProfScope ps(ws, st, FUMI_PH_GEMM_A0S); if ((rc = launch_gemm(st, g, 0, 0))) return rc; }
-        g = gemm_args(p.B * p.Qn, h0, p.D, p.x_q, p.D, p.W[0], p.D, w.A0q, h0);
-        { ProfScope ps(ws, st, FUMI_PH_GEMM_A0Q); if ((rc = launch_gemm(st, g, 0, 0))) return rc; }
-        ProfScope ps(ws, st, FUMI_PH_GRAM);
-        g = gemm_args(p.S, p.S, p.D, p.x_s, p.D, p.x_s, p.D, w.Gss, p.S);
-        g.nbatch = p.B; g.sA = (long)p.S * p.D; g.sB = (long)p.S * p.D; g.sC = (long)p.S * p.S;
-        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
-        g = gemm_args(p.Qn, p.S, p.D, p.x_q, p.D, p.x_s, p.D, w.Gqs, p.S);
-        g.nbatch = p.B; g.sA = (long)p.Qn * p.D; g.sB = (long)p.S * p.D; g.sC = (long)p.Qn * p.S;
-        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+        ProfScope ps(ws, st, FUMI_PH_XPANEL_FWD);
+        if ((rc = launch_xpanel_fwd(st, p.B, p.S, p.Qn, p.D, h0, p.x_s, p.x_q, p.W[0], w.A0, w.G))) return rc;
     }
     // ---- per-episode phases
     EpiParams prm;
@@ -611,23 +602,15 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
         }
         if ((rc = launch_reduce_slabs(st, w.b0b, p.B, h0, h0, p.grad_scale, p.gb[0]))) return rc;
     }
-    ProfScope pg(ws, st, FUMI_PH_GEMM_GW0);
-    // ---- shared GEMM 2: gW0 = Abar0^T X, contraction over all rows of all episodes, split into slabs
+    // ---- shared pass 2 over X: gW0 = Abar0^T [Xs;Xq], contraction over all B*R rows split into slabs (xpanel.hip)
     {
-        const long Ks = (long)p.B * p.S, Kq = (long)p.B * p.Qn;
-        const int ns = d.second_order ? (int)((Ks + GW0_KCHUNK - 1) / GW0_KCHUNK) : 0;
-        const int nq = (int)((Kq + GW0_KCHUNK - 1) / GW0_KCHUNK);
+        ProfScope pg(ws, st, FUMI_PH_XPANEL_BWD);
+        int kc;
+        const int ns = xpanel_bwd_nsplit(p.B, p.S, p.Qn, p.D, h0, &kc);
         const long slab = (long)h0 * p.D;
-        float* slabs = ws_f(ws, (size_t)(ns + nq) * slab);
-        if (ns) {
-            GemmArgs g = gemm_args(h0, p.D, (int)Ks, w.A0bar_s, h0, p.x_s, p.D, slabs, p.D);
-            g.kchunk = GW0_KCHUNK; g.nsplit = ns; g.sCsplit = slab;
-            if ((rc = launch_gemm(st, g, 1, 1))) return rc;
-        }
-        GemmArgs g = gemm_args(h0, p.D, (int)Kq, w.A0bar_q, h0, p.x_q, p.D, slabs + (long)ns * slab, p.D);
-        g.kchunk = GW0_KCHUNK; g.nsplit = nq; g.sCsplit = slab;
-        if ((rc = launch_gemm(st, g, 1, 1))) return rc;
-        if ((rc = launch_reduce_slabs(st, slabs, ns + nq, slab, slab, p.grad_scale, p.gW[0]))) return rc;
+        float* slabs = ws_f(ws, (size_t)ns * slab);
+        if ((rc = launch_xpanel_bwd(st, p.B, p.S, p.Qn, p.D, h0, p.x_s, p.x_q, w.A0bar, slabs, kc, ns))) return rc;
+        if ((rc = launch_reduce_slabs(st, slabs, ns, slab, slab, p.grad_scale, p.gW[0]))) return rc;
     }
     return FUMI_OK;
 }

@@ -1,0 +1,384 @@
+// The two shared GEMM passes over the 2048-wide inputs -- the only kernels of a meta-step that touch X.
+//
+//   xpanel_fwd_kernel:  for every episode b,  [A0_b | G_b] = [Xs_b ; Xq_b] . [W0 ; Xs_b]^T
+//        A0_b [R, h0] = layer-0 pre-activations of all R = S+Qn rows with the SHARED meta-weight W0   (torchmeta
+//        MetaLinear.forward via fumi/models/fumi.py:215 at inner step 0), G_b [R, S] = Gram matrix against the support
+//        rows (what turns the per-episode fast weight W0 - alpha*D^T Xs of later steps into a rank-S correction).
+//   xpanel_bwd_kernel:  gW0 = sum_b Abar0_b^T [Xs_b ; Xq_b]   (autograd's AddmmBackward of layer 0 summed over every
+//        use inside the second-order graph, fumi/models/fumi.py:192), contraction over all B*R rows split into slabs.
+//
+// Both run on v_mfma_f32_32x32x2_f32 (exact fp32; 157 TFLOP/s peak).  Tiling: 64x64 output tile per 256-thread
+// workgroup (2x2 waves, one 32x32 accumulator each), 32-deep contraction slabs double-buffered in LDS with the next slab
+// prefetched into registers behind the MFMAs.  X is never copied: a "virtual row" r of episode b is read from
+// x_s[b, r] (r < S) or x_q[b, r-S]; a virtual column c of the forward pass from W0[c] (c < h0) or x_s[b, c-h0].
+//
+// XCD-aware placement (forward): workgroup ids that are equal mod 8 share an XCD (round-robin dispatch), so episode
+// b is given only ids with id % 8 == b % 8: all column tiles of an episode's row panel, and the W0 slab they all stream,
+// hit one 4 MiB L2.  Placement only affects speed.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int KC_LD = BK + 4;           // row stride of a k-contiguous LDS image: 144 B -> conflict-free ds_read_b128
+constexpr int TILE_F = 64 * KC_LD;
+
+struct XPanel {
+    const float* x_s; const float* x_q; const float* W0;
+    int B, S, Qn, D, h0;
+};
+
+__device__ __forceinline__ const float* xrow(const XPanel& p, int b, int r) {
+    return r < p.S ? p.x_s + ((long)b * p.S + r) * p.D : p.x_q + ((long)b * p.Qn + (r - p.S)) * p.D;
+}
+
+// ---- forward -----------------------------------------------------------------------------------------------------
+// Generic-shape forward (any D / alignment): simple 32-deep double-buffered loop.  The bench shapes take
+// xpanel_fwd_kernel below.
+template <bool FAST>
+__global__ __launch_bounds__(256) void xpanel_fwd_generic_kernel(XPanel p, float* __restrict__ A0, float* __restrict__ G,
+                                                         int tiles_m, int tiles_n, int stagger) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][TILE_F];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int R = p.S + p.Qn, C = p.h0 + p.S, K = p.D;
+    // id -> (episode, tile) with id % 8 == episode % 8
+    const int tiles = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int b = xcd + 8 * (j / tiles), t = j % tiles;
+    if (b >= p.B) return;
+    const int m0 = (t / tiles_n) * 64, n0 = (t % tiles_n) * 64;
+
+    // each thread stages 2 float4 of the A tile and 2 of the B tile per slab: rows (f>>3), k offset (f&7)*4
+    const float* arow[2]; const float* brow[2]; bool aok[2], bok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + 256 * i;
+        const int r = m0 + (f >> 3), c = n0 + (f >> 3);
+        aok[i] = r < R; bok[i] = c < C;
+        arow[i] = xrow(p, b, aok[i] ? r : 0);
+        brow[i] = c < p.h0 ? p.W0 + (long)c * K : p.x_s + ((long)b * p.S + (bok[i] ? c - p.h0 : 0)) * K;
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load = [&](f32x4 (&ra)[2], f32x4 (&rb)[2], int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = k0 + (((tid + 256 * i) & 7) << 2);
+            if (FAST) {
+                ra[i] = *(const f32x4*)(arow[i] + k);       // raw; masked when written to LDS (keeps the loads in
+                rb[i] = *(const f32x4*)(brow[i] + k);       // flight behind the MFMAs instead of waiting here)
+            } else {
+                f32x4 va = zero4, vb = zero4;
+                for (int e = 0; e < 4; ++e) if (aok[i] && k + e < K) va[e] = arow[i][k + e];
+                for (int e = 0; e < 4; ++e) if (bok[i] && k + e < K) vb[e] = brow[i][k + e];
+                ra[i] = va; rb[i] = vb;
+            }
+        }
+    };
+    auto store = [&](const f32x4 (&ra)[2], const f32x4 (&rb)[2], int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            *(f32x4*)(lds[buf][0] + (f >> 3) * KC_LD + ((f & 7) << 2)) = (!FAST || aok[i]) ? ra[i] : zero4;
+            *(f32x4*)(lds[buf][1] + (f >> 3) * KC_LD + ((f & 7) << 2)) = (!FAST || bok[i]) ? rb[i] : zero4;
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    f32x4 ra[2], rb[2];
+    const int nslab = (K + BK - 1) / BK;
+    // rotate the slab order per workgroup: workgroups that run in lock-step then stream different 128-byte columns of
+    // their 8 KiB-strided rows at any moment (spreads the L2/fabric channels); the sum order per tile stays fixed
+    const int s0 = stagger ? (int)(((long)blockIdx.x * stagger) % nslab) : 0;
+    auto slab_k = [&](int s) { int q = s + s0; if (q >= nslab) q -= nslab; return q * BK; };
+    load(ra, rb, slab_k(0));
+    store(ra, rb, 0);
+    __syncthreads();
+    const int li = lane & 31, kh = lane >> 5;
+    for (int s = 0; s < nslab; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nslab) load(ra, rb, slab_k(s + 1));
+        const float* TA = lds[cur][0] + (wm * 32 + li) * KC_LD + 4 * kh;
+        const float* TB = lds[cur][1] + (wn * 32 + li) * KC_LD + 4 * kh;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 av = *(const f32x4*)(TA + 8 * c);
+            const f32x4 bv = *(const f32x4*)(TB + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
+        }
+        if (s + 1 < nslab) store(ra, rb, cur ^ 1);
+        __syncthreads();
+    }
+    // epilogue: column n -> A0 (n < h0) or G (n - h0 < S); register r of lane l is row (r&3)+8*(r>>2)+4*(l>>5)
+    const int n = n0 + wn * 32 + li;
+    if (n < C) {
+        float* base; long ld; int col;
+        if (n < p.h0) { base = A0 + (long)b * R * p.h0; ld = p.h0; col = n; }
+        else          { base = G + (long)b * R * p.S;  ld = p.S;  col = n - p.h0; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (m < R) base[(long)m * ld + col] = acc[r];
+        }
+    }
+}
+
+
+// ---- forward, fast path (D % 64 == 0, 16-byte aligned rows): the dominant kernel of a meta-step ---------------------
+// 64x64 tile, 64-deep slabs in two LDS buffers, software-pipelined by hand so the matrix pipe never waits for memory:
+//   * global -> registers for slab s+1 is issued at the top of slab s and written to the other LDS buffer only after
+//     24 of the slab's 32 MFMAs have been issued (unconditional float4 loads: hipcc turns guarded per-element loads into
+//     branches separated by vmcnt(0), i.e. dependent L2 round trips; rows past the panel are clamped and zeroed at the
+//     LDS write instead)
+//   * MFMA operand fragments are double-buffered in registers per group of 8 MFMAs (16 k): the ds_read_b128s of group
+//     g+1 are in flight while group g runs, so only the first group after the slab barrier exposes LDS latency
+// A lone workgroup is then ~90 % matrix-bound, which is what lets two co-resident workgroups share a CU without the
+// older one starving the younger (measured: with a memory-latency-bound loop the second workgroup only got the gaps).
+constexpr int FBK = 64, FLD = FBK + 4;          // 272-byte rows: 16 consecutive rows hit 16 distinct 4-bank slots
+// NST = depth of the register staging ring: the global loads of slab s+NST are issued while slab s is multiplied, so a
+// load has NST*2048 matrix-pipe cycles to return (an HBM/Infinity-Cache miss under load is ~2 us = ~4000 cycles).
+template <int NST>
+__global__ __launch_bounds__(256) void xpanel_fwd_kernel(XPanel p, float* __restrict__ A0, float* __restrict__ G,
+                                                         int tiles_m, int tiles_n, unsigned long long* trace) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][64 * FLD];
+    unsigned long long t_rt = 0, t_ck = 0;
+    if (trace) { t_rt = __builtin_amdgcn_s_memrealtime(); t_ck = __builtin_amdgcn_s_memtime(); }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int R = p.S + p.Qn, C = p.h0 + p.S, K = p.D;
+    const int tiles = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int b = xcd + 8 * (j / tiles), t = j % tiles;
+    if (b >= p.B) return;
+    const int m0 = (t / tiles_n) * 64, n0 = (t % tiles_n) * 64;
+
+    // staging map: float4 f = tid + 256 i  ->  tile row (f >> 4), k offset (f & 15) * 4
+    const float* arow[4]; const float* brow[4]; bool aok[4], bok[4];
+    const int k4 = (tid & 15) << 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = (tid >> 4) + 16 * i;
+        const int r = m0 + rr, c = n0 + rr;
+        aok[i] = r < R; bok[i] = c < C;
+        arow[i] = xrow(p, b, aok[i] ? r : 0) + k4;
+        brow[i] = (c < p.h0 ? p.W0 + (long)c * K : p.x_s + ((long)b * p.S + (bok[i] ? c - p.h0 : 0)) * K) + k4;
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ga[NST][4], gb[NST][4];
+    const int li = lane & 31, kh = lane >> 5;
+    const int aoff = (wm * 32 + li) * FLD + 4 * kh, boff = (wn * 32 + li) * FLD + 4 * kh;
+    f32x4 fa[2][2], fb[2][2];                   // [register buffer][half of the 16-k group]
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int nslab = K / FBK;
+
+#define XP_GLOAD(st, k0)                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+        ga[st][i] = *(const f32x4*)(arow[i] + (k0)); gb[st][i] = *(const f32x4*)(brow[i] + (k0)); }
+#define XP_LSTORE(st, buf)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+        const int off = ((tid >> 4) + 16 * i) * FLD + k4;                                                    \
+        *(f32x4*)(lds[buf][0] + off) = aok[i] ? ga[st][i] : zero4;                                           \
+        *(f32x4*)(lds[buf][1] + off) = bok[i] ? gb[st][i] : zero4; }
+#define XP_FREAD(rb, buf, g)                                                                                 \
+    { fa[rb][0] = *(const f32x4*)(lds[buf][0] + aoff + 16 * (g));     fb[rb][0] = *(const f32x4*)(lds[buf][1] + boff + 16 * (g)); \
+      fa[rb][1] = *(const f32x4*)(lds[buf][0] + aoff + 16 * (g) + 8); fb[rb][1] = *(const f32x4*)(lds[buf][1] + boff + 16 * (g) + 8); }
+#define XP_MMA8(rb)                                                                                          \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h) _Pragma("unroll") for (int e = 0; e < 4; ++e)              \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rb][h][e], fb[rb][h][e], acc, 0, 0, 0);
+// one slab: stage ST holds slab s+1 (loaded NST slabs ago) and is refilled with slab s+1+NST after it went to LDS
+#define XP_SLAB(ST, s)                                                                                       \
+    if ((s) < nslab) {                                                                                       \
+        const int cur = (s) & 1;                                                                             \
+        const bool more = (s) + 1 < nslab;                                                                   \
+        XP_FREAD(1, cur, 1) XP_MMA8(0)                                                                       \
+        XP_FREAD(0, cur, 2) XP_MMA8(1)                                                                       \
+        XP_FREAD(1, cur, 3) XP_MMA8(0)                                                                       \
+        if (more) { XP_LSTORE(ST, cur ^ 1) }                                                                 \
+        if ((s) + 1 + NST < nslab) { XP_GLOAD(ST, ((s) + 1 + NST) * FBK) }                                   \
+        XP_MMA8(1)                                                                                           \
+        __syncthreads();                                                                                     \
+        if (more) XP_FREAD(0, cur ^ 1, 0)                                                                    \
+    }
+
+    // prologue: slab 0 straight to LDS, slabs 1..NST into the ring (stage of slab q is (q-1) % NST)
+    XP_GLOAD(0, 0)
+    XP_LSTORE(0, 0)
+    if (1 < nslab) { XP_GLOAD(0, 1 * FBK) }
+    if (NST > 1 && 2 < nslab) { XP_GLOAD(1 % NST, 2 * FBK) }
+    if (NST > 2 && 3 < nslab) { XP_GLOAD(2 % NST, 3 * FBK) }
+    __syncthreads();
+    XP_FREAD(0, 0, 0)
+    for (int s = 0; s < nslab; s += NST) {
+        XP_SLAB(0, s)
+        if (NST > 1) { XP_SLAB(1 % NST, s + 1) }
+        if (NST > 2) { XP_SLAB(2 % NST, s + 2) }
+    }
+#undef XP_GLOAD
+#undef XP_LSTORE
+#undef XP_FREAD
+#undef XP_MMA8
+#undef XP_SLAB
+    if (trace && tid == 0) {      // dev tracing (tools/trace_xpanel.py): wall ticks (100 MHz), shader cycles, placement
+        trace[blockIdx.x * 6 + 0] = t_rt;
+        trace[blockIdx.x * 6 + 1] = __builtin_amdgcn_s_memrealtime();
+        trace[blockIdx.x * 6 + 2] = t_ck;
+        trace[blockIdx.x * 6 + 3] = __builtin_amdgcn_s_memtime();
+        trace[blockIdx.x * 6 + 4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+        trace[blockIdx.x * 6 + 5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+    }
+    const int n = n0 + wn * 32 + li;
+    if (n < C) {
+        float* base; long ld; int col;
+        if (n < p.h0) { base = A0 + (long)b * R * p.h0; ld = p.h0; col = n; }
+        else          { base = G + (long)b * R * p.S;  ld = p.S;  col = n - p.h0; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (m < R) base[(long)m * ld + col] = acc[r];
+        }
+    }
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------------
+// slab[z][i, j] = sum over global rows g in [z*kchunk, (z+1)*kchunk) of Abar0[g, i] * X(g)[j];  g = b*R + r
+template <bool FAST>     // FAST: h0 % 64 == 0, D % 64 == 0, aligned -> unconditional float4 staging loads (see forward)
+__global__ __launch_bounds__(256) void xpanel_bwd_kernel(XPanel p, const float* __restrict__ Abar, float* __restrict__ slabs,
+                                                         int kchunk) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][32 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int R = p.S + p.Qn, M = p.h0, Nn = p.D;
+    const long Ktot = (long)p.B * R;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const long kbeg = (long)blockIdx.z * kchunk;
+    const long kend = min(Ktot, kbeg + kchunk);
+    float* C = slabs + (long)blockIdx.z * M * Nn;
+
+    // staging map: float4 f -> contraction row (f>>4), columns (f&15)*4 .. +3 of the tile.  The (episode, row) of each
+    // thread's contraction row is tracked incrementally (+32 rows per slab) instead of dividing by R every slab.
+    bool okf[2] = {true, true};
+    int gb[2], gr[2];                        // episode / row-in-panel of contraction row  kbeg + s*BK + (f>>4)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long g = kbeg + ((tid + 256 * i) >> 4);
+        gb[i] = (int)(g / R); gr[i] = (int)(g - (long)gb[i] * R);
+    }
+    auto load = [&](f32x4 (&ra)[2], f32x4 (&rb)[2], long k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            const long g = k0 + (f >> 4);
+            const int c4 = (f & 15) << 2;
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            const bool ok = g < kend;
+            const int b = ok ? gb[i] : 0, r = ok ? gr[i] : 0;
+            const float* pa = Abar + ((long)b * R + r) * M + m0 + c4;
+            const float* pb = xrow(p, b, r) + n0 + c4;
+            if (FAST) {
+                ra[i] = *(const f32x4*)pa;                  // raw; masked when written to LDS
+                rb[i] = *(const f32x4*)pb;
+                okf[i] = ok;
+            } else {
+                f32x4 va = zero4, vb = zero4;
+                for (int e = 0; e < 4; ++e) if (ok && m0 + c4 + e < M) va[e] = pa[e];
+                for (int e = 0; e < 4; ++e) if (ok && n0 + c4 + e < Nn) vb[e] = pb[e];
+                ra[i] = va; rb[i] = vb;
+            }
+            gr[i] += BK;                                    // next slab's row
+            while (gr[i] >= R) { gr[i] -= R; ++gb[i]; }
+        }
+    };
+    auto store = [&](const f32x4 (&ra)[2], const f32x4 (&rb)[2], int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            *(f32x4*)(lds[buf][0] + (f >> 4) * 64 + ((f & 15) << 2)) = (!FAST || okf[i]) ? ra[i] : zero4;
+            *(f32x4*)(lds[buf][1] + (f >> 4) * 64 + ((f & 15) << 2)) = (!FAST || okf[i]) ? rb[i] : zero4;
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    f32x4 ra[2], rb[2];
+    const int nslab = (int)((kend - kbeg + BK - 1) / BK);
+    if (nslab > 0) { load(ra, rb, kbeg); store(ra, rb, 0); }
+    __syncthreads();
+    const int li = lane & 31, kh = lane >> 5;
+    for (int s = 0; s < nslab; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nslab) load(ra, rb, kbeg + (long)(s + 1) * BK);
+        const float* TA = lds[cur][0] + wm * 32 + li;
+        const float* TB = lds[cur][1] + wn * 32 + li;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const int k = 2 * k2 + kh;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(TA[k * 64], TB[k * 64], acc, 0, 0, 0);
+        }
+        if (s + 1 < nslab) store(ra, rb, cur ^ 1);
+        __syncthreads();
+    }
+    const int n = n0 + wn * 32 + li;
+    if (n < Nn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (m < M) C[(long)m * Nn + n] = acc[r];
+        }
+    }
+}
+
+inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
+unsigned long long* g_trace = nullptr;      // dev tracing only (tools/trace_xpanel.py)
+
+}  // namespace
+
+extern "C" void fumi_dbg_set_trace(void* p) { g_trace = (unsigned long long*)p; }
+
+int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
+                      const float* W0, float* A0, float* G) {
+    XPanel p{x_s, x_q, W0, B, S, Qn, D, h0};
+    const int tiles_m = (S + Qn + 63) / 64, tiles_n = (h0 + S + 63) / 64;
+    const int nper = (B + 7) / 8;
+    const bool aligned = al16(x_s) && al16(x_q) && al16(W0);
+    const dim3 grid(8 * nper * tiles_m * tiles_n);
+    static const int nst = getenv("FUMI_XP_NST") ? atoi(getenv("FUMI_XP_NST")) : 2;
+    if (aligned && D % FBK == 0) {
+        if (nst == 1) hipLaunchKernelGGL(xpanel_fwd_kernel<1>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, g_trace);
+        else if (nst == 2) hipLaunchKernelGGL(xpanel_fwd_kernel<2>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, g_trace);
+        else hipLaunchKernelGGL(xpanel_fwd_kernel<3>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, g_trace);
+    }
+    else if (aligned && D % BK == 0) hipLaunchKernelGGL(xpanel_fwd_generic_kernel<true>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, 0);
+    else hipLaunchKernelGGL(xpanel_fwd_generic_kernel<false>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, 0);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+int xpanel_bwd_nsplit(int B, int S, int Qn, int D, int h0, int* kchunk_out) {
+    const long Ktot = (long)B * (S + Qn);
+    const long tiles = (long)((h0 + 63) / 64) * ((D + 63) / 64);
+    long ns = (1024 + tiles - 1) / tiles;                // ~4 workgroups per CU
+    if (ns < 1) ns = 1;
+    if (ns > 32) ns = 32;
+    long kc = ((Ktot + ns - 1) / ns + BK - 1) / BK * BK;
+    if (kc < BK) kc = BK;
+    *kchunk_out = (int)kc;
+    return (int)((Ktot + kc - 1) / kc);
+}
+
+int launch_xpanel_bwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
+                      const float* Abar, float* slabs, int kchunk, int nsplit) {
+    XPanel p{x_s, x_q, nullptr, B, S, Qn, D, h0};
+    const bool fast = (D % 64 == 0) && (h0 % 64 == 0) && al16(x_s) && al16(x_q) && al16(Abar);
+    const dim3 grid((D + 63) / 64, (h0 + 63) / 64, nsplit);
+    if (fast) hipLaunchKernelGGL(xpanel_bwd_kernel<true>, grid, dim3(256), 0, st, p, Abar, slabs, kchunk);
+    else hipLaunchKernelGGL(xpanel_bwd_kernel<false>, grid, dim3(256), 0, st, p, Abar, slabs, kchunk);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}

@@ -20,7 +20,7 @@ SYMBOLS = [
     "fumi_hip_workspace_create", "fumi_hip_workspace_destroy", "fumi_hip_workspace_bytes", "fumi_hip_read_status",
     "fumi_hip_set_profiling", "fumi_hip_get_profile", "fumi_hip_phase_name",
     "fumi_hip_fumi_step", "fumi_hip_maml_step", "fumi_hip_am3_step",
-    "fumi_hip_glove_bag", "fumi_hip_class_text_select",
+    "fumi_hip_glove_bag", "fumi_hip_class_text_select", "fumi_hip_xpanel_fwd", "fumi_hip_xpanel_bwd",
     "fumi_hip_linear_fwd", "fumi_hip_linear_bwd_data", "fumi_hip_linear_bwd_weight",
 ]
 
@@ -74,6 +74,8 @@ def lib():
         L.fumi_hip_glove_bag.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int, c_int,
                                          c_int, c_void_p]
         L.fumi_hip_class_text_select.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p] * 3
+        L.fumi_hip_xpanel_fwd.argtypes = [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 5
+        L.fumi_hip_xpanel_bwd.argtypes = [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 3 + [c_float, c_void_p]
         L.fumi_hip_linear_fwd.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 3 + [c_int, c_void_p]
         L.fumi_hip_linear_bwd_data.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 3
         L.fumi_hip_linear_bwd_weight.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 4
@@ -331,6 +333,28 @@ def class_text_select(ws, text_s, y_s, n_way):
                                           _i64(y_s, "y_s"), _f32(out, "out"))
     _check(rc, "fumi_hip_class_text_select")
     return out
+
+
+def xpanel_fwd(ws, x_s, x_q, W0):
+    """A0 [B,S+Qn,h0], G [B,S+Qn,S] (support rows first)."""
+    dev = _dev(x_s)
+    B, S, D = x_s.shape
+    Qn, h0 = x_q.shape[1], W0.shape[0]
+    A0 = torch.empty(B, S + Qn, h0, device=dev, dtype=torch.float32)
+    G = torch.empty(B, S + Qn, S, device=dev, dtype=torch.float32)
+    _check(lib().fumi_hip_xpanel_fwd(ws.handle, _stream(dev), B, S, Qn, D, h0, _f32(x_s, "x_s"), _f32(x_q, "x_q"),
+                                     _f32(W0, "W0"), _f32(A0, "A0"), _f32(G, "G")), "fumi_hip_xpanel_fwd")
+    return A0, G
+
+
+def xpanel_bwd(ws, x_s, x_q, Abar, scale=1.0):
+    dev = _dev(x_s)
+    B, S, D = x_s.shape
+    Qn, h0 = x_q.shape[1], Abar.shape[2]
+    gW0 = torch.empty(h0, D, device=dev, dtype=torch.float32)
+    _check(lib().fumi_hip_xpanel_bwd(ws.handle, _stream(dev), B, S, Qn, D, h0, _f32(x_s, "x_s"), _f32(x_q, "x_q"),
+                                     _f32(Abar, "Abar"), float(scale), _f32(gW0, "gW0")), "fumi_hip_xpanel_bwd")
+    return gW0
 
 
 def linear_fwd(ws, x, W, b=None, act=0):

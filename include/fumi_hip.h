@@ -64,14 +64,14 @@ int   fumi_hip_read_status(fumi_ws_t* ws, fumi_stream_t stream, int* status_out)
  * Used by bench.py to time the dominant kernel live inside the timed region.  Off by default (no events recorded). */
 #define FUMI_PH_SELECT     0   /* class text select                                   */
 #define FUMI_PH_HYPER_FWD  1   /* hypernetwork forward (2 GEMMs)                       */
-#define FUMI_PH_GEMM_A0S   2   /* A0s = Xs W0^T                                        */
-#define FUMI_PH_GEMM_A0Q   3   /* A0q = Xq W0^T   <- dominant kernel of the FuMI step  */
-#define FUMI_PH_GRAM       4   /* Gss, Gqs (batched X Xs^T)                            */
+#define FUMI_PH_GEMM_A0S   2   /* AM3: image encoder on the support rows               */
+#define FUMI_PH_GEMM_A0Q   3   /* AM3: image encoder on the query rows                 */
+#define FUMI_PH_XPANEL_FWD 4   /* [A0|G] = [Xs;Xq][W0;Xs]^T  <- dominant kernel of the FuMI/MAML step */
 #define FUMI_PH_ADAPT      5   /* inner loop                                           */
 #define FUMI_PH_QUERY      6   /* query forward/backward                               */
 #define FUMI_PH_REVERSE    7   /* second-order reverse sweep                           */
 #define FUMI_PH_REDUCE     8   /* sums over episodes                                   */
-#define FUMI_PH_GEMM_GW0   9   /* gW0 = Abar0^T X (split-K GEMMs + slab reduce)        */
+#define FUMI_PH_XPANEL_BWD 9   /* gW0 = Abar0^T X (split-K slabs + slab reduce)        */
 #define FUMI_PH_HYPER_BWD 10   /* hypernetwork backward                                */
 #define FUMI_PH_AM3       11   /* AM3 fused head kernels                               */
 #define FUMI_PH_COUNT     12
@@ -126,6 +126,13 @@ int fumi_hip_glove_bag(fumi_ws_t* ws, fumi_stream_t stream, const int64_t* tok, 
 /* out[b,n,:] = text_s[b, first s with y_s[b,s]==n, :] */
 int fumi_hip_class_text_select(fumi_ws_t* ws, fumi_stream_t stream, int B, int N, int S, int Dt,
         const float* text_s, const int64_t* y_s, float* out);
+/* The two shared passes over the wide inputs (csrc/xpanel.hip), exported for unit parity tests and tuning:
+ *   fwd: A0[B,S+Qn,h0] = [Xs;Xq] W0^T, G[B,S+Qn,S] = [Xs;Xq] Xs^T per episode (support rows first)
+ *   bwd: gW0[h0,D] = scale * sum_b Abar[b]^T [Xs_b;Xq_b]   (Abar [B,S+Qn,h0]) */
+int fumi_hip_xpanel_fwd(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int Qn, int D, int h0,
+        const float* x_s, const float* x_q, const float* W0, float* A0, float* G);
+int fumi_hip_xpanel_bwd(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int Qn, int D, int h0,
+        const float* x_s, const float* x_q, const float* Abar, float scale, float* gW0);
 /* y[M,N] = act(x[M,K] W[N,K]^T + b[N]);  act: 0 none, 1 relu, 2 tanh.  b may be NULL. */
 int fumi_hip_linear_fwd(fumi_ws_t* ws, fumi_stream_t stream, int M, int N, int K,
         const float* x, const float* W, const float* b, int act, float* y);
