@@ -13,6 +13,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ------------------------------------------------------------------------------------------------------------
 // workspace: one hipMalloc'd slab, carved per call by a bump allocator (all sizes known on the host).
 // ------------------------------------------------------------------------------------------------------------
+struct f32pair { float x, y; };      // two-float "pre" value of wg_mm2 epilogues
 struct ProfRec { int phase; hipEvent_t a, b; };
 struct fumi_ws {
     int device;
@@ -128,15 +129,58 @@ int launch_split_head_grad(hipStream_t st, int B, int N, int H, const float* hea
 
 #ifdef __HIPCC__
 // ------------------------------------------------------------------------------------------------------------
-// wg_mm: workgroup-cooperative small matrix product straight from (L2-resident) memory on the f32 MFMA.
+// wg_mm: workgroup-cooperative small matrix product on the f32 MFMA, operands staged through LDS.
 //   for m<M, n<N:  epi(m, n, sum_k A(m,k) * B(k,n)),   A(m,k) = A[m*sam + k*sak],  B(k,n) = B[k*sbk + n*sbn]
-// Every wave owns 16x16 output tiles (v_mfma_f32_16x16x4_f32: lane l feeds A[l&15][l>>4], B[l>>4][l&15]; result
-// register r of lane l is row 4*(l>>4)+r, column l&15).  All lanes run the MFMAs (loop bounds are wave-uniform);
-// out-of-range operands are fed as zeros.  The caller synchronises (__syncthreads) between dependent products.
+//
+// The per-episode matrices ([S|32, <=256] activations, [64,256] fast weights) live in L2; reading MFMA fragments
+// straight from there made every 4-MFMA step a dependent L2 round trip.  Instead the whole workgroup copies the two
+// operands (or a K-chunk of them when they do not fit `lds_cap` floats) into LDS with coalesced 16-byte loads -- one
+// L2 latency per product -- and the waves then run v_mfma_f32_16x16x4_f32 from LDS (lane l feeds A[l&15][k] and
+// B[k][l&15] with k = kk + 4*(l>>4) + j for the j-th MFMA of a 16-deep step; result register r of lane l is row
+// 4*(l>>4)+r, column l&15).  Images are zero-padded to multiples of 16 so no operand needs a bounds check.
+//   operand contiguous along k  -> image [row][kp+4]: one ds_read_b128 gives the 4 k values of a step
+//   operand contiguous along m/n-> image [k][dim+4] : 4 ds_read_b32, conflict-free (row stride = 4 mod 8 floats)
+// Every thread of the block must call it (it contains __syncthreads); products whose outputs feed each other still
+// need the caller's __syncthreads() in between, exactly as before.
 // ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wg_r16(int x) { return (x + 15) & ~15; }
+
+// copy a [rows x cols] matrix whose cols are contiguous in memory (row stride rs) into img[r*ld + c], zero-padded to
+// [rows_p x cols_p]
+__device__ __forceinline__ void wg_stage(float* img, int ld, int rows, int rows_p, int cols, int cols_p,
+                                         const float* src, long rs) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const bool vec = ((rs & 3) == 0) && ((cols & 3) == 0) && ((((uintptr_t)src) & 15) == 0);
+    if (vec) {
+        // 4 independent 16-byte loads in flight per thread before the first LDS write: one L2 latency per 4 elements
+        const int c4n = cols_p >> 2, tot = rows_p * c4n;
+        for (int i0 = tid; i0 < tot; i0 += 4 * nt) {
+            f32x4 v[4]; int off[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * nt;
+                const int r = i / c4n, c = (i - r * c4n) << 2;
+                off[u] = i < tot ? r * ld + c : -1;
+                const bool ok = i < tot && r < rows && c < cols;
+                const float* q = src + (long)(ok ? r : 0) * rs + (ok ? c : 0);
+                const f32x4 t = *(const f32x4*)q;
+                v[u] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (off[u] >= 0) *(f32x4*)(img + off[u]) = v[u];
+        }
+    } else {
+        for (int i = tid; i < rows_p * cols_p; i += nt) {
+            const int r = i / cols_p, c = i - r * cols_p;
+            img[r * ld + c] = (r < rows && c < cols) ? src[(long)r * rs + c] : 0.f;
+        }
+    }
+}
+
+// fallback for operands with no unit stride: fragments straight from memory (correct for any strides, slow)
 template <class Epi>
-__device__ __forceinline__ void wg_mm(int M, int N, int K, const float* A, long sam, long sak,
-                                      const float* B, long sbk, long sbn, Epi&& epi) {
+__device__ __forceinline__ void wg_mm_direct(int M, int N, int K, const float* A, long sam, long sak,
+                                             const float* B, long sbk, long sbn, Epi&& epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int tm = (M + 15) >> 4, tn = (N + 15) >> 4;
     const int r = lane & 15, q = lane >> 4;
@@ -147,20 +191,7 @@ __device__ __forceinline__ void wg_mm(int M, int N, int K, const float* A, long 
         const float* ap = A + (long)(aok ? am : 0) * sam;
         const float* bp = B + (long)(bok ? bn : 0) * sbn;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        int k = 0;
-        for (; k + 16 <= K; k += 16) {
-            float a0 = ap[(long)(k + q) * sak], a1 = ap[(long)(k + 4 + q) * sak];
-            float a2 = ap[(long)(k + 8 + q) * sak], a3 = ap[(long)(k + 12 + q) * sak];
-            float b0 = bp[(long)(k + q) * sbk], b1 = bp[(long)(k + 4 + q) * sbk];
-            float b2 = bp[(long)(k + 8 + q) * sbk], b3 = bp[(long)(k + 12 + q) * sbk];
-            if (!aok) { a0 = a1 = a2 = a3 = 0.f; }
-            if (!bok) { b0 = b1 = b2 = b3 = 0.f; }
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc, 0, 0, 0);
-        }
-        for (; k < K; k += 4) {
+        for (int k = 0; k < K; k += 4) {
             const int kk = k + q;
             const bool kok = kk < K;
             float a = ap[(long)(kok ? kk : 0) * sak], b = bp[(long)(kok ? kk : 0) * sbk];
@@ -176,12 +207,224 @@ __device__ __forceinline__ void wg_mm(int M, int N, int K, const float* A, long 
     }
 }
 
-// column sums of X[M,N] (row stride ld): f(n, sum_m X[m,n]); one thread per column
+// wg_mm2: as wg_mm with a two-part epilogue: pre(m,n) -> small POD is evaluated for all of a lane's output elements BEFORE
+// the MFMA loop (its global loads -- masks, old values, bias terms -- are all in flight together and hidden behind the
+// product), post(m, n, acc, pre_value) consumes them afterwards.
+template <class Pre, class Post>
+__device__ __forceinline__ void wg_mm2(float* lds, int lds_cap, int M, int N, int K, const float* A, long sam, long sak,
+                                       const float* B, long sbk, long sbn, Pre&& pre, Post&& post) {
+    constexpr int TPW = 2;                       // output tiles a wave accumulates at once
+    const bool a_kc = sak == 1, b_kc = sbk == 1;
+    auto epi = [&](int m, int n, float acc) { post(m, n, acc, pre(m, n)); };
+    if ((!a_kc && sam != 1) || (!b_kc && sbn != 1) || M <= 0 || N <= 0) {
+        wg_mm_direct(M, N, K, A, sam, sak, B, sbk, sbn, epi);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int Mp = wg_r16(M), Np = wg_r16(N);
+    const int tm = Mp >> 4, tn = Np >> 4, ntiles = tm * tn;
+    // K-chunk that fits: A image + B image <= lds_cap floats
+    auto need = [&](int kp) { return (a_kc ? Mp * (kp + 4) : kp * (Mp + 4)) + (b_kc ? Np * (kp + 4) : kp * (Np + 4)); };
+    int kc = wg_r16(K > 0 ? K : 1);
+    while (kc > 16 && need(kc) > lds_cap) kc = wg_r16(kc >> 1);
+    if (need(kc) > lds_cap) { wg_mm_direct(M, N, K, A, sam, sak, B, sbk, sbn, epi); return; }
+    const int lda = a_kc ? kc + 4 : Mp + 4, ldb = b_kc ? kc + 4 : Np + 4;
+    float* Ai = lds;
+    float* Bi = lds + (a_kc ? Mp * lda : kc * lda);
+
+    // operands that fit in one chunk are staged once, before the passes over the output tiles
+    const bool single = kc >= K;
+    if (single && K > 0) {
+        const int kp = wg_r16(K);
+        __syncthreads();                                 // previous users of the LDS images are done
+        if (a_kc) wg_stage(Ai, lda, M, Mp, K, kp, A, sam);
+        else      wg_stage(Ai, lda, K, kp, M, Mp, A, sak);
+        if (b_kc) wg_stage(Bi, ldb, N, Np, K, kp, B, sbn);
+        else      wg_stage(Bi, ldb, K, kp, N, Np, B, sbk);
+        __syncthreads();
+    }
+    for (int base = 0; base < ntiles; base += nw * TPW) {
+        using PV = decltype(pre(0, 0));              // any small POD (float, or a pair of floats)
+        f32x4 acc[TPW];
+        PV pv[TPW][4];
+        int tm0[TPW], tn0[TPW];
+        // Branch-free on purpose: tiles past the end are clamped to the last tile (their results are dropped), so the
+        // TPW*4 pre-loads sit in ONE basic block and are all in flight together.  hipcc otherwise gives every guarded
+        // load its own block with a wait: dependent L2 round trips.
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int t = min(base + wave + nw * i, ntiles - 1);
+            tm0[i] = (t / tn) << 4; tn0[i] = (t % tn) << 4;
+            acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pv[i][e] = pre(min(tm0[i] + q * 4 + e, M - 1), min(tn0[i] + r, N - 1));
+        for (int k0 = 0; k0 < K; k0 += kc) {
+            const int kv = min(kc, K - k0);              // valid depth of this chunk
+            const int kp = wg_r16(kv);
+            if (!single) {
+                __syncthreads();
+                if (a_kc) wg_stage(Ai, lda, M, Mp, kv, kp, A + k0, sam);
+                else      wg_stage(Ai, lda, kv, kp, M, Mp, A + (long)k0 * sak, sak);
+                if (b_kc) wg_stage(Bi, ldb, N, Np, kv, kp, B + k0, sbn);
+                else      wg_stage(Bi, ldb, kv, kp, N, Np, B + (long)k0 * sbk, sbk);
+                __syncthreads();
+            }
+            for (int kk = 0; kk < kp; kk += 16) {        // the TPW tiles' fragment reads are independent: all in flight
+                f32x4 av[TPW], bv[TPW];
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const float* ap = a_kc ? Ai + (tm0[i] + r) * lda + 4 * q + kk : Ai + (4 * q + kk) * lda + tm0[i] + r;
+                    const float* bp = b_kc ? Bi + (tn0[i] + r) * ldb + 4 * q + kk : Bi + (4 * q + kk) * ldb + tn0[i] + r;
+                    if (a_kc) av[i] = *(const f32x4*)ap;
+                    else { av[i][0] = ap[0]; av[i][1] = ap[lda]; av[i][2] = ap[2 * lda]; av[i][3] = ap[3 * lda]; }
+                    if (b_kc) bv[i] = *(const f32x4*)bp;
+                    else { bv[i][0] = bp[0]; bv[i][1] = bp[ldb]; bv[i][2] = bp[2 * ldb]; bv[i][3] = bp[3 * ldb]; }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][e], bv[i][e], acc[i], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            if (base + wave + nw * i < ntiles) {         // wave-uniform
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = tm0[i] + q * 4 + e, n = tn0[i] + r;
+                    if (m < M && n < N) post(m, n, acc[i][e], pv[i][e]);
+                }
+            }
+        }
+    }
+}
+
+template <class Epi>
+__device__ __forceinline__ void wg_mm(float* lds, int lds_cap, int M, int N, int K, const float* A, long sam, long sak,
+                                      const float* B, long sbk, long sbn, Epi&& epi) {
+    wg_mm2(lds, lds_cap, M, N, K, A, sam, sak, B, sbk, sbn, [](int, int) { return 0.f; },
+           [&](int m, int n, float acc, float) { epi(m, n, acc); });
+}
+
+// dst[i] = f(i, a[i], b[i], c[i]) for i < n (unused inputs may be nullptr).  float4 accesses, two per input in flight per
+// thread before any use: an elementwise loop written naively is one dependent memory round trip per iteration.
 template <class F>
-__device__ __forceinline__ void wg_colsum(int M, int N, const float* X, long ld, F&& f) {
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+__device__ __forceinline__ void wg_ew(long n, float* dst, const float* a, const float* b, const float* c, F&& f) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    auto al = [](const void* p) { return p == nullptr || ((((uintptr_t)p) & 15) == 0); };
+    if ((n & 3) == 0 && al(dst) && al(a) && al(b) && al(c)) {
+        const long n4 = n >> 2;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        for (long i0 = tid; i0 < n4; i0 += 2L * nt) {
+            const long i1 = i0 + nt;
+            const bool two = i1 < n4;
+            const long j1 = two ? i1 : i0;
+            const f32x4 a0 = a ? *(const f32x4*)(a + 4 * i0) : z4, a1 = a ? *(const f32x4*)(a + 4 * j1) : z4;
+            const f32x4 b0 = b ? *(const f32x4*)(b + 4 * i0) : z4, b1 = b ? *(const f32x4*)(b + 4 * j1) : z4;
+            const f32x4 c0 = c ? *(const f32x4*)(c + 4 * i0) : z4, c1 = c ? *(const f32x4*)(c + 4 * j1) : z4;
+            f32x4 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o0[e] = f(4 * i0 + e, a0[e], b0[e], c0[e]); o1[e] = f(4 * j1 + e, a1[e], b1[e], c1[e]); }
+            *(f32x4*)(dst + 4 * i0) = o0;
+            if (two) *(f32x4*)(dst + 4 * i1) = o1;
+        }
+    } else {
+        for (long i = tid; i < n; i += nt) dst[i] = f(i, a ? a[i] : 0.f, b ? b[i] : 0.f, c ? c[i] : 0.f);
+    }
+}
+
+// dst[i] = sum_t src[t*stride + i], i < n: several independent 16-byte loads in flight per thread (a plain loop is a
+// chain of dependent-latency iterations)
+__device__ __forceinline__ void wg_sum_slabs(float* dst, const float* src, int nslab, long stride, long n) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const bool vec = ((n & 3) == 0) && ((stride & 3) == 0) && ((((uintptr_t)src) & 15) == 0) && ((((uintptr_t)dst) & 15) == 0);
+    if (vec) {
+        const long n4 = n >> 2;
+        for (long i0 = tid; i0 < n4; i0 += 2L * nt) {
+            const long i1 = i0 + nt;
+            const bool two = i1 < n4;
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+            int t = 0;
+            for (; t + 1 < nslab; t += 2) {
+                const f32x4 a0 = *(const f32x4*)(src + t * stride + 4 * i0);
+                const f32x4 a1 = *(const f32x4*)(src + (t + 1) * stride + 4 * i0);
+                const f32x4 b0 = *(const f32x4*)(src + t * stride + 4 * (two ? i1 : i0));
+                const f32x4 b1 = *(const f32x4*)(src + (t + 1) * stride + 4 * (two ? i1 : i0));
+                s0 += a0; s0 += a1; s1 += b0; s1 += b1;
+            }
+            if (t < nslab) {
+                s0 += *(const f32x4*)(src + t * stride + 4 * i0);
+                s1 += *(const f32x4*)(src + t * stride + 4 * (two ? i1 : i0));
+            }
+            *(f32x4*)(dst + 4 * i0) = s0;
+            if (two) *(f32x4*)(dst + 4 * i1) = s1;
+        }
+    } else {
+        for (long i = tid; i < n; i += nt) {
+            float s_ = 0.f;
+            for (int t = 0; t < nslab; ++t) s_ += src[t * stride + i];
+            dst[i] = s_;
+        }
+    }
+}
+
+// dst[i] = src[i], i < n (4 independent 16-byte loads in flight per thread)
+__device__ __forceinline__ void wg_copy(float* dst, const float* src, long n) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const bool vec = ((n & 3) == 0) && ((((uintptr_t)src) & 15) == 0) && ((((uintptr_t)dst) & 15) == 0);
+    if (vec) {
+        const long n4 = n >> 2;
+        for (long i0 = tid; i0 < n4; i0 += 4L * nt) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const long i = i0 + (long)u * nt; v[u] = *(const f32x4*)(src + 4 * (i < n4 ? i : i0)); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const long i = i0 + (long)u * nt; if (i < n4) *(f32x4*)(dst + 4 * i) = v[u]; }
+        }
+    } else {
+        for (long i = tid; i < n; i += nt) dst[i] = src[i];
+    }
+}
+
+// column sums of X[M,N] (row stride ld): f(n, sum_m X[m,n]).  All threads take part: the rows are split over
+// blockDim/N (at most 16) row groups whose partial sums meet in LDS, so a thread has only a few independent loads in
+// flight instead of M dependent-latency iterations.  Contains __syncthreads; `lds` needs 16*N floats at most.
+template <class F>
+__device__ __forceinline__ void wg_colsum(float* lds, int lds_cap, int M, int N, const float* X, long ld, F&& f) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int parts = nt / (N > 0 ? N : 1);
+    if (parts > 16) parts = 16;
+    if (parts > M) parts = M;
+    if (parts < 2 || parts * N > lds_cap) {
+        for (int n = tid; n < N; n += nt) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int m = 0;
+            for (; m + 3 < M; m += 4) {
+                s0 += X[(long)m * ld + n]; s1 += X[(long)(m + 1) * ld + n];
+                s2 += X[(long)(m + 2) * ld + n]; s3 += X[(long)(m + 3) * ld + n];
+            }
+            for (; m < M; ++m) s0 += X[(long)m * ld + n];
+            f(n, (s0 + s1) + (s2 + s3));
+        }
+        return;
+    }
+    __syncthreads();
+    if (tid < parts * N) {
+        const int part = tid / N, n = tid - part * N;
+        float s0 = 0.f, s1 = 0.f;
+        int m = part;
+        for (; m + parts < M; m += 2 * parts) { s0 += X[(long)m * ld + n]; s1 += X[(long)(m + parts) * ld + n]; }
+        if (m < M) s0 += X[(long)m * ld + n];
+        lds[part * N + n] = s0 + s1;
+    }
+    __syncthreads();
+    for (int n = tid; n < N; n += nt) {
         float s = 0.f;
-        for (int m = 0; m < M; ++m) s += X[(long)m * ld + n];
+        for (int pp = 0; pp < parts; ++pp) s += lds[pp * N + n];
         f(n, s);
     }
 }

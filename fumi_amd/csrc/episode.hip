@@ -17,9 +17,11 @@
 //       reverse (1 workgroup / episode)       sums the slabs, then walks the tape backwards (second order)
 //   Small products run on v_mfma_f32_16x16x4_f32 straight from memory (wg_mm in common.h).
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
+unsigned long long* g_epi_trace = nullptr;     // dev tracing only
 constexpr int QR = 32;                 // query rows per workgroup
 constexpr int MAXL = FUMI_MAX_HIDDEN;
 
@@ -36,6 +38,8 @@ struct EpiBuf {
     float *abar[MAXL], *X0, *X1, *eb, *lb;     // reverse scratch
     float *A0bar;                              // [B,R,h0] adjoint of A0 (support rows: sum over inner steps)
     int nslot, ntape, ntile, maxh;
+    unsigned long long* trace;                 // dev: per-phase wall-clock stamps of block 0 (tools/trace_adapt.py)
+    int lds_adapt, lds_query, lds_reverse;     // floats of dynamic LDS each kernel stages its products through
 };
 
 struct EpiDims {
@@ -59,8 +63,13 @@ __device__ __forceinline__ int label(const int64_t* y, long i, int N, int* statu
 // ------------------------------------------------------------------------------------------------------------
 // adapt: T inner SGD steps on the support set of one episode
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void adapt_kernel(EpiDims d, EpiBuf w, EpiParams prm, const int64_t* y_s,
+__global__ __launch_bounds__(512) void adapt_kernel(EpiDims d, EpiBuf w, EpiParams prm, const int64_t* y_s,
                                                      const float* head, int* status) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int sm_cap = w.lds_adapt;
+    int stamp_i = 0;
+#define STAMP() if (w.trace && threadIdx.x == 0 && blockIdx.x == 0) w.trace[stamp_i++] = __builtin_amdgcn_s_memrealtime();
+    STAMP()
     const float* const* Wm = prm.W;
     const float* const* bm = prm.b;
     const float* b0 = prm.b[0];
@@ -79,8 +88,7 @@ __global__ __launch_bounds__(1024) void adapt_kernel(EpiDims d, EpiBuf w, EpiPar
     for (int i = tid; i < S * h0; i += nt) D[i] = 0.f;
     for (int i = 1; i < L; ++i) {
         const long sz = (long)d.h[i] * d.h[i - 1];
-        float* dst = w.Wslot[i] + (long)b * w.nslot * sz;
-        for (long j = tid; j < sz; j += nt) dst[j] = Wm[i][j];
+        wg_copy(w.Wslot[i] + (long)b * w.nslot * sz, Wm[i], sz);
         float* bd = w.bcur[i] + (long)b * d.h[i];
         for (int j = tid; j < d.h[i]; j += nt) bd[j] = bm[i][j];
     }
@@ -90,47 +98,54 @@ __global__ __launch_bounds__(1024) void adapt_kernel(EpiDims d, EpiBuf w, EpiPar
         for (int j = tid; j < N * H; j += nt) dst[j] = hb[(j / H) * (H + 1) + (j % H)];
         for (int j = tid; j < N; j += nt) bh[j] = hb[j * (H + 1) + H];
     }
-    __syncthreads();
+    __syncthreads(); STAMP()
 
     for (int t = 0; t < d.T; ++t) {
         const int slot = d.taped ? t : 0, nslot = d.taped ? t + 1 : 0, tp = d.taped ? t : 0;
-        float* a[MAXL]; float* dz[MAXL]; const float* Wc[MAXL]; float* Wn[MAXL];
-        for (int i = 0; i < L; ++i) {
-            a[i] = w.ta[i] + ((long)b * w.ntape + tp) * S * d.h[i];
-            dz[i] = w.tdz[i] + ((long)b * w.ntape + tp) * S * d.h[i];
-            if (i >= 1) {
-                const long sz = (long)d.h[i] * d.h[i - 1];
-                Wc[i] = w.Wslot[i] + ((long)b * w.nslot + slot) * sz;
-                Wn[i] = w.Wslot[i] + ((long)b * w.nslot + nslot) * sz;
-            }
-        }
+        // pointers are recomputed from the kernel arguments where needed: local pointer arrays indexed at run time
+        // would live in scratch memory
+        auto a = [&](int i) { return w.ta[i] + ((long)b * w.ntape + tp) * S * d.h[i]; };
+        auto dz = [&](int i) { return w.tdz[i] + ((long)b * w.ntape + tp) * S * d.h[i]; };
+        auto Wc = [&](int i) { return (const float*)(w.Wslot[i] + ((long)b * w.nslot + slot) * ((long)d.h[i] * d.h[i - 1])); };
+        auto Wn = [&](int i) { return w.Wslot[i] + ((long)b * w.nslot + nslot) * ((long)d.h[i] * d.h[i - 1]); };
         const float* Whc = w.Whslot + ((long)b * w.nslot + slot) * N * H;
         float* Whn = w.Whslot + ((long)b * w.nslot + nslot) * N * H;
         float* p = w.tp + ((long)b * w.ntape + tp) * S * N;
         float* e = w.te + ((long)b * w.ntape + tp) * S * N;
 
-        // 1. layer 0 through the low-rank form
-        wg_colsum(S, h0, D, h0, [&](int n, float s) { cs[n] = s; });
-        __syncthreads();
-        wg_mm(S, h0, S, Gss, S, 1, D, h0, 1, [&](int m, int n, float acc) {
-            const float z = A0s[(long)m * h0 + n] - alpha * acc + (b0[n] - alpha * cs[n]);
-            a[0][(long)m * h0 + n] = z > 0.f ? z : 0.f;
-        });
-        __syncthreads();
+        // 1. layer 0 through the low-rank form (D_0 = 0: the first step is just relu(A0s + b0))
+        if (t == 0) {
+            wg_ew((long)S * h0, a(0), A0s, nullptr, nullptr, [&](long i, float x, float, float) {
+                const float z = x + b0[i % h0];
+                return z > 0.f ? z : 0.f;
+            });
+        } else {
+            wg_colsum(sm, sm_cap, S, h0, D, h0, [&](int n, float s) { cs[n] = s; });
+            __syncthreads(); STAMP()
+            float* a0 = a(0);
+            wg_mm2(sm, sm_cap, S, h0, S, Gss, S, 1, D, h0, 1,
+                   [&](int m, int n) { return A0s[(long)m * h0 + n] + (b0[n] - alpha * cs[n]); },
+                   [&](int m, int n, float acc, float pre) {
+                       const float z = pre - alpha * acc;
+                       a0[(long)m * h0 + n] = z > 0.f ? z : 0.f;
+                   });
+        }
+        __syncthreads(); STAMP()
         // 2. deeper layers with the episode's fast weights
         for (int i = 1; i < L; ++i) {
             const int hi = d.h[i], hp = d.h[i - 1];
             const float* bi = w.bcur[i] + (long)b * hi;
-            float* ai = a[i];
-            wg_mm(S, hi, hp, a[i - 1], hp, 1, Wc[i], 1, hp, [&](int m, int n, float acc) {
-                const float z = acc + bi[n];
-                ai[(long)m * hi + n] = z > 0.f ? z : 0.f;
-            });
-            __syncthreads();
+            float* ai = a(i);
+            wg_mm2(sm, sm_cap, S, hi, hp, a(i - 1), hp, 1, Wc(i), 1, hp, [&](int m, int n) { return bi[n]; },
+                   [&](int m, int n, float acc, float pre) {
+                       const float z = acc + pre;
+                       ai[(long)m * hi + n] = z > 0.f ? z : 0.f;
+                   });
+            __syncthreads(); STAMP()
         }
         // 3. head logits, softmax, e = (p - onehot)/S
-        wg_mm(S, N, H, a[L - 1], H, 1, Whc, 1, H, [&](int m, int n, float acc) { lg[m * N + n] = acc + bh[n]; });
-        __syncthreads();
+        wg_mm(sm, sm_cap, S, N, H, a(L - 1), H, 1, Whc, 1, H, [&](int m, int n, float acc) { lg[m * N + n] = acc + bh[n]; });
+        __syncthreads(); STAMP()
         for (int s = tid; s < S; s += nt) {
             const int y = label(ys, s, N, status);
             float mx = lg[s * N];
@@ -144,39 +159,37 @@ __global__ __launch_bounds__(1024) void adapt_kernel(EpiDims d, EpiBuf w, EpiPar
                 e[s * N + n] = (pv - (n == y ? 1.f : 0.f)) / (float)S;
             }
         }
-        __syncthreads();
+        __syncthreads(); STAMP()
         // 4. backward through the head: dz_{L-1} = (e Wh) * relu'   (before Wh may be overwritten in place)
         {
-            float* dzl = dz[L - 1]; const float* al = a[L - 1];
-            wg_mm(S, H, N, e, N, 1, Whc, H, 1, [&](int m, int n, float acc) {
-                dzl[(long)m * H + n] = al[(long)m * H + n] > 0.f ? acc : 0.f;
-            });
+            float* dzl = dz(L - 1); const float* al = a(L - 1);
+            wg_mm2(sm, sm_cap, S, H, N, e, N, 1, Whc, H, 1, [&](int m, int n) { return al[(long)m * H + n]; },
+                   [&](int m, int n, float acc, float pre) { dzl[(long)m * H + n] = pre > 0.f ? acc : 0.f; });
         }
-        __syncthreads();
+        __syncthreads(); STAMP()
         // head update: Wh <- Wh - alpha e^T a,  bh <- bh - alpha colsum(e)
-        wg_mm(N, H, S, e, 1, N, a[L - 1], H, 1, [&](int m, int n, float acc) {
-            Whn[m * H + n] = Whc[m * H + n] - alpha * acc;
-        });
-        wg_colsum(S, N, e, N, [&](int n, float s) { bh[n] -= alpha * s; });
+        wg_mm2(sm, sm_cap, N, H, S, e, 1, N, a(L - 1), H, 1, [&](int m, int n) { return Whc[m * H + n]; },
+               [&](int m, int n, float acc, float pre) { Whn[m * H + n] = pre - alpha * acc; });
+        wg_colsum(sm, sm_cap, S, N, e, N, [&](int n, float s) { bh[n] -= alpha * s; });
         // 5. hidden layers, top down
         for (int i = L - 1; i >= 1; --i) {
             const int hi = d.h[i], hp = d.h[i - 1];
-            float* dzp = dz[i - 1]; const float* ap = a[i - 1];
-            wg_mm(S, hp, hi, dz[i], hi, 1, Wc[i], hp, 1, [&](int m, int n, float acc) {
-                dzp[(long)m * hp + n] = ap[(long)m * hp + n] > 0.f ? acc : 0.f;
-            });
-            __syncthreads();
-            const float* Wci = Wc[i]; float* Wni = Wn[i];
-            wg_mm(hi, hp, S, dz[i], 1, hi, a[i - 1], hp, 1, [&](int m, int n, float acc) {
-                Wni[(long)m * hp + n] = Wci[(long)m * hp + n] - alpha * acc;
-            });
+            float* dzp = dz(i - 1); const float* ap = a(i - 1);
+            wg_mm2(sm, sm_cap, S, hp, hi, dz(i), hi, 1, Wc(i), hp, 1, [&](int m, int n) { return ap[(long)m * hp + n]; },
+                   [&](int m, int n, float acc, float pre) { dzp[(long)m * hp + n] = pre > 0.f ? acc : 0.f; });
+            __syncthreads(); STAMP()
+            const float* Wci = Wc(i); float* Wni = Wn(i);
+            wg_mm2(sm, sm_cap, hi, hp, S, dz(i), 1, hi, a(i - 1), hp, 1, [&](int m, int n) { return Wci[(long)m * hp + n]; },
+                   [&](int m, int n, float acc, float pre) { Wni[(long)m * hp + n] = pre - alpha * acc; });
             float* bi = w.bcur[i] + (long)b * hi;
-            wg_colsum(S, hi, dz[i], hi, [&](int n, float s) { bi[n] -= alpha * s; });
+            wg_colsum(sm, sm_cap, S, hi, dz(i), hi, [&](int n, float s) { bi[n] -= alpha * s; });
         }
         if (L == 1) __syncthreads();
         // 6. layer 0: only the low-rank factor moves
-        for (int i = tid; i < S * h0; i += nt) D[i] += dz[0][i];
-        __syncthreads();
+        {
+            wg_ew((long)S * h0, D, D, dz(0), nullptr, [&](long, float x, float y, float) { return x + y; });
+        }
+        __syncthreads(); STAMP()
     }
 }
 
@@ -185,6 +198,8 @@ __global__ __launch_bounds__(1024) void adapt_kernel(EpiDims d, EpiBuf w, EpiPar
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const float* const b0, const int64_t* y_q,
                                                     float* logits_q, int64_t* preds_q, int* status) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int sm_cap = w.lds_query;
     const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
     const int S = d.S, N = d.N, L = d.L, H = d.H, h0 = d.h[0], Qn = d.Qn;
     const int r0 = tile * QR, nr = min(QR, Qn - r0);
@@ -199,31 +214,34 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
     float* lq = logits_q + ((long)b * Qn + r0) * N;
     float* lbar = w.lbar + ((long)b * Qn + r0) * N;
     const int64_t* yq = y_q + (long)b * Qn + r0;
-    float* a[MAXL]; float* z[MAXL]; const float* Wc[MAXL];
-    for (int i = 0; i < L; ++i) {
-        a[i] = w.aq[i] + ((long)b * Qn + r0) * d.h[i];
-        z[i] = w.zq[i] + ((long)b * Qn + r0) * d.h[i];
-        if (i >= 1) Wc[i] = w.Wslot[i] + ((long)b * w.nslot + slot) * (long)d.h[i] * d.h[i - 1];
-    }
+    auto a = [&](int i) { return w.aq[i] + ((long)b * Qn + r0) * d.h[i]; };
+    auto z = [&](int i) { return w.zq[i] + ((long)b * Qn + r0) * d.h[i]; };
+    auto Wc = [&](int i) { return (const float*)(w.Wslot[i] + ((long)b * w.nslot + slot) * ((long)d.h[i] * d.h[i - 1])); };
 
-    wg_colsum(S, h0, D, h0, [&](int n, float s) { cs[n] = s; });
+    wg_colsum(sm, sm_cap, S, h0, D, h0, [&](int n, float s) { cs[n] = s; });
     __syncthreads();
-    wg_mm(nr, h0, S, Gqs, S, 1, D, h0, 1, [&](int m, int n, float acc) {
-        const float v = A0q[(long)m * h0 + n] - alpha * acc + (b0[n] - alpha * cs[n]);
-        a[0][(long)m * h0 + n] = v > 0.f ? v : 0.f;
-    });
+    {
+        float* a0 = a(0);
+        wg_mm2(sm, sm_cap, nr, h0, S, Gqs, S, 1, D, h0, 1,
+               [&](int m, int n) { return A0q[(long)m * h0 + n] + (b0[n] - alpha * cs[n]); },
+               [&](int m, int n, float acc, float pre) {
+                   const float v = pre - alpha * acc;
+                   a0[(long)m * h0 + n] = v > 0.f ? v : 0.f;
+               });
+    }
     __syncthreads();
     for (int i = 1; i < L; ++i) {
         const int hi = d.h[i], hp = d.h[i - 1];
         const float* bi = w.bcur[i] + (long)b * hi;
-        float* ai = a[i];
-        wg_mm(nr, hi, hp, a[i - 1], hp, 1, Wc[i], 1, hp, [&](int m, int n, float acc) {
-            const float v = acc + bi[n];
-            ai[(long)m * hi + n] = v > 0.f ? v : 0.f;
-        });
+        float* ai = a(i);
+        wg_mm2(sm, sm_cap, nr, hi, hp, a(i - 1), hp, 1, Wc(i), 1, hp, [&](int m, int n) { return bi[n]; },
+               [&](int m, int n, float acc, float pre) {
+                   const float v = acc + pre;
+                   ai[(long)m * hi + n] = v > 0.f ? v : 0.f;
+               });
         __syncthreads();
     }
-    wg_mm(nr, N, H, a[L - 1], H, 1, Whc, 1, H, [&](int m, int n, float acc) { lq[m * N + n] = acc + bh[n]; });
+    wg_mm(sm, sm_cap, nr, N, H, a(L - 1), H, 1, Whc, 1, H, [&](int m, int n, float acc) { lq[m * N + n] = acc + bh[n]; });
     __syncthreads();
 
     // per row: log-softmax loss, first arg-max (torch.max semantics, fumi.py:180), lbar = (p - onehot)/Qn
@@ -255,43 +273,42 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
     const long pt = (long)b * w.ntile + tile;
     {
         float* pWh = w.pWh + pt * N * H;
-        wg_mm(N, H, nr, lbar, 1, N, a[L - 1], H, 1, [&](int m, int n, float acc) { pWh[m * H + n] = acc; });
+        wg_mm(sm, sm_cap, N, H, nr, lbar, 1, N, a(L - 1), H, 1, [&](int m, int n, float acc) { pWh[m * H + n] = acc; });
         float* pbh = w.pbh + pt * N;
-        wg_colsum(nr, N, lbar, N, [&](int n, float s) { pbh[n] = s; });
-        float* zl = z[L - 1]; const float* al = a[L - 1];
-        wg_mm(nr, H, N, lbar, N, 1, Whc, H, 1, [&](int m, int n, float acc) {
-            zl[(long)m * H + n] = al[(long)m * H + n] > 0.f ? acc : 0.f;
-        });
+        wg_colsum(sm, sm_cap, nr, N, lbar, N, [&](int n, float s) { pbh[n] = s; });
+        float* zl = z(L - 1); const float* al = a(L - 1);
+        wg_mm2(sm, sm_cap, nr, H, N, lbar, N, 1, Whc, H, 1, [&](int m, int n) { return al[(long)m * H + n]; },
+               [&](int m, int n, float acc, float pre) { zl[(long)m * H + n] = pre > 0.f ? acc : 0.f; });
     }
     __syncthreads();
     for (int i = L - 1; i >= 1; --i) {
         const int hi = d.h[i], hp = d.h[i - 1];
         float* pWi = w.pW[i] + pt * (long)hi * hp;
-        wg_mm(hi, hp, nr, z[i], 1, hi, a[i - 1], hp, 1, [&](int m, int n, float acc) { pWi[(long)m * hp + n] = acc; });
+        wg_mm(sm, sm_cap, hi, hp, nr, z(i), 1, hi, a(i - 1), hp, 1, [&](int m, int n, float acc) { pWi[(long)m * hp + n] = acc; });
         float* pbi = w.pb[i] + pt * hi;
-        wg_colsum(nr, hi, z[i], hi, [&](int n, float s) { pbi[n] = s; });
-        float* zp = z[i - 1]; const float* ap = a[i - 1];
-        wg_mm(nr, hp, hi, z[i], hi, 1, Wc[i], hp, 1, [&](int m, int n, float acc) {
-            zp[(long)m * hp + n] = ap[(long)m * hp + n] > 0.f ? acc : 0.f;
-        });
+        wg_colsum(sm, sm_cap, nr, hi, z(i), hi, [&](int n, float s) { pbi[n] = s; });
+        float* zp = z(i - 1); const float* ap = a(i - 1);
+        wg_mm2(sm, sm_cap, nr, hp, hi, z(i), hi, 1, Wc(i), hp, 1, [&](int m, int n) { return ap[(long)m * hp + n]; },
+               [&](int m, int n, float acc, float pre) { zp[(long)m * hp + n] = pre > 0.f ? acc : 0.f; });
         __syncthreads();
     }
     // layer 0: Abar0 rows of the query set, b0bar, and the adjoint of the low-rank factor D_T
     float* A0bq = w.A0bar + ((long)b * (S + Qn) + S + r0) * h0;
-    for (int i = tid; i < nr * h0; i += nt) A0bq[i] = z[0][i];
+    wg_copy(A0bq, z(0), (long)nr * h0);
     float* pb0 = w.pb0 + pt * h0;
-    wg_colsum(nr, h0, z[0], h0, [&](int n, float s) { pb0[n] = s; });
+    wg_colsum(sm, sm_cap, nr, h0, z(0), h0, [&](int n, float s) { pb0[n] = s; });
     __syncthreads();
     float* pD = w.pD + pt * (long)S * h0;
-    wg_mm(S, h0, nr, Gqs, 1, S, z[0], h0, 1, [&](int m, int n, float acc) {
-        pD[(long)m * h0 + n] = -alpha * (acc + pb0[n]);
-    });
+    wg_mm2(sm, sm_cap, S, h0, nr, Gqs, 1, S, z(0), h0, 1, [&](int m, int n) { return pb0[n]; },
+           [&](int m, int n, float acc, float pre) { pD[(long)m * h0 + n] = -alpha * (acc + pre); });
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // reverse: sum the query slabs, then the second-order sweep back through the T inner steps
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void reverse_kernel(EpiDims d, EpiBuf w, float* loss_b, float* acc_b, float* head_bar) {
+__global__ __launch_bounds__(512) void reverse_kernel(EpiDims d, EpiBuf w, float* loss_b, float* acc_b, float* head_bar) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int sm_cap = w.lds_reverse;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int S = d.S, N = d.N, L = d.L, H = d.H, h0 = d.h[0];
     const float alpha = d.alpha;
@@ -305,25 +322,20 @@ __global__ __launch_bounds__(1024) void reverse_kernel(EpiDims d, EpiBuf w, floa
     }
     if (!d.need_grad) return;
 
-    float* Wb[MAXL]; float* bb[MAXL];
+    auto Wb = [&](int i) { return w.Wb[i] + (long)b * ((long)d.h[i] * d.h[i - 1]); };
+    auto bb = [&](int i) { return w.bb[i] + (long)b * d.h[i]; };
     float* Whb = w.Whb + (long)b * N * H;
     float* bhb = w.bhb + (long)b * N;
     float* b0b = w.b0b + (long)b * h0;
     float* Db = w.Db + (long)b * S * h0;
     float* A0bs = w.A0bar + (long)b * (S + d.Qn) * h0;
     auto sum_tiles = [&](float* dst, const float* src, long sz) {
-        for (long i = tid; i < sz; i += nt) {
-            float s = 0.f;
-            for (int t = 0; t < ntile; ++t) s += src[((long)b * ntile + t) * sz + i];
-            dst[i] = s;
-        }
+        wg_sum_slabs(dst, src + (long)b * ntile * sz, ntile, sz, sz);
     };
     for (int i = 1; i < L; ++i) {
         const long sz = (long)d.h[i] * d.h[i - 1];
-        Wb[i] = w.Wb[i] + (long)b * sz;
-        bb[i] = w.bb[i] + (long)b * d.h[i];
-        sum_tiles(Wb[i], w.pW[i], sz);
-        sum_tiles(bb[i], w.pb[i], d.h[i]);
+        sum_tiles(Wb(i), w.pW[i], sz);
+        sum_tiles(bb(i), w.pb[i], d.h[i]);
     }
     sum_tiles(Whb, w.pWh, (long)N * H);
     sum_tiles(bhb, w.pbh, N);
@@ -337,58 +349,65 @@ __global__ __launch_bounds__(1024) void reverse_kernel(EpiDims d, EpiBuf w, floa
         float* cs = w.cs + (long)b * h0;
         float* eb = w.eb + (long)b * S * N;
         float* lb = w.lb + (long)b * S * N;
-        float* X[2] = {w.X0 + (long)b * S * w.maxh, w.X1 + (long)b * S * w.maxh};
+        float* const Xa = w.X0 + (long)b * S * w.maxh;
+        float* const Xb = w.X1 + (long)b * S * w.maxh;
+        auto X = [&](int i) { return i ? Xb : Xa; };
         for (int t = d.T - 1; t >= 0; --t) {
-            const float* a[MAXL]; const float* dz[MAXL]; const float* Wc[MAXL]; float* ab[MAXL];
-            for (int i = 0; i < L; ++i) {
-                a[i] = w.ta[i] + ((long)b * w.ntape + t) * S * d.h[i];
-                dz[i] = w.tdz[i] + ((long)b * w.ntape + t) * S * d.h[i];
-                ab[i] = w.abar[i] + (long)b * S * d.h[i];
-                if (i >= 1) Wc[i] = w.Wslot[i] + ((long)b * w.nslot + t) * (long)d.h[i] * d.h[i - 1];
-            }
+            auto a = [&](int i) { return (const float*)(w.ta[i] + ((long)b * w.ntape + t) * S * d.h[i]); };
+            auto dz = [&](int i) { return (const float*)(w.tdz[i] + ((long)b * w.ntape + t) * S * d.h[i]); };
+            auto ab = [&](int i) { return w.abar[i] + (long)b * S * d.h[i]; };
+            auto Wc = [&](int i) { return (const float*)(w.Wslot[i] + ((long)b * w.nslot + t) * ((long)d.h[i] * d.h[i - 1])); };
             const float* Whc = w.Whslot + ((long)b * w.nslot + t) * N * H;
             const float* p = w.tp + ((long)b * w.ntape + t) * S * N;
             const float* e = w.te + ((long)b * w.ntape + t) * S * N;
 
             // abar_i = 0 ; dab = Dbar * relu'(z0)          (dz0bar = adjoint of D_{t+1})
-            for (int i = 0; i < L; ++i)
-                for (int j = tid; j < S * d.h[i]; j += nt) ab[i][j] = 0.f;
+            for (int i = 0; i < L; ++i) {
+                float* abi = ab(i);
+                for (int j = tid; j < S * d.h[i]; j += nt) abi[j] = 0.f;
+            }
             int cur = 0;
-            for (int j = tid; j < S * h0; j += nt) X[0][j] = a[0][j] > 0.f ? Db[j] : 0.f;
+            {
+                wg_ew((long)S * h0, Xa, a(0), Db, nullptr, [&](long, float m_, float v, float) { return m_ > 0.f ? v : 0.f; });
+            }
             __syncthreads();
             // ---- reverse of the backward pass, bottom up
             for (int i = 1; i < L; ++i) {
                 const int hi = d.h[i], hp = d.h[i - 1];
-                const float* dab = X[cur]; float* nxt = X[cur ^ 1];
-                const float* bbi = bb[i]; const float* Wbi = Wb[i]; const float* ai = a[i];
+                const float* dab = X(cur); float* nxt = X(cur ^ 1);
+                const float* bbi = bb(i); const float* Wbi = Wb(i); const float* ai = a(i);
                 // dzbar_i = dab W_i^T - alpha bbar_i - alpha a_{i-1} Wbar_i^T ; next dab = dzbar_i * relu'(z_i)
-                wg_mm(S, hi, hp, dab, hp, 1, Wc[i], 1, hp, [&](int m, int n, float acc) {
-                    nxt[(long)m * hi + n] = acc - alpha * bbi[n];
-                });
-                wg_mm(S, hi, hp, a[i - 1], hp, 1, Wbi, 1, hp, [&](int m, int n, float acc) {      // same thread, same (m,n)
-                    const float v = nxt[(long)m * hi + n] - alpha * acc;
-                    nxt[(long)m * hi + n] = ai[(long)m * hi + n] > 0.f ? v : 0.f;
-                });
+                wg_mm2(sm, sm_cap, S, hi, hp, dab, hp, 1, Wc(i), 1, hp, [&](int m, int n) { return bbi[n]; },
+                       [&](int m, int n, float acc, float pre) { nxt[(long)m * hi + n] = acc - alpha * pre; });
+                wg_mm2(sm, sm_cap, S, hi, hp, a(i - 1), hp, 1, Wbi, 1, hp,                                   // same thread, same (m,n)
+                       [&](int m, int n) { return f32pair{nxt[(long)m * hi + n], ai[(long)m * hi + n]}; },
+                       [&](int m, int n, float acc, f32pair pre) {
+                           nxt[(long)m * hi + n] = pre.y > 0.f ? pre.x - alpha * acc : 0.f;
+                       });
                 // abar_{i-1} += dz_i (-alpha Wbar_i)
-                float* abp = ab[i - 1];
-                wg_mm(S, hp, hi, dz[i], hi, 1, Wbi, hp, 1, [&](int m, int n, float acc) {
-                    abp[(long)m * hp + n] -= alpha * acc;
-                });
+                float* abp = ab(i - 1);
+                wg_mm2(sm, sm_cap, S, hp, hi, dz(i), hi, 1, Wbi, hp, 1, [&](int m, int n) { return abp[(long)m * hp + n]; },
+                       [&](int m, int n, float acc, float pre) { abp[(long)m * hp + n] = pre - alpha * acc; });
                 __syncthreads();
                 // Wbar_i += dz_i^T dab
-                float* Wbw = Wb[i];
-                wg_mm(hi, hp, S, dz[i], 1, hi, dab, hp, 1, [&](int m, int n, float acc) { Wbw[(long)m * hp + n] += acc; });
+                float* Wbw = Wb(i);
+                wg_mm2(sm, sm_cap, hi, hp, S, dz(i), 1, hi, dab, hp, 1, [&](int m, int n) { return Wbw[(long)m * hp + n]; },
+                       [&](int m, int n, float acc, float pre) { Wbw[(long)m * hp + n] = pre + acc; });
                 __syncthreads();
                 cur ^= 1;
             }
             {   // head: ebar = dab Wh^T - alpha bhbar - alpha a Whbar^T ; abar += e (-alpha Whbar) ; Whbar += e^T dab
-                const float* dab = X[cur];
-                wg_mm(S, N, H, dab, H, 1, Whc, 1, H, [&](int m, int n, float acc) { eb[m * N + n] = acc - alpha * bhb[n]; });
-                wg_mm(S, N, H, a[L - 1], H, 1, Whb, 1, H, [&](int m, int n, float acc) { eb[m * N + n] -= alpha * acc; });
-                float* abl = ab[L - 1];
-                wg_mm(S, H, N, e, N, 1, Whb, H, 1, [&](int m, int n, float acc) { abl[(long)m * H + n] -= alpha * acc; });
+                const float* dab = X(cur);
+                wg_mm2(sm, sm_cap, S, N, H, dab, H, 1, Whc, 1, H, [&](int m, int n) { return bhb[n]; },
+                       [&](int m, int n, float acc, float pre) { eb[m * N + n] = acc - alpha * pre; });
+                wg_mm2(sm, sm_cap, S, N, H, a(L - 1), H, 1, Whb, 1, H, [&](int m, int n) { return eb[m * N + n]; },
+                       [&](int m, int n, float acc, float pre) { eb[m * N + n] = pre - alpha * acc; });
+                float* abl = ab(L - 1);
+                wg_mm2(sm, sm_cap, S, H, N, e, N, 1, Whb, H, 1, [&](int m, int n) { return abl[(long)m * H + n]; },
+                       [&](int m, int n, float acc, float pre) { abl[(long)m * H + n] = pre - alpha * acc; });
                 __syncthreads();
-                wg_mm(N, H, S, e, 1, N, dab, H, 1, [&](int m, int n, float acc) { Whb[m * H + n] += acc; });
+                wg_mm2(sm, sm_cap, N, H, S, e, 1, N, dab, H, 1, [&](int m, int n) { return Whb[m * H + n]; },
+                       [&](int m, int n, float acc, float pre) { Whb[m * H + n] = pre + acc; });
                 // softmax-CE second derivative: lbar = p * (pbar - <p,pbar>),  pbar = ebar / S
                 for (int s = tid; s < S; s += nt) {
                     float dot = 0.f;
@@ -397,35 +416,39 @@ __global__ __launch_bounds__(1024) void reverse_kernel(EpiDims d, EpiBuf w, floa
                 }
                 __syncthreads();
                 // ---- reverse of the forward pass
-                wg_mm(S, H, N, lb, N, 1, Whc, H, 1, [&](int m, int n, float acc) { abl[(long)m * H + n] += acc; });
-                wg_mm(N, H, S, lb, 1, N, a[L - 1], H, 1, [&](int m, int n, float acc) { Whb[m * H + n] += acc; });
-                wg_colsum(S, N, lb, N, [&](int n, float s) { bhb[n] += s; });
+                wg_mm2(sm, sm_cap, S, H, N, lb, N, 1, Whc, H, 1, [&](int m, int n) { return abl[(long)m * H + n]; },
+                       [&](int m, int n, float acc, float pre) { abl[(long)m * H + n] = pre + acc; });
+                wg_mm2(sm, sm_cap, N, H, S, lb, 1, N, a(L - 1), H, 1, [&](int m, int n) { return Whb[m * H + n]; },
+                       [&](int m, int n, float acc, float pre) { Whb[m * H + n] = pre + acc; });
+                wg_colsum(sm, sm_cap, S, N, lb, N, [&](int n, float s) { bhb[n] += s; });
                 __syncthreads();
             }
             for (int i = L - 1; i >= 1; --i) {
                 const int hi = d.h[i], hp = d.h[i - 1];
-                float* zb = ab[i];
-                for (int j = tid; j < S * hi; j += nt) zb[j] = a[i][j] > 0.f ? zb[j] : 0.f;
+                float* zb = ab(i);
+                {
+                    wg_ew((long)S * hi, zb, a(i), zb, nullptr, [&](long, float m_, float v, float) { return m_ > 0.f ? v : 0.f; });
+                }
                 __syncthreads();
-                float* abp = ab[i - 1]; float* Wbw = Wb[i]; float* bbw = bb[i];
-                wg_mm(S, hp, hi, zb, hi, 1, Wc[i], hp, 1, [&](int m, int n, float acc) { abp[(long)m * hp + n] += acc; });
-                wg_mm(hi, hp, S, zb, 1, hi, a[i - 1], hp, 1, [&](int m, int n, float acc) { Wbw[(long)m * hp + n] += acc; });
-                wg_colsum(S, hi, zb, hi, [&](int n, float s) { bbw[n] += s; });
+                float* abp = ab(i - 1); float* Wbw = Wb(i); float* bbw = bb(i);
+                wg_mm2(sm, sm_cap, S, hp, hi, zb, hi, 1, Wc(i), hp, 1, [&](int m, int n) { return abp[(long)m * hp + n]; },
+                       [&](int m, int n, float acc, float pre) { abp[(long)m * hp + n] = pre + acc; });
+                wg_mm2(sm, sm_cap, hi, hp, S, zb, 1, hi, a(i - 1), hp, 1, [&](int m, int n) { return Wbw[(long)m * hp + n]; },
+                       [&](int m, int n, float acc, float pre) { Wbw[(long)m * hp + n] = pre + acc; });
+                wg_colsum(sm, sm_cap, S, hi, zb, hi, [&](int n, float s) { bbw[n] += s; });
                 __syncthreads();
             }
             // layer 0: z0bar -> Abar0 rows of the support set, b0bar, Dbar
-            float* z0b = ab[0];
-            for (int j = tid; j < S * h0; j += nt) {
-                const float v = a[0][j] > 0.f ? z0b[j] : 0.f;
-                z0b[j] = v;
-                A0bs[j] += v;
-            }
+            float* z0b = ab(0);
+            wg_ew((long)S * h0, z0b, a(0), z0b, nullptr, [&](long, float m_, float v, float) { return m_ > 0.f ? v : 0.f; });
             __syncthreads();
-            wg_colsum(S, h0, z0b, h0, [&](int n, float s) { cs[n] = s; b0b[n] += s; });
+            wg_ew((long)S * h0, A0bs, A0bs, z0b, nullptr, [&](long, float x, float y, float) { return x + y; });
             __syncthreads();
-            wg_mm(S, h0, S, Gss, S, 1, z0b, h0, 1, [&](int m, int n, float acc) {
-                Db[(long)m * h0 + n] -= alpha * (acc + cs[n]);
-            });
+            wg_colsum(sm, sm_cap, S, h0, z0b, h0, [&](int n, float s) { cs[n] = s; b0b[n] += s; });
+            __syncthreads();
+            wg_mm2(sm, sm_cap, S, h0, S, Gss, S, 1, z0b, h0, 1,
+                   [&](int m, int n) { return f32pair{Db[(long)m * h0 + n], cs[n]}; },
+                   [&](int m, int n, float acc, f32pair pre) { Db[(long)m * h0 + n] = pre.x - alpha * (acc + pre.y); });
             __syncthreads();
         }
     }
@@ -506,6 +529,23 @@ void carve(Carver& c, const EpisodeProblem& p, EpiBuf& w) {
     int maxh = 0;
     for (int i = 0; i < p.L; ++i) maxh = p.h[i] > maxh ? p.h[i] : maxh;
     w.maxh = maxh;
+    {   // LDS for wg_mm's operand images: enough for the largest product of each kernel in one chunk, capped
+        auto r16 = [](int x) { return (x + 15) & ~15; };
+        auto need = [&](int M, int N_, int K) { return (long)(r16(M) + 4 + r16(N_) + 4) * (r16(K) + 4); };
+        const int S_ = p.S, N_ = p.N, H_ = p.h[p.L - 1], h0_ = p.h[0], R_ = QR;
+        long a = need(S_, h0_, S_), q = need(R_, h0_, S_), r = need(S_, h0_, S_);
+        a = std::max({a, need(S_, N_, H_), need(S_, H_, N_), need(N_, H_, S_)});
+        q = std::max({q, need(R_, N_, H_), need(N_, H_, R_), need(R_, H_, N_), need(S_, h0_, R_)});
+        r = std::max({r, need(S_, N_, H_), need(S_, H_, N_), need(N_, H_, S_)});
+        for (int i = 1; i < p.L; ++i) {
+            const int hi = p.h[i], hp = p.h[i - 1];
+            a = std::max({a, need(S_, hi, hp), need(S_, hp, hi), need(hi, hp, S_)});
+            q = std::max({q, need(R_, hi, hp), need(R_, hp, hi), need(hi, hp, R_)});
+            r = std::max({r, need(S_, hi, hp), need(S_, hp, hi), need(hi, hp, S_)});
+        }
+        const long cap = 38000;               // 152 KB of the CU's 160 KB
+        w.lds_adapt = (int)std::min(a, cap); w.lds_query = (int)std::min(q, cap); w.lds_reverse = (int)std::min(r, cap);
+    }
     const size_t nt = w.ntile;
     w.A0 = c.take(B * (S + Qn) * h0); w.G = c.take(B * (S + Qn) * S);
     w.D = c.take(B * S * h0); w.cs = c.take(B * h0);
@@ -540,9 +580,12 @@ void carve(Carver& c, const EpisodeProblem& p, EpiBuf& w) {
 
 }  // namespace
 
+extern "C" void fumi_dbg_set_epi_trace(void* p) { g_epi_trace = (unsigned long long*)p; }
+
 size_t episode_workspace_bytes(const EpisodeProblem& p) {
     Carver c{nullptr, 0};
     EpiBuf w;
+    w.trace = nullptr;
     carve(c, p, w);
     if (p.need_grad) {
         int kc;
@@ -558,6 +601,7 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     EpiBuf w;
     Carver c{ws, 0};
     carve(c, p, w);
+    w.trace = g_epi_trace;
     EpiDims d;
     d.B = p.B; d.N = p.N; d.S = p.S; d.Qn = p.Qn; d.L = p.L; d.T = p.T; d.H = p.h[p.L - 1];
     for (int i = 0; i < MAXL; ++i) d.h[i] = i < p.L ? p.h[i] : 0;
@@ -576,18 +620,21 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     for (int i = 0; i < MAXL; ++i) { prm.W[i] = i < p.L ? p.W[i] : nullptr; prm.b[i] = i < p.L ? p.b[i] : nullptr; }
     {
         ProfScope ps(ws, st, FUMI_PH_ADAPT);
-        hipLaunchKernelGGL(adapt_kernel, dim3(p.B), dim3(1024), 0, st, d, w, prm, p.y_s, p.head, ws->status);
+        HIP_TRY(hipFuncSetAttribute((const void*)adapt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, w.lds_adapt * 4));
+        hipLaunchKernelGGL(adapt_kernel, dim3(p.B), dim3(512), w.lds_adapt * 4, st, d, w, prm, p.y_s, p.head, ws->status);
         LAUNCH_CHECK();
     }
     {
         ProfScope ps(ws, st, FUMI_PH_QUERY);
-        hipLaunchKernelGGL(query_kernel, dim3(w.ntile, p.B), dim3(512), 0, st, d, w, p.b[0], p.y_q, p.logits_q, p.preds_q,
-                           ws->status);
+        HIP_TRY(hipFuncSetAttribute((const void*)query_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, w.lds_query * 4));
+        hipLaunchKernelGGL(query_kernel, dim3(w.ntile, p.B), dim3(512), w.lds_query * 4, st, d, w, p.b[0], p.y_q, p.logits_q,
+                           p.preds_q, ws->status);
         LAUNCH_CHECK();
     }
     {
         ProfScope ps(ws, st, FUMI_PH_REVERSE);
-        hipLaunchKernelGGL(reverse_kernel, dim3(p.B), dim3(1024), 0, st, d, w, p.loss_b, p.acc_b, p.head_bar);
+        HIP_TRY(hipFuncSetAttribute((const void*)reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, w.lds_reverse * 4));
+        hipLaunchKernelGGL(reverse_kernel, dim3(p.B), dim3(512), w.lds_reverse * 4, st, d, w, p.loss_b, p.acc_b, p.head_bar);
         LAUNCH_CHECK();
     }
     if (!p.need_grad) return FUMI_OK;
