@@ -2,8 +2,13 @@
 // Replaces WordEmbedding.forward (fumi/models/common.py:23-41):
 //   mean: sum over ALL L positions of table[tok] divided by the number of non-PAD tokens (common.py:34-37)
 //   max : max over ALL L positions, PAD rows included (common.py:38-39)
-// HBM/L2-bound gather: one wave per output row, lanes stride the embedding dim (float4 when E % 4 == 0), the token id is
-// wave-uniform so every table row is read as contiguous 16-byte-per-lane segments.
+// and, in its "select" form, also the per-class first-support-row pick of fumi/models/fumi.py:207-210 (FuMI only needs
+// the text of N class rows per episode, not of all S support rows: 5x fewer table rows gathered).
+//
+// HBM/L2-bound gather: one wave per output row.  The row's token ids are read 64 at a time with one coalesced load and
+// handed out by cross-lane shuffles; the table rows of 8 tokens are requested back to back (8 independent 16-byte-per-
+// lane gathers in flight) before any is accumulated -- a loop that reads a token id and then its row is two dependent
+// memory round trips per token.
 #include "common.h"
 
 namespace {
@@ -11,38 +16,77 @@ namespace {
 template <bool VEC>
 __global__ __launch_bounds__(256) void glove_bag_kernel(const int64_t* __restrict__ tok, int R, int L, int64_t pad_id,
                                                         const float* __restrict__ table, int V, int E, int mode,
-                                                        float* __restrict__ out, int* status) {
+                                                        float* __restrict__ out, int* status,
+                                                        const int64_t* __restrict__ y_s, int N, int S) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= R) return;
-    const int64_t* t = tok + (long)r * L;
-    int cnt = 0;
+    long src_row = r;
+    if (y_s) {                                   // select form: output row r = (episode, class); source = first support row of the class
+        const int b = r / N, c = r - b * N;
+        const int64_t* ys = y_s + (long)b * S;
+        int first = S;
+        for (int s0 = 0; s0 < S && first == S; s0 += 64) {
+            const int s_ = s0 + lane;
+            const unsigned long long m = __ballot(s_ < S && ys[s_] == c);
+            if (m) first = s0 + __ffsll((long long)m) - 1;
+        }
+        if (first == S) {                        // the reference raises IndexError here (fumi.py:209)
+            if (lane == 0) atomicOr(status, FUMI_ST_CLASS_MISSING);
+            for (int j = lane; j < E; j += 64) out[(long)r * E + j] = __builtin_nanf("");
+            return;
+        }
+        src_row = (long)b * S + first;
+    }
+    const int64_t* t = tok + src_row * L;
     constexpr int W = VEC ? 4 : 1;
-    const int nchunk = (E / W + 63) / 64;            // chunks of 64 lanes x W floats
+    const int nchunk = (E / W + 63) / 64;        // chunks of 64 lanes x W floats
     for (int c = 0; c < nchunk; ++c) {
         const int j = (c * 64 + lane) * W;
         const bool ok = j < E;
+        const int jc = ok ? j : 0;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (mode == 1) acc = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        cnt = 0;
-        for (int l = 0; l < L; ++l) {
-            int64_t id = t[l];
-            if (id != pad_id) ++cnt;
-            if (id < 0 || id >= V) { if (lane == 0) atomicOr(status, FUMI_ST_LABEL_RANGE); id = 0; }
-            if (ok) {
-                const float* row = table + id * (long)E + j;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (VEC) v = *(const f32x4*)row; else v[0] = row[0];
-                if (mode == 0) acc += v;
-                else { acc[0] = fmaxf(acc[0], v[0]); acc[1] = fmaxf(acc[1], v[1]); acc[2] = fmaxf(acc[2], v[2]); acc[3] = fmaxf(acc[3], v[3]); }
+        int cnt = 0;
+        for (int l0 = 0; l0 < L; l0 += 64) {
+            const int nl = min(64, L - l0);
+            long my = lane < nl ? t[l0 + lane] : pad_id;
+            cnt += __popcll(__ballot(lane < nl && my != pad_id));
+            if (my < 0 || my >= V) { if (lane < nl) atomicOr(status, FUMI_ST_LABEL_RANGE); my = 0; }
+            const int mylo = (int)my;
+            for (int u0 = 0; u0 < nl; u0 += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int id = __shfl(mylo, min(u0 + u, nl - 1), 64);
+                    const float* row = table + (long)id * E + jc;
+                    if (VEC) v[u] = *(const f32x4*)row; else { v[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; v[u][0] = row[0]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (u0 + u < nl) {
+                        if (mode == 0) acc += v[u];
+                        else { acc[0] = fmaxf(acc[0], v[u][0]); acc[1] = fmaxf(acc[1], v[u][1]); acc[2] = fmaxf(acc[2], v[u][2]); acc[3] = fmaxf(acc[3], v[u][3]); }
+                    }
+                }
             }
         }
         if (ok) {
             float* o = out + (long)r * E + j;
-            if (mode == 0) { const float d = (float)cnt; acc[0] /= d; acc[1] /= d; acc[2] /= d; acc[3] /= d; }
+            if (mode == 0) { const float dn = (float)cnt; acc[0] /= dn; acc[1] /= dn; acc[2] /= dn; acc[3] /= dn; }
             if (VEC) *(f32x4*)o = acc; else o[0] = acc[0];
         }
     }
+}
+
+int launch_bag(fumi_ws_t* ws, hipStream_t st, const int64_t* tok, int R, int L, int64_t pad_id, const float* table, int V,
+               int E, int mode, float* out, const int64_t* y_s, int N, int S) {
+    const bool vec = E % 4 == 0 && ((uintptr_t)table & 15) == 0 && ((uintptr_t)out & 15) == 0;
+    dim3 grid((R + 3) / 4), block(256);
+    if (vec) hipLaunchKernelGGL(glove_bag_kernel<true>, grid, block, 0, st, tok, R, L, pad_id, table, V, E, mode, out, ws->status, y_s, N, S);
+    else hipLaunchKernelGGL(glove_bag_kernel<false>, grid, block, 0, st, tok, R, L, pad_id, table, V, E, mode, out, ws->status, y_s, N, S);
+    LAUNCH_CHECK();
+    return FUMI_OK;
 }
 
 }  // namespace
@@ -51,11 +95,13 @@ extern "C" int fumi_hip_glove_bag(fumi_ws_t* ws, fumi_stream_t stream, const int
         const float* table, int V, int E, int mode, float* out) {
     if (!ws || !tok || !table || !out || R < 1 || L < 1 || V < 1 || E < 1 || mode < 0 || mode > 1) return FUMI_EINVAL;
     HIP_TRY(hipSetDevice(ws->device));
-    hipStream_t st = (hipStream_t)stream;
-    const bool vec = E % 4 == 0 && ((uintptr_t)table & 15) == 0 && ((uintptr_t)out & 15) == 0;
-    dim3 grid((R + 3) / 4), block(256);
-    if (vec) hipLaunchKernelGGL(glove_bag_kernel<true>, grid, block, 0, st, tok, R, L, pad_id, table, V, E, mode, out, ws->status);
-    else hipLaunchKernelGGL(glove_bag_kernel<false>, grid, block, 0, st, tok, R, L, pad_id, table, V, E, mode, out, ws->status);
-    LAUNCH_CHECK();
-    return FUMI_OK;
+    return launch_bag(ws, (hipStream_t)stream, tok, R, L, pad_id, table, V, E, mode, out, nullptr, 0, 0);
+}
+
+extern "C" int fumi_hip_glove_bag_select(fumi_ws_t* ws, fumi_stream_t stream, const int64_t* tok_s, const int64_t* y_s,
+        int B, int N, int S, int L, int64_t pad_id, const float* table, int V, int E, int mode, float* out) {
+    if (!ws || !tok_s || !y_s || !table || !out || B < 1 || N < 1 || S < 1 || L < 1 || V < 1 || E < 1 || mode < 0 || mode > 1)
+        return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(ws->device));
+    return launch_bag(ws, (hipStream_t)stream, tok_s, B * N, L, pad_id, table, V, E, mode, out, y_s, N, S);
 }

@@ -20,7 +20,8 @@ SYMBOLS = [
     "fumi_hip_workspace_create", "fumi_hip_workspace_destroy", "fumi_hip_workspace_bytes", "fumi_hip_read_status",
     "fumi_hip_set_profiling", "fumi_hip_get_profile", "fumi_hip_phase_name",
     "fumi_hip_fumi_step", "fumi_hip_maml_step", "fumi_hip_am3_step",
-    "fumi_hip_glove_bag", "fumi_hip_class_text_select", "fumi_hip_xpanel_fwd", "fumi_hip_xpanel_bwd",
+    "fumi_hip_glove_bag", "fumi_hip_glove_bag_select", "fumi_hip_class_text_select", "fumi_hip_xpanel_fwd", "fumi_hip_xpanel_bwd",
+    "fumi_hip_adam_step",
     "fumi_hip_linear_fwd", "fumi_hip_linear_bwd_data", "fumi_hip_linear_bwd_weight",
 ]
 
@@ -73,9 +74,12 @@ def lib():
             [c_void_p, c_void_p] + [c_int] * 10 + [c_float] + [c_void_p] * 5 + [PP] + [c_void_p] * 4 + [PP])
         L.fumi_hip_glove_bag.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int, c_int,
                                          c_int, c_void_p]
+        L.fumi_hip_glove_bag_select.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64,
+                                                c_void_p, c_int, c_int, c_int, c_void_p]
         L.fumi_hip_class_text_select.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p] * 3
         L.fumi_hip_xpanel_fwd.argtypes = [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 5
         L.fumi_hip_xpanel_bwd.argtypes = [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 3 + [c_float, c_void_p]
+        L.fumi_hip_adam_step.argtypes = [c_void_p, c_void_p, c_int, PP, PP, PP, PP, POINTER(ctypes.c_long)] + [c_float] * 5 + [c_int]
         L.fumi_hip_linear_fwd.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 3 + [c_int, c_void_p]
         L.fumi_hip_linear_bwd_data.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 3
         L.fumi_hip_linear_bwd_weight.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 4
@@ -325,6 +329,21 @@ def glove_bag(ws, tokens, table, pad_id, mode="mean"):
     return out
 
 
+def glove_bag_select(ws, tokens_s, y_s, n_way, table, pad_id, mode="mean"):
+    """[B,N,E] pooled text of the first support row of each class (fumi.py:207-210 + common.py:23-41 in one kernel)."""
+    if mode not in ("mean", "max"):
+        raise NameError(f"{mode} pooling strat not defined")
+    dev = _dev(tokens_s)
+    B, S, Lseq = tokens_s.shape
+    V, E = table.shape
+    out = torch.empty(B, n_way, E, device=dev, dtype=torch.float32)
+    rc = lib().fumi_hip_glove_bag_select(ws.handle, _stream(dev), _i64(tokens_s, "tokens"), _i64(y_s, "y_s"), B, n_way, S,
+                                         Lseq, int(pad_id), _f32(table, "table"), V, E, 0 if mode == "mean" else 1,
+                                         _f32(out, "out"))
+    _check(rc, "fumi_hip_glove_bag_select")
+    return out
+
+
 def class_text_select(ws, text_s, y_s, n_way):
     dev = _dev(text_s)
     B, S, Dt = text_s.shape
@@ -355,6 +374,23 @@ def xpanel_bwd(ws, x_s, x_q, Abar, scale=1.0):
     _check(lib().fumi_hip_xpanel_bwd(ws.handle, _stream(dev), B, S, Qn, D, h0, _f32(x_s, "x_s"), _f32(x_q, "x_q"),
                                      _f32(Abar, "Abar"), float(scale), _f32(gW0, "gW0")), "fumi_hip_xpanel_bwd")
     return gW0
+
+
+class AdamArgs:
+    """Cached pointer tables of one fused Adam call (rebuilt only when a tensor is reallocated)."""
+
+    def __init__(self, params, grads, exp_avg, exp_avg_sq):
+        self.key = tuple(t.data_ptr() for t in params + grads + exp_avg + exp_avg_sq)
+        self.n = len(params)
+        self.p, self.g = _parr(params, "params"), _parr(grads, "grads")
+        self.m, self.v = _parr(exp_avg, "exp_avg"), _parr(exp_avg_sq, "exp_avg_sq")
+        self.numel = (ctypes.c_long * self.n)(*[t.numel() for t in params])
+
+
+def adam_step(ws, args, lr, beta1, beta2, eps, weight_decay, step, device):
+    rc = lib().fumi_hip_adam_step(ws.handle, _stream(device), args.n, args.p, args.g, args.m, args.v, args.numel,
+                                  float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step))
+    _check(rc, "fumi_hip_adam_step")
 
 
 def linear_fwd(ws, x, W, b=None, act=0):

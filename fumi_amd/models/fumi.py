@@ -165,17 +165,27 @@ class FUMI(nn.Module):
         lo, hi = fdist.shard(B)
         to = lambda t: t[lo:hi].to(dev).contiguous()
         x_s, x_q, y_s, y_q = to(s_im).float(), to(q_im).float(), to(s_y), to(q_y)
-        text_s = self._encode_text(to(s_text), dev)
         T = args.num_train_adapt_steps if train else args.num_test_adapt_steps
-
         eng = _engine.get_engine()
+        text_s = cls_text = None
+        if isinstance(self.text_encoder, WordEmbedding):
+            # only the N class rows of an episode are ever used (fumi.py:207-210): select, gather and pool them in one
+            # kernel instead of pooling all S support rows first
+            if self.pooling_strat not in ("mean", "max"):
+                raise NameError(f"{self.pooling_strat} pooling strat not defined")
+            cls_text = eng.glove_bag_select(to(s_text), y_s, self.n_way, self.text_encoder.embed.weight.detach(),
+                                            self.text_encoder.padding_token, self.pooling_strat)
+        else:
+            text_s = self._encode_text(to(s_text), dev)
+
         theta = [p.detach() for p in self._theta()]
         phi = [p.detach() for p in self._phi()]
         fg = self._flat_grads() if train else None
         nth = len(theta)
         out = eng.fumi_step(self.n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, args.step_size, self.norm_hypernet,
                             need_grad=train, grad_scale=1.0 / B,
-                            g_theta=fg.views[:nth] if train else None, g_phi=fg.views[nth:] if train else None)
+                            g_theta=fg.views[:nth] if train else None, g_phi=fg.views[nth:] if train else None,
+                            cls_text=cls_text)
         # [.. grads .. | sum loss / B | sum acc / B] -> one all-reduce(sum) -> global means on every rank
         if train:
             tail = fg.tail

@@ -122,7 +122,8 @@ def _linear_warmup_schedule(opt, num_warmup_steps, num_training_steps):
 def init_optim(args, model):
     """Optimizer factory (utils.py:277-299); may return an (optimizer, scheduler) tuple."""
     if args.optim == "adam":
-        return torch.optim.Adam(params=model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+        from ..optim import Adam            # torch.optim.Adam whose step() is one fused HIP launch on the GPU
+        return Adam(params=model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
     if args.optim == "SGD":
         return torch.optim.SGD(params=model.parameters(), lr=args.lr, weight_decay=args.weight_decay,
                                momentum=args.momentum)

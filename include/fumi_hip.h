@@ -123,6 +123,10 @@ int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
 /* out[r,:] = mean (mode 0: sum / #non-PAD tokens) or max (mode 1: over ALL L positions) of table[tok[r,l],:]. */
 int fumi_hip_glove_bag(fumi_ws_t* ws, fumi_stream_t stream, const int64_t* tok, int R, int L, int64_t pad_id,
         const float* table, int V, int E, int mode, float* out);
+/* Fused form for FuMI: out[b,n,:] = bag(tok_s[b, first s with y_s[b,s]==n, :])  -> [B,N,E]  (common.py:23-41 applied to
+ * the N class rows that fumi.py:207-210 selects). */
+int fumi_hip_glove_bag_select(fumi_ws_t* ws, fumi_stream_t stream, const int64_t* tok_s, const int64_t* y_s,
+        int B, int N, int S, int L, int64_t pad_id, const float* table, int V, int E, int mode, float* out);
 /* out[b,n,:] = text_s[b, first s with y_s[b,s]==n, :] */
 int fumi_hip_class_text_select(fumi_ws_t* ws, fumi_stream_t stream, int B, int N, int S, int Dt,
         const float* text_s, const int64_t* y_s, float* out);
@@ -133,6 +137,11 @@ int fumi_hip_xpanel_fwd(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int Q
         const float* x_s, const float* x_q, const float* W0, float* A0, float* G);
 int fumi_hip_xpanel_bwd(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int Qn, int D, int h0,
         const float* x_s, const float* x_q, const float* Abar, float scale, float* gW0);
+/* One fused launch of torch.optim.Adam's update (coupled L2 weight decay, bias correction; fumi/utils/utils.py:280-283) for
+ * up to 32 tensors.  Pointer/size arrays are HOST arrays; `step` is the 1-based step count. */
+int fumi_hip_adam_step(fumi_ws_t* ws, fumi_stream_t stream, int n_tensors, float* const* params,
+        const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const long* numel,
+        float lr, float beta1, float beta2, float eps, float weight_decay, int step);
 /* y[M,N] = act(x[M,K] W[N,K]^T + b[N]);  act: 0 none, 1 relu, 2 tanh.  b may be NULL. */
 int fumi_hip_linear_fwd(fumi_ws_t* ws, fumi_stream_t stream, int M, int N, int K,
         const float* x, const float* W, const float* b, int act, float* y);

@@ -10,9 +10,15 @@ from oracle import fumi_ref as R
 class OracleEngine:
     name = "oracle-cpu (tests only)"
 
+    def glove_bag_select(self, tokens_s, y_s, n_way, table, pad_id, mode):
+        rows = torch.stack([R.class_text_select(tokens_s[b], y_s[b], n_way) for b in range(tokens_s.shape[0])])
+        return R.word_embedding_pool(rows, table, pad_id, mode)
+
     def fumi_step(self, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head, need_grad, grad_scale,
-                  g_theta=None, g_phi=None):
+                  g_theta=None, g_phi=None, cls_text=None):
         B = x_s.shape[0]
+        if cls_text is not None:                # expand the per-class rows back to per-sample rows for the oracle
+            text_s = torch.gather(cls_text, 1, y_s[..., None].expand(-1, -1, cls_text.shape[-1]))
         th = [t.detach().clone().requires_grad_(True) for t in theta]
         ph = [t.detach().clone().requires_grad_(True) for t in phi]
         out = R.fumi_meta_step(th, ph, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha, tanh_head, need_grad=need_grad)

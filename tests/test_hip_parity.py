@@ -190,6 +190,13 @@ def test_glove_bag_matches_reference(dev, ws):
         assert rel_to_max(out, R.word_embedding_pool(tok, table, 0, mode)) <= 1e-6
     with pytest.raises(NameError):
         hip.glove_bag(ws, _g(tok, dev), _g(table, dev), 0, "median")
+    # fused select + bag (what FUMI.evaluate uses): first support row of each class, unsorted labels
+    ep = cg.make_episodes(9, 2, 5, 5, 2, 8, 8, tokens=(V, L, 0))
+    for mode in ("mean", "max"):
+        out = hip.glove_bag_select(ws, _g(ep["text_s"], dev), _g(ep["y_s"], dev), 5, _g(table, dev), 0, mode).cpu()
+        rows = torch.stack([R.class_text_select(ep["text_s"][b], ep["y_s"][b], 5) for b in range(2)])
+        assert rel_to_max(out, R.word_embedding_pool(rows, table, 0, mode)) <= 1e-6
+    assert ws.read_status() == 0
 
 
 # ---- full-size property checks (BASELINE.json configs[1]) ----------------------------------------------------------
@@ -282,3 +289,24 @@ def test_am3_eval_mode_matches_train_forward(dev, ws):
     la, pa = float(a["loss"]), a["preds"].clone()
     b = hip.am3_step(*args, need_grad=False)
     assert abs(la - float(b["loss"])) < 1e-6 and torch.equal(pa, b["preds"])
+
+
+def test_fused_adam_matches_torch_adam(dev, ws):
+    """fumi_hip_adam_step == torch.optim.Adam(lr, weight_decay) (utils.py:280-283) over several steps, odd sizes included."""
+    from fumi_amd.optim import Adam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(256, 2048), (256,), (64, 256), (65,), (7, 3), (1,)]
+    pa = [torch.randn(*s, generator=g).to(dev).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa, ob = Adam(pa, lr=3e-3, weight_decay=5e-4), torch.optim.Adam(pb, lr=3e-3, weight_decay=5e-4)
+    for it in range(4):
+        for x, y in zip(pa, pb):
+            gr = torch.randn(x.shape, generator=g).to(dev)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    for x, y in zip(pa, pb):
+        assert rel_to_max(x.detach().cpu(), y.detach().cpu()) <= 2e-7
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["state"].keys() == sb["state"].keys() and set(sa["state"][0]) == set(sb["state"][0])
+    assert float(sa["state"][0]["step"]) == float(sb["state"][0]["step"]) == 4.0
+    ob.load_state_dict(sa)                                     # checkpoints interchange with torch.optim.Adam

@@ -213,3 +213,28 @@ def test_product_engine_refuses_cpu():
     ep = cg.make_episodes(1, 2, c["N"], c["K"], c["Q"], c["D"], c["Dt"])
     with pytest.raises(hip.FumiHipError):
         m.evaluate(_args(1), cg.to_batch(ep), None, "test")
+
+
+def test_fumi_glove_path_uses_class_rows_only(oracle_engine):
+    """text_encoder='glove': evaluate pools only the N class rows (select + bag) and matches the all-rows reference order."""
+    from fumi_amd.models.fumi import FUMI
+    from fumi_amd.models import common
+    from oracle import fumi_ref as R
+    V, L, E = 50, 7, 12
+    rs = np.random.RandomState(0)
+    words = [f"w{i}" for i in range(V)]
+    common.register_word_vectors("glove", common.ArrayKeyedVectors(words, rs.standard_normal((V, E)).astype(np.float32)))
+    dictionary = {"PAD": 0, **{w: i for i, w in enumerate(words) if i > 0}}
+    c = dict(B=3, N=4, K=2, Q=3, D=32, hid=[16, 8], Ht=10)
+    ep = cg.make_episodes(4, c["B"], c["N"], c["K"], c["Q"], c["D"], 1, tokens=(V, L, 0))
+    m = FUMI(n_way=c["N"], im_emb_dim=c["D"], im_hid_dim=c["hid"], text_encoder="glove", text_hid_dim=c["Ht"],
+             dictionary=dictionary, norm_hypernet=False)
+    assert m.text_emb_dim == E and "text_encoder.embed.weight" in m.state_dict()
+    args = SimpleNamespace(device=torch.device("cpu"), num_train_adapt_steps=2, num_test_adapt_steps=2, step_size=cg.ALPHA,
+                           first_order=False, num_ways=c["N"], batch_size=c["B"])
+    loss, acc, preds, _ = m.evaluate(args, cg.to_batch(ep), None, "test")
+    text = R.word_embedding_pool(ep["text_s"], m.text_encoder.embed.weight.detach(), 0, "mean")
+    th = [p.detach().clone().requires_grad_(True) for p in m._theta()]
+    ph = [p.detach().clone().requires_grad_(True) for p in m._phi()]
+    ref = R.fumi_meta_step(th, ph, text, ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], c["N"], 2, cg.ALPHA, False, need_grad=False)
+    assert abs(float(loss) - float(ref["loss"])) < 1e-5 and np.array_equal(preds.numpy().astype(np.int64), ref["preds"].numpy())
