@@ -81,6 +81,13 @@ def flops_dominant(B):
     return 2.0 * B * (S + Qn) * (c["hid"][0] + S) * c["D"]
 
 
+def bytes_dominant(B):
+    """xpanel_fwd algorithmic HBM bytes: X and W0 read once, A0 and G written once."""
+    c = CFG
+    S, Qn, h0 = c["N"] * c["K"], c["N"] * c["Q"], c["hid"][0]
+    return 4.0 * (B * (S + Qn) * c["D"] + h0 * c["D"] + B * (S + Qn) * (h0 + S))
+
+
 def flops_step_algorithmic(B):
     """F_ep(T) = S T (4u0 + 9 sum u_i + 9 u_head) + Qn (2u0 + 3 sum u_i + 3 u_head) + hypernet."""
     c = CFG
@@ -203,8 +210,16 @@ def main():
             tot, n = prof["xpanel_fwd"]
             dur = tot / n * 1e-3
             ach = flops_dominant(c["B_per_gpu"]) / dur / 1e12
+            traffic = None       # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/<round>/pmc_traffic.json)
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))[-1:]:
+                k = json.load(open(f))["kernels"]
+                key = [x for x in k if x.startswith("xpanel_fwd_kernel")]
+                if key and "hbm_bytes_per_launch" in k[key[0]]:
+                    traffic = int(k[key[0]]["hbm_bytes_per_launch"])
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                               "algorithmic_bytes": int(bytes_dominant(c["B_per_gpu"])),
                                "kernel": "xpanel_fwd_kernel ([A0|G] = [Xs;Xq][W0;Xs]^T per episode: 32 x (185 x 281 x 2048), fp32 MFMA 32x32x2)",
                                "avg_us": round(dur * 1e6, 2), "launches": n}
             out["phase_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items()}

@@ -87,6 +87,15 @@ static inline GemmArgs gemm_args(int M, int N, int K, const float* A, long lda, 
 int launch_gemm(hipStream_t st, const GemmArgs& g, int AL, int BL);
 // out[i] = scale * sum_s slabs[s*stride + i]  (+ optional second slab set), i < n
 int launch_reduce_slabs(hipStream_t st, const float* slabs, int nslab, long stride, long n, float scale, float* out);
+// up to 24 small slab reductions in one launch
+struct ReduceSegs {
+    const float* src[24]; float* dst[24]; long end[24]; long stride[24]; int nslab[24];
+    int n; float scale;
+    void add(const float* s, int ns, long st, long cnt, float* d) {
+        src[n] = s; nslab[n] = ns; stride[n] = st; dst[n] = d; end[n] = (n ? end[n - 1] : 0) + cnt; ++n;
+    }
+};
+int launch_reduce_multi(hipStream_t st, ReduceSegs& sg);
 // out[n] = scale * sum_m X[m*ld + n]
 int launch_colsum(hipStream_t st, const float* X, int M, int N, long ld, float scale, float* out);
 
@@ -115,6 +124,7 @@ struct EpisodeProblem {
     float* logits_q; int64_t* preds_q; float* loss_b; float* acc_b;
     float* gW[FUMI_MAX_HIDDEN]; float* gb[FUMI_MAX_HIDDEN];   // outputs (scaled sums over episodes)
     float* head_bar;                // [B,N,H+1] d loss_b / d head_b   (unscaled, per episode)
+    float* stats;                   // optional [2]: grad_scale * (sum_b loss_b, sum_b acc_b)
 };
 size_t episode_workspace_bytes(const EpisodeProblem& p);
 int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p);

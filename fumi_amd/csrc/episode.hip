@@ -637,18 +637,22 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
         hipLaunchKernelGGL(reverse_kernel, dim3(p.B), dim3(512), w.lds_reverse * 4, st, d, w, p.loss_b, p.acc_b, p.head_bar);
         LAUNCH_CHECK();
     }
-    if (!p.need_grad) return FUMI_OK;
-
-    // ---- meta-gradients of the hidden layers: sums over episodes
+    // ---- sums over episodes in one launch: meta-gradients of the hidden layers, layer-0 bias, loss/accuracy totals
     {
         ProfScope pr(ws, st, FUMI_PH_REDUCE);
-        for (int i = 1; i < p.L; ++i) {
-            const long sz = (long)p.h[i] * p.h[i - 1];
-            if ((rc = launch_reduce_slabs(st, w.Wb[i], p.B, sz, sz, p.grad_scale, p.gW[i]))) return rc;
-            if ((rc = launch_reduce_slabs(st, w.bb[i], p.B, p.h[i], p.h[i], p.grad_scale, p.gb[i]))) return rc;
+        ReduceSegs sg; sg.n = 0; sg.scale = p.grad_scale;
+        if (p.stats) { sg.add(p.loss_b, p.B, 1, 1, p.stats); sg.add(p.acc_b, p.B, 1, 1, p.stats + 1); }
+        if (p.need_grad) {
+            for (int i = 1; i < p.L; ++i) {
+                const long sz = (long)p.h[i] * p.h[i - 1];
+                sg.add(w.Wb[i], p.B, sz, sz, p.gW[i]);
+                sg.add(w.bb[i], p.B, p.h[i], p.h[i], p.gb[i]);
+            }
+            sg.add(w.b0b, p.B, h0, h0, p.gb[0]);
         }
-        if ((rc = launch_reduce_slabs(st, w.b0b, p.B, h0, h0, p.grad_scale, p.gb[0]))) return rc;
+        if ((rc = launch_reduce_multi(st, sg))) return rc;
     }
+    if (!p.need_grad) return FUMI_OK;
     // ---- shared pass 2 over X: gW0 = Abar0^T [Xs;Xq], contraction over all B*R rows split into slabs (xpanel.hip)
     {
         ProfScope pg(ws, st, FUMI_PH_XPANEL_BWD);

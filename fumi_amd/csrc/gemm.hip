@@ -157,6 +157,21 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, 
     }
 }
 
+// several small slab reductions in ONE launch: segment k: dst[i] = scale * sum_t src[t*stride + i], i < n
+__global__ void reduce_multi_kernel(ReduceSegs sg) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= sg.end[sg.n - 1]) return;
+    int k = 0;
+    while (k + 1 < sg.n && i >= sg.end[k]) ++k;
+    const long e = i - (k ? sg.end[k - 1] : 0);
+    const float* src = sg.src[k] + e;
+    float s0 = 0.f, s1 = 0.f;
+    int t = 0;
+    for (; t + 1 < sg.nslab[k]; t += 2) { s0 += src[t * sg.stride[k]]; s1 += src[(t + 1) * sg.stride[k]]; }
+    if (t < sg.nslab[k]) s0 += src[t * sg.stride[k]];
+    sg.dst[k][e] = sg.scale * (s0 + s1);
+}
+
 __global__ void colsum_kernel(const float* __restrict__ X, int M, int N, long ld, float scale, float* __restrict__ out) {
     // one wave-column-group per block: blockDim = (64, 4); each y-slice sums a strided subset of rows
     __shared__ float part[4][64];
@@ -192,6 +207,15 @@ int launch_reduce_slabs(hipStream_t st, const float* slabs, int nslab, long stri
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, nslab, stride, n, scale, out);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+int launch_reduce_multi(hipStream_t st, ReduceSegs& sg) {
+    if (sg.n < 1) return FUMI_OK;
+    const long tot = sg.end[sg.n - 1];
+    if (tot < 1) return FUMI_OK;
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sg);
     LAUNCH_CHECK();
     return FUMI_OK;
 }

@@ -66,10 +66,10 @@ def lib():
         PP = POINTER(c_void_p)
         L.fumi_hip_fumi_step.argtypes = (
             [c_void_p, c_void_p] + [c_int] * 6 + [POINTER(c_int), c_int, c_int, c_int, c_float, c_int, c_int, c_float]
-            + [c_void_p] * 6 + [PP, PP] + [c_void_p] * 4 + [PP, PP])
+            + [c_void_p] * 6 + [PP, PP] + [c_void_p] * 5 + [PP, PP])
         L.fumi_hip_maml_step.argtypes = (
             [c_void_p, c_void_p] + [c_int] * 6 + [POINTER(c_int), c_int, c_float, c_int, c_int, c_float]
-            + [c_void_p] * 4 + [PP] + [c_void_p] * 4 + [PP])
+            + [c_void_p] * 4 + [PP] + [c_void_p] * 5 + [PP])
         L.fumi_hip_am3_step.argtypes = (
             [c_void_p, c_void_p] + [c_int] * 10 + [c_float] + [c_void_p] * 5 + [PP] + [c_void_p] * 4 + [PP])
         L.fumi_hip_glove_bag.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int, c_int,
@@ -201,7 +201,7 @@ def raise_on_status(status):
 
 # ----------------------------------------------------------------------------------------------------------------
 def fumi_step(ws, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head, *, cls_text=None, text_s=None,
-              need_grad=True, grad_scale=None, g_theta=None, g_phi=None):
+              need_grad=True, grad_scale=None, g_theta=None, g_phi=None, stats=None):
     """One FuMI meta-step over B episodes (fumi/models/fumi.py:146-192).  Returns a dict of GPU tensors."""
     dev = _dev(x_s)
     B, S, D = x_s.shape
@@ -213,11 +213,11 @@ def fumi_step(ws, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head, *, cls_te
     if N is None:
         raise FumiHipError("fumi_step: pass n_way through cls_text=[B,N,Dt] or use fumi_step_select")
     return _fumi_step(ws, dev, B, N, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head,
-                      cls_text, text_s, need_grad, grad_scale, g_theta, g_phi)
+                      cls_text, text_s, need_grad, grad_scale, g_theta, g_phi, stats)
 
 
 def fumi_step_select(ws, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head, *,
-                     need_grad=True, grad_scale=None, g_theta=None, g_phi=None):
+                     need_grad=True, grad_scale=None, g_theta=None, g_phi=None, stats=None):
     """Same, selecting the per-class text rows from text_s [B,S,Dt] on the device (fumi.py:207-210)."""
     dev = _dev(x_s)
     B, S, D = x_s.shape
@@ -226,11 +226,11 @@ def fumi_step_select(ws, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha
     hid = [int(theta[2 * i].shape[0]) for i in range(n_hidden)]
     Ht, Dt = int(phi[0].shape[0]), int(phi[0].shape[1])
     return _fumi_step(ws, dev, B, n_way, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head,
-                      None, text_s, need_grad, grad_scale, g_theta, g_phi)
+                      None, text_s, need_grad, grad_scale, g_theta, g_phi, stats)
 
 
 def _fumi_step(ws, dev, B, N, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head,
-               cls_text, text_s, need_grad, grad_scale, g_theta, g_phi):
+               cls_text, text_s, need_grad, grad_scale, g_theta, g_phi, stats=None):
     L = lib()
     logits = torch.empty(B, Qn, N, device=dev, dtype=torch.float32)
     preds = torch.empty(B, Qn, device=dev, dtype=torch.int64)
@@ -252,13 +252,14 @@ def _fumi_step(ws, dev, B, N, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, 
         _f32(text_s, "text_s") if text_s is not None else None,
         _parr(theta, "theta"), _parr(phi, "phi"),
         _f32(logits, "logits"), _i64(preds, "preds"), _f32(loss_b, "loss_b"), _f32(acc_b, "acc_b"),
+        _f32(stats, "stats") if stats is not None else None,
         _parr(g_theta, "g_theta") if need_grad else None, _parr(g_phi, "g_phi") if need_grad else None)
     _check(rc, "fumi_hip_fumi_step")
-    return dict(logits=logits, preds=preds, loss_b=loss_b, acc_b=acc_b, g_theta=g_theta, g_phi=g_phi)
+    return dict(logits=logits, preds=preds, loss_b=loss_b, acc_b=acc_b, g_theta=g_theta, g_phi=g_phi, stats=stats)
 
 
 def maml_step(ws, x_s, y_s, x_q, y_q, params, T, alpha, first_order=False, *, need_grad=True, grad_scale=None,
-              g_params=None):
+              g_params=None, stats=None):
     """One MAML meta-step (fumi/models/maml.py:156-191).  params = hidden (W,b)* then lin_final W [N,H], b [N]."""
     dev = _dev(x_s)
     L = lib()
@@ -281,9 +282,10 @@ def maml_step(ws, x_s, y_s, x_q, y_q, params, T, alpha, first_order=False, *, ne
         int(bool(need_grad)), float(grad_scale),
         _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"), _parr(params, "params"),
         _f32(logits, "logits"), _i64(preds, "preds"), _f32(loss_b, "loss_b"), _f32(acc_b, "acc_b"),
+        _f32(stats, "stats") if stats is not None else None,
         _parr(g_params, "g_params") if need_grad else None)
     _check(rc, "fumi_hip_maml_step")
-    return dict(logits=logits, preds=preds, loss_b=loss_b, acc_b=acc_b, g_params=g_params)
+    return dict(logits=logits, preds=preds, loss_b=loss_b, acc_b=acc_b, g_params=g_params, stats=stats)
 
 
 AM3_KEYS = ["Wi", "bi", "G0", "g0", "G1", "g1", "H0", "h0", "H1", "h1"]

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import dist as fdist
+from .. import lazy
 from .. import engine as _engine
 from ..flatgrad import FlatGrads
 from ..meta import MetaLinear, MetaSequential
@@ -182,17 +183,12 @@ class FUMI(nn.Module):
         phi = [p.detach() for p in self._phi()]
         fg = self._flat_grads() if train else None
         nth = len(theta)
+        # [.. grads .. | sum loss / B | sum acc / B], written by the engine -> one all-reduce(sum) -> global means everywhere
+        tail = fg.tail if train else torch.empty(2, device=x_s.device, dtype=torch.float32)
         out = eng.fumi_step(self.n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, args.step_size, self.norm_hypernet,
                             need_grad=train, grad_scale=1.0 / B,
                             g_theta=fg.views[:nth] if train else None, g_phi=fg.views[nth:] if train else None,
-                            cls_text=cls_text)
-        # [.. grads .. | sum loss / B | sum acc / B] -> one all-reduce(sum) -> global means on every rank
-        if train:
-            tail = fg.tail
-        else:
-            tail = torch.empty(2, device=x_s.device, dtype=torch.float32)
-        torch.stack([out["loss_b"].sum(), out["acc_b"].sum()], out=tail)
-        tail.mul_(1.0 / B)
+                            cls_text=cls_text, stats=tail)
         fdist.all_reduce_sum_(fg.flat if train else tail)
         if train:
             optimizer.zero_grad()
@@ -201,9 +197,9 @@ class FUMI(nn.Module):
         preds = out["preds"]
         if fdist.world()[1] > 1 and not train:
             preds = fdist.all_gather_rows(preds)
-        stats = tail.detach().cpu().numpy()                      # the one host sync of the step (fumi.py:195)
+        loss, acc = lazy.scalars(tail, 2)                        # read back asynchronously (fumi.py:195 blocks here)
         test_preds = preds.to(torch.float32) if preds.shape[0] == B else None
-        return stats[0], stats[1], test_preds, q_y.to(dev)
+        return loss, acc, test_preds, q_y.to(dev)
 
 
 def training_run(args, model, optimizer, train_loader, val_loader, max_test_batches):

@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import dist as fdist
+from .. import lazy
 from .. import engine as _engine
 from ..flatgrad import FlatGrads
 from ..meta import MetaLinear, MetaModule, MetaSequential
@@ -64,19 +65,16 @@ def evaluate(args, model, batch, optimizer, task="train"):
     x_s, x_q, y_s, y_q = to(s_im).float(), to(q_im).float(), to(s_y), to(q_y)
     T = args.num_train_adapt_steps if train else args.num_test_adapt_steps
     fg = model._flat_grads() if train else None
-    out = _engine.get_engine().maml_step(x_s, y_s, x_q, y_q, [p.detach() for p in model._params()], T, args.step_size,
-                                         bool(args.first_order), need_grad=train, grad_scale=1.0 / B,
-                                         g_params=fg.views if train else None)
     tail = fg.tail if train else torch.empty(2, device=x_s.device, dtype=torch.float32)
-    torch.stack([out["loss_b"].sum(), out["acc_b"].sum()], out=tail)
-    tail.mul_(1.0 / B)
+    _engine.get_engine().maml_step(x_s, y_s, x_q, y_q, [p.detach() for p in model._params()], T, args.step_size,
+                                   bool(args.first_order), need_grad=train, grad_scale=1.0 / B,
+                                   g_params=fg.views if train else None, stats=tail)
     fdist.all_reduce_sum_(fg.flat if train else tail)
     if train:
         optimizer.zero_grad()
         fg.attach()
         optimizer.step()
-    stats = tail.detach().cpu().numpy()
-    return stats[0], stats[1]
+    return lazy.scalars(tail, 2)
 
 
 def training_run(args, model, optimizer, train_loader, val_loader, max_test_batches):

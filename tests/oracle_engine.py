@@ -15,7 +15,7 @@ class OracleEngine:
         return R.word_embedding_pool(rows, table, pad_id, mode)
 
     def fumi_step(self, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head, need_grad, grad_scale,
-                  g_theta=None, g_phi=None, cls_text=None):
+                  g_theta=None, g_phi=None, cls_text=None, stats=None):
         B = x_s.shape[0]
         if cls_text is not None:                # expand the per-class rows back to per-sample rows for the oracle
             text_s = torch.gather(cls_text, 1, y_s[..., None].expand(-1, -1, cls_text.shape[-1]))
@@ -25,15 +25,19 @@ class OracleEngine:
         if need_grad:
             for dst, g in zip(list(g_theta) + list(g_phi), out["g_theta"] + out["g_phi"]):
                 dst.copy_(g * (B * grad_scale))               # oracle returns mean-loss grads = (1/B) sum_b
+        if stats is not None:
+            stats.copy_(torch.stack([out["loss_b"].sum(), out["acc_b"].sum()]) * grad_scale)
         return dict(logits=out["logits"], preds=out["preds"], loss_b=out["loss_b"], acc_b=out["acc_b"])
 
-    def maml_step(self, x_s, y_s, x_q, y_q, params, T, alpha, first_order, need_grad, grad_scale, g_params=None):
+    def maml_step(self, x_s, y_s, x_q, y_q, params, T, alpha, first_order, need_grad, grad_scale, g_params=None, stats=None):
         B = x_s.shape[0]
         p = [t.detach().clone().requires_grad_(True) for t in params]
         out = R.maml_meta_step(p, x_s, y_s, x_q, y_q, T, alpha, first_order, need_grad=need_grad)
         if need_grad:
             for dst, g in zip(g_params, out["g_params"]):
                 dst.copy_(g * (B * grad_scale))
+        if stats is not None:
+            stats.copy_(torch.stack([out["loss_b"].sum(), out["acc_b"].sum()]) * grad_scale)
         return dict(logits=out["logits"], preds=out["preds"], loss_b=out["loss_b"], acc_b=out["acc_b"])
 
     def am3_step(self, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad, grad_scale, g_w=None):

@@ -232,9 +232,10 @@ def test_fumi_linearity_in_grad_scale_and_episode_sum(dev, ws):
                                     _g(ep["y_q"][sl], dev), _g(ep["text_s"][sl], dev), th, ph, T, cg.ALPHA, True,
                                     grad_scale=scale)
     full = run(slice(0, B), 1.0 / B)
-    full = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in full.items()}
+    keep = lambda d: {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in d.items() if v is not None}
+    full = keep(full)
     a = run(slice(0, B // 2), 1.0 / B)
-    a = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in a.items()}
+    a = keep(a)
     b = run(slice(B // 2, B), 1.0 / B)
     assert torch.equal(torch.cat([a["preds"], b["preds"]]), full["preds"])
     assert rel_to_max(torch.cat([a["logits"], b["logits"]]).cpu(), full["logits"].cpu()) <= 1e-6
@@ -310,3 +311,43 @@ def test_fused_adam_matches_torch_adam(dev, ws):
     assert sa["state"].keys() == sb["state"].keys() and set(sa["state"][0]) == set(sb["state"][0])
     assert float(sa["state"][0]["step"]) == float(sb["state"][0]["step"]) == 4.0
     ob.load_state_dict(sa)                                     # checkpoints interchange with torch.optim.Adam
+
+
+def test_step_stats_output(dev, ws):
+    """stats = grad_scale * (sum loss_b, sum acc_b), what FUMI.evaluate puts in the all-reduce buffer."""
+    from fumi_amd import hip
+    c = cg.FUMI_CASES["fumi_t1"]
+    ep = cg.make_episodes(2, c["B"], c["N"], c["K"], c["Q"], c["D"], c["Dt"])
+    theta, phi = cg.make_fumi_params(2, c["D"], c["hid"], c["Dt"], c["Ht"])
+    for need_grad in (True, False):
+        stats = torch.zeros(2, device=dev)
+        out = hip.fumi_step_select(ws, c["N"], _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev),
+                                   _g(ep["text_s"], dev), [_g(t, dev) for t in theta], [_g(t, dev) for t in phi], c["T"],
+                                   cg.ALPHA, False, need_grad=need_grad, grad_scale=0.25, stats=stats)
+        assert abs(float(stats[0]) - 0.25 * float(out["loss_b"].sum())) < 1e-6
+        assert abs(float(stats[1]) - 0.25 * float(out["acc_b"].sum())) < 1e-6
+
+
+def test_fumi_evaluate_on_gpu_lazy_scalars(dev):
+    """FUMI.evaluate end to end on the GPU: returned scalars behave like the reference's 0-d arrays."""
+    from types import SimpleNamespace
+    from fumi_amd.models.fumi import FUMI
+    from fumi_amd.optim import Adam
+    name = "fumi_t5_tanh"
+    c, gold = cg.FUMI_CASES[name], load_golden(name)
+    seed = case_seed(name)
+    ep = cg.make_episodes(seed, c["B"], c["N"], c["K"], c["Q"], c["D"], c["Dt"], blocked=c["blocked"])
+    theta, phi = cg.make_fumi_params(seed, c["D"], c["hid"], c["Dt"], c["Ht"])
+    m = FUMI(n_way=c["N"], im_emb_dim=c["D"], im_hid_dim=c["hid"], text_encoder="BERT", text_emb_dim=c["Dt"],
+             text_hid_dim=c["Ht"], norm_hypernet=c["tanh"])
+    m.load_state_dict(cg.fumi_state_dict(theta, phi))
+    m.to(dev)
+    opt = Adam(m.parameters(), lr=3e-5, weight_decay=5e-4)
+    args = SimpleNamespace(device=dev, num_train_adapt_steps=c["T"], num_test_adapt_steps=c["T"], step_size=cg.ALPHA,
+                           first_order=False, num_ways=c["N"], batch_size=c["B"])
+    loss, acc, preds, tgt = m.evaluate(args, cg.to_batch(ep), opt, "train")
+    assert abs(float(loss) - float(gold["loss"])) < 1e-4 and abs(float(acc) - float(gold["acc"])) < 1e-6
+    assert np.isfinite(np.asarray(loss)) and (loss < 10.0) and f"{loss:.3f}" == f"{float(loss):.3f}"
+    assert np.array_equal(preds.cpu().numpy().astype(np.int64), gold["preds"])
+    for n, p in m.named_parameters():                        # fused Adam step == the reference's torch.optim.Adam step
+        np.testing.assert_allclose(cg.digest(p.detach().cpu())[3:], gold[f"post.{n}.digest"][3:], rtol=0, atol=3e-7)
