@@ -21,57 +21,69 @@ constexpr int BM = 64, BN = 64, BK = 32;
 constexpr int KC_LD = BK + 4;     // row stride (floats) of a k-contiguous LDS image
 constexpr int TILE_F = 64 * KC_LD; // floats reserved per operand image (>= 32*64 for the other layout)
 
-// global -> registers for one operand tile (64 rows/cols x 32 k), 2 float4 per thread
-template <int LAYOUT>
-__device__ __forceinline__ void load_tile(f32x4 (&r)[2], const float* __restrict__ P, long ld, int row0, int rows,
-                                          int k0, int kend, bool vec) {
+// global -> registers for one operand tile (64 rows/cols x 32 k), 2 float4 per thread.
+// VEC (16-byte aligned rows, no float4 straddles a bound): every load is an UNCONDITIONAL float4 from a clamped, always
+// valid address and the out-of-range ones are zeroed when the tile is written to LDS.  hipcc turns guarded loads into
+// branches separated by vmcnt(0), i.e. one dependent memory round trip per guard; the scalar path below keeps the guards
+// and is only taken for unaligned / odd-sized operands.
+template <int LAYOUT, bool VEC>
+__device__ __forceinline__ void load_tile(f32x4 (&r)[2], bool (&ok)[2], const float* __restrict__ P, long ld, int row0,
+                                          int rows, int k0, int kbeg, int kend) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int f = tid + 256 * j;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (LAYOUT == 0) {                       // P(row,k) = P[row*ld + k]
             const int row = row0 + (f >> 3), k = k0 + ((f & 7) << 2);
-            if (row < rows) {
-                const float* p = P + (long)row * ld + k;
-                if (vec && k + 3 < kend) v = *(const f32x4*)p;
-                else {
+            if (VEC) {
+                ok[j] = row < rows && k + 3 < kend;
+                r[j] = *(const f32x4*)(P + (long)(ok[j] ? row : 0) * ld + (ok[j] ? k : kbeg));
+            } else {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row < rows) {
+                    const float* p = P + (long)row * ld + k;
                     if (k < kend) v[0] = p[0];
                     if (k + 1 < kend) v[1] = p[1];
                     if (k + 2 < kend) v[2] = p[2];
                     if (k + 3 < kend) v[3] = p[3];
                 }
+                r[j] = v; ok[j] = true;
             }
         } else {                                 // P(row,k) = P[k*ld + row]
             const int k = k0 + (f >> 4), row = row0 + ((f & 15) << 2);
-            if (k < kend) {
-                const float* p = P + (long)k * ld + row;
-                if (vec && row + 3 < rows) v = *(const f32x4*)p;
-                else {
+            if (VEC) {
+                ok[j] = k < kend && row + 3 < rows;
+                r[j] = *(const f32x4*)(P + (long)(ok[j] ? k : kbeg) * ld + (ok[j] ? row : 0));
+            } else {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k < kend) {
+                    const float* p = P + (long)k * ld + row;
                     if (row < rows) v[0] = p[0];
                     if (row + 1 < rows) v[1] = p[1];
                     if (row + 2 < rows) v[2] = p[2];
                     if (row + 3 < rows) v[3] = p[3];
                 }
+                r[j] = v; ok[j] = true;
             }
         }
-        r[j] = v;
     }
 }
 
 template <int LAYOUT>
-__device__ __forceinline__ void store_tile(const f32x4 (&r)[2], float* T) {
+__device__ __forceinline__ void store_tile(const f32x4 (&r)[2], const bool (&ok)[2], float* T) {
     const int tid = threadIdx.x;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int f = tid + 256 * j;
-        if (LAYOUT == 0) *(f32x4*)(T + (f >> 3) * KC_LD + ((f & 7) << 2)) = r[j];
-        else             *(f32x4*)(T + (f >> 4) * 64 + ((f & 15) << 2)) = r[j];
+        const f32x4 v = ok[j] ? r[j] : zero4;
+        if (LAYOUT == 0) *(f32x4*)(T + (f >> 3) * KC_LD + ((f & 7) << 2)) = v;
+        else             *(f32x4*)(T + (f >> 4) * 64 + ((f & 15) << 2)) = v;
     }
 }
 
-template <int AL, int BL>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int avec, int bvec) {
+template <int AL, int BL, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][TILE_F];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -88,20 +100,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int avec, int bve
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
     f32x4 ra[2], rb[2];
+    bool oka[2], okb[2];
     const int nslab = (kend - kbeg + BK - 1) / BK;
     if (nslab > 0) {
-        load_tile<AL>(ra, A, g.lda, m0, g.M, kbeg, kend, avec);
-        load_tile<BL>(rb, B, g.ldb, n0, g.N, kbeg, kend, bvec);
-        store_tile<AL>(ra, lds[0][0]);
-        store_tile<BL>(rb, lds[0][1]);
+        load_tile<AL, VEC>(ra, oka, A, g.lda, m0, g.M, kbeg, kbeg, kend);
+        load_tile<BL, VEC>(rb, okb, B, g.ldb, n0, g.N, kbeg, kbeg, kend);
+        store_tile<AL>(ra, oka, lds[0][0]);
+        store_tile<BL>(rb, okb, lds[0][1]);
     }
     __syncthreads();
     const int li = lane & 31, kh = lane >> 5;
     for (int s = 0; s < nslab; ++s) {
         const int cur = s & 1;
         if (s + 1 < nslab) {
-            load_tile<AL>(ra, A, g.lda, m0, g.M, kbeg + (s + 1) * BK, kend, avec);
-            load_tile<BL>(rb, B, g.ldb, n0, g.N, kbeg + (s + 1) * BK, kend, bvec);
+            load_tile<AL, VEC>(ra, oka, A, g.lda, m0, g.M, kbeg + (s + 1) * BK, kbeg, kend);
+            load_tile<BL, VEC>(rb, okb, B, g.ldb, n0, g.N, kbeg + (s + 1) * BK, kbeg, kend);
         }
         const float* TA = lds[cur][0];
         const float* TB = lds[cur][1];
@@ -122,8 +135,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int avec, int bve
             for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
         }
         if (s + 1 < nslab) {
-            store_tile<AL>(ra, lds[cur ^ 1][0]);
-            store_tile<BL>(rb, lds[cur ^ 1][1]);
+            store_tile<AL>(ra, oka, lds[cur ^ 1][0]);
+            store_tile<BL>(rb, okb, lds[cur ^ 1][1]);
         }
         __syncthreads();
     }
@@ -190,14 +203,19 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 int launch_gemm(hipStream_t st, const GemmArgs& g, int AL, int BL) {
     if (g.M <= 0 || g.N <= 0) return FUMI_OK;
     if (g.K < 0 || g.nsplit < 1 || g.nbatch < 1 || !g.A || !g.B || !g.C) return FUMI_EINVAL;
-    // float4 path needs every float4 to be 16-byte aligned and never to straddle a tile bound
-    const bool avec = aligned16(g.A) && g.lda % 4 == 0 && g.sA % 4 == 0 && (AL == 0 ? (g.kchunk % 4 == 0) : true);
-    const bool bvec = aligned16(g.B) && g.ldb % 4 == 0 && g.sB % 4 == 0 && (BL == 0 ? (g.kchunk % 4 == 0) : true);
+    // float4 path: every float4 16-byte aligned and never straddling a bound (row length / tile extent multiple of 4)
+    const bool avec = aligned16(g.A) && g.lda % 4 == 0 && g.sA % 4 == 0 && g.kchunk % 4 == 0 && (AL == 0 ? g.K % 4 == 0 : g.M % 4 == 0);
+    const bool bvec = aligned16(g.B) && g.ldb % 4 == 0 && g.sB % 4 == 0 && g.kchunk % 4 == 0 && (BL == 0 ? g.K % 4 == 0 : g.N % 4 == 0);
+    const bool vec = avec && bvec;
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.nbatch * g.nsplit), block(256);
-    if (AL == 0 && BL == 0) hipLaunchKernelGGL((gemm_kernel<0, 0>), grid, block, 0, st, g, avec, bvec);
-    else if (AL == 0 && BL == 1) hipLaunchKernelGGL((gemm_kernel<0, 1>), grid, block, 0, st, g, avec, bvec);
-    else if (AL == 1 && BL == 0) hipLaunchKernelGGL((gemm_kernel<1, 0>), grid, block, 0, st, g, avec, bvec);
-    else hipLaunchKernelGGL((gemm_kernel<1, 1>), grid, block, 0, st, g, avec, bvec);
+#define GEMM_LAUNCH(a, b)                                                                              \
+    if (vec) hipLaunchKernelGGL((gemm_kernel<a, b, true>), grid, block, 0, st, g);                   \
+    else hipLaunchKernelGGL((gemm_kernel<a, b, false>), grid, block, 0, st, g);
+    if (AL == 0 && BL == 0) { GEMM_LAUNCH(0, 0) }
+    else if (AL == 0 && BL == 1) { GEMM_LAUNCH(0, 1) }
+    else if (AL == 1 && BL == 0) { GEMM_LAUNCH(1, 0) }
+    else { GEMM_LAUNCH(1, 1) }
+#undef GEMM_LAUNCH
     LAUNCH_CHECK();
     return FUMI_OK;
 }

@@ -5,7 +5,7 @@
 // and, in its "select" form, also the per-class first-support-row pick of fumi/models/fumi.py:207-210 (FuMI only needs
 // the text of N class rows per episode, not of all S support rows: 5x fewer table rows gathered).
 //
-// HBM/L2-bound gather: one wave per output row.  The row's token ids are read 64 at a time with one coalesced load and
+// HBM/L2-bound gather: one workgroup (4 waves) per output row.  A wave's token ids are read 64 at a time with one coalesced load and
 // handed out by cross-lane shuffles; the table rows of 8 tokens are requested back to back (8 independent 16-byte-per-
 // lane gathers in flight) before any is accumulated -- a loop that reads a token id and then its row is two dependent
 // memory round trips per token.
@@ -13,14 +13,20 @@
 
 namespace {
 
+// one 256-thread workgroup per output row: the row's L tokens are split over the 4 waves (4x the gathers in flight per
+// row; the whole launch is only B*N = 160 rows at the bench shape, so a wave per row left most CUs idle)
 template <bool VEC>
 __global__ __launch_bounds__(256) void glove_bag_kernel(const int64_t* __restrict__ tok, int R, int L, int64_t pad_id,
                                                         const float* __restrict__ table, int V, int E, int mode,
                                                         float* __restrict__ out, int* status,
                                                         const int64_t* __restrict__ y_s, int N, int S) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (r >= R) return;
+    extern __shared__ __attribute__((aligned(16))) float part[];      // [4][Ep] partial sums / maxima, then [4] counts
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x;
+    constexpr int W = VEC ? 4 : 1;
+    const int nchunk = (E / W + 63) / 64;        // chunks of 64 lanes x W floats
+    const int Ep = nchunk * 64 * W;
+    float* cnts = part + 4 * Ep;
     long src_row = r;
     if (y_s) {                                   // select form: output row r = (episode, class); source = first support row of the class
         const int b = r / N, c = r - b * N;
@@ -32,24 +38,23 @@ __global__ __launch_bounds__(256) void glove_bag_kernel(const int64_t* __restric
             if (m) first = s0 + __ffsll((long long)m) - 1;
         }
         if (first == S) {                        // the reference raises IndexError here (fumi.py:209)
-            if (lane == 0) atomicOr(status, FUMI_ST_CLASS_MISSING);
-            for (int j = lane; j < E; j += 64) out[(long)r * E + j] = __builtin_nanf("");
+            if (threadIdx.x == 0) atomicOr(status, FUMI_ST_CLASS_MISSING);
+            for (int j = threadIdx.x; j < E; j += blockDim.x) out[(long)r * E + j] = __builtin_nanf("");
             return;
         }
         src_row = (long)b * S + first;
     }
     const int64_t* t = tok + src_row * L;
-    constexpr int W = VEC ? 4 : 1;
-    const int nchunk = (E / W + 63) / 64;        // chunks of 64 lanes x W floats
+    const int lw = (L + 3) / 4;                  // tokens per wave
+    const int lbeg = wave * lw, lend = min(L, lbeg + lw);
     for (int c = 0; c < nchunk; ++c) {
         const int j = (c * 64 + lane) * W;
-        const bool ok = j < E;
-        const int jc = ok ? j : 0;
+        const int jc = j < E ? j : 0;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (mode == 1) acc = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int cnt = 0;
-        for (int l0 = 0; l0 < L; l0 += 64) {
-            const int nl = min(64, L - l0);
+        for (int l0 = lbeg; l0 < lend; l0 += 64) {
+            const int nl = min(64, lend - l0);
             long my = lane < nl ? t[l0 + lane] : pad_id;
             cnt += __popcll(__ballot(lane < nl && my != pad_id));
             if (my < 0 || my >= V) { if (lane < nl) atomicOr(status, FUMI_ST_LABEL_RANGE); my = 0; }
@@ -71,20 +76,28 @@ __global__ __launch_bounds__(256) void glove_bag_kernel(const int64_t* __restric
                 }
             }
         }
-        if (ok) {
-            float* o = out + (long)r * E + j;
-            if (mode == 0) { const float dn = (float)cnt; acc[0] /= dn; acc[1] /= dn; acc[2] /= dn; acc[3] /= dn; }
-            if (VEC) *(f32x4*)o = acc; else o[0] = acc[0];
-        }
+        float* pp = part + wave * Ep + (c * 64 + lane) * W;
+        if (VEC) *(f32x4*)pp = acc; else pp[0] = acc[0];
+        if (lane == 0 && c == 0) cnts[wave] = (float)cnt;
+    }
+    __syncthreads();
+    const float dn = cnts[0] + cnts[1] + cnts[2] + cnts[3];
+    for (int j = threadIdx.x; j < E; j += blockDim.x) {
+        const float a0 = part[j], a1 = part[Ep + j], a2 = part[2 * Ep + j], a3 = part[3 * Ep + j];
+        out[(long)r * E + j] = mode == 0 ? ((a0 + a1) + (a2 + a3)) / dn : fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
     }
 }
 
 int launch_bag(fumi_ws_t* ws, hipStream_t st, const int64_t* tok, int R, int L, int64_t pad_id, const float* table, int V,
                int E, int mode, float* out, const int64_t* y_s, int N, int S) {
     const bool vec = E % 4 == 0 && ((uintptr_t)table & 15) == 0 && ((uintptr_t)out & 15) == 0;
-    dim3 grid((R + 3) / 4), block(256);
-    if (vec) hipLaunchKernelGGL(glove_bag_kernel<true>, grid, block, 0, st, tok, R, L, pad_id, table, V, E, mode, out, ws->status, y_s, N, S);
-    else hipLaunchKernelGGL(glove_bag_kernel<false>, grid, block, 0, st, tok, R, L, pad_id, table, V, E, mode, out, ws->status, y_s, N, S);
+    dim3 grid(R), block(256);
+    const int W = vec ? 4 : 1;
+    const int Ep = ((E / W + 63) / 64) * 64 * W;
+    const size_t lds = (size_t)(4 * Ep + 4) * sizeof(float);
+    if (lds > 64 * 1024) return FUMI_ENOTSUP;
+    if (vec) hipLaunchKernelGGL(glove_bag_kernel<true>, grid, block, lds, st, tok, R, L, pad_id, table, V, E, mode, out, ws->status, y_s, N, S);
+    else hipLaunchKernelGGL(glove_bag_kernel<false>, grid, block, lds, st, tok, R, L, pad_id, table, V, E, mode, out, ws->status, y_s, N, S);
     LAUNCH_CHECK();
     return FUMI_OK;
 }
