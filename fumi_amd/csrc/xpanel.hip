@@ -206,6 +206,29 @@ __global__ __launch_bounds__(256) void xpanel_fwd_kernel(XPanel p, float* __rest
         if (more) XP_FREAD(0, cur ^ 1, 0)                                                                    \
     }
 
+// steady-state slab (s + 1 + NST < nslab): no conditionals, one scheduling region, with the issue order spelled out --
+// the 8 LDS writes of the staged slab and the 8 global loads that refill the stage are dealt one per MFMA into the
+// shadows of the dependent MFMA chain (an MFMA occupies the pipe for 64 cycles; whatever sits between two MFMAs in
+// program order issues for free), instead of in two clusters during which the matrix pipe drains.
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
+#define XP_SLAB_MAIN(ST, s)                                                                                  \
+    {                                                                                                        \
+        const int cur = (s) & 1;                                                                             \
+        XP_FREAD(1, cur, 1) XP_MMA8(0)                                                                       \
+        XP_FREAD(0, cur, 2) XP_MMA8(1)                                                                       \
+        XP_FREAD(1, cur, 3) XP_MMA8(0)                                                                       \
+        XP_LSTORE(ST, cur ^ 1)                                                                               \
+        XP_GLOAD(ST, ((s) + 1 + NST) * FBK)                                                                  \
+        XP_MMA8(1)                                                                                           \
+        SGB(0x100, 8) SGB(0x008, 8) SGB(0x100, 4)                                                            \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) { SGB(0x008, 1) SGB(0x002, 4) SGB(0x200, 1) }          \
+        SGB(0x100, 4)                                                                                        \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) { SGB(0x008, 1) SGB(0x002, 2) SGB(0x020, 1) }          \
+        SGB(0x008, 8)                                                                                        \
+        __syncthreads();                                                                                     \
+        XP_FREAD(0, cur ^ 1, 0)                                                                              \
+    }
+
     // prologue: slab 0 straight to LDS, slabs 1..NST into the ring (stage of slab q is (q-1) % NST)
     XP_GLOAD(0, 0)
     XP_LSTORE(0, 0)
@@ -214,11 +237,19 @@ __global__ __launch_bounds__(256) void xpanel_fwd_kernel(XPanel p, float* __rest
     if (NST > 2 && 3 < nslab) { XP_GLOAD(2 % NST, 3 * FBK) }
     __syncthreads();
     XP_FREAD(0, 0, 0)
-    for (int s = 0; s < nslab; s += NST) {
+    int s = 0;
+    for (; s + 2 * NST < nslab; s += NST) {          // every slab of this round has s' + 1 + NST < nslab
+        XP_SLAB_MAIN(0, s)
+        if (NST > 1) { XP_SLAB_MAIN(1 % NST, s + 1) }
+        if (NST > 2) { XP_SLAB_MAIN(2 % NST, s + 2) }
+    }
+    for (; s < nslab; s += NST) {
         XP_SLAB(0, s)
         if (NST > 1) { XP_SLAB(1 % NST, s + 1) }
         if (NST > 2) { XP_SLAB(2 % NST, s + 2) }
     }
+#undef XP_SLAB_MAIN
+#undef SGB
 #undef XP_GLOAD
 #undef XP_LSTORE
 #undef XP_FREAD
@@ -241,6 +272,107 @@ __global__ __launch_bounds__(256) void xpanel_fwd_kernel(XPanel p, float* __rest
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             if (m < R) base[(long)m * ld + col] = acc[r];
+        }
+    }
+}
+
+// ---- forward, 8-wave variant: the same 64x64x64 slabs, but two waves per 32x32 output quadrant, each multiplying half
+// of every slab's k range (k-groups {0,1} / {2,3}); their accumulators are added through LDS at the end.  Two waves per
+// SIMD from the SAME workgroup share the staged data, so one wave's stalls (LDS latency after the slab barrier, the
+// staging writes) are covered by its partner's MFMAs without any extra memory traffic.
+template <int NST>
+__global__ __launch_bounds__(512) void xpanel_fwd8_kernel(XPanel p, float* __restrict__ A0, float* __restrict__ G,
+                                                          int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][64 * FLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wq = wave & 3, kg = wave >> 2;             // output quadrant, k-half
+    const int wm = wq >> 1, wn = wq & 1;
+    const int R = p.S + p.Qn, C = p.h0 + p.S, K = p.D;
+    const int tiles = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int b = xcd + 8 * (j / tiles), t = j % tiles;
+    if (b >= p.B) return;
+    const int m0 = (t / tiles_n) * 64, n0 = (t % tiles_n) * 64;
+
+    const float* arow[2]; const float* brow[2]; bool aok[2], bok[2];
+    const int k4 = (tid & 15) << 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rr = (tid >> 4) + 32 * i;
+        const int r = m0 + rr, c = n0 + rr;
+        aok[i] = r < R; bok[i] = c < C;
+        arow[i] = xrow(p, b, aok[i] ? r : 0) + k4;
+        brow[i] = (c < p.h0 ? p.W0 + (long)c * K : p.x_s + ((long)b * p.S + (bok[i] ? c - p.h0 : 0)) * K) + k4;
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ga[NST][2], gb[NST][2];
+    const int li = lane & 31, kh = lane >> 5;
+    const int aoff = (wm * 32 + li) * FLD + 4 * kh + 32 * kg, boff = (wn * 32 + li) * FLD + 4 * kh + 32 * kg;
+    f32x4 fa[2][2], fb[2][2];
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int nslab = K / FBK;
+#define XP_GLOAD(st, k0)                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
+        ga[st][i] = *(const f32x4*)(arow[i] + (k0)); gb[st][i] = *(const f32x4*)(brow[i] + (k0)); }
+#define XP_LSTORE(st, buf)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
+        const int off = ((tid >> 4) + 32 * i) * FLD + k4;                                                    \
+        *(f32x4*)(lds[buf][0] + off) = aok[i] ? ga[st][i] : zero4;                                           \
+        *(f32x4*)(lds[buf][1] + off) = bok[i] ? gb[st][i] : zero4; }
+#define XP_FREAD(rb, buf, g)                                                                                 \
+    { fa[rb][0] = *(const f32x4*)(lds[buf][0] + aoff + 16 * (g));     fb[rb][0] = *(const f32x4*)(lds[buf][1] + boff + 16 * (g)); \
+      fa[rb][1] = *(const f32x4*)(lds[buf][0] + aoff + 16 * (g) + 8); fb[rb][1] = *(const f32x4*)(lds[buf][1] + boff + 16 * (g) + 8); }
+#define XP_MMA8(rb)                                                                                          \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h) _Pragma("unroll") for (int e = 0; e < 4; ++e)              \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rb][h][e], fb[rb][h][e], acc, 0, 0, 0);
+#define XP_SLAB(ST, s)                                                                                       \
+    if ((s) < nslab) {                                                                                       \
+        const int cur = (s) & 1;                                                                             \
+        const bool more = (s) + 1 < nslab;                                                                   \
+        XP_FREAD(1, cur, 1) XP_MMA8(0)                                                                       \
+        if (more) { XP_LSTORE(ST, cur ^ 1) }                                                                 \
+        if ((s) + 1 + NST < nslab) { XP_GLOAD(ST, ((s) + 1 + NST) * FBK) }                                   \
+        XP_MMA8(1)                                                                                           \
+        __syncthreads();                                                                                     \
+        if (more) XP_FREAD(0, cur ^ 1, 0)                                                                    \
+    }
+    XP_GLOAD(0, 0)
+    XP_LSTORE(0, 0)
+    if (1 < nslab) { XP_GLOAD(0, 1 * FBK) }
+    if (NST > 1 && 2 < nslab) { XP_GLOAD(1 % NST, 2 * FBK) }
+    __syncthreads();
+    XP_FREAD(0, 0, 0)
+    for (int s = 0; s < nslab; s += NST) {
+        XP_SLAB(0, s)
+        if (NST > 1) { XP_SLAB(1 % NST, s + 1) }
+    }
+#undef XP_GLOAD
+#undef XP_LSTORE
+#undef XP_FREAD
+#undef XP_MMA8
+#undef XP_SLAB
+    // add the two k-halves: waves 4..7 park their accumulators in LDS (the staging buffers are free after the last barrier)
+    float* red = &lds[0][0][0];
+    if (kg == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wq * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[(wq * 16 + r) * 64 + lane];
+        const int n = n0 + wn * 32 + li;
+        if (n < C) {
+            float* base; long ld; int col;
+            if (n < p.h0) { base = A0 + (long)b * R * p.h0; ld = p.h0; col = n; }
+            else          { base = G + (long)b * R * p.S;  ld = p.S;  col = n - p.h0; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (m < R) base[(long)m * ld + col] = acc[r];
+            }
         }
     }
 }
@@ -349,7 +481,11 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
     const bool aligned = al16(x_s) && al16(x_q) && al16(W0);
     const dim3 grid(8 * nper * tiles_m * tiles_n);
     static const int nst = getenv("FUMI_XP_NST") ? atoi(getenv("FUMI_XP_NST")) : 2;
-    if (aligned && D % FBK == 0) {
+    static const int w8 = getenv("FUMI_XP_W8") ? atoi(getenv("FUMI_XP_W8")) : 0;
+    if (aligned && D % FBK == 0 && w8) {
+        if (nst == 1) hipLaunchKernelGGL(xpanel_fwd8_kernel<1>, grid, dim3(512), 0, st, p, A0, G, tiles_m, tiles_n);
+        else hipLaunchKernelGGL(xpanel_fwd8_kernel<2>, grid, dim3(512), 0, st, p, A0, G, tiles_m, tiles_n);
+    } else if (aligned && D % FBK == 0) {
         if (nst == 1) hipLaunchKernelGGL(xpanel_fwd_kernel<1>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, g_trace);
         else if (nst == 2) hipLaunchKernelGGL(xpanel_fwd_kernel<2>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, g_trace);
         else hipLaunchKernelGGL(xpanel_fwd_kernel<3>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, g_trace);
