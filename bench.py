@@ -122,6 +122,18 @@ def cpu_baseline(table, budget_s=12.0):
         opt.step()
         return out
     step(batches[0])                                                          # warm-up
+    # the eager per-episode loop is dispatch-bound: more threads than ~16 only add contention, so the port
+    # gets the thread count that is fastest on this host
+    best = (0.0, torch.get_num_threads())
+    for nt_ in sorted({1, 8, 16, max(1, (os.cpu_count() or 1) // 2)}):
+        if nt_ > (os.cpu_count() or 1):
+            continue
+        torch.set_num_threads(nt_)
+        step(batches[1])
+        t1 = time.perf_counter(); step(batches[0]); r_ = 1.0 / (time.perf_counter() - t1)
+        if r_ > best[0]:
+            best = (r_, nt_)
+    torch.set_num_threads(best[1])
     n, t0 = 0, time.perf_counter()
     while True:
         step(batches[n % 2])
