@@ -138,7 +138,7 @@ int fumi_hip_read_status(fumi_ws_t* ws, fumi_stream_t stream, int* status_out) {
 // ------------------------------------------------------------------------------------------------------------
 int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
         int B, int N, int S, int Qn, int D, int n_hidden, const int* hid, int Dt, int Ht,
-        int T, float alpha, int tanh_head, int need_grad, float grad_scale,
+        int T, float alpha, int tanh_head, int need_grad, float grad_scale, float dropout_p, uint64_t seed,
         const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
         const float* cls_text, const float* text_s,
         const float* const* theta, const float* const* phi,
@@ -157,6 +157,8 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
     memset(&p, 0, sizeof(p));
     p.B = B; p.N = N; p.S = S; p.Qn = Qn; p.D = D; p.L = n_hidden; p.T = T; p.alpha = alpha;
     p.need_grad = need_grad ? 1 : 0; p.second_order = 1; p.grad_scale = grad_scale;
+    if (dropout_p < 0.f || dropout_p >= 1.f) return FUMI_EINVAL;
+    p.dropout_p = dropout_p; p.seed = seed;
     for (int i = 0; i < n_hidden; ++i) {
         if (hid[i] < 1 || !theta[2 * i] || !theta[2 * i + 1]) return FUMI_EINVAL;
         p.h[i] = hid[i]; p.W[i] = theta[2 * i]; p.b[i] = theta[2 * i + 1];

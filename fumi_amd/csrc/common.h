@@ -125,6 +125,8 @@ struct EpisodeProblem {
     float* gW[FUMI_MAX_HIDDEN]; float* gb[FUMI_MAX_HIDDEN];   // outputs (scaled sums over episodes)
     float* head_bar;                // [B,N,H+1] d loss_b / d head_b   (unscaled, per episode)
     float* stats;                   // optional [2]: grad_scale * (sum_b loss_b, sum_b acc_b)
+    float dropout_p;                // inner-loop dropout probability (0 = off) and the step's 64-bit seed
+    unsigned long long seed;
 };
 size_t episode_workspace_bytes(const EpisodeProblem& p);
 int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p);

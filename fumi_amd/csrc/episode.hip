@@ -47,7 +47,29 @@ struct EpiDims {
     int h[MAXL];
     float alpha;
     int need_grad, second_order, taped;
+    // inner-loop dropout (fumi.py:93-99, train mode): keep iff hash(seed, episode, call, layer, element) >= drop_thr,
+    // kept activations are scaled by mscale = 1/(1-p); every ReLU-derivative mask carries the same factor
+    unsigned drop_thr, seed_lo, seed_hi;
+    float mscale;
 };
+
+// counter-based dropout mask: the same function is restated in numpy by the tests (tests/helpers.py:dropout_keep)
+__device__ __forceinline__ unsigned drop_mix(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned drop_key(const EpiDims& d, int b, int call, int layer) {
+    unsigned h = drop_mix(d.seed_lo + 0x9E3779B9U * (unsigned)b);
+    h = drop_mix(h ^ (d.seed_hi + 0x85EBCA6BU * (unsigned)call));
+    return drop_mix(h + 0xC2B2AE35U * (unsigned)layer);
+}
+// relu + dropout of a pre-activation z at flat element index idx of its [rows, h] matrix
+__device__ __forceinline__ float drop_relu(const EpiDims& d, unsigned key, long idx, float z) {
+    if (z <= 0.f) return 0.f;
+    if (d.drop_thr == 0) return z;
+    return drop_mix(key ^ (unsigned)idx) >= d.drop_thr ? z * d.mscale : 0.f;
+}
+constexpr int QUERY_CALL = 1 << 20;      // "call" id of the query forward (support step t uses t)
 
 struct EpiParams {                             // meta-parameters of the hidden layers (device pointers)
     const float* W[MAXL];
@@ -115,19 +137,19 @@ __global__ __launch_bounds__(512) void adapt_kernel(EpiDims d, EpiBuf w, EpiPara
 
         // 1. layer 0 through the low-rank form (D_0 = 0: the first step is just relu(A0s + b0))
         if (t == 0) {
+            const unsigned key0 = drop_key(d, b, t, 0);
             wg_ew((long)S * h0, a(0), A0s, nullptr, nullptr, [&](long i, float x, float, float) {
-                const float z = x + b0[i % h0];
-                return z > 0.f ? z : 0.f;
+                return drop_relu(d, key0, i, x + b0[i % h0]);
             });
         } else {
             wg_colsum(sm, sm_cap, S, h0, D, h0, [&](int n, float s) { cs[n] = s; });
             __syncthreads(); STAMP()
             float* a0 = a(0);
+            const unsigned key0 = drop_key(d, b, t, 0);
             wg_mm2(sm, sm_cap, S, h0, S, Gss, S, 1, D, h0, 1,
                    [&](int m, int n) { return A0s[(long)m * h0 + n] + (b0[n] - alpha * cs[n]); },
                    [&](int m, int n, float acc, float pre) {
-                       const float z = pre - alpha * acc;
-                       a0[(long)m * h0 + n] = z > 0.f ? z : 0.f;
+                       a0[(long)m * h0 + n] = drop_relu(d, key0, (long)m * h0 + n, pre - alpha * acc);
                    });
         }
         __syncthreads(); STAMP()
@@ -136,10 +158,10 @@ __global__ __launch_bounds__(512) void adapt_kernel(EpiDims d, EpiBuf w, EpiPara
             const int hi = d.h[i], hp = d.h[i - 1];
             const float* bi = w.bcur[i] + (long)b * hi;
             float* ai = a(i);
+            const unsigned keyi = drop_key(d, b, t, i);
             wg_mm2(sm, sm_cap, S, hi, hp, a(i - 1), hp, 1, Wc(i), 1, hp, [&](int m, int n) { return bi[n]; },
                    [&](int m, int n, float acc, float pre) {
-                       const float z = acc + pre;
-                       ai[(long)m * hi + n] = z > 0.f ? z : 0.f;
+                       ai[(long)m * hi + n] = drop_relu(d, keyi, (long)m * hi + n, acc + pre);
                    });
             __syncthreads(); STAMP()
         }
@@ -164,7 +186,7 @@ __global__ __launch_bounds__(512) void adapt_kernel(EpiDims d, EpiBuf w, EpiPara
         {
             float* dzl = dz(L - 1); const float* al = a(L - 1);
             wg_mm2(sm, sm_cap, S, H, N, e, N, 1, Whc, H, 1, [&](int m, int n) { return al[(long)m * H + n]; },
-                   [&](int m, int n, float acc, float pre) { dzl[(long)m * H + n] = pre > 0.f ? acc : 0.f; });
+                   [&](int m, int n, float acc, float pre) { dzl[(long)m * H + n] = pre > 0.f ? acc * d.mscale : 0.f; });
         }
         __syncthreads(); STAMP()
         // head update: Wh <- Wh - alpha e^T a,  bh <- bh - alpha colsum(e)
@@ -176,7 +198,7 @@ __global__ __launch_bounds__(512) void adapt_kernel(EpiDims d, EpiBuf w, EpiPara
             const int hi = d.h[i], hp = d.h[i - 1];
             float* dzp = dz(i - 1); const float* ap = a(i - 1);
             wg_mm2(sm, sm_cap, S, hp, hi, dz(i), hi, 1, Wc(i), hp, 1, [&](int m, int n) { return ap[(long)m * hp + n]; },
-                   [&](int m, int n, float acc, float pre) { dzp[(long)m * hp + n] = pre > 0.f ? acc : 0.f; });
+                   [&](int m, int n, float acc, float pre) { dzp[(long)m * hp + n] = pre > 0.f ? acc * d.mscale : 0.f; });
             __syncthreads(); STAMP()
             const float* Wci = Wc(i); float* Wni = Wn(i);
             wg_mm2(sm, sm_cap, hi, hp, S, dz(i), 1, hi, a(i - 1), hp, 1, [&](int m, int n) { return Wci[(long)m * hp + n]; },
@@ -222,11 +244,11 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
     __syncthreads();
     {
         float* a0 = a(0);
+        const unsigned keyq0 = drop_key(d, b, QUERY_CALL, 0);
         wg_mm2(sm, sm_cap, nr, h0, S, Gqs, S, 1, D, h0, 1,
                [&](int m, int n) { return A0q[(long)m * h0 + n] + (b0[n] - alpha * cs[n]); },
                [&](int m, int n, float acc, float pre) {
-                   const float v = pre - alpha * acc;
-                   a0[(long)m * h0 + n] = v > 0.f ? v : 0.f;
+                   a0[(long)m * h0 + n] = drop_relu(d, keyq0, (long)(r0 + m) * h0 + n, pre - alpha * acc);
                });
     }
     __syncthreads();
@@ -234,10 +256,10 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
         const int hi = d.h[i], hp = d.h[i - 1];
         const float* bi = w.bcur[i] + (long)b * hi;
         float* ai = a(i);
+        const unsigned keyqi = drop_key(d, b, QUERY_CALL, i);
         wg_mm2(sm, sm_cap, nr, hi, hp, a(i - 1), hp, 1, Wc(i), 1, hp, [&](int m, int n) { return bi[n]; },
                [&](int m, int n, float acc, float pre) {
-                   const float v = acc + pre;
-                   ai[(long)m * hi + n] = v > 0.f ? v : 0.f;
+                   ai[(long)m * hi + n] = drop_relu(d, keyqi, (long)(r0 + m) * hi + n, acc + pre);
                });
         __syncthreads();
     }
@@ -278,7 +300,7 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
         wg_colsum(sm, sm_cap, nr, N, lbar, N, [&](int n, float s) { pbh[n] = s; });
         float* zl = z(L - 1); const float* al = a(L - 1);
         wg_mm2(sm, sm_cap, nr, H, N, lbar, N, 1, Whc, H, 1, [&](int m, int n) { return al[(long)m * H + n]; },
-               [&](int m, int n, float acc, float pre) { zl[(long)m * H + n] = pre > 0.f ? acc : 0.f; });
+               [&](int m, int n, float acc, float pre) { zl[(long)m * H + n] = pre > 0.f ? acc * d.mscale : 0.f; });
     }
     __syncthreads();
     for (int i = L - 1; i >= 1; --i) {
@@ -289,7 +311,7 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
         wg_colsum(sm, sm_cap, nr, hi, z(i), hi, [&](int n, float s) { pbi[n] = s; });
         float* zp = z(i - 1); const float* ap = a(i - 1);
         wg_mm2(sm, sm_cap, nr, hp, hi, z(i), hi, 1, Wc(i), hp, 1, [&](int m, int n) { return ap[(long)m * hp + n]; },
-               [&](int m, int n, float acc, float pre) { zp[(long)m * hp + n] = pre > 0.f ? acc : 0.f; });
+               [&](int m, int n, float acc, float pre) { zp[(long)m * hp + n] = pre > 0.f ? acc * d.mscale : 0.f; });
         __syncthreads();
     }
     // layer 0: Abar0 rows of the query set, b0bar, and the adjoint of the low-rank factor D_T
@@ -368,7 +390,7 @@ __global__ __launch_bounds__(512) void reverse_kernel(EpiDims d, EpiBuf w, float
             }
             int cur = 0;
             {
-                wg_ew((long)S * h0, Xa, a(0), Db, nullptr, [&](long, float m_, float v, float) { return m_ > 0.f ? v : 0.f; });
+                wg_ew((long)S * h0, Xa, a(0), Db, nullptr, [&](long, float m_, float v, float) { return m_ > 0.f ? v * d.mscale : 0.f; });
             }
             __syncthreads();
             // ---- reverse of the backward pass, bottom up
@@ -382,7 +404,7 @@ __global__ __launch_bounds__(512) void reverse_kernel(EpiDims d, EpiBuf w, float
                 wg_mm2(sm, sm_cap, S, hi, hp, a(i - 1), hp, 1, Wbi, 1, hp,                                   // same thread, same (m,n)
                        [&](int m, int n) { return f32pair{nxt[(long)m * hi + n], ai[(long)m * hi + n]}; },
                        [&](int m, int n, float acc, f32pair pre) {
-                           nxt[(long)m * hi + n] = pre.y > 0.f ? pre.x - alpha * acc : 0.f;
+                           nxt[(long)m * hi + n] = pre.y > 0.f ? (pre.x - alpha * acc) * d.mscale : 0.f;
                        });
                 // abar_{i-1} += dz_i (-alpha Wbar_i)
                 float* abp = ab(i - 1);
@@ -427,7 +449,7 @@ __global__ __launch_bounds__(512) void reverse_kernel(EpiDims d, EpiBuf w, float
                 const int hi = d.h[i], hp = d.h[i - 1];
                 float* zb = ab(i);
                 {
-                    wg_ew((long)S * hi, zb, a(i), zb, nullptr, [&](long, float m_, float v, float) { return m_ > 0.f ? v : 0.f; });
+                    wg_ew((long)S * hi, zb, a(i), zb, nullptr, [&](long, float m_, float v, float) { return m_ > 0.f ? v * d.mscale : 0.f; });
                 }
                 __syncthreads();
                 float* abp = ab(i - 1); float* Wbw = Wb(i); float* bbw = bb(i);
@@ -440,7 +462,7 @@ __global__ __launch_bounds__(512) void reverse_kernel(EpiDims d, EpiBuf w, float
             }
             // layer 0: z0bar -> Abar0 rows of the support set, b0bar, Dbar
             float* z0b = ab(0);
-            wg_ew((long)S * h0, z0b, a(0), z0b, nullptr, [&](long, float m_, float v, float) { return m_ > 0.f ? v : 0.f; });
+            wg_ew((long)S * h0, z0b, a(0), z0b, nullptr, [&](long, float m_, float v, float) { return m_ > 0.f ? v * d.mscale : 0.f; });
             __syncthreads();
             wg_ew((long)S * h0, A0bs, A0bs, z0b, nullptr, [&](long, float x, float y, float) { return x + y; });
             __syncthreads();
@@ -607,6 +629,13 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     for (int i = 0; i < MAXL; ++i) d.h[i] = i < p.L ? p.h[i] : 0;
     d.alpha = p.alpha; d.need_grad = p.need_grad; d.second_order = p.second_order;
     d.taped = (p.need_grad && p.second_order && p.T > 0) ? 1 : 0;
+    d.drop_thr = 0; d.mscale = 1.f; d.seed_lo = (unsigned)(p.seed & 0xffffffffULL); d.seed_hi = (unsigned)(p.seed >> 32);
+    if (p.dropout_p > 0.f) {
+        if (!(p.dropout_p < 1.f)) return FUMI_EINVAL;
+        d.drop_thr = (unsigned)((double)p.dropout_p * 4294967296.0);
+        if (d.drop_thr == 0) d.drop_thr = 1;
+        d.mscale = 1.f / (1.f - p.dropout_p);
+    }
     const int h0 = p.h[0];
     int rc;
 

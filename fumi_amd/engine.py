@@ -16,14 +16,16 @@ class HipEngine:
         return hip.Workspace.get(t.device if isinstance(t, torch.Tensor) and t.is_cuda else hip._dev(t))
 
     def fumi_step(self, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head, need_grad, grad_scale,
-                  g_theta=None, g_phi=None, cls_text=None, stats=None):
+                  g_theta=None, g_phi=None, cls_text=None, stats=None, dropout_p=0.0, seed=0):
         """text_s [B,S,Dt] (class rows selected on the device) or cls_text [B,N,Dt] (already selected).
         stats [2] (optional) receives grad_scale * (sum loss_b, sum acc_b)."""
         if cls_text is not None:
             return hip.fumi_step(self._ws(x_s), x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head, cls_text=cls_text,
-                                 need_grad=need_grad, grad_scale=grad_scale, g_theta=g_theta, g_phi=g_phi, stats=stats)
+                                 need_grad=need_grad, grad_scale=grad_scale, g_theta=g_theta, g_phi=g_phi, stats=stats,
+                                 dropout_p=dropout_p, seed=seed)
         return hip.fumi_step_select(self._ws(x_s), n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head,
-                                    need_grad=need_grad, grad_scale=grad_scale, g_theta=g_theta, g_phi=g_phi, stats=stats)
+                                    need_grad=need_grad, grad_scale=grad_scale, g_theta=g_theta, g_phi=g_phi, stats=stats,
+                                    dropout_p=dropout_p, seed=seed)
 
     def glove_bag_select(self, tokens_s, y_s, n_way, table, pad_id, mode):
         return hip.glove_bag_select(self._ws(tokens_s), tokens_s, y_s, n_way, table, pad_id, mode)

@@ -65,7 +65,8 @@ def lib():
         L.fumi_hip_phase_name.restype = c_char_p
         PP = POINTER(c_void_p)
         L.fumi_hip_fumi_step.argtypes = (
-            [c_void_p, c_void_p] + [c_int] * 6 + [POINTER(c_int), c_int, c_int, c_int, c_float, c_int, c_int, c_float]
+            [c_void_p, c_void_p] + [c_int] * 6 + [POINTER(c_int), c_int, c_int, c_int, c_float, c_int, c_int, c_float,
+                                                 c_float, ctypes.c_uint64]
             + [c_void_p] * 6 + [PP, PP] + [c_void_p] * 5 + [PP, PP])
         L.fumi_hip_maml_step.argtypes = (
             [c_void_p, c_void_p] + [c_int] * 6 + [POINTER(c_int), c_int, c_float, c_int, c_int, c_float]
@@ -201,7 +202,7 @@ def raise_on_status(status):
 
 # ----------------------------------------------------------------------------------------------------------------
 def fumi_step(ws, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head, *, cls_text=None, text_s=None,
-              need_grad=True, grad_scale=None, g_theta=None, g_phi=None, stats=None):
+              need_grad=True, grad_scale=None, g_theta=None, g_phi=None, stats=None, dropout_p=0.0, seed=0):
     """One FuMI meta-step over B episodes (fumi/models/fumi.py:146-192).  Returns a dict of GPU tensors."""
     dev = _dev(x_s)
     B, S, D = x_s.shape
@@ -213,11 +214,11 @@ def fumi_step(ws, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head, *, cls_te
     if N is None:
         raise FumiHipError("fumi_step: pass n_way through cls_text=[B,N,Dt] or use fumi_step_select")
     return _fumi_step(ws, dev, B, N, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head,
-                      cls_text, text_s, need_grad, grad_scale, g_theta, g_phi, stats)
+                      cls_text, text_s, need_grad, grad_scale, g_theta, g_phi, stats, dropout_p, seed)
 
 
 def fumi_step_select(ws, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head, *,
-                     need_grad=True, grad_scale=None, g_theta=None, g_phi=None, stats=None):
+                     need_grad=True, grad_scale=None, g_theta=None, g_phi=None, stats=None, dropout_p=0.0, seed=0):
     """Same, selecting the per-class text rows from text_s [B,S,Dt] on the device (fumi.py:207-210)."""
     dev = _dev(x_s)
     B, S, D = x_s.shape
@@ -226,11 +227,11 @@ def fumi_step_select(ws, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha
     hid = [int(theta[2 * i].shape[0]) for i in range(n_hidden)]
     Ht, Dt = int(phi[0].shape[0]), int(phi[0].shape[1])
     return _fumi_step(ws, dev, B, n_way, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head,
-                      None, text_s, need_grad, grad_scale, g_theta, g_phi, stats)
+                      None, text_s, need_grad, grad_scale, g_theta, g_phi, stats, dropout_p, seed)
 
 
 def _fumi_step(ws, dev, B, N, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head,
-               cls_text, text_s, need_grad, grad_scale, g_theta, g_phi, stats=None):
+               cls_text, text_s, need_grad, grad_scale, g_theta, g_phi, stats=None, dropout_p=0.0, seed=0):
     L = lib()
     logits = torch.empty(B, Qn, N, device=dev, dtype=torch.float32)
     preds = torch.empty(B, Qn, device=dev, dtype=torch.int64)
@@ -246,7 +247,7 @@ def _fumi_step(ws, dev, B, N, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, 
     hid_arr = (c_int * len(hid))(*hid)
     rc = L.fumi_hip_fumi_step(
         ws.handle, _stream(dev), B, N, S, Qn, D, len(hid), hid_arr, Dt, Ht, int(T), float(alpha), int(bool(tanh_head)),
-        int(bool(need_grad)), float(grad_scale),
+        int(bool(need_grad)), float(grad_scale), float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
         _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"),
         _f32(cls_text, "cls_text") if cls_text is not None else None,
         _f32(text_s, "text_s") if text_s is not None else None,

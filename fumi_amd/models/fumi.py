@@ -156,9 +156,13 @@ class FUMI(nn.Module):
             self.zero_grad()
         else:
             self.eval()
-        if train and self.dropout_rate > 0:
-            raise NotImplementedError("inner-loop dropout (fumi.py:93-99) is not implemented by the MI355X engine; "
-                                      "run with --dropout 0 (the parity configuration)")
+        # train-mode Dropout after each ReLU of im_net (fumi.py:93-99; CLI default --dropout 0.25): masks are drawn inside
+        # the engine from a counter-based hash of a per-step seed taken from torch's CPU generator (so torch.manual_seed
+        # reproduces a run); eval mode uses none, like nn.Dropout
+        drop_p = float(self.dropout_rate) if (train and self.dropout_rate > 0) else 0.0
+        drop_seed = 0
+        if drop_p > 0:
+            drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) + 7919 * fdist.world()[0]
         dev = args.device
         (_, s_text, s_im), s_y = batch['train']
         (_, q_text, q_im), q_y = batch['test']
@@ -188,7 +192,7 @@ class FUMI(nn.Module):
         out = eng.fumi_step(self.n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, args.step_size, self.norm_hypernet,
                             need_grad=train, grad_scale=1.0 / B,
                             g_theta=fg.views[:nth] if train else None, g_phi=fg.views[nth:] if train else None,
-                            cls_text=cls_text, stats=tail)
+                            cls_text=cls_text, stats=tail, dropout_p=drop_p, seed=drop_seed)
         fdist.all_reduce_sum_(fg.flat if train else tail)
         if train:
             optimizer.zero_grad()

@@ -89,10 +89,13 @@ const char*  fumi_hip_phase_name(int phase);
  *           stats [2] (optional, may be NULL) = grad_scale * (sum_b loss_b, sum_b acc_b): with grad_scale = 1/B the
  *           meta-batch mean loss / accuracy that fumi.py:187-188 computes, ready for the same all-reduce as the gradients;
  *           g_theta/g_phi (same shapes as theta/phi) only when need_grad != 0.
- * second-order outer gradient always (fumi.py:176 hard-codes first_order=False). */
+ * second-order outer gradient always (fumi.py:176 hard-codes first_order=False).
+ * dropout_p > 0 applies the reference's train-mode Dropout after every ReLU of im_net (fumi.py:93-99) with a fresh mask per
+ * forward call (each inner step and the query pass), drawn from a counter-based hash of (seed, episode, call, layer,
+ * element): statistically the reference's nn.Dropout, not its RNG stream.  Pass 0 for task != "train". */
 int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
         int B, int N, int S, int Qn, int D, int n_hidden, const int* hid, int Dt, int Ht,
-        int T, float alpha, int tanh_head, int need_grad, float grad_scale,
+        int T, float alpha, int tanh_head, int need_grad, float grad_scale, float dropout_p, uint64_t seed,
         const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
         const float* cls_text, const float* text_s,
         const float* const* theta, const float* const* phi,

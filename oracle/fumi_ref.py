@@ -51,17 +51,21 @@ def hyper_net(c, phi, tanh_head):
     return torch.tanh(h) if tanh_head else h
 
 
-def im_net(x, theta):
-    """fumi.py:89-100 / torchmeta MetaSequential(MetaLinear, ReLU)* with external params.
-    theta = [W0,b0,W1,b1,...]; every layer is followed by ReLU (dropout excluded: parity runs use 0)."""
+def im_net(x, theta, masks=None):
+    """fumi.py:89-100 / torchmeta MetaSequential(MetaLinear, ReLU[, Dropout])* with external params.
+    theta = [W0,b0,W1,b1,...]; every layer is followed by ReLU and, in train mode with dropout_rate > 0, by nn.Dropout:
+    ``masks[i]`` is that layer's mask already scaled by 1/(1-p) (the reference draws it from torch's RNG; parity tests
+    feed the engine's counter-based masks instead)."""
     for i in range(0, len(theta), 2):
         x = torch.relu(F.linear(x, theta[i], theta[i + 1]))
+        if masks is not None:
+            x = x * masks[i // 2]
     return x
 
 
-def im_forward(x, theta, h):
+def im_forward(x, theta, h, masks=None):
     """fumi.py:214-218 -- features @ h[:, :-1].T + h[:, -1]  (probe-verified equal to the matmul/squeeze form)."""
-    feat = im_net(x, theta)
+    feat = im_net(x, theta, masks)
     return feat @ h[:, :-1].t() + h[:, -1]
 
 
@@ -79,22 +83,28 @@ def word_embedding_pool(tokens, table, pad_id, mode="mean"):
 # ----------------------------------------------------------------------------------------------
 # FuMI meta-step
 # ----------------------------------------------------------------------------------------------
-def fumi_episode(theta, phi, text_s, x_s, y_s, x_q, n_way, T, alpha, tanh_head, first_order=False):
-    """One episode up to the query logits (graph kept).  fumi.py:156-178."""
+QUERY_CALL = 1 << 20
+
+
+def fumi_episode(theta, phi, text_s, x_s, y_s, x_q, n_way, T, alpha, tanh_head, first_order=False, drop=None):
+    """One episode up to the query logits (graph kept).  fumi.py:156-178.
+    drop(call, layer, rows, width) -> scaled dropout mask of that forward call (call = inner step, QUERY_CALL = query)."""
     c = class_text_select(text_s, y_s, n_way)
     h = hyper_net(c, phi, tanh_head)
     th = list(theta)
-    for _ in range(T):
-        logit = im_forward(x_s, th, h)
+    L = len(theta) // 2
+    mk = lambda call, x: None if drop is None else [drop(call, i, x.shape[0], theta[2 * i].shape[0]) for i in range(L)]
+    for t in range(T):
+        logit = im_forward(x_s, th, h, mk(t, x_s))
         inner = F.cross_entropy(logit, y_s)
         grads = torch.autograd.grad(inner, [h] + th, create_graph=not first_order)
         h = h - alpha * grads[0]
         th = [p - alpha * g for p, g in zip(th, grads[1:])]
-    return im_forward(x_q, th, h)
+    return im_forward(x_q, th, h, mk(QUERY_CALL, x_q))
 
 
 def fumi_meta_step(theta, phi, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha, tanh_head,
-                   need_grad=True, first_order=False):
+                   need_grad=True, first_order=False, dropout=None):
     """fumi.py:115-196.  theta/phi: lists of leaf tensors (requires_grad set by the caller when need_grad).
     text_s [B,S,Dt] (already text-encoded), x_s [B,S,D], y_s [B,S], x_q [B,Qn,D], y_q [B,Qn].
     Returns dict(logits [B,Qn,N], preds [B,Qn] int64, loss_b [B], acc_b [B], loss, acc,
@@ -102,8 +112,9 @@ def fumi_meta_step(theta, phi, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha, tanh
     B = x_s.shape[0]
     logits, loss_b = [], []
     for b in range(B):
+        drop = None if dropout is None else (lambda call, layer, rows, width, b=b: dropout(b, call, layer, rows, width))
         lq = fumi_episode(theta, phi, text_s[b], x_s[b], y_s[b], x_q[b], n_way, T, alpha, tanh_head,
-                          first_order)
+                          first_order, drop)
         logits.append(lq)
         loss_b.append(F.cross_entropy(lq, y_q[b]))
     loss = torch.stack(loss_b).sum() / B

@@ -58,3 +58,26 @@ def safe_margin_mask(logits, min_margin):
     """Rows whose top-1/top-2 margin exceeds the noise floor (argmax must be bit-exact there)."""
     top2 = torch.as_tensor(logits).topk(2, dim=-1)[0]
     return (top2[..., 0] - top2[..., 1]) > min_margin
+
+
+# ---- the engine's counter-based dropout mask, restated in numpy (csrc/episode.hip: drop_mix / drop_key / drop_relu) ------------
+def _mix(x):
+    x = x.astype(np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF
+    x ^= x >> 15; x = (x * 0x846ca68b) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def dropout_mask(seed, p, b, call, layer, rows, width):
+    """[rows, width] float32 mask in {0, 1/(1-p)} for episode b, forward call `call`, hidden layer `layer`."""
+    lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    one = lambda v: _mix(np.array([v & 0xFFFFFFFF], dtype=np.uint64))[0]
+    h = one(lo + 0x9E3779B9 * b)
+    h = one(int(h) ^ ((hi + 0x85EBCA6B * call) & 0xFFFFFFFF))
+    h = one(int(h) + 0xC2B2AE35 * layer)
+    idx = np.arange(rows * width, dtype=np.uint64)
+    u = _mix((np.uint64(int(h)) ^ idx) & 0xFFFFFFFF)
+    thr = max(1, int(p * 4294967296.0))
+    keep = (u >= thr).reshape(rows, width)
+    return torch.from_numpy(keep.astype(np.float32) / np.float32(1.0 - p))

@@ -15,13 +15,17 @@ class OracleEngine:
         return R.word_embedding_pool(rows, table, pad_id, mode)
 
     def fumi_step(self, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head, need_grad, grad_scale,
-                  g_theta=None, g_phi=None, cls_text=None, stats=None):
+                  g_theta=None, g_phi=None, cls_text=None, stats=None, dropout_p=0.0, seed=0):
         B = x_s.shape[0]
         if cls_text is not None:                # expand the per-class rows back to per-sample rows for the oracle
             text_s = torch.gather(cls_text, 1, y_s[..., None].expand(-1, -1, cls_text.shape[-1]))
         th = [t.detach().clone().requires_grad_(True) for t in theta]
         ph = [t.detach().clone().requires_grad_(True) for t in phi]
-        out = R.fumi_meta_step(th, ph, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha, tanh_head, need_grad=need_grad)
+        drop = None
+        if dropout_p > 0:
+            from helpers import dropout_mask
+            drop = lambda b, call, layer, rows, width: dropout_mask(seed, dropout_p, b, call, layer, rows, width)
+        out = R.fumi_meta_step(th, ph, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha, tanh_head, need_grad=need_grad, dropout=drop)
         if need_grad:
             for dst, g in zip(list(g_theta) + list(g_phi), out["g_theta"] + out["g_phi"]):
                 dst.copy_(g * (B * grad_scale))               # oracle returns mean-loss grads = (1/B) sum_b

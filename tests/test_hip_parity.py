@@ -351,3 +351,31 @@ def test_fumi_evaluate_on_gpu_lazy_scalars(dev):
     assert np.array_equal(preds.cpu().numpy().astype(np.int64), gold["preds"])
     for n, p in m.named_parameters():                        # fused Adam step == the reference's torch.optim.Adam step
         np.testing.assert_allclose(cg.digest(p.detach().cpu())[3:], gold[f"post.{n}.digest"][3:], rtol=0, atol=3e-7)
+
+
+@pytest.mark.parametrize("name,p", [("fumi_t5", 0.25), ("fumi_3layer", 0.5), ("fumi_1shot", 0.1)])
+def test_fumi_inner_loop_dropout_matches_oracle_with_same_masks(name, p, dev, ws):
+    """Train-mode Dropout after every ReLU of im_net (fumi.py:93-99; CLI default 0.25): the engine's counter-based masks are
+    regenerated on the host and fed to the oracle -- logits, loss and all second-order meta-gradients must agree."""
+    from fumi_amd import hip
+    from helpers import dropout_mask
+    c = cg.FUMI_CASES[name]
+    seed_ep = case_seed(name)
+    ep = cg.make_episodes(seed_ep, c["B"], c["N"], c["K"], c["Q"], c["D"], c["Dt"], blocked=c["blocked"])
+    theta, phi = cg.make_fumi_params(seed_ep, c["D"], c["hid"], c["Dt"], c["Ht"])
+    seed = 0x1234_5678_9ABC_DEF1
+    out = hip.fumi_step_select(ws, c["N"], _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev),
+                               _g(ep["text_s"], dev), [_g(t, dev) for t in theta], [_g(t, dev) for t in phi],
+                               c["T"], cg.ALPHA, c["tanh"], dropout_p=p, seed=seed)
+    th = [t.clone().requires_grad_(True) for t in theta]
+    ph = [t.clone().requires_grad_(True) for t in phi]
+    ref = R.fumi_meta_step(th, ph, ep["text_s"], ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], c["N"], c["T"], cg.ALPHA, c["tanh"],
+                           dropout=lambda b, call, layer, rows, width: dropout_mask(seed, p, b, call, layer, rows, width))
+    assert rel_to_max(out["logits"].cpu(), ref["logits"]) <= LOGIT_TOL
+    assert rel_to_max(out["loss_b"].cpu(), ref["loss_b"]) <= LOGIT_TOL
+    _check_grads([str(i) for i in range(len(theta) + 4)], out["g_theta"] + out["g_phi"], None, ref["g_theta"] + ref["g_phi"])
+    # the masks really drop ~p of the active units: compare with the no-dropout run
+    base = hip.fumi_step_select(ws, c["N"], _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev),
+                                _g(ep["text_s"], dev), [_g(t, dev) for t in theta], [_g(t, dev) for t in phi],
+                                c["T"], cg.ALPHA, c["tanh"])
+    assert rel_to_max(out["logits"].cpu(), base["logits"].cpu()) > 1e-3

@@ -169,14 +169,24 @@ def test_macro_metrics_equal_sklearn():
         assert abs(acc - accuracy_score(t, p)) < 1e-12 and abs(f1 - f) < 1e-12 and abs(prec - pr) < 1e-12 and abs(rec - rc) < 1e-12
 
 
-def test_dropout_in_train_mode_is_refused(oracle_engine):
+def test_fumi_dropout_train_vs_eval(oracle_engine):
+    """--dropout > 0 (CLI default 0.25): active in train mode with a fresh seed per step, off in eval mode (fumi.py:93-99,123-127)."""
     from fumi_amd.models.fumi import FUMI
     c = cg.FUMI_CASES["fumi_t1"]
-    m = FUMI(n_way=c["N"], im_emb_dim=c["D"], im_hid_dim=c["hid"], text_emb_dim=c["Dt"], text_hid_dim=c["Ht"], dropout_rate=0.25)
+    m = FUMI(n_way=c["N"], im_emb_dim=c["D"], im_hid_dim=c["hid"], text_emb_dim=c["Dt"], text_hid_dim=c["Ht"], dropout_rate=0.25,
+             text_encoder="BERT")
     assert "im_net.linear0.weight" in m.state_dict() and hasattr(m.im_net, "dropout0")
     ep = cg.make_episodes(1, 2, c["N"], c["K"], c["Q"], c["D"], c["Dt"])
-    with pytest.raises(NotImplementedError):
-        m.evaluate(_args(1), cg.to_batch(ep), torch.optim.SGD(m.parameters(), lr=0.1), "train")
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    torch.manual_seed(0)
+    l1 = float(m.evaluate(_args(1), cg.to_batch(ep), opt, "train")[0])
+    l2 = float(m.evaluate(_args(1), cg.to_batch(ep), opt, "train")[0])
+    torch.manual_seed(0)
+    l3 = float(m.evaluate(_args(1), cg.to_batch(ep), opt, "train")[0])
+    assert l1 != l2 and l1 == l3                               # new mask every step, reproducible from torch.manual_seed
+    e1 = float(m.evaluate(_args(1), cg.to_batch(ep), None, "test")[0])
+    e2 = float(m.evaluate(_args(1), cg.to_batch(ep), None, "test")[0])
+    assert e1 == e2
 
 
 def test_cli_maml_synthetic_cpu_plumbing(oracle_engine, tmp_path, monkeypatch):
