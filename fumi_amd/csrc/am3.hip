@@ -157,13 +157,22 @@ __global__ __launch_bounds__(256) void am3_head_kernel(int N, int S, int Qn, int
 
 extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
         int B, int N, int S, int Qn, int D, int Dt, int Ht, int P, int lamda_fixed, int need_grad, float grad_scale,
+        float dropout_p, uint64_t seed,
         const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q, const float* text_s,
         const float* const* w, float* loss, int64_t* preds_q, float* lamda_s, float* correct, float* const* g_w) {
     if (!ws || !x_s || !y_s || !x_q || !y_q || !text_s || !w || !loss || !preds_q || !lamda_s || !correct) return FUMI_EINVAL;
     if (B < 1 || N < 1 || S < 1 || Qn < 1 || D < 1 || Dt < 1 || Ht < 1 || P < 1 || lamda_fixed < -1 || lamda_fixed > 1) return FUMI_EINVAL;
     for (int i = 0; i < 10; ++i) if (!w[i] || (need_grad && (!g_w || !g_w[i]))) return FUMI_EINVAL;
+    if (dropout_p < 0.f || dropout_p >= 1.f) return FUMI_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ws->device));
+    // train-mode Dropout after the ReLU of g and of h (am3.py:82,88): counter-based masks keyed by (seed, tag, element)
+    unsigned thr = 0; float dsc = 1.f;
+    if (dropout_p > 0.f) { thr = (unsigned)((double)dropout_p * 4294967296.0); if (!thr) thr = 1; dsc = 1.f / (1.f - dropout_p); }
+    auto dkey = [&](unsigned tag) {
+        auto mix = [](unsigned x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; };
+        return mix(mix((unsigned)(seed & 0xffffffffULL) ^ (0x9E3779B9U * tag)) ^ (unsigned)(seed >> 32));
+    };
     const float *Wi = w[0], *bi = w[1], *G0 = w[2], *g0 = w[3], *G1 = w[4], *g1 = w[5], *H0 = w[6], *h0 = w[7], *H1 = w[8], *h1 = w[9];
     const long Rs = (long)B * S, Rq = (long)B * Qn;
     const int nwaves = 4;
@@ -199,11 +208,13 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     {
         ProfScope ps(ws, st, FUMI_PH_HYPER_FWD);
         g = gemm_args((int)Rs, Ht, Dt, text_s, Dt, G0, Dt, t1, Ht); g.bias = g0; g.act = 1;
+        g.drop_thr = thr; g.drop_key = dkey(1); g.drop_scale = dsc;
         if ((rc = launch_gemm(st, g, 0, 0))) return rc;
         g = gemm_args((int)Rs, P, Ht, t1, Ht, G1, Ht, tx, P); g.bias = g1;
         if ((rc = launch_gemm(st, g, 0, 0))) return rc;
         if (lamda_fixed < 0) {
             g = gemm_args((int)Rs, Ht, P, tx, P, H0, P, l1, Ht); g.bias = h0; g.act = 1;
+            g.drop_thr = thr; g.drop_key = dkey(2); g.drop_scale = dsc;
             if ((rc = launch_gemm(st, g, 0, 0))) return rc;
             g = gemm_args((int)Rs, 1, Ht, l1, Ht, H1, Ht, lamda_s, 1); g.bias = h1; g.act = 3;
             if ((rc = launch_gemm(st, g, 0, 0))) return rc;
@@ -234,7 +245,7 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
         if ((rc = launch_colsum(st, zlb, (int)Rs, 1, 1, 1.f, g_w[9]))) return rc;
         g = gemm_args((int)Rs, Ht, 1, zlb, 1, H1, Ht, l1b, Ht);                        // l1bar = zlbar H1, masked
         if ((rc = launch_gemm(st, g, 0, 1))) return rc;
-        if ((rc = launch_relu_mask_mul(st, Rs * Ht, l1, l1b))) return rc;
+        if ((rc = launch_relu_mask_mul(st, Rs * Ht, l1, l1b, dsc))) return rc;
         g = gemm_args(Ht, P, (int)Rs, l1b, Ht, tx, P, g_w[6], P);                      // gH0 = l1bar^T tx
         if ((rc = launch_gemm(st, g, 1, 1))) return rc;
         if ((rc = launch_colsum(st, l1b, (int)Rs, Ht, Ht, 1.f, g_w[7]))) return rc;
@@ -250,7 +261,7 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     if ((rc = launch_colsum(st, txb, (int)Rs, P, P, 1.f, g_w[5]))) return rc;
     g = gemm_args((int)Rs, Ht, P, txb, P, G1, Ht, t1b, Ht);                            // t1bar = txbar G1, masked
     if ((rc = launch_gemm(st, g, 0, 1))) return rc;
-    if ((rc = launch_relu_mask_mul(st, Rs * Ht, t1, t1b))) return rc;
+    if ((rc = launch_relu_mask_mul(st, Rs * Ht, t1, t1b, dsc))) return rc;
     g = gemm_args(Ht, Dt, (int)Rs, t1b, Ht, text_s, Dt, g_w[2], Dt);                   // gG0 = t1bar^T text
     if ((rc = launch_gemm(st, g, 1, 1))) return rc;
     if ((rc = launch_colsum(st, t1b, (int)Rs, Ht, Ht, 1.f, g_w[3]))) return rc;

@@ -75,6 +75,7 @@ struct GemmArgs {
     int act;               // 0 none, 1 relu, 2 tanh, 3 sigmoid
     float alpha;
     int accumulate;        // C += result
+    unsigned drop_thr, drop_key; float drop_scale;   // act == 1 only: dropout after the ReLU (keep iff mix(key ^ (m*N+n)) >= thr)
 };
 static inline GemmArgs gemm_args(int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                                  float* C, long ldc) {
@@ -82,6 +83,7 @@ static inline GemmArgs gemm_args(int M, int N, int K, const float* A, long lda, 
     g.M = M; g.N = N; g.K = K; g.kchunk = K; g.nsplit = 1; g.nbatch = 1;
     g.A = A; g.lda = lda; g.sA = 0; g.B = B; g.ldb = ldb; g.sB = 0;
     g.C = C; g.ldc = ldc; g.sC = 0; g.sCsplit = 0; g.bias = nullptr; g.act = 0; g.alpha = 1.f; g.accumulate = 0;
+    g.drop_thr = 0; g.drop_key = 0; g.drop_scale = 1.f;
     return g;
 }
 int launch_gemm(hipStream_t st, const GemmArgs& g, int AL, int BL);
@@ -136,7 +138,7 @@ int launch_class_text_select(hipStream_t st, int B, int N, int S, int Dt, const 
                              float* out, int* status);
 int launch_broadcast_head(hipStream_t st, int B, int N, int H, const float* Wf, const float* bf, float* head);
 int launch_tanh_bwd(hipStream_t st, long n, const float* h, const float* hbar, float* out);
-int launch_relu_mask_mul(hipStream_t st, long n, const float* u, float* g_inout);
+int launch_relu_mask_mul(hipStream_t st, long n, const float* u, float* g_inout, float scale = 1.f);
 int launch_split_head_grad(hipStream_t st, int B, int N, int H, const float* head_bar, float scale, float* gW, float* gb);
 
 #ifdef __HIPCC__

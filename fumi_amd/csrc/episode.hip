@@ -518,9 +518,9 @@ __global__ void tanh_bwd_kernel(long n, const float* h, const float* hbar, float
         out[i] = hbar[i] * (1.f - h[i] * h[i]);
 }
 
-__global__ void relu_mask_mul_kernel(long n, const float* u, float* g) {
+__global__ void relu_mask_mul_kernel(long n, const float* u, float* g, float scale) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        g[i] = u[i] > 0.f ? g[i] : 0.f;
+        g[i] = u[i] > 0.f ? g[i] * scale : 0.f;
 }
 
 __global__ void split_head_grad_kernel(int B, int N, int H, const float* head_bar, float scale, float* gW, float* gb) {
@@ -711,8 +711,8 @@ int launch_tanh_bwd(hipStream_t st, long n, const float* h, const float* hbar, f
     LAUNCH_CHECK();
     return FUMI_OK;
 }
-int launch_relu_mask_mul(hipStream_t st, long n, const float* u, float* g) {
-    hipLaunchKernelGGL(relu_mask_mul_kernel, dim3(blocks_for(n)), dim3(256), 0, st, n, u, g);
+int launch_relu_mask_mul(hipStream_t st, long n, const float* u, float* g, float scale) {
+    hipLaunchKernelGGL(relu_mask_mul_kernel, dim3(blocks_for(n)), dim3(256), 0, st, n, u, g, scale);
     LAUNCH_CHECK();
     return FUMI_OK;
 }

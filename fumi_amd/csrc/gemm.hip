@@ -150,7 +150,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             if (m < g.M) {
                 float v = g.alpha * acc[r] + bias;
-                if (g.act == 1) v = v > 0.f ? v : 0.f;
+                if (g.act == 1) {
+                    v = v > 0.f ? v : 0.f;
+                    if (g.drop_thr) {                       // dropout after the ReLU (AM3 g / h, am3.py:80-88)
+                        unsigned x = g.drop_key ^ (unsigned)((long)m * g.N + n);
+                        x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+                        v = x >= g.drop_thr ? v * g.drop_scale : 0.f;
+                    }
+                }
                 else if (g.act == 2) v = tanhf(v);
                 else if (g.act == 3) v = 1.f / (1.f + expf(-v));
                 float* c = C + (long)m * g.ldc + n;

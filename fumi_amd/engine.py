@@ -35,9 +35,10 @@ class HipEngine:
         return hip.maml_step(self._ws(x_s), x_s, y_s, x_q, y_q, params, T, alpha, first_order, need_grad=need_grad,
                              grad_scale=grad_scale, g_params=g_params, stats=stats)
 
-    def am3_step(self, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad, grad_scale, g_w=None):
+    def am3_step(self, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad, grad_scale, g_w=None,
+                 dropout_p=0.0, seed=0):
         return hip.am3_step(self._ws(x_s), x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad=need_grad,
-                            grad_scale=grad_scale, g_w=g_w)
+                            grad_scale=grad_scale, g_w=g_w, dropout_p=dropout_p, seed=seed)
 
     def glove_bag(self, tokens, table, pad_id, mode):
         return hip.glove_bag(self._ws(tokens), tokens, table, pad_id, mode)

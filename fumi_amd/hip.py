@@ -72,7 +72,7 @@ def lib():
             [c_void_p, c_void_p] + [c_int] * 6 + [POINTER(c_int), c_int, c_float, c_int, c_int, c_float]
             + [c_void_p] * 4 + [PP] + [c_void_p] * 5 + [PP])
         L.fumi_hip_am3_step.argtypes = (
-            [c_void_p, c_void_p] + [c_int] * 10 + [c_float] + [c_void_p] * 5 + [PP] + [c_void_p] * 4 + [PP])
+            [c_void_p, c_void_p] + [c_int] * 10 + [c_float, c_float, ctypes.c_uint64] + [c_void_p] * 5 + [PP] + [c_void_p] * 4 + [PP])
         L.fumi_hip_glove_bag.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int, c_int,
                                          c_int, c_void_p]
         L.fumi_hip_glove_bag_select.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64,
@@ -292,7 +292,8 @@ def maml_step(ws, x_s, y_s, x_q, y_q, params, T, alpha, first_order=False, *, ne
 AM3_KEYS = ["Wi", "bi", "G0", "g0", "G1", "g1", "H0", "h0", "H1", "h1"]
 
 
-def am3_step(ws, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed=None, *, need_grad=True, grad_scale=None, g_w=None):
+def am3_step(ws, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed=None, *, need_grad=True, grad_scale=None, g_w=None,
+             dropout_p=0.0, seed=0):
     """One AM3 step (fumi/models/am3.py:160-200).  w: list of the 10 tensors in AM3_KEYS order."""
     dev = _dev(x_s)
     L = lib()
@@ -310,6 +311,7 @@ def am3_step(ws, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed=None, *, need
         grad_scale = 1.0 / B
     rc = L.fumi_hip_am3_step(
         ws.handle, _stream(dev), B, n_way, S, Qn, D, Dt, Ht, P, lf, int(bool(need_grad)), float(grad_scale),
+        float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
         _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"), _f32(text_s, "text_s"),
         _parr(w, "w"), _f32(loss, "loss"), _i64(preds, "preds"), _f32(lam, "lamda_s"), _f32(correct, "correct"),
         _parr(g_w, "g_w") if need_grad else None)

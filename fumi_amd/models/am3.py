@@ -101,9 +101,8 @@ class AM3(nn.Module):
             self.train()
         else:
             self.eval()
-        if train and self.dropout > 0:
-            raise NotImplementedError("dropout inside g/h (am3.py:82,88) is not implemented by the MI355X engine; "
-                                      "run with --dropout 0 (the parity configuration)")
+        drop_p = float(self.dropout) if (train and self.dropout > 0) else 0.0       # nn.Dropout of g / h, train mode only
+        drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) + 7919 * fdist.world()[0] if drop_p > 0 else 0
         (s_idx, s_text, s_im), s_y = batch['train']
         (q_idx, _, q_im), q_y = batch['test']
         B, Qn = q_im.shape[0], q_im.shape[1]
@@ -115,7 +114,7 @@ class AM3(nn.Module):
         fg = self._flat_grads() if need_grad else None
         out = _engine.get_engine().am3_step(x_s, y_s, x_q, y_q, text, [p.detach() for p in self._w()], num_ways,
                                             self.lamda_fixed, need_grad=need_grad, grad_scale=1.0 / B,
-                                            g_w=fg.views if need_grad else None)
+                                            g_w=fg.views if need_grad else None, dropout_p=drop_p, seed=drop_seed)
         tail = fg.tail if need_grad else torch.empty(3, device=x_s.device, dtype=torch.float32)
         torch.stack([out["loss"].reshape(()), out["correct"].reshape(()) / (B * Qn),
                      out["lamda_s"].sum() / (B * out["lamda_s"].shape[1])], out=tail)

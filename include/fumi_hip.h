@@ -115,10 +115,12 @@ int fumi_hip_maml_step(fumi_ws_t* ws, fumi_stream_t stream,
 /* ---- AM3 step (replaces am3.py:160-200 + utils.py:302-402, dropout 0) -----------------------------------------
  * w: 10 pointers  Wi [P,D], bi [P], G0 [Ht,Dt], g0 [Ht], G1 [P,Ht], g1 [P], H0 [Ht,P], h0 [Ht], H1 [1,Ht], h1 [1]
  * lamda_fixed: -1 = learned, 0 or 1 = fixed (am3.py:174-179).
+ * dropout_p > 0: train-mode Dropout after the ReLU of g and of h (am3.py:82,88), counter-based masks from `seed`.
  * outputs: loss [1] (mean over B*Qn), preds_q [B,Qn] (first arg-min of the distances), lamda_s [B,S],
  *          correct [1] (number of correct query predictions, float); g_w (10 pointers) when need_grad. */
 int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
         int B, int N, int S, int Qn, int D, int Dt, int Ht, int P, int lamda_fixed, int need_grad, float grad_scale,
+        float dropout_p, uint64_t seed,
         const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q, const float* text_s,
         const float* const* w,
         float* loss, int64_t* preds_q, float* lamda_s, float* correct,

@@ -198,13 +198,20 @@ def prototypical_loss(prototypes, emb, targets):
     return F.cross_entropy(-sq_distances(prototypes, emb), targets)
 
 
-def am3_step(w, text_s, x_s, y_s, x_q, y_q, n_way, lamda_fixed=None, need_grad=True):
+def am3_step(w, text_s, x_s, y_s, x_q, y_q, n_way, lamda_fixed=None, need_grad=True, masks=None):
     """am3.py:128-212 with dropout 0.  w = dict(Wi,bi, G0,g0,G1,g1, H0,h0,H1,h1) (image_encoder, g, h).
     text_s [B,S,Dt] is the per-sample text encoding (identical within a class in the dataset, not required)."""
     im_s = F.linear(x_s, w["Wi"], w["bi"])
     im_q = F.linear(x_q, w["Wi"], w["bi"])
-    tx = F.linear(torch.relu(F.linear(text_s, w["G0"], w["g0"])), w["G1"], w["g1"])
-    lam = torch.sigmoid(F.linear(torch.relu(F.linear(tx, w["H0"], w["h0"])), w["H1"], w["h1"]))
+    # masks = (mask_g [B*S,Ht], mask_h [B*S,Ht]) scaled by 1/(1-p): the train-mode nn.Dropout of g and h (am3.py:82,88)
+    t1 = torch.relu(F.linear(text_s, w["G0"], w["g0"]))
+    if masks is not None:
+        t1 = t1 * masks[0].view_as(t1)
+    tx = F.linear(t1, w["G1"], w["g1"])
+    l1 = torch.relu(F.linear(tx, w["H0"], w["h0"]))
+    if masks is not None:
+        l1 = l1 * masks[1].view_as(l1)
+    lam = torch.sigmoid(F.linear(l1, w["H1"], w["h1"]))
     if lamda_fixed == 0:
         lam = torch.zeros_like(lam)
     elif lamda_fixed == 1:

@@ -81,3 +81,13 @@ def dropout_mask(seed, p, b, call, layer, rows, width):
     thr = max(1, int(p * 4294967296.0))
     keep = (u >= thr).reshape(rows, width)
     return torch.from_numpy(keep.astype(np.float32) / np.float32(1.0 - p))
+
+
+def dropout_mask_flat(seed, p, tag, rows, width):
+    """[rows, width] mask of a GEMM epilogue (csrc/am3.hip: dkey(tag); csrc/gemm.hip epilogue)."""
+    lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    one = lambda v: _mix(np.array([v & 0xFFFFFFFF], dtype=np.uint64))[0]
+    key = one(int(one(lo ^ ((0x9E3779B9 * tag) & 0xFFFFFFFF))) ^ hi)
+    u = _mix((np.uint64(int(key)) ^ np.arange(rows * width, dtype=np.uint64)) & 0xFFFFFFFF)
+    keep = (u >= max(1, int(p * 4294967296.0))).reshape(rows, width)
+    return torch.from_numpy(keep.astype(np.float32) / np.float32(1.0 - p))

@@ -44,11 +44,16 @@ class OracleEngine:
             stats.copy_(torch.stack([out["loss_b"].sum(), out["acc_b"].sum()]) * grad_scale)
         return dict(logits=out["logits"], preds=out["preds"], loss_b=out["loss_b"], acc_b=out["acc_b"])
 
-    def am3_step(self, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad, grad_scale, g_w=None):
+    def am3_step(self, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad, grad_scale, g_w=None, dropout_p=0.0, seed=0):
         from fumi_amd.hip import AM3_KEYS
         B, Qn = x_q.shape[0], x_q.shape[1]
         wd = {k: t.detach().clone().requires_grad_(True) for k, t in zip(AM3_KEYS, w)}
-        out = R.am3_step(wd, text_s, x_s, y_s, x_q, y_q, n_way, lamda_fixed, need_grad=need_grad)
+        masks = None
+        if dropout_p > 0:
+            from helpers import dropout_mask_flat
+            Rs, Ht = x_s.shape[0] * x_s.shape[1], w[2].shape[0]
+            masks = (dropout_mask_flat(seed, dropout_p, 1, Rs, Ht), dropout_mask_flat(seed, dropout_p, 2, Rs, Ht))
+        out = R.am3_step(wd, text_s, x_s, y_s, x_q, y_q, n_way, lamda_fixed, need_grad=need_grad, masks=masks)
         if need_grad:
             for dst, k in zip(g_w, AM3_KEYS):
                 dst.copy_(out["grads"][k] * (B * grad_scale))

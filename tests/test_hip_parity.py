@@ -379,3 +379,21 @@ def test_fumi_inner_loop_dropout_matches_oracle_with_same_masks(name, p, dev, ws
                                 _g(ep["text_s"], dev), [_g(t, dev) for t in theta], [_g(t, dev) for t in phi],
                                 c["T"], cg.ALPHA, c["tanh"])
     assert rel_to_max(out["logits"].cpu(), base["logits"].cpu()) > 1e-3
+
+
+def test_am3_dropout_matches_oracle_with_same_masks(dev, ws):
+    """AM3 train-mode Dropout inside g and h (am3.py:82,88; reference default 0.7/CLI 0.25) with the engine's masks."""
+    from fumi_amd import hip
+    from helpers import dropout_mask_flat
+    c = cg.AM3_CASES["am3_lam"]
+    ep = cg.make_episodes(6, c["B"], c["N"], c["K"], c["Q"], c["D"], c["Dt"])
+    w = cg.make_am3_params(6, c["D"], c["Dt"], c["Ht"], c["P"])
+    p, seed, Rs = 0.3, 0xABCDEF0123456789, c["B"] * c["N"] * c["K"]
+    out = hip.am3_step(ws, _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev), _g(ep["text_s"], dev),
+                       [_g(w[k], dev) for k in hip.AM3_KEYS], c["N"], None, dropout_p=p, seed=seed)
+    wr = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    masks = (dropout_mask_flat(seed, p, 1, Rs, c["Ht"]), dropout_mask_flat(seed, p, 2, Rs, c["Ht"]))
+    ref = R.am3_step(wr, ep["text_s"], ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], c["N"], None, masks=masks)
+    assert abs(float(out["loss"]) - float(ref["loss"])) <= LOGIT_TOL * max(1.0, abs(float(ref["loss"])))
+    assert rel_to_max(out["lamda_s"].cpu(), ref["lamda_s"]) <= 1e-5
+    _check_grads(list(hip.AM3_KEYS), out["grads"], None, [ref["grads"][k] for k in hip.AM3_KEYS])
