@@ -141,6 +141,29 @@ int launch_tanh_bwd(hipStream_t st, long n, const float* h, const float* hbar, f
 int launch_relu_mask_mul(hipStream_t st, long n, const float* u, float* g_inout, float scale = 1.f);
 int launch_split_head_grad(hipStream_t st, int B, int N, int H, const float* head_bar, float scale, float* gW, float* gb);
 
+// ------------------------------------------------------------------------------------------------------------
+// Staging plan of an LDS-resident kernel: a list of dense [rows x cols] copies global -> LDS image, built on the host
+// (all shapes and alignments are known there) and passed as a kernel argument.  A job's source is
+// base + b*sb + tile*st (episode / tile of the workgroup); rows < 0 means "the tile's row count" (last tile may be
+// short).  The copy unit is one (row, segment): 64 lanes x 16 bytes of a row (or x 4 bytes when the row is not
+// 16-byte aligned), i.e. one wave-wide load instruction; units are numbered job after job (ubase).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int WG_MAXJOB = 24;
+struct StageTab {
+    const float* base[WG_MAXJOB]; long sb[WG_MAXJOB], st[WG_MAXJOB];
+    int rs[WG_MAXJOB], rows[WG_MAXJOB], cols[WG_MAXJOB], off[WG_MAXJOB], ld[WG_MAXJOB], vec[WG_MAXJOB], segs[WG_MAXJOB];
+    int ubase[WG_MAXJOB + 1];
+    int njobs, nunits;
+    void add(const float* b_, long sb_, long st_, long rs_, int rows_, int max_rows, int cols_, int off_, int ld_) {
+        const int j = njobs++;
+        base[j] = b_; sb[j] = sb_; st[j] = st_; rs[j] = (int)rs_; rows[j] = rows_; cols[j] = cols_; off[j] = off_; ld[j] = ld_;
+        vec[j] = ((rs_ & 3) == 0) && ((sb_ & 3) == 0) && ((st_ & 3) == 0) && ((cols_ & 3) == 0) && ((((uintptr_t)b_) & 15) == 0);
+        const int per = vec[j] ? 256 : 64;
+        segs[j] = (cols_ + per - 1) / per;
+        ubase[j] = nunits; nunits += max_rows * segs[j]; ubase[j + 1] = nunits;
+    }
+};
+
 #ifdef __HIPCC__
 // ------------------------------------------------------------------------------------------------------------
 // wg_mm: workgroup-cooperative small matrix product on the f32 MFMA, operands staged through LDS.
@@ -440,6 +463,284 @@ __device__ __forceinline__ void wg_colsum(float* lds, int lds_cap, int M, int N,
         float s = 0.f;
         for (int pp = 0; pp < parts; ++pp) s += lds[pp * N + n];
         f(n, s);
+    }
+}
+// ------------------------------------------------------------------------------------------------------------
+// LDS-resident products.  The per-episode kernels whose working set fits the CU's 160 KiB keep EVERY matrix of a
+// phase chain in LDS: operands are staged once at kernel start, products read and write LDS images only, and global
+// memory sees just the final outputs.  (With global intermediates every phase cost two dependent L2 round trips --
+// operand staging and the drain of the epilogue's stores at the barrier -- about 4-5 us of a 32-row product that
+// needs 1 us of MFMA.)
+//   image: row-major [rows][ld], ld = wg_ld(cols) = 4 (mod 32) floats: a k-contiguous operand is read with one
+//   ds_read_b128 per 16-deep step, a k-major one with 4 ds_read_b32, both conflict-free.  The arena is zeroed once at
+//   kernel start: rows/cols past the logical shape stay zero (K padding must be), M/N padding is never written.
+// ------------------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int wg_ld(int cols) { return ((cols + 31) & ~31) + 4; }
+
+// executes a StageTab whose copy `Tl` sits in LDS (wg_stage_tab_to_lds).  The units go round-robin over the waves
+// (unit u -> wave u % nw).  Step A: every LANE works out one of its wave's units (job search, row, source row pointer,
+// LDS offset) -- 64 descriptors in parallel, one short dependent chain.  Step B: the wave walks its units, U wave-wide
+// loads in flight before the first LDS write, fetching each unit's descriptor from the owning lane with v_readlane;
+// loads are unconditional from clamped addresses (a guarded load is a basic block of its own with a full wait).
+// Needs nunits <= 64 * (waves per workgroup).
+__device__ __forceinline__ void wg_stage_tab_to_lds(StageTab* Tl) {
+    // the plan must be the kernel's FIRST argument: it is read straight from the kernarg segment (taking the address of
+    // a by-value argument would copy it to scratch)
+    const int* src = (const int*)__builtin_amdgcn_kernarg_segment_ptr();
+    int* dst = (int*)Tl;
+    for (int i = threadIdx.x; i < (int)(sizeof(StageTab) / 4); i += blockDim.x) dst[i] = src[i];
+}
+template <int U>
+__device__ __forceinline__ void wg_stage_rows(const StageTab* Tl, long b, long tile, int nr, float* lds) {
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nunits = Tl->nunits, njobs = Tl->njobs;
+    // ---- A: lane l describes unit wave + nw*l
+    const int myu = wave + nw * lane;
+    const bool live = myu < nunits;
+    const int u = live ? myu : nunits - 1;
+    int j = 0;
+    for (int jj = 1; jj < njobs; ++jj) if (u >= Tl->ubase[jj]) j = jj;
+    const int ru = u - Tl->ubase[j], segs = Tl->segs[j];
+    const int r = ru / segs, sg = ru - r * segs;
+    const int rows = Tl->rows[j] < 0 ? nr : Tl->rows[j];
+    const bool rok = live && r < rows;
+    const float* d_src = Tl->base[j] + b * Tl->sb[j] + tile * Tl->st[j] + (long)(rok ? r : 0) * Tl->rs[j];
+    const int d_off = Tl->off[j] + r * Tl->ld[j];
+    const int d_cols = rok ? Tl->cols[j] : 0;
+    const int d_seg = (sg << 6) | (Tl->vec[j] ? 1 << 30 : 0);
+    const unsigned d_lo = (unsigned)(uintptr_t)d_src, d_hi = (unsigned)((uintptr_t)d_src >> 32);
+    // ---- B
+    const int mine = (nunits - wave + nw - 1) / nw;                  // units of this wave (uniform)
+    for (int x0 = 0; x0 < mine; x0 += U) {
+        f32x4 v[U]; int off[U]; int md[U];
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+            const int l = min(x0 + x, 63);
+            const unsigned lo = __builtin_amdgcn_readlane(d_lo, l), hi = __builtin_amdgcn_readlane(d_hi, l);
+            const int o = __builtin_amdgcn_readlane(d_off, l), cols = __builtin_amdgcn_readlane(d_cols, l);
+            const int sgv = __builtin_amdgcn_readlane(d_seg, l);
+            const bool isv = (sgv >> 30) & 1;
+            const int cb = (sgv & 0xffffff) + lane;
+            const int c = isv ? cb << 2 : cb;
+            const bool ok = (x0 + x < mine) && c < cols;
+            const float* p = (const float*)(((uintptr_t)hi << 32) | lo) + (ok ? c : 0);
+            const float* p4 = (const float*)((uintptr_t)p & ~(uintptr_t)15);   // aligned float4 holding *p (vec: p itself)
+            const f32x4 t = *(const f32x4*)p4;
+            const int sub = (int)(p - p4);
+            v[x] = t;
+            if (!isv) v[x][0] = sub == 0 ? t[0] : sub == 1 ? t[1] : sub == 2 ? t[2] : t[3];
+            off[x] = o + c;
+            md[x] = ok ? (isv ? 2 : 1) : 0;
+        }
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+            if (md[x] == 2) *(f32x4*)(lds + off[x]) = v[x];
+            else if (md[x] == 1) lds[off[x]] = v[x][0];
+        }
+    }
+}
+
+// barrier between two phases that only exchange LDS data: waits for the wave's LDS traffic, NOT for its global stores
+// (__syncthreads drains vmcnt too, i.e. every phase that writes results to memory would pay the store latency)
+__device__ __forceinline__ void wg_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// store the first cnt (1..4) elements of v at p: one 16-byte store when complete and aligned
+__device__ __forceinline__ void wg_st4(float* p, const f32x4& v, int cnt) {
+    if (cnt == 4 && ((((uintptr_t)p) & 15) == 0)) *(f32x4*)p = v;
+    else { for (int e = 0; e < cnt; ++e) p[e] = v[e]; }
+}
+
+// epi(m, n, acc4, cnt) for m < M and n = 0, 4, 8, ... < N:  acc4[e] = sum_k A(m,k) B(k,n+e), cnt = min(4, N-n) valid
+// elements (the others are 0).  Both operands are LDS images:
+//   AKC: A(m,k) = A[m*lda + k]   else A(m,k) = A[k*lda + m]      BKC: B(k,n) = B[n*ldb + k]   else B(k,n) = B[k*ldb + n]
+// 16x16 output tiles round-robin over the waves, computed TRANSPOSED (the MFMA's row operand is B, its column operand
+// A): lane l then holds row m0 + (l&15), columns n0 + 4*(l>>4) .. +3 -- four consecutive floats of one output row, so
+// an epilogue is one 16-byte LDS or global access per lane instead of four scalar ones.  Every wave keeps two
+// accumulation chains going: two tiles when there are enough, otherwise the even / odd 16-deep steps of one tile.
+// K is walked in 16-deep steps (lane l feeds k = kk + 4*(l>>4) + j to the j-th MFMA; the next step's fragments are read
+// before the current step's MFMAs) and a 4-deep tail (k = kk + (l>>4)); images must be zero for k in [K, K+3].
+template <bool AKC, bool BKC, class Epi>
+__device__ __forceinline__ void wg_lmm(int M, int N, int K, const float* A, int lda, const float* B, int ldb, Epi&& epi) {
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform on purpose: scalar branches
+    const int r = lane & 15, q = lane >> 4;
+    const int tn = (N + 15) >> 4, ntiles = ((M + 15) >> 4) * tn;
+    const int nsteps = K >> 4;
+    const bool ksplit = ntiles <= nw;
+    const int kst = ksplit ? 32 : 16, kofs1 = ksplit ? 16 : 0;
+    const int n_it = ksplit ? nsteps >> 1 : nsteps;
+    const int sa = AKC ? 1 : lda, sb = BKC ? 1 : ldb;            // address step per k
+    struct Frag { f32x4 a0, b0, a1, b1; };
+    for (int t0 = wave; t0 < ntiles; t0 += ksplit ? nw : 2 * nw) {
+        const bool two = !ksplit && t0 + nw < ntiles;
+        const int t1 = two ? t0 + nw : t0;
+        const int m00 = (t0 / tn) << 4, n00 = (t0 % tn) << 4, m01 = (t1 / tn) << 4, n01 = (t1 % tn) << 4;
+        const float* ap0 = AKC ? A + (m00 + r) * lda + 4 * q : A + (4 * q) * lda + m00 + r;
+        const float* bp0 = BKC ? B + (n00 + r) * ldb + 4 * q : B + (4 * q) * ldb + n00 + r;
+        const float* ap1 = (AKC ? A + (m01 + r) * lda + 4 * q : A + (4 * q) * lda + m01 + r) + kofs1 * sa;
+        const float* bp1 = (BKC ? B + (n01 + r) * ldb + 4 * q : B + (4 * q) * ldb + n01 + r) + kofs1 * sb;
+        // no conditionals inside: a chain without a tile of its own repeats tile 0 and is dropped afterwards
+        auto load = [&](int k) {
+            Frag f;
+            const float* pa0 = ap0 + k * sa; const float* pb0 = bp0 + k * sb;
+            const float* pa1 = ap1 + k * sa; const float* pb1 = bp1 + k * sb;
+            if (AKC) { f.a0 = *(const f32x4*)pa0; f.a1 = *(const f32x4*)pa1; }
+            else { f.a0[0] = pa0[0]; f.a0[1] = pa0[lda]; f.a0[2] = pa0[2 * lda]; f.a0[3] = pa0[3 * lda];
+                   f.a1[0] = pa1[0]; f.a1[1] = pa1[lda]; f.a1[2] = pa1[2 * lda]; f.a1[3] = pa1[3 * lda]; }
+            if (BKC) { f.b0 = *(const f32x4*)pb0; f.b1 = *(const f32x4*)pb1; }
+            else { f.b0[0] = pb0[0]; f.b0[1] = pb0[ldb]; f.b0[2] = pb0[2 * ldb]; f.b0[3] = pb0[3 * ldb];
+                   f.b1[0] = pb1[0]; f.b1[1] = pb1[ldb]; f.b1[2] = pb1[2 * ldb]; f.b1[3] = pb1[3 * ldb]; }
+            return f;
+        };
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        auto mma = [&](const Frag& f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f.b0[e], f.a0[e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f.b1[e], f.a1[e], acc1, 0, 0, 0);
+            }
+        };
+        if (n_it > 0) {
+            // two register sets alternate; the next step's fragments are read before the current step's MFMAs issue
+            Frag fa = load(0);
+            int it = 0;
+            for (; it + 1 < n_it; it += 2) {              // sched_barrier: keep the reads ahead of the MFMAs they overlap
+                const Frag fb = load((it + 1) * kst);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(fa);
+                __builtin_amdgcn_sched_barrier(0);
+                fa = load(min(it + 2, n_it - 1) * kst);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(fb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (it < n_it) mma(fa);
+        }
+        if (ksplit && (nsteps & 1)) {                            // odd 16-deep step left over by the even/odd split
+            const int k = (nsteps - 1) << 4;
+            f32x4 av, bv;
+            const float* pa = ap0 + k * sa; const float* pb = bp0 + k * sb;
+            if (AKC) av = *(const f32x4*)pa; else { av[0] = pa[0]; av[1] = pa[lda]; av[2] = pa[2 * lda]; av[3] = pa[3 * lda]; }
+            if (BKC) bv = *(const f32x4*)pb; else { bv[0] = pb[0]; bv[1] = pb[ldb]; bv[2] = pb[2 * ldb]; bv[3] = pb[3 * ldb]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[e], av[e], acc0, 0, 0, 0);
+        }
+        for (int kk = nsteps << 4; kk < K; kk += 4) {            // 4-deep tail, plain k = kk + q
+            const float a0 = AKC ? A[(m00 + r) * lda + kk + q] : A[(kk + q) * lda + m00 + r];
+            const float b0 = BKC ? B[(n00 + r) * ldb + kk + q] : B[(kk + q) * ldb + n00 + r];
+            const float a1 = AKC ? A[(m01 + r) * lda + kk + q] : A[(kk + q) * lda + m01 + r];
+            const float b1 = BKC ? B[(n01 + r) * ldb + kk + q] : B[(kk + q) * ldb + n01 + r];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0, a0, acc0, 0, 0, 0);
+            if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1, a1, acc1, 0, 0, 0);
+        }
+        if (ksplit) acc0 += acc1;
+        {
+            const int m = m00 + r, n = n00 + 4 * q;
+            if (m < M && n < N) {
+                const int cnt = min(4, N - n);
+#pragma unroll
+                for (int e = 1; e < 4; ++e) if (e >= cnt) acc0[e] = 0.f;
+                epi(m, n, acc0, cnt);
+            }
+        }
+        if (two) {
+            const int m = m01 + r, n = n01 + 4 * q;
+            if (m < M && n < N) {
+                const int cnt = min(4, N - n);
+#pragma unroll
+                for (int e = 1; e < 4; ++e) if (e >= cnt) acc1[e] = 0.f;
+                epi(m, n, acc1, cnt);
+            }
+        }
+    }
+}
+
+// The same product for a k-major B image (B(k,n) = B[k*ldb + n], rows of B contiguous along n), organised so that one
+// ds_read_b128 of a B row feeds FOUR MFMAs: a wave owns a 16 x 64 output block made of four column tiles
+// c = 0..3 = columns {n0 + 4*j + c}; the read of row k at columns n0 + 4*(l&15) .. +3 gives lane l its B value for each
+// of them.  Lane l ends up with the 4x4 block rows m0 + 4*(l>>4) .. +3, columns n0 + 4*(l&15) .. +3, i.e. four 16-byte
+// epilogue accesses.  Per 16-deep step: 1 (AKC) or 4 reads for A, 4 for B, 16 MFMAs -- a third of the LDS instructions
+// wg_lmm needs for this layout.  epi(m, n, acc4, cnt) as in wg_lmm.
+template <bool AKC, class Epi>
+__device__ __forceinline__ void wg_lmm_wide(int M, int N, int K, const float* A, int lda, const float* B, int ldb, Epi&& epi) {
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int tn = (N + 63) >> 6, nblk = ((M + 15) >> 4) * tn;
+    const int nsteps = K >> 4;
+    struct Frag { f32x4 a, b0, b1, b2, b3; };
+    for (int t = wave; t < nblk; t += nw) {
+        const int m0 = (t / tn) << 4, n0 = (t % tn) << 6;
+        const float* ap = AKC ? A + (m0 + r) * lda + 4 * q : A + (4 * q) * lda + m0 + r;
+        const float* bp = B + (4 * q) * ldb + n0 + 4 * r;
+        auto load = [&](int k) {
+            Frag f;
+            const float* pa = ap + k * (AKC ? 1 : lda);
+            if (AKC) f.a = *(const f32x4*)pa;
+            else { f.a[0] = pa[0]; f.a[1] = pa[lda]; f.a[2] = pa[2 * lda]; f.a[3] = pa[3 * lda]; }
+            const float* pb = bp + k * ldb;
+            f.b0 = *(const f32x4*)pb; f.b1 = *(const f32x4*)(pb + ldb);
+            f.b2 = *(const f32x4*)(pb + 2 * ldb); f.b3 = *(const f32x4*)(pb + 3 * ldb);
+            return f;
+        };
+        f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        auto mma = [&](const Frag& f) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[0], f.b0[c], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[1], f.b1[c], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[2], f.b2[c], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[3], f.b3[c], acc[c], 0, 0, 0);
+            }
+        };
+        if (nsteps > 0) {
+            Frag fa = load(0);
+            int it = 0;
+            for (; it + 1 < nsteps; it += 2) {
+                const Frag fb = load((it + 1) << 4);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(fa);
+                __builtin_amdgcn_sched_barrier(0);
+                fa = load(min(it + 2, nsteps - 1) << 4);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(fb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (it < nsteps) mma(fa);
+        }
+        for (int kk = nsteps << 4; kk < K; kk += 4) {            // 4-deep tail, plain k = kk + q
+            const float a = AKC ? A[(m0 + r) * lda + kk + q] : A[(kk + q) * lda + m0 + r];
+            const f32x4 bv = *(const f32x4*)(B + (kk + q) * ldb + n0 + 4 * r);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[c], acc[c], 0, 0, 0);
+        }
+        const int n = n0 + 4 * r;
+        if (n < N) {
+            const int cnt = min(4, N - n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + 4 * q + e;
+                if (m < M) {
+                    f32x4 v = {acc[0][e], cnt > 1 ? acc[1][e] : 0.f, cnt > 2 ? acc[2][e] : 0.f, cnt > 3 ? acc[3][e] : 0.f};
+                    epi(m, n, v, cnt);
+                }
+            }
+        }
+    }
+}
+
+// f(n, sum_{m<M} X[m*ld + n]) for n < N on an LDS image: one thread per column, 4 independent chains
+template <class F>
+__device__ __forceinline__ void wg_lcolsum(int M, int N, const float* X, int ld, F&& f) {
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int m = 0;
+        for (; m + 3 < M; m += 4) { s0 += X[m * ld + n]; s1 += X[(m + 1) * ld + n]; s2 += X[(m + 2) * ld + n]; s3 += X[(m + 3) * ld + n]; }
+        for (; m < M; ++m) s0 += X[m * ld + n];
+        f(n, (s0 + s1) + (s2 + s3));
     }
 }
 #endif

@@ -18,6 +18,7 @@
 //   Small products run on v_mfma_f32_16x16x4_f32 straight from memory (wg_mm in common.h).
 #include "common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace {
 
@@ -68,6 +69,12 @@ __device__ __forceinline__ float drop_relu(const EpiDims& d, unsigned key, long 
     if (z <= 0.f) return 0.f;
     if (d.drop_thr == 0) return z;
     return drop_mix(key ^ (unsigned)idx) >= d.drop_thr ? z * d.mscale : 0.f;
+}
+__device__ __forceinline__ f32x4 drop_relu4(const EpiDims& d, unsigned key, long idx, const f32x4& z) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = drop_relu(d, key, idx + e, z[e]);
+    return o;
 }
 constexpr int QUERY_CALL = 1 << 20;      // "call" id of the query forward (support step t uses t)
 
@@ -213,6 +220,8 @@ __global__ __launch_bounds__(512) void adapt_kernel(EpiDims d, EpiBuf w, EpiPara
         }
         __syncthreads(); STAMP()
     }
+    // colsum(D_T): every query tile needs it (b0_T = b0 - alpha * colsum(D_T))
+    wg_colsum(sm, sm_cap, S, h0, D, h0, [&](int n, float s) { cs[n] = s; });
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
     const float alpha = d.alpha;
     const int slot = d.taped ? d.T : 0;
     const float* D = w.D + (long)b * S * h0;
-    float* cs = w.qcs + ((long)b * w.ntile + tile) * h0;
+    const float* cs = w.cs + (long)b * h0;                 // colsum(D_T), left by adapt
     const float* A0q = w.A0 + ((long)b * (S + Qn) + S + r0) * h0;
     const float* Gqs = w.G + ((long)b * (S + Qn) + S + r0) * S;
     const float* bh = w.bh + (long)b * N;
@@ -240,8 +249,6 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
     auto z = [&](int i) { return w.zq[i] + ((long)b * Qn + r0) * d.h[i]; };
     auto Wc = [&](int i) { return (const float*)(w.Wslot[i] + ((long)b * w.nslot + slot) * ((long)d.h[i] * d.h[i - 1])); };
 
-    wg_colsum(sm, sm_cap, S, h0, D, h0, [&](int n, float s) { cs[n] = s; });
-    __syncthreads();
     {
         float* a0 = a(0);
         const unsigned keyq0 = drop_key(d, b, QUERY_CALL, 0);
@@ -323,6 +330,179 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
     float* pD = w.pD + pt * (long)S * h0;
     wg_mm2(sm, sm_cap, S, h0, nr, Gqs, 1, S, z(0), h0, 1, [&](int m, int n) { return pb0[n]; },
            [&](int m, int n, float acc, float pre) { pD[(long)m * h0 + n] = -alpha * (acc + pre); });
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// query, LDS-resident form: the same arithmetic as query_kernel, but the tile's whole phase chain lives in LDS
+// (common.h "LDS-resident products").  Staged once: the tile's A0 rows (into a_0), its G rows, D_T, the adapted fast
+// weights of every deeper layer, the head, the bias vectors.  z_i overwrites a_i in place (same-position dependence
+// only), so the footprint is  QR*sum ld(h_i) + sum h_i*ld(h_{i-1}) + S*ld(h0) + small.  Taken when that fits
+// (query_layout().total <= QLDS_CAP), i.e. for the reference's [256, 64] image network and anything smaller.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int QLDS_CAP = 40000;         // floats of dynamic LDS (160 KiB = 40960 less the kernel's static arrays)
+struct QLay { int a[MAXL], W[MAXL], bi[MAXL], Wh, Gq, D, lq, b0, cs, pb0, bh, total; };
+__host__ __device__ inline int q_r4(int x) { return (x + 3) & ~3; }
+__host__ __device__ inline int q_r16(int x) { return (x + 15) & ~15; }
+__host__ __device__ inline void query_layout(QLay& y, int L, const int* h, int S, int N) {
+    int off = 0;
+    for (int i = 0; i < MAXL; ++i) { y.a[i] = y.W[i] = y.bi[i] = 0; }
+    for (int i = 0; i < L; ++i) { y.a[i] = off; off += QR * wg_ld(h[i]); }
+    for (int i = 1; i < L; ++i) { y.W[i] = off; off += q_r16(h[i]) * wg_ld(h[i - 1]); y.bi[i] = off; off += q_r4(h[i]); }
+    y.Wh = off; off += q_r16(N) * wg_ld(h[L - 1]);
+    y.Gq = off; off += QR * wg_ld(S);
+    y.D = off; off += q_r4(S) * wg_ld(h[0]);
+    y.lq = off; off += QR * wg_ld(N);
+    y.b0 = off; off += q_r4(h[0]);
+    y.cs = off; off += q_r4(h[0]);
+    y.pb0 = off; off += q_r4(h[0]);
+    y.bh = off; off += q_r4(N);
+    y.total = off;
+}
+
+__global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d, EpiBuf w, QLay y, const int64_t* y_q,
+                                                        float* logits_q, int64_t* preds_q, int* status) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float s_loss[QR];
+    __shared__ float s_corr[QR];
+    __shared__ StageTab s_stg;
+    const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    int qi = 0;
+#define QSTAMP() if (w.trace && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) w.trace[64 + qi++] = __builtin_amdgcn_s_memrealtime();
+    QSTAMP()
+    const int S = d.S, N = d.N, L = d.L, H = d.H, h0 = d.h[0], Qn = d.Qn;
+    const int r0 = tile * QR, nr = min(QR, Qn - r0);
+    const float alpha = d.alpha;
+    const int ldq = wg_ld(N), ldG = wg_ld(S), ld0 = wg_ld(h0), ldH = wg_ld(H);
+    auto a = [&](int i) { return sm + y.a[i]; };
+    auto lda = [&](int i) { return wg_ld(d.h[i]); };
+
+    // ---- zero the arena (padding must read as zero), then stage everything this tile needs in one batch (plan: host)
+    wg_stage_tab_to_lds(&s_stg);
+    for (int i = tid * 4, tot = y.total; i < tot; i += nt * 4) *(f32x4*)(sm + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads(); QSTAMP()
+    wg_stage_rows<12>(&s_stg, b, tile, nr, sm);
+    wg_lds_barrier(); QSTAMP()
+
+    // ---- forward (epilogues handle 4 consecutive columns of one row: wg_lmm)
+    {
+        float* a0 = a(0);
+        const float* b0l = sm + y.b0; const float* csl = sm + y.cs;
+        const unsigned keyq0 = drop_key(d, b, QUERY_CALL, 0);
+        wg_lmm_wide<true>(nr, h0, S, sm + y.Gq, ldG, sm + y.D, ld0, [&](int m, int n, const f32x4& acc, int) {
+            float* p = a0 + m * ld0 + n;
+            const f32x4 pre = *(const f32x4*)p + (*(const f32x4*)(b0l + n) - alpha * *(const f32x4*)(csl + n));
+            *(f32x4*)p = drop_relu4(d, keyq0, (long)(r0 + m) * h0 + n, pre - alpha * acc);
+        });
+    }
+    wg_lds_barrier(); QSTAMP()
+    for (int i = 1; i < L; ++i) {
+        const int hi = d.h[i], hp = d.h[i - 1];
+        float* ai = a(i); const int ldi = lda(i);
+        const float* bi = sm + y.bi[i];
+        const unsigned keyqi = drop_key(d, b, QUERY_CALL, i);
+        wg_lmm<true, true>(nr, hi, hp, a(i - 1), lda(i - 1), sm + y.W[i], wg_ld(hp), [&](int m, int n, const f32x4& acc, int) {
+            *(f32x4*)(ai + m * ldi + n) = drop_relu4(d, keyqi, (long)(r0 + m) * hi + n, acc + *(const f32x4*)(bi + n));
+        });
+        wg_lds_barrier(); QSTAMP()
+    }
+    float* lq = sm + y.lq;
+    {
+        float* lg = logits_q + ((long)b * Qn + r0) * N;
+        const float* bhl = sm + y.bh;
+        wg_lmm<true, true>(nr, N, H, a(L - 1), ldH, sm + y.Wh, ldH, [&](int m, int n, const f32x4& acc, int cnt) {
+            const f32x4 v = acc + *(const f32x4*)(bhl + n);        // bh is zero-padded: columns past N stay 0
+            *(f32x4*)(lq + m * ldq + n) = v;
+            wg_st4(lg + m * N + n, v, cnt);
+        });
+    }
+    wg_lds_barrier(); QSTAMP()
+    // per row: log-softmax loss, first arg-max (torch.max semantics, fumi.py:180), lbar = (p - onehot)/Qn in place
+    for (int m = tid; m < nr; m += nt) {
+        const int yy = label(y_q + (long)b * Qn + r0, m, N, status);
+        float* row = lq + m * ldq;
+        float mx = row[0]; int arg = 0;
+        for (int n = 1; n < N; ++n) { const float v = row[n]; if (v > mx) { mx = v; arg = n; } }
+        float sum = 0.f;
+        for (int n = 0; n < N; ++n) sum += expf(row[n] - mx);
+        const float lse = mx + logf(sum), inv = 1.f / sum;
+        s_loss[m] = lse - row[yy];
+        s_corr[m] = (arg == yy) ? 1.f : 0.f;
+        preds_q[(long)b * Qn + r0 + m] = arg;
+        for (int n = 0; n < N; ++n) row[n] = (expf(row[n] - mx) * inv - (n == yy ? 1.f : 0.f)) / (float)Qn;
+    }
+    wg_lds_barrier(); QSTAMP()
+    if (tid == 0) {
+        float ls = 0.f, cs_ = 0.f;
+        for (int m = 0; m < nr; ++m) { ls += s_loss[m]; cs_ += s_corr[m]; }
+        w.ploss[(long)b * w.ntile + tile] = ls;
+        w.pcorr[(long)b * w.ntile + tile] = cs_;
+    }
+    if (!d.need_grad) return;
+
+    // ---- backward of the query loss w.r.t. (theta_T, h_T): partial sums over this tile's rows
+    const long pt = (long)b * w.ntile + tile;
+    const float* lbar = lq;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    auto relu_bwd4 = [&](const f32x4& act, const f32x4& g) {      // g * relu'(z) with the dropout scale folded in
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = act[e] > 0.f ? g[e] * d.mscale : 0.f;
+        return o;
+    };
+    {
+        float* pWh = w.pWh + pt * N * H;
+        wg_lmm_wide<false>(N, H, nr, lbar, ldq, a(L - 1), ldH, [&](int m, int n, const f32x4& acc, int cnt) {
+            wg_st4(pWh + m * H + n, acc, cnt);
+        });
+        float* pbh = w.pbh + pt * N;
+        wg_lcolsum(nr, N, lbar, ldq, [&](int n, float s) { pbh[n] = s; });
+    }
+    wg_lds_barrier(); QSTAMP()
+    {
+        float* zl = a(L - 1);
+        wg_lmm_wide<true>(nr, H, N, lbar, ldq, sm + y.Wh, ldH, [&](int m, int n, const f32x4& acc, int) {
+            float* p = zl + m * ldH + n;
+            *(f32x4*)p = relu_bwd4(*(const f32x4*)p, acc);
+        });
+    }
+    wg_lds_barrier(); QSTAMP()
+    for (int i = L - 1; i >= 1; --i) {
+        const int hi = d.h[i], hp = d.h[i - 1];
+        const float* zi = a(i); const int ldi = lda(i), ldp = lda(i - 1);
+        float* pWi = w.pW[i] + pt * (long)hi * hp;
+        wg_lmm_wide<false>(hi, hp, nr, zi, ldi, a(i - 1), ldp, [&](int m, int n, const f32x4& acc, int cnt) {
+            wg_st4(pWi + (long)m * hp + n, acc, cnt);
+        });
+        float* pbi = w.pb[i] + pt * hi;
+        wg_lcolsum(nr, hi, zi, ldi, [&](int n, float s) { pbi[n] = s; });
+        wg_lds_barrier(); QSTAMP()
+        float* zp = a(i - 1);
+        wg_lmm_wide<true>(nr, hp, hi, zi, ldi, sm + y.W[i], wg_ld(hp), [&](int m, int n, const f32x4& acc, int) {
+            float* p = zp + m * ldp + n;
+            *(f32x4*)p = relu_bwd4(*(const f32x4*)p, acc);
+        });
+        wg_lds_barrier(); QSTAMP()
+    }
+    // layer 0: Abar0 rows of the query set, b0bar, and the adjoint of the low-rank factor D_T
+    const float* z0 = a(0);
+    float* A0bq = w.A0bar + ((long)b * (S + Qn) + S + r0) * h0;
+    {
+        const int c4n = (h0 + 3) >> 2;
+        for (int i = tid; i < nr * c4n; i += nt) {
+            const int m = i / c4n, n = (i - m * c4n) << 2;
+            wg_st4(A0bq + (long)m * h0 + n, *(const f32x4*)(z0 + m * ld0 + n), min(4, h0 - n));
+        }
+    }
+    float* pb0 = w.pb0 + pt * h0; float* pb0l = sm + y.pb0;
+    wg_lcolsum(nr, h0, z0, ld0, [&](int n, float s) { pb0[n] = s; pb0l[n] = s; });
+    wg_lds_barrier(); QSTAMP()
+    float* pD = w.pD + pt * (long)S * h0;
+    wg_lmm_wide<false>(S, h0, nr, sm + y.Gq, ldG, z0, ld0, [&](int m, int n, const f32x4& acc, int cnt) {
+        wg_st4(pD + (long)m * h0 + n, -alpha * (acc + *(const f32x4*)(pb0l + n)), cnt);
+    });
+    (void)z4;
+    QSTAMP()
+#undef QSTAMP
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -655,9 +835,37 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     }
     {
         ProfScope ps(ws, st, FUMI_PH_QUERY);
-        HIP_TRY(hipFuncSetAttribute((const void*)query_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, w.lds_query * 4));
-        hipLaunchKernelGGL(query_kernel, dim3(w.ntile, p.B), dim3(512), w.lds_query * 4, st, d, w, p.b[0], p.y_q, p.logits_q,
-                           p.preds_q, ws->status);
+        QLay ql; query_layout(ql, p.L, p.h, p.S, p.N);
+        static const bool force_global = getenv("FUMI_EPI_GLOBAL") != nullptr;     // dev/test: take the generic kernels
+        bool lds_form = ql.total <= QLDS_CAP && 7 + 2 * (p.L - 1) <= WG_MAXJOB && !force_global;
+        StageTab tb; tb.njobs = 0; tb.nunits = 0;
+        if (lds_form) {
+            // staging plan: source = base + episode*sb + tile*st
+            const long R = p.S + p.Qn, S = p.S, N = p.N, H = d.H;
+            const long slot = d.taped ? p.T : 0;
+            tb.add(w.A0 + S * h0, R * h0, (long)QR * h0, h0, -1, QR, h0, ql.a[0], wg_ld(h0));
+            tb.add(w.D, S * h0, 0, h0, p.S, p.S, h0, ql.D, wg_ld(h0));
+            for (int i = 1; i < p.L; ++i) {
+                const long sz = (long)p.h[i] * p.h[i - 1];
+                tb.add(w.Wslot[i] + slot * sz, w.nslot * sz, 0, p.h[i - 1], p.h[i], p.h[i], p.h[i - 1], ql.W[i], wg_ld(p.h[i - 1]));
+            }
+            tb.add(w.G + S * S, R * S, (long)QR * S, S, -1, QR, p.S, ql.Gq, wg_ld(p.S));
+            tb.add(w.Whslot + slot * N * H, w.nslot * N * H, 0, H, p.N, p.N, (int)H, ql.Wh, wg_ld((int)H));
+            tb.add(p.b[0], 0, 0, h0, 1, 1, h0, ql.b0, h0);
+            tb.add(w.cs, h0, 0, h0, 1, 1, h0, ql.cs, h0);
+            for (int i = 1; i < p.L; ++i) tb.add(w.bcur[i], p.h[i], 0, p.h[i], 1, 1, p.h[i], ql.bi[i], p.h[i]);
+            tb.add(w.bh, N, 0, N, 1, 1, p.N, ql.bh, p.N);
+            lds_form = tb.nunits <= 64 * 8;                 // wg_stage_rows: one unit per lane and wave
+        }
+        if (lds_form) {
+            HIP_TRY(hipFuncSetAttribute((const void*)query_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ql.total * 4));
+            hipLaunchKernelGGL(query_lds_kernel, dim3(w.ntile, p.B), dim3(512), ql.total * 4, st, tb, d, w, ql, p.y_q,
+                               p.logits_q, p.preds_q, ws->status);
+        } else {
+            HIP_TRY(hipFuncSetAttribute((const void*)query_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, w.lds_query * 4));
+            hipLaunchKernelGGL(query_kernel, dim3(w.ntile, p.B), dim3(512), w.lds_query * 4, st, d, w, p.b[0], p.y_q, p.logits_q,
+                               p.preds_q, ws->status);
+        }
         LAUNCH_CHECK();
     }
     {

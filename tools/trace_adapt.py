@@ -9,13 +9,16 @@ ep = cg.make_episodes(1, B, N, K, Q, D, Dt); theta, phi = cg.make_fumi_params(1,
 g = lambda t: t.to(dev).contiguous()
 args = (ws, N, g(ep["x_s"]), g(ep["y_s"]), g(ep["x_q"]), g(ep["y_q"]), g(ep["text_s"]), [g(t) for t in theta], [g(t) for t in phi], T, 0.01, False)
 for _ in range(3): hip.fumi_step_select(*args)
-tr = torch.zeros(64, dtype=torch.int64, device=dev)
+tr = torch.zeros(256, dtype=torch.int64, device=dev)
 L = hip.lib(); L.fumi_dbg_set_epi_trace.argtypes = [ctypes.c_void_p]
 L.fumi_dbg_set_epi_trace(ctypes.c_void_p(tr.data_ptr()))
 hip.fumi_step_select(*args); torch.cuda.synchronize()
 L.fumi_dbg_set_epi_trace(None)
-t = tr.cpu(); n = int((t > 0).sum())
+t = tr.cpu(); n = int((t[:32] > 0).sum())
 d = [(int(t[i + 1]) - int(t[i])) / 100.0 for i in range(n - 1)]
 mm = [(int(t[32 + i + 1]) - int(t[32 + i])) / 100.0 for i in range(6)]
 print("z0 wg_mm2 internal (entry->acc init+pre, ->sync1, stage, ->sync2, compute, post):", [round(x, 2) for x in mm])
 print("adapt phase durations (us):", [round(x, 1) for x in d], "total", round(sum(d), 1))
+q = t[64:128]; nq = int((q > 0).sum())
+dq = [(int(q[i + 1]) - int(q[i])) / 100.0 for i in range(nq - 1)]
+print("query_lds phase durations (us):", [round(x, 2) for x in dq], "total", round(sum(dq), 1))
