@@ -144,23 +144,43 @@ int launch_split_head_grad(hipStream_t st, int B, int N, int H, const float* hea
 // ------------------------------------------------------------------------------------------------------------
 // Staging plan of an LDS-resident kernel: a list of dense [rows x cols] copies global -> LDS image, built on the host
 // (all shapes and alignments are known there) and passed as a kernel argument.  A job's source is
-// base + b*sb + tile*st (episode / tile of the workgroup); rows < 0 means "the tile's row count" (last tile may be
-// short).  The copy unit is one (row, segment): 64 lanes x 16 bytes of a row (or x 4 bytes when the row is not
-// 16-byte aligned), i.e. one wave-wide load instruction; units are numbered job after job (ubase).
+// base + b*sb + tile*st + part*sc (episode / tile-or-step / column part of the workgroup; element strides); rows < 0
+// means "the tile's row count" (last tile may be short).  nsum > 1 sums nsum source slabs sstride apart while
+// copying (the per-tile partial sums of the query pass).  The copy unit is one wave-wide load instruction: 64 lanes x 16
+// bytes (x 4 bytes when a row is not 16-byte aligned) covering one 64-lane segment of a wide row, or 64 >> lg whole rows of
+// a narrow one (2^lg lanes per row); units are numbered job after job (ubase).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int WG_MAXJOB = 24;
 struct StageTab {
-    const float* base[WG_MAXJOB]; long sb[WG_MAXJOB], st[WG_MAXJOB];
-    int rs[WG_MAXJOB], rows[WG_MAXJOB], cols[WG_MAXJOB], off[WG_MAXJOB], ld[WG_MAXJOB], vec[WG_MAXJOB], segs[WG_MAXJOB];
-    int ubase[WG_MAXJOB + 1];
-    int njobs, nunits;
-    void add(const float* b_, long sb_, long st_, long rs_, int rows_, int max_rows, int cols_, int off_, int ld_) {
+    const float* base[WG_MAXJOB];
+    int sb[WG_MAXJOB], st[WG_MAXJOB], sc[WG_MAXJOB], rs[WG_MAXJOB], off[WG_MAXJOB], sstride[WG_MAXJOB];
+    short rows[WG_MAXJOB], cols[WG_MAXJOB], ld[WG_MAXJOB];
+    unsigned char vec[WG_MAXJOB], segs[WG_MAXJOB], nsum[WG_MAXJOB], lg[WG_MAXJOB];
+    short ubase[WG_MAXJOB + 1];
+    short njobs, nunits;
+    int bad;                   // a field did not fit its type: the caller must take the generic kernel
+    void init() { njobs = 0; nunits = 0; bad = 0; }
+    void add(const float* b_, long sb_, long st_, long sc_, long rs_, int rows_, int max_rows, int cols_, int off_, int ld_,
+             int nsum_ = 1, long sstride_ = 0) {
+        if (njobs >= WG_MAXJOB) { bad = 1; return; }
         const int j = njobs++;
-        base[j] = b_; sb[j] = sb_; st[j] = st_; rs[j] = (int)rs_; rows[j] = rows_; cols[j] = cols_; off[j] = off_; ld[j] = ld_;
-        vec[j] = ((rs_ & 3) == 0) && ((sb_ & 3) == 0) && ((st_ & 3) == 0) && ((cols_ & 3) == 0) && ((((uintptr_t)b_) & 15) == 0);
-        const int per = vec[j] ? 256 : 64;
-        segs[j] = (cols_ + per - 1) / per;
-        ubase[j] = nunits; nunits += max_rows * segs[j]; ubase[j + 1] = nunits;
+        auto fits = [](long v) { return v >= 0 && v < (1L << 31); };
+        if (!fits(sb_) || !fits(st_) || !fits(sc_) || !fits(rs_) || !fits(sstride_) || rows_ > 32767 || cols_ > 32767 ||
+            ld_ > 32767 || nsum_ > 255) bad = 1;
+        base[j] = b_; sb[j] = (int)sb_; st[j] = (int)st_; sc[j] = (int)sc_; rs[j] = (int)rs_; off[j] = off_;
+        sstride[j] = (int)sstride_; rows[j] = (short)rows_; cols[j] = (short)cols_; ld[j] = (short)ld_; nsum[j] = (unsigned char)nsum_;
+        vec[j] = ((rs_ & 3) == 0) && ((sb_ & 3) == 0) && ((st_ & 3) == 0) && ((sc_ & 3) == 0) && ((sstride_ & 3) == 0) &&
+                 ((cols_ & 3) == 0) && ((((uintptr_t)b_) & 15) == 0);
+        // lanes a row needs (one float4 or one float each), rounded to a power of two: a unit is 64 / that many rows,
+        // or one 64-lane segment of a row that needs more
+        const int need = vec[j] ? (cols_ + 3) / 4 : cols_;
+        int lgv = 0; while ((1 << lgv) < need && lgv < 6) ++lgv;
+        lg[j] = (unsigned char)lgv;
+        const int sg = (need + 63) / 64;
+        const int nu = sg > 1 ? max_rows * sg : (max_rows + (64 >> lgv) - 1) / (64 >> lgv);
+        if (sg > 255 || nunits + nu > 32767) bad = 1;
+        segs[j] = (unsigned char)sg;
+        ubase[j] = nunits; nunits = (short)(nunits + nu); ubase[j + 1] = nunits;
     }
 };
 
@@ -483,15 +503,17 @@ __host__ __device__ __forceinline__ int wg_ld(int cols) { return ((cols + 31) & 
 // loads in flight before the first LDS write, fetching each unit's descriptor from the owning lane with v_readlane;
 // loads are unconditional from clamped addresses (a guarded load is a basic block of its own with a full wait).
 // Needs nunits <= 64 * (waves per workgroup).
-__device__ __forceinline__ void wg_stage_tab_to_lds(StageTab* Tl) {
-    // the plan must be the kernel's FIRST argument: it is read straight from the kernarg segment (taking the address of
-    // a by-value argument would copy it to scratch)
+__device__ __forceinline__ void wg_stage_tab_to_lds(StageTab* Tl, int ntab = 1) {
+    // the plans must be the kernel's FIRST arguments: they are read straight from the kernarg segment (taking the
+    // address of a by-value argument would copy it to scratch)
     const int* src = (const int*)__builtin_amdgcn_kernarg_segment_ptr();
     int* dst = (int*)Tl;
-    for (int i = threadIdx.x; i < (int)(sizeof(StageTab) / 4); i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < ntab * (int)(sizeof(StageTab) / 4); i += blockDim.x) dst[i] = src[i];
 }
-template <int U>
-__device__ __forceinline__ void wg_stage_rows(const StageTab* Tl, long b, long tile, int nr, float* lds) {
+static_assert(sizeof(StageTab) % 8 == 0, "consecutive StageTab kernel arguments must be contiguous");
+// U units in flight per wave, each the sum of up to NS slabs (NS = 1: plain copy)
+template <int U, int NS = 1>
+__device__ __forceinline__ void wg_stage_rows(const StageTab* Tl, long b, long tile, long part, int nr, float* lds) {
     const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nunits = Tl->nunits, njobs = Tl->njobs;
@@ -501,14 +523,18 @@ __device__ __forceinline__ void wg_stage_rows(const StageTab* Tl, long b, long t
     const int u = live ? myu : nunits - 1;
     int j = 0;
     for (int jj = 1; jj < njobs; ++jj) if (u >= Tl->ubase[jj]) j = jj;
-    const int ru = u - Tl->ubase[j], segs = Tl->segs[j];
-    const int r = ru / segs, sg = ru - r * segs;
+    const int ru = u - Tl->ubase[j], segs = Tl->segs[j], lgv = Tl->lg[j];
+    const int r0 = segs > 1 ? ru / segs : ru << (6 - lgv);            // first row of the unit
+    const int sg = segs > 1 ? ru - r0 * segs : 0;
     const int rows = Tl->rows[j] < 0 ? nr : Tl->rows[j];
-    const bool rok = live && r < rows;
-    const float* d_src = Tl->base[j] + b * Tl->sb[j] + tile * Tl->st[j] + (long)(rok ? r : 0) * Tl->rs[j];
-    const int d_off = Tl->off[j] + r * Tl->ld[j];
-    const int d_cols = rok ? Tl->cols[j] : 0;
-    const int d_seg = (sg << 6) | (Tl->vec[j] ? 1 << 30 : 0);
+    const bool rok = live && r0 < rows;
+    const float* d_src = Tl->base[j] + b * Tl->sb[j] + tile * Tl->st[j] + part * Tl->sc[j] + (long)(rok ? r0 : 0) * Tl->rs[j];
+    const int d_off = Tl->off[j] + r0 * Tl->ld[j];
+    const int d_left = rok ? rows - r0 : 0;                           // rows from r0 on (a unit takes at most 64 >> lg)
+    const int d_cols = Tl->cols[j];
+    const int d_misc = (sg << 6) | (lgv << 24) | (Tl->vec[j] ? 1 << 30 : 0);
+    const int d_rs = Tl->rs[j], d_ld = Tl->ld[j];
+    const int d_ns = Tl->nsum[j], d_ss = Tl->sstride[j];
     const unsigned d_lo = (unsigned)(uintptr_t)d_src, d_hi = (unsigned)((uintptr_t)d_src >> 32);
     // ---- B
     const int mine = (nunits - wave + nw - 1) / nw;                  // units of this wave (uniform)
@@ -519,18 +545,29 @@ __device__ __forceinline__ void wg_stage_rows(const StageTab* Tl, long b, long t
             const int l = min(x0 + x, 63);
             const unsigned lo = __builtin_amdgcn_readlane(d_lo, l), hi = __builtin_amdgcn_readlane(d_hi, l);
             const int o = __builtin_amdgcn_readlane(d_off, l), cols = __builtin_amdgcn_readlane(d_cols, l);
-            const int sgv = __builtin_amdgcn_readlane(d_seg, l);
-            const bool isv = (sgv >> 30) & 1;
-            const int cb = (sgv & 0xffffff) + lane;
+            const int left = __builtin_amdgcn_readlane(d_left, l), misc = __builtin_amdgcn_readlane(d_misc, l);
+            const int rs = __builtin_amdgcn_readlane(d_rs, l), ld = __builtin_amdgcn_readlane(d_ld, l);
+            const bool isv = (misc >> 30) & 1;
+            const int lgu = (misc >> 24) & 7;
+            const int i = lane >> lgu;                               // row of the unit this lane copies
+            const int cb = (misc & 0xffffff) + (lane & ((1 << lgu) - 1));
             const int c = isv ? cb << 2 : cb;
-            const bool ok = (x0 + x < mine) && c < cols;
-            const float* p = (const float*)(((uintptr_t)hi << 32) | lo) + (ok ? c : 0);
+            const bool ok = (x0 + x < mine) && i < left && c < cols;
+            const float* p = (const float*)(((uintptr_t)hi << 32) | lo) + (ok ? (long)i * rs + c : 0);
             const float* p4 = (const float*)((uintptr_t)p & ~(uintptr_t)15);   // aligned float4 holding *p (vec: p itself)
-            const f32x4 t = *(const f32x4*)p4;
             const int sub = (int)(p - p4);
+            f32x4 t = *(const f32x4*)p4;
+            if (NS > 1) {
+                const int ns = __builtin_amdgcn_readlane(d_ns, l), ss = __builtin_amdgcn_readlane(d_ss, l);
+                f32x4 tk[NS];
+#pragma unroll
+                for (int k = 1; k < NS; ++k) tk[k] = *(const f32x4*)(p4 + (long)(k < ns ? k : 0) * ss);
+#pragma unroll
+                for (int k = 1; k < NS; ++k) if (k < ns) t += tk[k];          // (scalar jobs: sstride keeps the sub-offset)
+            }
             v[x] = t;
             if (!isv) v[x][0] = sub == 0 ? t[0] : sub == 1 ? t[1] : sub == 2 ? t[2] : t[3];
-            off[x] = o + c;
+            off[x] = o + i * ld + c;
             md[x] = ok ? (isv ? 2 : 1) : 0;
         }
 #pragma unroll
@@ -658,12 +695,15 @@ __device__ __forceinline__ void wg_lmm(int M, int N, int K, const float* A, int 
     }
 }
 
+template <int V> struct WgInt { static constexpr int value = V; };
+
 // The same product for a k-major B image (B(k,n) = B[k*ldb + n], rows of B contiguous along n), organised so that one
 // ds_read_b128 of a B row feeds FOUR MFMAs: a wave owns a 16 x 64 output block made of four column tiles
 // c = 0..3 = columns {n0 + 4*j + c}; the read of row k at columns n0 + 4*(l&15) .. +3 gives lane l its B value for each
 // of them.  Lane l ends up with the 4x4 block rows m0 + 4*(l>>4) .. +3, columns n0 + 4*(l&15) .. +3, i.e. four 16-byte
 // epilogue accesses.  Per 16-deep step: 1 (AKC) or 4 reads for A, 4 for B, 16 MFMAs -- a third of the LDS instructions
-// wg_lmm needs for this layout.  epi(m, n, acc4, cnt) as in wg_lmm.
+// wg_lmm needs for this layout.  epi(m, n, acc4, cnt, WgInt<e>) as in wg_lmm; e = m & 3 says which of the lane's four
+// rows this is (a compile-time tag, so per-lane register state can be indexed with it).  Block t goes to wave t % nw.
 template <bool AKC, class Epi>
 __device__ __forceinline__ void wg_lmm_wide(int M, int N, int K, const float* A, int lda, const float* B, int ldb, Epi&& epi) {
     const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
@@ -720,14 +760,15 @@ __device__ __forceinline__ void wg_lmm_wide(int M, int N, int K, const float* A,
         const int n = n0 + 4 * r;
         if (n < N) {
             const int cnt = min(4, N - n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            auto out = [&](auto ec) {                            // ec: which of the lane's 4 rows (compile-time)
+                constexpr int e = decltype(ec)::value;
                 const int m = m0 + 4 * q + e;
                 if (m < M) {
                     f32x4 v = {acc[0][e], cnt > 1 ? acc[1][e] : 0.f, cnt > 2 ? acc[2][e] : 0.f, cnt > 3 ? acc[3][e] : 0.f};
-                    epi(m, n, v, cnt);
+                    epi(m, n, v, cnt, ec);
                 }
-            }
+            };
+            out(WgInt<0>{}); out(WgInt<1>{}); out(WgInt<2>{}); out(WgInt<3>{});
         }
     }
 }

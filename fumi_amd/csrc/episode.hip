@@ -38,6 +38,7 @@ struct EpiBuf {
     float *Wb[MAXL], *bb[MAXL], *Whb, *bhb, *b0b, *Db;                   // adjoint state per episode
     float *abar[MAXL], *X0, *X1, *eb, *lb;     // reverse scratch
     float *A0bar;                              // [B,R,h0] adjoint of A0 (support rows: sum over inner steps)
+    float *xpart; int *xcnt;                   // reverse_lds: [B,2,8,S*h_1] partial sums exchanged between the column parts; [B] arrival counters
     int nslot, ntape, ntile, maxh;
     unsigned long long* trace;                 // dev: per-phase wall-clock stamps of block 0 (tools/trace_adapt.py)
     int lds_adapt, lds_query, lds_reverse;     // floats of dynamic LDS each kernel stages its products through
@@ -225,6 +226,239 @@ __global__ __launch_bounds__(512) void adapt_kernel(EpiDims d, EpiBuf w, EpiPara
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// adapt, LDS-resident form: the episode's whole inner loop runs out of LDS (common.h "LDS-resident products").
+// Staged once: G_ss, the fast weights of every deeper layer, the head.  D_t, colsum(D_t), the activations a_i and
+// the pre-activation gradients dz_i (i >= 1) live in LDS; dz_0 only exists inside the epilogue that adds it to D_t.
+// The constant part of layer 0, A0_s + b0, sits in REGISTERS: the 16 x 64 block a wave owns in the layer-0 products
+// never changes (needs ceil(S/16)*ceil(h0/64) <= 8 blocks, one per wave).  Global memory only sees the tape (stores,
+// never waited for) and the final state.  Taken when adapt_layout().total <= ALDS_CAP and the block count fits.
+// ------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline int q_r4(int x) { return (x + 3) & ~3; }
+__host__ __device__ inline int q_r16(int x) { return (x + 15) & ~15; }
+constexpr int ALDS_CAP = 40000;
+struct ALay { int a[MAXL], dz[MAXL], W[MAXL], bi[MAXL], Wh, G, D, e, cs, bh, total; };
+__host__ __device__ inline void adapt_layout(ALay& y, int L, const int* h, int S, int N) {
+    int off = 0;
+    const int RS = q_r4(S);
+    for (int i = 0; i < MAXL; ++i) { y.a[i] = y.dz[i] = y.W[i] = y.bi[i] = 0; }
+    for (int i = 0; i < L; ++i) { y.a[i] = off; off += RS * wg_ld(h[i]); }
+    for (int i = 1; i < L; ++i) { y.dz[i] = off; off += RS * wg_ld(h[i]); }
+    y.G = off; off += RS * wg_ld(S);
+    y.e = off; off += RS * wg_ld(N);
+    y.D = off; off += RS * wg_ld(h[0]);
+    for (int i = 1; i < L; ++i) { y.W[i] = off; off += q_r16(h[i]) * wg_ld(h[i - 1]); y.bi[i] = off; off += q_r4(h[i]); }
+    y.Wh = off; off += q_r16(N) * wg_ld(h[L - 1]);
+    y.cs = off; off += q_r4(h[0]);
+    y.bh = off; off += q_r4(N);
+    y.total = off + 64;
+}
+
+__global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d, EpiBuf w, ALay y, EpiParams prm,
+                                                        const int64_t* y_s, int* status) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ StageTab s_stg;
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    int stamp_i = 0;
+#define STAMP() if (w.trace && tid == 0 && blockIdx.x == 0) w.trace[stamp_i++] = __builtin_amdgcn_s_memrealtime();
+    STAMP()
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = d.S, N = d.N, L = d.L, H = d.H, h0 = d.h[0];
+    const float alpha = d.alpha;
+    const int64_t* ys = y_s + (long)b * S;
+    const int ldS = wg_ld(S), ldN = wg_ld(N), ld0 = wg_ld(h0), ldH = wg_ld(H);
+    auto a = [&](int i) { return sm + y.a[i]; };
+    auto dz = [&](int i) { return sm + y.dz[i]; };
+    auto ldh = [&](int i) { return wg_ld(d.h[i]); };
+    float* D = sm + y.D; float* cs = sm + y.cs; float* e_ = sm + y.e; float* Wh = sm + y.Wh; float* bh = sm + y.bh;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+    wg_stage_tab_to_lds(&s_stg);
+    for (int i = tid * 4, tot = y.total; i < tot; i += nt * 4) *(f32x4*)(sm + i) = z4;
+    // A0_s + b0 of the lane's 4x4 block of the layer-0 products (block = wave)
+    f32x4 preZ[4];
+    {
+        const int tn = (h0 + 63) >> 6;
+        const int m0 = (wave / tn) << 4, n = ((wave % tn) << 6) + 4 * (lane & 15);
+        const float* A0s = w.A0 + (long)b * (S + d.Qn) * h0;
+        const bool vec = ((h0 & 3) == 0) && ((((uintptr_t)A0s) & 15) == 0) && ((((uintptr_t)prm.b[0]) & 15) == 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + 4 * (lane >> 4) + e;
+            f32x4 v = z4;
+            if (m < S && n < h0) {
+                if (vec) v = *(const f32x4*)(A0s + (long)m * h0 + n) + *(const f32x4*)(prm.b[0] + n);
+                else for (int c = 0; c < 4 && n + c < h0; ++c) v[c] = A0s[(long)m * h0 + n + c] + prm.b[0][n + c];
+            }
+            preZ[e] = v;
+        }
+    }
+    wg_lds_barrier(); STAMP()                   // (LDS only: the preZ loads stay in flight behind the staging)
+    wg_stage_rows<12>(&s_stg, b, 0, 0, 0, sm);
+    wg_lds_barrier(); STAMP()
+    // slot 0 of the tape = the initial fast weights (reverse needs W_t of every step)
+    auto store_img = [&](float* dst, const float* img, int ld, int rows, int cols) {      // LDS image -> dense global
+        const int c4n = (cols + 3) >> 2;
+        for (int i = tid; i < rows * c4n; i += nt) {
+            const int r = i / c4n, c = (i - r * c4n) << 2;
+            wg_st4(dst + (long)r * cols + c, *(const f32x4*)(img + r * ld + c), min(4, cols - c));
+        }
+    };
+    if (d.taped) {
+        for (int i = 1; i < L; ++i)
+            store_img(w.Wslot[i] + (long)b * w.nslot * ((long)d.h[i] * d.h[i - 1]), sm + y.W[i], ldh(i - 1), d.h[i], d.h[i - 1]);
+        store_img(w.Whslot + (long)b * w.nslot * N * H, Wh, ldH, N, H);
+    }
+
+    for (int t = 0; t < d.T; ++t) {
+        const long tp = (long)b * w.ntape + (d.taped ? t : 0);
+        // 1. layer 0 through the low-rank form: a0 = relu(A0s + b0 - alpha (G D_t + colsum D_t))
+        {
+            float* a0 = a(0);
+            float* ta0 = w.ta[0] + tp * S * h0;
+            const unsigned key0 = drop_key(d, b, t, 0);
+            auto fin = [&](int m, int n, const f32x4& pre, int cnt) {
+                const f32x4 v = drop_relu4(d, key0, (long)m * h0 + n, pre);
+                f32x4 o = v;
+#pragma unroll
+                for (int c = 1; c < 4; ++c) if (c >= cnt) o[c] = 0.f;
+                *(f32x4*)(a0 + m * ld0 + n) = o;
+                if (d.taped) wg_st4(ta0 + (long)m * h0 + n, o, cnt);
+            };
+            if (t == 0) {                         // D_0 = 0
+                const int tn = (h0 + 63) >> 6;
+                const int m0 = (wave / tn) << 4, n = ((wave % tn) << 6) + 4 * (lane & 15);
+                if (wave < ((S + 15) >> 4) * tn && n < h0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int m = m0 + 4 * (lane >> 4) + e;
+                        if (m < S) fin(m, n, preZ[e], min(4, h0 - n));
+                    }
+                }
+            } else {
+                wg_lmm_wide<true>(S, h0, S, sm + y.G, ldS, D, ld0, [&](int m, int n, const f32x4& acc, int cnt, auto ec) {
+                    fin(m, n, preZ[decltype(ec)::value] - alpha * (acc + *(const f32x4*)(cs + n)), cnt);
+                });
+            }
+        }
+        wg_lds_barrier(); STAMP()
+        // 2. deeper layers with the episode's fast weights
+        for (int i = 1; i < L; ++i) {
+            const int hi = d.h[i], hp = d.h[i - 1];
+            float* ai = a(i); const int ldi = ldh(i);
+            const float* bi = sm + y.bi[i];
+            float* tai = w.ta[i] + tp * S * hi;
+            const unsigned keyi = drop_key(d, b, t, i);
+            wg_lmm<true, true>(S, hi, hp, a(i - 1), ldh(i - 1), sm + y.W[i], wg_ld(hp), [&](int m, int n, const f32x4& acc, int cnt) {
+                f32x4 o = drop_relu4(d, keyi, (long)m * hi + n, acc + *(const f32x4*)(bi + n));
+#pragma unroll
+                for (int c = 1; c < 4; ++c) if (c >= cnt) o[c] = 0.f;
+                *(f32x4*)(ai + m * ldi + n) = o;
+                if (d.taped) wg_st4(tai + (long)m * hi + n, o, cnt);
+            });
+            wg_lds_barrier(); STAMP()
+        }
+        // 3. head logits (into e_), softmax, e = (p - onehot)/S
+        wg_lmm<true, true>(S, N, H, a(L - 1), ldH, Wh, ldH, [&](int m, int n, const f32x4& acc, int) {
+            *(f32x4*)(e_ + m * ldN + n) = acc + *(const f32x4*)(bh + n);          // bh zero-padded
+        });
+        wg_lds_barrier(); STAMP()
+        {
+            float* tpp = w.tp + tp * S * N; float* tee = w.te + tp * S * N;
+            for (int s_ = tid; s_ < S; s_ += nt) {
+                const int yy = label(ys, s_, N, status);
+                float* row = e_ + s_ * ldN;
+                float mx = row[0];
+                for (int n = 1; n < N; ++n) mx = fmaxf(mx, row[n]);
+                float sum = 0.f;
+                for (int n = 0; n < N; ++n) sum += expf(row[n] - mx);
+                const float inv = 1.f / sum;
+                for (int n = 0; n < N; ++n) {
+                    const float pv = expf(row[n] - mx) * inv;
+                    const float ev = (pv - (n == yy ? 1.f : 0.f)) / (float)S;
+                    row[n] = ev;
+                    if (d.taped) { tpp[s_ * N + n] = pv; tee[s_ * N + n] = ev; }
+                }
+                for (int n = N; n < ldN - 4; ++n) row[n] = 0.f;                  // K padding of e (logits wrote bias-free zeros anyway)
+            }
+        }
+        wg_lds_barrier(); STAMP()
+        // 4. backward through the head: dz_{L-1} = (e Wh) * relu'   (reads Wh before it is updated)
+        {
+            const float* al = a(L - 1);
+            float* tdl = w.tdz[L - 1] + tp * S * H;
+            auto put = [&](int m, int n, const f32x4& acc, int cnt) {
+                const f32x4 act = *(const f32x4*)(al + m * ldH + n);
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = (c < cnt && act[c] > 0.f) ? acc[c] * d.mscale : 0.f;
+                if (L > 1) *(f32x4*)(dz(L - 1) + m * ldH + n) = o;
+                else {                                                          // single hidden layer: this is dz_0
+                    float* pd = D + m * ld0 + n; *(f32x4*)pd = *(const f32x4*)pd + o;
+                }
+                if (d.taped) wg_st4(tdl + (long)m * H + n, o, cnt);
+            };
+            wg_lmm_wide<true>(S, H, N, e_, ldN, Wh, ldH, [&](int m, int n, const f32x4& acc, int cnt, auto) { put(m, n, acc, cnt); });
+        }
+        wg_lds_barrier(); STAMP()
+        // head update: Wh <- Wh - alpha e^T a,  bh <- bh - alpha colsum(e); next slot of the tape
+        {
+            float* Whn = w.Whslot + ((long)b * w.nslot + (d.taped ? t + 1 : 0)) * N * H;
+            wg_lmm_wide<false>(N, H, S, e_, ldN, a(L - 1), ldH, [&](int m, int n, const f32x4& acc, int cnt, auto) {
+                float* pw = Wh + m * ldH + n;
+                const f32x4 o = *(const f32x4*)pw - alpha * acc;
+                *(f32x4*)pw = o;
+                if (d.taped) wg_st4(Whn + m * H + n, o, cnt);
+            });
+            wg_lcolsum(S, N, e_, ldN, [&](int n, float s_) { bh[n] -= alpha * s_; });
+        }
+        // 5. hidden layers, top down (the head update above touches neither dz_{L-1} nor W_i)
+        for (int i = L - 1; i >= 1; --i) {
+            const int hi = d.h[i], hp = d.h[i - 1];
+            const float* ap = a(i - 1); const int ldp = ldh(i - 1), ldi = ldh(i);
+            float* tdp = w.tdz[i - 1] + tp * S * hp;
+            wg_lmm_wide<true>(S, hp, hi, dz(i), ldi, sm + y.W[i], wg_ld(hp), [&](int m, int n, const f32x4& acc, int cnt, auto) {
+                const f32x4 act = *(const f32x4*)(ap + m * ldp + n);
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = (c < cnt && act[c] > 0.f) ? acc[c] * d.mscale : 0.f;
+                if (i > 1) *(f32x4*)(dz(i - 1) + m * ldp + n) = o;
+                else { float* pd = D + m * ld0 + n; *(f32x4*)pd = *(const f32x4*)pd + o; }     // 6. D_{t+1} = D_t + dz_0
+                if (d.taped) wg_st4(tdp + (long)m * hp + n, o, cnt);
+            });
+            wg_lds_barrier(); STAMP()
+            float* Wi = sm + y.W[i]; const int ldw = wg_ld(hp);
+            float* Wn = w.Wslot[i] + ((long)b * w.nslot + (d.taped ? t + 1 : 0)) * ((long)hi * hp);
+            wg_lmm_wide<false>(hi, hp, S, dz(i), ldi, ap, ldp, [&](int m, int n, const f32x4& acc, int cnt, auto) {
+                float* pw = Wi + m * ldw + n;
+                const f32x4 o = *(const f32x4*)pw - alpha * acc;
+                *(f32x4*)pw = o;
+                if (d.taped) wg_st4(Wn + (long)m * hp + n, o, cnt);
+            });
+            float* bi = sm + y.bi[i];
+            wg_lcolsum(S, hi, dz(i), ldi, [&](int n, float s_) { bi[n] -= alpha * s_; });
+            if (i == 1) wg_lcolsum(S, h0, D, ld0, [&](int n, float s_) { cs[n] = s_; });           // colsum(D_{t+1})
+        }
+        if (L == 1) { wg_lds_barrier(); wg_lcolsum(S, h0, D, ld0, [&](int n, float s_) { cs[n] = s_; }); }
+        wg_lds_barrier(); STAMP()
+    }
+    // ---- final state for the query tiles / the reverse sweep
+    store_img(w.D + (long)b * S * h0, D, ld0, S, h0);
+    for (int n = tid; n < h0; n += nt) w.cs[(long)b * h0 + n] = cs[n];
+    for (int n = tid; n < N; n += nt) w.bh[(long)b * N + n] = bh[n];
+    for (int i = 1; i < L; ++i) {
+        const float* bi = sm + y.bi[i];
+        for (int n = tid; n < d.h[i]; n += nt) w.bcur[i][(long)b * d.h[i] + n] = bi[n];
+    }
+    if (!d.taped) {
+        for (int i = 1; i < L; ++i)
+            store_img(w.Wslot[i] + (long)b * w.nslot * ((long)d.h[i] * d.h[i - 1]), sm + y.W[i], ldh(i - 1), d.h[i], d.h[i - 1]);
+        store_img(w.Whslot + (long)b * w.nslot * N * H, Wh, ldH, N, H);
+    }
+    STAMP()
+#undef STAMP
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // query: forward with the adapted weights, loss / argmax, first-order backward of the query loss (partial slabs)
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const float* const b0, const int64_t* y_q,
@@ -295,6 +529,7 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
         for (int m = 0; m < nr; ++m) { ls += s_loss[m]; cs_ += s_corr[m]; }
         w.ploss[(long)b * w.ntile + tile] = ls;
         w.pcorr[(long)b * w.ntile + tile] = cs_;
+        if (tile == 0 && d.need_grad) w.xcnt[b] = 0;          // arrival counter of reverse_lds_kernel's exchanges
     }
     if (!d.need_grad) return;
 
@@ -341,8 +576,6 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
 // ------------------------------------------------------------------------------------------------------------
 constexpr int QLDS_CAP = 40000;         // floats of dynamic LDS (160 KiB = 40960 less the kernel's static arrays)
 struct QLay { int a[MAXL], W[MAXL], bi[MAXL], Wh, Gq, D, lq, b0, cs, pb0, bh, total; };
-__host__ __device__ inline int q_r4(int x) { return (x + 3) & ~3; }
-__host__ __device__ inline int q_r16(int x) { return (x + 15) & ~15; }
 __host__ __device__ inline void query_layout(QLay& y, int L, const int* h, int S, int N) {
     int off = 0;
     for (int i = 0; i < MAXL; ++i) { y.a[i] = y.W[i] = y.bi[i] = 0; }
@@ -380,7 +613,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d,
     wg_stage_tab_to_lds(&s_stg);
     for (int i = tid * 4, tot = y.total; i < tot; i += nt * 4) *(f32x4*)(sm + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads(); QSTAMP()
-    wg_stage_rows<12>(&s_stg, b, tile, nr, sm);
+    wg_stage_rows<20>(&s_stg, b, tile, 0, nr, sm);
     wg_lds_barrier(); QSTAMP()
 
     // ---- forward (epilogues handle 4 consecutive columns of one row: wg_lmm)
@@ -388,7 +621,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d,
         float* a0 = a(0);
         const float* b0l = sm + y.b0; const float* csl = sm + y.cs;
         const unsigned keyq0 = drop_key(d, b, QUERY_CALL, 0);
-        wg_lmm_wide<true>(nr, h0, S, sm + y.Gq, ldG, sm + y.D, ld0, [&](int m, int n, const f32x4& acc, int) {
+        wg_lmm_wide<true>(nr, h0, S, sm + y.Gq, ldG, sm + y.D, ld0, [&](int m, int n, const f32x4& acc, int, auto) {
             float* p = a0 + m * ld0 + n;
             const f32x4 pre = *(const f32x4*)p + (*(const f32x4*)(b0l + n) - alpha * *(const f32x4*)(csl + n));
             *(f32x4*)p = drop_relu4(d, keyq0, (long)(r0 + m) * h0 + n, pre - alpha * acc);
@@ -436,6 +669,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d,
         for (int m = 0; m < nr; ++m) { ls += s_loss[m]; cs_ += s_corr[m]; }
         w.ploss[(long)b * w.ntile + tile] = ls;
         w.pcorr[(long)b * w.ntile + tile] = cs_;
+        if (tile == 0 && d.need_grad) w.xcnt[b] = 0;          // arrival counter of reverse_lds_kernel's exchanges
     }
     if (!d.need_grad) return;
 
@@ -451,7 +685,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d,
     };
     {
         float* pWh = w.pWh + pt * N * H;
-        wg_lmm_wide<false>(N, H, nr, lbar, ldq, a(L - 1), ldH, [&](int m, int n, const f32x4& acc, int cnt) {
+        wg_lmm_wide<false>(N, H, nr, lbar, ldq, a(L - 1), ldH, [&](int m, int n, const f32x4& acc, int cnt, auto) {
             wg_st4(pWh + m * H + n, acc, cnt);
         });
         float* pbh = w.pbh + pt * N;
@@ -460,7 +694,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d,
     wg_lds_barrier(); QSTAMP()
     {
         float* zl = a(L - 1);
-        wg_lmm_wide<true>(nr, H, N, lbar, ldq, sm + y.Wh, ldH, [&](int m, int n, const f32x4& acc, int) {
+        wg_lmm_wide<true>(nr, H, N, lbar, ldq, sm + y.Wh, ldH, [&](int m, int n, const f32x4& acc, int, auto) {
             float* p = zl + m * ldH + n;
             *(f32x4*)p = relu_bwd4(*(const f32x4*)p, acc);
         });
@@ -470,14 +704,14 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d,
         const int hi = d.h[i], hp = d.h[i - 1];
         const float* zi = a(i); const int ldi = lda(i), ldp = lda(i - 1);
         float* pWi = w.pW[i] + pt * (long)hi * hp;
-        wg_lmm_wide<false>(hi, hp, nr, zi, ldi, a(i - 1), ldp, [&](int m, int n, const f32x4& acc, int cnt) {
+        wg_lmm_wide<false>(hi, hp, nr, zi, ldi, a(i - 1), ldp, [&](int m, int n, const f32x4& acc, int cnt, auto) {
             wg_st4(pWi + (long)m * hp + n, acc, cnt);
         });
         float* pbi = w.pb[i] + pt * hi;
         wg_lcolsum(nr, hi, zi, ldi, [&](int n, float s) { pbi[n] = s; });
         wg_lds_barrier(); QSTAMP()
         float* zp = a(i - 1);
-        wg_lmm_wide<true>(nr, hp, hi, zi, ldi, sm + y.W[i], wg_ld(hp), [&](int m, int n, const f32x4& acc, int) {
+        wg_lmm_wide<true>(nr, hp, hi, zi, ldi, sm + y.W[i], wg_ld(hp), [&](int m, int n, const f32x4& acc, int, auto) {
             float* p = zp + m * ldp + n;
             *(f32x4*)p = relu_bwd4(*(const f32x4*)p, acc);
         });
@@ -497,7 +731,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d,
     wg_lcolsum(nr, h0, z0, ld0, [&](int n, float s) { pb0[n] = s; pb0l[n] = s; });
     wg_lds_barrier(); QSTAMP()
     float* pD = w.pD + pt * (long)S * h0;
-    wg_lmm_wide<false>(S, h0, nr, sm + y.Gq, ldG, z0, ld0, [&](int m, int n, const f32x4& acc, int cnt) {
+    wg_lmm_wide<false>(S, h0, nr, sm + y.Gq, ldG, z0, ld0, [&](int m, int n, const f32x4& acc, int cnt, auto) {
         wg_st4(pD + (long)m * h0 + n, -alpha * (acc + *(const f32x4*)(pb0l + n)), cnt);
     });
     (void)z4;
@@ -661,6 +895,289 @@ __global__ __launch_bounds__(512) void reverse_kernel(EpiDims d, EpiBuf w, float
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// reverse, LDS-resident form, split over P workgroups per episode along the columns of layer 0.
+//
+// Everything that is h0 wide -- Wbar_1, W_1, Dbar, a_0, the adjoints of a_0 / z_0 -- is a column block per workgroup
+// (h0c = h0/P columns), which is what makes the sweep fit LDS (one workgroup would need Wbar_1 AND W_1 AND four
+// [S,h0] matrices: > 160 KiB for the reference network) and puts P CUs on an episode instead of one.  All products that
+// involve those matrices are column-local except one: dzbar_1 = dab_0 W_1^T - alpha a_0 Wbar_1^T contracts over h0.
+// Each part computes its partial [S,h_1] sum, publishes it with agent-coherent (sc1) stores, bumps the episode's arrival
+// counter and -- after doing its Wbar_1 update in the meantime -- waits for the other parts and adds the P partials in
+// part order (so every part gets the same bits).  The deeper layers and the head are small and computed redundantly by
+// every part; part 0 writes their adjoints.
+// Workgroup ids: the parts of an episode are 8 ids apart (same XCD, dispatched together); a workgroup only ever waits
+// for workgroups with neighbouring ids, so a grid larger than the chip cannot deadlock (in-order dispatch).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int RLDS_CAP = 40000;
+struct RLay {
+    int Wb[MAXL], bb[MAXL], a[MAXL], dz[MAXL], W[MAXL], ab[MAXL];
+    int Db, A0bs, b0b, Whb, bhb, Wh, p, e, eb, G, dab0, X0, X1, cs, ldX, total;
+};
+inline void reverse_layout(RLay& y, int L, const int* h, int S, int N, int P) {
+    int off = 0;
+    const int RS = q_r4(S), h0c = h[0] / P, H = h[L - 1];
+    auto take = [&](int rows, int ld) { const int o = off; off += rows * ld; return o; };
+    for (int i = 0; i < MAXL; ++i) y.Wb[i] = y.bb[i] = y.a[i] = y.dz[i] = y.W[i] = y.ab[i] = 0;
+    int maxh1 = 4;
+    for (int i = 1; i < L; ++i) maxh1 = h[i] > maxh1 ? h[i] : maxh1;
+    y.ldX = wg_ld(maxh1);
+    for (int i = 1; i < L; ++i) {
+        const int kc = i == 1 ? h0c : h[i - 1];
+        y.Wb[i] = take(q_r16(h[i]), wg_ld(kc)); y.W[i] = take(q_r16(h[i]), wg_ld(kc)); y.bb[i] = take(1, q_r4(h[i]));
+        y.a[i] = take(RS, wg_ld(h[i])); y.dz[i] = take(RS, wg_ld(h[i])); y.ab[i] = take(RS, wg_ld(h[i]));
+    }
+    y.a[0] = take(RS, wg_ld(h0c)); y.ab[0] = take(RS, wg_ld(h0c)); y.dab0 = take(RS, wg_ld(h0c));
+    y.Db = take(RS, wg_ld(h0c)); y.A0bs = take(RS, wg_ld(h0c));
+    y.X0 = take(RS, y.ldX); y.X1 = take(RS, y.ldX);
+    y.Whb = take(q_r16(N), wg_ld(H)); y.Wh = take(q_r16(N), wg_ld(H));
+    y.p = take(RS, wg_ld(N)); y.e = take(RS, wg_ld(N)); y.eb = take(RS, wg_ld(N)); y.G = take(RS, wg_ld(S));
+    y.b0b = take(1, q_r4(h0c)); y.cs = take(1, q_r4(h0c)); y.bhb = take(1, q_r4(N));
+    y.total = off + 64;
+}
+
+__global__ __launch_bounds__(512) void reverse_lds_kernel(StageTab stg_init, StageTab stg_step, EpiDims d, EpiBuf w, RLay y,
+                                                          int P, float* loss_b, float* acc_b, float* head_bar) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ StageTab s_stg[2];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    const int b = xcd + 8 * (jq / P), c = jq % P;
+    if (b >= d.B) return;
+    int ri = 0;
+#define RSTAMP() if (w.trace && tid == 0 && blockIdx.x == 0) w.trace[128 + ri++] = __builtin_amdgcn_s_memrealtime();
+    RSTAMP()
+    const int S = d.S, N = d.N, L = d.L, H = d.H, h0 = d.h[0], h0c = h0 / P, c0 = c * h0c, h1 = d.h[1];
+    const float alpha = d.alpha, ms = d.mscale;
+    const int ntile = w.ntile;
+    if (tid == 0 && c == 0) {
+        float ls = 0.f, cr = 0.f;
+        for (int t = 0; t < ntile; ++t) { ls += w.ploss[(long)b * ntile + t]; cr += w.pcorr[(long)b * ntile + t]; }
+        loss_b[b] = ls / (float)d.Qn;
+        acc_b[b] = cr / (float)d.Qn;
+    }
+    if (!d.need_grad) return;
+
+    const int ldc = wg_ld(h0c), ldN = wg_ld(N), ldS = wg_ld(S), ldH = wg_ld(H), ldX = y.ldX;
+    auto ldh = [&](int i) { return wg_ld(d.h[i]); };
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    auto relu_bwd4 = [&](const f32x4& act, const f32x4& g) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = act[e] > 0.f ? g[e] * ms : 0.f;
+        return o;
+    };
+    // elementwise pass over the valid [S x cols] part of LDS images (4 columns per thread)
+    auto ew = [&](int cols, auto&& f) {
+        const int c4n = (cols + 3) >> 2;
+        for (int i = tid; i < S * c4n; i += nt) { const int m = i / c4n; f(m, (i - m * c4n) << 2); }
+    };
+    auto store_img = [&](float* dst, long drs, const float* img, int ld, int rows, int cols) {   // LDS image -> global
+        const int c4n = (cols + 3) >> 2;
+        for (int i = tid; i < rows * c4n; i += nt) {
+            const int r = i / c4n, cc = (i - r * c4n) << 2;
+            wg_st4(dst + (long)r * drs + cc, *(const f32x4*)(img + r * ld + cc), min(4, cols - cc));
+        }
+    };
+
+    wg_stage_tab_to_lds(s_stg, 2);
+    for (int i = tid * 4, tot = y.total; i < tot; i += nt * 4) *(f32x4*)(sm + i) = z4;
+    __syncthreads(); RSTAMP()
+    // adjoints after the query pass = sums of the tiles' partial slabs (this part's columns); G_ss
+    wg_stage_rows<3, 8>(&s_stg[0], b, 0, c, 0, sm);
+    wg_lds_barrier(); RSTAMP()
+
+    float* Wb1 = sm + y.Wb[1]; float* Db = sm + y.Db; float* A0bs = sm + y.A0bs; float* b0b = sm + y.b0b;
+    float* Whb = sm + y.Whb; float* bhb = sm + y.bhb; float* cs = sm + y.cs;
+    float* a0 = sm + y.a[0]; float* ab0 = sm + y.ab[0]; float* dab0 = sm + y.dab0; float* W1 = sm + y.W[1];
+    float* Wh = sm + y.Wh; float* pp = sm + y.p; float* ee = sm + y.e; float* eb = sm + y.eb; float* G = sm + y.G;
+    float* Xa = sm + y.X0; float* Xb = sm + y.X1;
+
+    if (d.second_order) {
+        for (int t = d.T - 1; t >= 0; --t) {
+            const int round = d.T - 1 - t;
+            wg_stage_rows<8, 1>(&s_stg[1], b, t, c, 0, sm);
+            wg_lds_barrier(); RSTAMP()
+            // abar_i = 0 ; dab_0 = Dbar * relu'(z_0)
+            for (int i = 1; i < L; ++i) { float* abi = sm + y.ab[i]; const int ldi = ldh(i); ew(d.h[i], [&](int m, int n) { *(f32x4*)(abi + m * ldi + n) = z4; }); }
+            ew(h0c, [&](int m, int n) {
+                *(f32x4*)(ab0 + m * ldc + n) = z4;
+                *(f32x4*)(dab0 + m * ldc + n) = relu_bwd4(*(const f32x4*)(a0 + m * ldc + n), *(const f32x4*)(Db + m * ldc + n));
+            });
+            wg_lds_barrier(); RSTAMP()
+            // ---- layer 1 (split): this part's share of dzbar_1, abar_0 -= alpha dz_1 Wbar_1
+            const float* dz1 = sm + y.dz[1]; const int ld1 = ldh(1);
+            wg_lmm<true, true>(S, h1, h0c, dab0, ldc, W1, ldc, [&](int m, int n, const f32x4& acc, int) { *(f32x4*)(Xa + m * ldX + n) = acc; });
+            wg_lmm<true, true>(S, h1, h0c, a0, ldc, Wb1, ldc, [&](int m, int n, const f32x4& acc, int) {
+                float* px = Xa + m * ldX + n; *(f32x4*)px = *(const f32x4*)px - alpha * acc;
+            });
+            wg_lmm_wide<true>(S, h0c, h1, dz1, ld1, Wb1, ldc, [&](int m, int n, const f32x4& acc, int, auto) {
+                float* pa = ab0 + m * ldc + n; *(f32x4*)pa = *(const f32x4*)pa - alpha * acc;
+            });
+            wg_lds_barrier(); RSTAMP()
+            float* xb = w.xpart + (((long)b * 2 + (round & 1)) * 8) * (long)S * h1;
+            if (P > 1) {
+                float* mine = xb + (long)c * S * h1;
+                for (int i = tid; i < S * h1; i += nt) {
+                    const int m = i / h1, n = i - m * h1;
+                    __hip_atomic_store(mine + i, Xa[m * ldX + n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            // Wbar_1 += dz_1^T dab_0   (column-local; runs while the partial sums travel)
+            wg_lmm_wide<false>(h1, h0c, S, dz1, ld1, dab0, ldc, [&](int m, int n, const f32x4& acc, int, auto) {
+                float* pw = Wb1 + m * ldc + n; *(f32x4*)pw = *(const f32x4*)pw + acc;
+            });
+            if (P > 1) {
+                __syncthreads();                                    // every wave's stores have left (vmcnt(0)) before the signal
+                if (tid == 0) {
+                    __hip_atomic_fetch_add(w.xcnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int target = P * (round + 1);
+                    // bounded: the parts of an episode are dispatched together, so this wait is microseconds; a grid that
+                    // somehow lost a part must not hang the device (its results would simply be wrong and fail parity)
+                    for (int spin = 0; spin < (1 << 22) &&
+                         __hip_atomic_load(w.xcnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin) __builtin_amdgcn_s_sleep(2);
+                }
+                __syncthreads();
+            } else {
+                wg_lds_barrier();
+            }
+            RSTAMP()
+            {   // dzbar_1 = sum of the parts - alpha bbar_1 ; dab_1 = dzbar_1 * relu'(z_1)  -> Xb
+                const float* a1 = sm + y.a[1]; const float* bb1 = sm + y.bb[1];
+                const int w4 = q_r4(h1);
+                for (int i = tid; i < S * w4; i += nt) {
+                    const int m = i / w4, n = i - m * w4;
+                    float v = 0.f;
+                    if (n < h1) {
+                        if (P > 1) { for (int cc = 0; cc < P; ++cc) v += __hip_atomic_load(xb + (long)cc * S * h1 + m * h1 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        else v = Xa[m * ldX + n];
+                        v = a1[m * ld1 + n] > 0.f ? (v - alpha * bb1[n]) * ms : 0.f;
+                    }
+                    Xb[m * ldX + n] = v;
+                }
+            }
+            wg_lds_barrier(); RSTAMP()
+            int cur = 1;
+            auto X = [&](int i) { return i ? Xb : Xa; };
+            // ---- deeper layers (not split; every part computes them)
+            for (int i = 2; i < L; ++i) {
+                const int hi = d.h[i], hp = d.h[i - 1], ldi = ldh(i), ldp = ldh(i - 1);
+                const float* dab = X(cur); float* nxt = X(cur ^ 1);
+                const float* bbi = sm + y.bb[i]; float* Wbi = sm + y.Wb[i]; const float* ai = sm + y.a[i];
+                const float* dzi = sm + y.dz[i]; float* abp = sm + y.ab[i - 1];
+                wg_lmm<true, true>(S, hi, hp, dab, ldX, sm + y.W[i], ldp, [&](int m, int n, const f32x4& acc, int) {
+                    *(f32x4*)(nxt + m * ldX + n) = acc - alpha * *(const f32x4*)(bbi + n);
+                });
+                wg_lmm<true, true>(S, hi, hp, sm + y.a[i - 1], ldp, Wbi, ldp, [&](int m, int n, const f32x4& acc, int) {
+                    float* px = nxt + m * ldX + n;
+                    *(f32x4*)px = relu_bwd4(*(const f32x4*)(ai + m * ldi + n), *(const f32x4*)px - alpha * acc);
+                });
+                wg_lmm_wide<true>(S, hp, hi, dzi, ldi, Wbi, ldp, [&](int m, int n, const f32x4& acc, int, auto) {
+                    float* pa = abp + m * ldp + n; *(f32x4*)pa = *(const f32x4*)pa - alpha * acc;
+                });
+                wg_lds_barrier();
+                wg_lmm_wide<false>(hi, hp, S, dzi, ldi, dab, ldX, [&](int m, int n, const f32x4& acc, int, auto) {
+                    float* pw = Wbi + m * ldp + n; *(f32x4*)pw = *(const f32x4*)pw + acc;
+                });
+                wg_lds_barrier();
+                cur ^= 1;
+            }
+            {   // ---- head
+                const float* dab = X(cur); const float* aL = sm + y.a[L - 1]; float* abl = sm + y.ab[L - 1];
+                wg_lmm<true, true>(S, N, H, dab, ldX, Wh, ldH, [&](int m, int n, const f32x4& acc, int) {
+                    *(f32x4*)(eb + m * ldN + n) = acc - alpha * *(const f32x4*)(bhb + n);
+                });
+                wg_lmm<true, true>(S, N, H, aL, ldH, Whb, ldH, [&](int m, int n, const f32x4& acc, int) {
+                    float* pe = eb + m * ldN + n; *(f32x4*)pe = *(const f32x4*)pe - alpha * acc;
+                });
+                wg_lmm_wide<true>(S, H, N, ee, ldN, Whb, ldH, [&](int m, int n, const f32x4& acc, int, auto) {
+                    float* pa = abl + m * ldH + n; *(f32x4*)pa = *(const f32x4*)pa - alpha * acc;
+                });
+                wg_lds_barrier(); RSTAMP()
+                wg_lmm_wide<false>(N, H, S, ee, ldN, dab, ldX, [&](int m, int n, const f32x4& acc, int, auto) {
+                    float* pw = Whb + m * ldH + n; *(f32x4*)pw = *(const f32x4*)pw + acc;
+                });
+                // softmax-CE second derivative: lbar = p * (pbar - <p,pbar>),  pbar = ebar / S   (in place of ebar)
+                for (int s_ = tid; s_ < S; s_ += nt) {
+                    float* re = eb + s_ * ldN; const float* rp = pp + s_ * ldN;
+                    float dot = 0.f;
+                    for (int n = 0; n < N; ++n) dot += rp[n] * re[n];
+                    for (int n = 0; n < N; ++n) re[n] = rp[n] * (re[n] - dot) / (float)S;
+                    for (int n = N; n < q_r4(N); ++n) re[n] = 0.f;
+                }
+                wg_lds_barrier(); RSTAMP()
+                const float* lb = eb;
+                wg_lmm_wide<true>(S, H, N, lb, ldN, Wh, ldH, [&](int m, int n, const f32x4& acc, int, auto) {
+                    float* pa = abl + m * ldH + n; *(f32x4*)pa = *(const f32x4*)pa + acc;
+                });
+                wg_lmm_wide<false>(N, H, S, lb, ldN, aL, ldH, [&](int m, int n, const f32x4& acc, int, auto) {
+                    float* pw = Whb + m * ldH + n; *(f32x4*)pw = *(const f32x4*)pw + acc;
+                });
+                wg_lcolsum(S, N, lb, ldN, [&](int n, float s_) { bhb[n] += s_; });
+                wg_lds_barrier(); RSTAMP()
+            }
+            // ---- reverse of the forward pass
+            for (int i = L - 1; i >= 1; --i) {
+                const int hi = d.h[i], ldi = ldh(i);
+                float* zb = sm + y.ab[i]; const float* ai = sm + y.a[i];
+                ew(hi, [&](int m, int n) { float* pz = zb + m * ldi + n; *(f32x4*)pz = relu_bwd4(*(const f32x4*)(ai + m * ldi + n), *(const f32x4*)pz); });
+                wg_lds_barrier();
+                float* bbw = sm + y.bb[i];
+                if (i >= 2) {
+                    const int hp = d.h[i - 1], ldp = ldh(i - 1);
+                    float* abp = sm + y.ab[i - 1]; float* Wbi = sm + y.Wb[i];
+                    wg_lmm_wide<true>(S, hp, hi, zb, ldi, sm + y.W[i], ldp, [&](int m, int n, const f32x4& acc, int, auto) {
+                        float* pa = abp + m * ldp + n; *(f32x4*)pa = *(const f32x4*)pa + acc;
+                    });
+                    wg_lmm_wide<false>(hi, hp, S, zb, ldi, sm + y.a[i - 1], ldp, [&](int m, int n, const f32x4& acc, int, auto) {
+                        float* pw = Wbi + m * ldp + n; *(f32x4*)pw = *(const f32x4*)pw + acc;
+                    });
+                } else {
+                    wg_lmm_wide<true>(S, h0c, hi, zb, ldi, W1, ldc, [&](int m, int n, const f32x4& acc, int, auto) {
+                        float* pa = ab0 + m * ldc + n; *(f32x4*)pa = *(const f32x4*)pa + acc;
+                    });
+                    wg_lmm_wide<false>(hi, h0c, S, zb, ldi, a0, ldc, [&](int m, int n, const f32x4& acc, int, auto) {
+                        float* pw = Wb1 + m * ldc + n; *(f32x4*)pw = *(const f32x4*)pw + acc;
+                    });
+                }
+                wg_lcolsum(S, hi, zb, ldi, [&](int n, float s_) { bbw[n] += s_; });
+                wg_lds_barrier(); RSTAMP()
+            }
+            // ---- layer 0: z0bar -> Abar0 rows of the support set, b0bar, Dbar
+            ew(h0c, [&](int m, int n) {
+                float* pz = ab0 + m * ldc + n;
+                const f32x4 z = relu_bwd4(*(const f32x4*)(a0 + m * ldc + n), *(const f32x4*)pz);
+                *(f32x4*)pz = z;
+                float* pA = A0bs + m * ldc + n; *(f32x4*)pA = *(const f32x4*)pA + z;
+            });
+            wg_lds_barrier();
+            wg_lcolsum(S, h0c, ab0, ldc, [&](int n, float s_) { cs[n] = s_; b0b[n] += s_; });
+            wg_lds_barrier();
+            wg_lmm_wide<true>(S, h0c, S, G, ldS, ab0, ldc, [&](int m, int n, const f32x4& acc, int, auto) {
+                float* pd = Db + m * ldc + n; *(f32x4*)pd = *(const f32x4*)pd - alpha * (acc + *(const f32x4*)(cs + n));
+            });
+            wg_lds_barrier(); RSTAMP()
+        }
+    }
+    // ---- outputs: this part's columns of the layer-0 / layer-1 adjoints; part 0 also the unsplit ones
+    store_img(w.Wb[1] + (long)b * h1 * h0 + c0, h0, Wb1, ldc, h1, h0c);
+    store_img(w.A0bar + (long)b * (S + d.Qn) * h0 + c0, h0, A0bs, ldc, S, h0c);
+    for (int n = tid; n < h0c; n += nt) w.b0b[(long)b * h0 + c0 + n] = b0b[n];
+    if (c == 0) {
+        for (int i = 1; i < L; ++i) {
+            const float* bbi = sm + y.bb[i];
+            for (int n = tid; n < d.h[i]; n += nt) w.bb[i][(long)b * d.h[i] + n] = bbi[n];
+            if (i >= 2) store_img(w.Wb[i] + (long)b * d.h[i] * d.h[i - 1], d.h[i - 1], sm + y.Wb[i], ldh(i - 1), d.h[i], d.h[i - 1]);
+        }
+        // d loss_b / d head_b = [Whbar | bhbar]
+        float* hb = head_bar + (long)b * N * (H + 1);
+        for (int j = tid; j < N * H; j += nt) { const int n = j / H, k = j - n * H; hb[n * (H + 1) + k] = Whb[n * ldH + k]; }
+        for (int j = tid; j < N; j += nt) hb[j * (H + 1) + H] = bhb[j];
+    }
+    RSTAMP()
+#undef RSTAMP
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------------------
 __global__ void class_text_select_kernel(int N, int S, int Dt, const float* text_s, const int64_t* y_s, float* out,
@@ -768,6 +1285,7 @@ void carve(Carver& c, const EpisodeProblem& p, EpiBuf& w) {
         w.Whb = c.take(B * N * H); w.bhb = c.take(B * N); w.b0b = c.take(B * h0); w.Db = c.take(B * S * h0);
         w.X0 = c.take(B * S * maxh); w.X1 = c.take(B * S * maxh); w.eb = c.take(B * S * N); w.lb = c.take(B * S * N);
         w.A0bar = c.take(B * (S + Qn) * h0);
+        w.xpart = c.take(B * 2 * 8 * S * (L > 1 ? (size_t)p.h[1] : 1)); w.xcnt = (int*)c.take(B);
         for (size_t i = 0; i < L; ++i) {
             const size_t hi = p.h[i], hp = i ? p.h[i - 1] : 0;
             w.abar[i] = c.take(B * S * hi);
@@ -829,8 +1347,30 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     for (int i = 0; i < MAXL; ++i) { prm.W[i] = i < p.L ? p.W[i] : nullptr; prm.b[i] = i < p.L ? p.b[i] : nullptr; }
     {
         ProfScope ps(ws, st, FUMI_PH_ADAPT);
-        HIP_TRY(hipFuncSetAttribute((const void*)adapt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, w.lds_adapt * 4));
-        hipLaunchKernelGGL(adapt_kernel, dim3(p.B), dim3(512), w.lds_adapt * 4, st, d, w, prm, p.y_s, p.head, ws->status);
+        static const bool force_global_a = getenv("FUMI_EPI_GLOBAL") != nullptr;   // dev/test: take the generic kernels
+        ALay al; adapt_layout(al, p.L, p.h, p.S, p.N);
+        const int H = d.H;
+        bool lds_form = al.total <= ALDS_CAP && 4 + 2 * (p.L - 1) <= WG_MAXJOB && !force_global_a &&
+                        ((p.S + 15) / 16) * ((h0 + 63) / 64) <= 8;         // one layer-0 block per wave (A0s + b0 in registers)
+        StageTab tb; tb.init();
+        if (lds_form) {
+            const long R = p.S + p.Qn, S = p.S, N = p.N;
+            tb.add(w.G, R * S, 0, 0, S, p.S, p.S, p.S, al.G, wg_ld(p.S));
+            for (int i = 1; i < p.L; ++i) {
+                tb.add(p.W[i], 0, 0, 0, p.h[i - 1], p.h[i], p.h[i], p.h[i - 1], al.W[i], wg_ld(p.h[i - 1]));
+                tb.add(p.b[i], 0, 0, 0, p.h[i], 1, 1, p.h[i], al.bi[i], p.h[i]);
+            }
+            tb.add(p.head, N * (H + 1), 0, 0, H + 1, p.N, p.N, H, al.Wh, wg_ld(H));
+            tb.add(p.head + H, N * (H + 1), 0, 0, H + 1, p.N, p.N, 1, al.bh, 1);
+            lds_form = !tb.bad && tb.nunits <= 64 * 8;
+        }
+        if (lds_form) {
+            HIP_TRY(hipFuncSetAttribute((const void*)adapt_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, al.total * 4));
+            hipLaunchKernelGGL(adapt_lds_kernel, dim3(p.B), dim3(512), al.total * 4, st, tb, d, w, al, prm, p.y_s, ws->status);
+        } else {
+            HIP_TRY(hipFuncSetAttribute((const void*)adapt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, w.lds_adapt * 4));
+            hipLaunchKernelGGL(adapt_kernel, dim3(p.B), dim3(512), w.lds_adapt * 4, st, d, w, prm, p.y_s, p.head, ws->status);
+        }
         LAUNCH_CHECK();
     }
     {
@@ -838,24 +1378,24 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
         QLay ql; query_layout(ql, p.L, p.h, p.S, p.N);
         static const bool force_global = getenv("FUMI_EPI_GLOBAL") != nullptr;     // dev/test: take the generic kernels
         bool lds_form = ql.total <= QLDS_CAP && 7 + 2 * (p.L - 1) <= WG_MAXJOB && !force_global;
-        StageTab tb; tb.njobs = 0; tb.nunits = 0;
+        StageTab tb; tb.init();
         if (lds_form) {
             // staging plan: source = base + episode*sb + tile*st
             const long R = p.S + p.Qn, S = p.S, N = p.N, H = d.H;
             const long slot = d.taped ? p.T : 0;
-            tb.add(w.A0 + S * h0, R * h0, (long)QR * h0, h0, -1, QR, h0, ql.a[0], wg_ld(h0));
-            tb.add(w.D, S * h0, 0, h0, p.S, p.S, h0, ql.D, wg_ld(h0));
+            tb.add(w.A0 + S * h0, R * h0, (long)QR * h0, 0, h0, -1, QR, h0, ql.a[0], wg_ld(h0));
+            tb.add(w.D, S * h0, 0, 0, h0, p.S, p.S, h0, ql.D, wg_ld(h0));
             for (int i = 1; i < p.L; ++i) {
                 const long sz = (long)p.h[i] * p.h[i - 1];
-                tb.add(w.Wslot[i] + slot * sz, w.nslot * sz, 0, p.h[i - 1], p.h[i], p.h[i], p.h[i - 1], ql.W[i], wg_ld(p.h[i - 1]));
+                tb.add(w.Wslot[i] + slot * sz, w.nslot * sz, 0, 0, p.h[i - 1], p.h[i], p.h[i], p.h[i - 1], ql.W[i], wg_ld(p.h[i - 1]));
             }
-            tb.add(w.G + S * S, R * S, (long)QR * S, S, -1, QR, p.S, ql.Gq, wg_ld(p.S));
-            tb.add(w.Whslot + slot * N * H, w.nslot * N * H, 0, H, p.N, p.N, (int)H, ql.Wh, wg_ld((int)H));
-            tb.add(p.b[0], 0, 0, h0, 1, 1, h0, ql.b0, h0);
-            tb.add(w.cs, h0, 0, h0, 1, 1, h0, ql.cs, h0);
-            for (int i = 1; i < p.L; ++i) tb.add(w.bcur[i], p.h[i], 0, p.h[i], 1, 1, p.h[i], ql.bi[i], p.h[i]);
-            tb.add(w.bh, N, 0, N, 1, 1, p.N, ql.bh, p.N);
-            lds_form = tb.nunits <= 64 * 8;                 // wg_stage_rows: one unit per lane and wave
+            tb.add(w.G + S * S, R * S, (long)QR * S, 0, S, -1, QR, p.S, ql.Gq, wg_ld(p.S));
+            tb.add(w.Whslot + slot * N * H, w.nslot * N * H, 0, 0, H, p.N, p.N, (int)H, ql.Wh, wg_ld((int)H));
+            tb.add(p.b[0], 0, 0, 0, h0, 1, 1, h0, ql.b0, h0);
+            tb.add(w.cs, h0, 0, 0, h0, 1, 1, h0, ql.cs, h0);
+            for (int i = 1; i < p.L; ++i) tb.add(w.bcur[i], p.h[i], 0, 0, p.h[i], 1, 1, p.h[i], ql.bi[i], p.h[i]);
+            tb.add(w.bh, N, 0, 0, N, 1, 1, p.N, ql.bh, p.N);
+            lds_form = !tb.bad && tb.nunits <= 64 * 8;      // wg_stage_rows: one unit per lane and wave
         }
         if (lds_form) {
             HIP_TRY(hipFuncSetAttribute((const void*)query_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ql.total * 4));
@@ -870,8 +1410,54 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     }
     {
         ProfScope ps(ws, st, FUMI_PH_REVERSE);
-        HIP_TRY(hipFuncSetAttribute((const void*)reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, w.lds_reverse * 4));
-        hipLaunchKernelGGL(reverse_kernel, dim3(p.B), dim3(512), w.lds_reverse * 4, st, d, w, p.loss_b, p.acc_b, p.head_bar);
+        static const bool force_global_r = getenv("FUMI_EPI_GLOBAL") != nullptr;   // dev/test: take the generic kernels
+        bool lds_form = p.L >= 2 && p.L <= 4 && w.ntile <= 8 && !force_global_r;
+        int P = 0; RLay rl; StageTab ti, tsx;
+        if (lds_form) {
+            for (int cand = 1; cand <= 8 && !P; cand *= 2) {
+                if (h0 % (4 * cand)) break;
+                reverse_layout(rl, p.L, p.h, p.S, p.N, cand);
+                if (rl.total <= RLDS_CAP) P = cand;
+            }
+            lds_form = P > 0;
+        }
+        if (lds_form) {
+            const long S = p.S, N = p.N, H = d.H, R = p.S + p.Qn, nt = w.ntile, h0c = h0 / P, h1 = p.h[1];
+            ti.init(); tsx.init();
+            // adjoints after the query pass: sums over the tiles' partial slabs (+ G_ss)
+            ti.add(w.pW[1], nt * h1 * h0, 0, h0c, h0, (int)h1, (int)h1, (int)h0c, rl.Wb[1], wg_ld((int)h0c), (int)nt, h1 * h0);
+            ti.add(w.pD, nt * S * h0, 0, h0c, h0, p.S, p.S, (int)h0c, rl.Db, wg_ld((int)h0c), (int)nt, S * h0);
+            ti.add(w.pb0, nt * h0, 0, h0c, h0, 1, 1, (int)h0c, rl.b0b, (int)h0c, (int)nt, h0);
+            ti.add(w.pWh, nt * N * H, 0, 0, H, p.N, p.N, (int)H, rl.Whb, wg_ld((int)H), (int)nt, N * H);
+            ti.add(w.pbh, nt * N, 0, 0, N, 1, 1, p.N, rl.bhb, p.N, (int)nt, N);
+            for (int i = 1; i < p.L; ++i) {
+                const long hi = p.h[i], hp = p.h[i - 1];
+                ti.add(w.pb[i], nt * hi, 0, 0, hi, 1, 1, (int)hi, rl.bb[i], (int)hi, (int)nt, hi);
+                if (i >= 2) ti.add(w.pW[i], nt * hi * hp, 0, 0, hp, (int)hi, (int)hi, (int)hp, rl.Wb[i], wg_ld((int)hp), (int)nt, hi * hp);
+            }
+            ti.add(w.G, R * S, 0, 0, S, p.S, p.S, p.S, rl.G, wg_ld(p.S));
+            // the tape of step t (t rides in the "tile" slot of the plan)
+            tsx.add(w.ta[0], w.ntape * S * h0, S * h0, h0c, h0, p.S, p.S, (int)h0c, rl.a[0], wg_ld((int)h0c));
+            tsx.add(w.Wslot[1], w.nslot * h1 * h0, h1 * h0, h0c, h0, (int)h1, (int)h1, (int)h0c, rl.W[1], wg_ld((int)h0c));
+            for (int i = 1; i < p.L; ++i) {
+                const long hi = p.h[i], hp = p.h[i - 1];
+                tsx.add(w.ta[i], w.ntape * S * hi, S * hi, 0, hi, p.S, p.S, (int)hi, rl.a[i], wg_ld((int)hi));
+                tsx.add(w.tdz[i], w.ntape * S * hi, S * hi, 0, hi, p.S, p.S, (int)hi, rl.dz[i], wg_ld((int)hi));
+                if (i >= 2) tsx.add(w.Wslot[i], w.nslot * hi * hp, hi * hp, 0, hp, (int)hi, (int)hi, (int)hp, rl.W[i], wg_ld((int)hp));
+            }
+            tsx.add(w.Whslot, w.nslot * N * H, N * H, 0, H, p.N, p.N, (int)H, rl.Wh, wg_ld((int)H));
+            tsx.add(w.tp, w.ntape * S * N, S * N, 0, N, p.S, p.S, p.N, rl.p, wg_ld(p.N));
+            tsx.add(w.te, w.ntape * S * N, S * N, 0, N, p.S, p.S, p.N, rl.e, wg_ld(p.N));
+            lds_form = !ti.bad && !tsx.bad && ti.nunits <= 64 * 8 && tsx.nunits <= 64 * 8;
+        }
+        if (lds_form) {
+            HIP_TRY(hipFuncSetAttribute((const void*)reverse_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rl.total * 4));
+            hipLaunchKernelGGL(reverse_lds_kernel, dim3(8 * ((p.B + 7) / 8) * P), dim3(512), rl.total * 4, st, ti, tsx, d, w, rl, P,
+                               p.loss_b, p.acc_b, p.head_bar);
+        } else {
+            HIP_TRY(hipFuncSetAttribute((const void*)reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, w.lds_reverse * 4));
+            hipLaunchKernelGGL(reverse_kernel, dim3(p.B), dim3(512), w.lds_reverse * 4, st, d, w, p.loss_b, p.acc_b, p.head_bar);
+        }
         LAUNCH_CHECK();
     }
     // ---- sums over episodes in one launch: meta-gradients of the hidden layers, layer-0 bias, loss/accuracy totals

@@ -22,3 +22,6 @@ print("adapt phase durations (us):", [round(x, 1) for x in d], "total", round(su
 q = t[64:128]; nq = int((q > 0).sum())
 dq = [(int(q[i + 1]) - int(q[i])) / 100.0 for i in range(nq - 1)]
 print("query_lds phase durations (us):", [round(x, 2) for x in dq], "total", round(sum(dq), 1))
+q = t[128:192]; nq = int((q > 0).sum())
+dq = [(int(q[i + 1]) - int(q[i])) / 100.0 for i in range(nq - 1)]
+print("reverse_lds phase durations (us):", [round(x, 2) for x in dq], "total", round(sum(dq), 1))
