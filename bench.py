@@ -153,6 +153,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-timing", action="store_true", help="do not record HIP events around the library's phases")
+    ap.add_argument("--all-phases", action="store_true",
+                    help="time every phase of the library (adds ~10 us of stream time per phase and step); default: only the "
+                         "roofline kernel's phase")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,7 +192,7 @@ def main():
         model.evaluate(args, batches[i % NBATCH], opt, "train")
     hip.raise_on_status(ws.read_status())
     if not a.no_phase_timing:
-        ws.set_profiling(True)
+        ws.set_profiling(True, None if a.all_phases else ["xpanel_fwd"])
     barrier()
     t0 = time.perf_counter()
     last = None

@@ -16,7 +16,7 @@ static hipEvent_t prof_event(fumi_ws* ws) {
     return e;
 }
 
-ProfScope::ProfScope(fumi_ws* w, hipStream_t s, int phase) : ws(w), st(s), b(nullptr), on(w && w->profiling) {
+ProfScope::ProfScope(fumi_ws* w, hipStream_t s, int phase) : ws(w), st(s), b(nullptr), on(w && ((w->profiling >> phase) & 1)) {
     if (!on) return;
     hipEvent_t a = prof_event(ws);
     b = prof_event(ws);
@@ -98,7 +98,7 @@ int fumi_hip_set_profiling(fumi_ws_t* ws, int on) {
     HIP_TRY(hipDeviceSynchronize());
     for (auto& r : *ws->recs) { ws->pool->push_back(r.a); ws->pool->push_back(r.b); }
     ws->recs->clear();
-    ws->profiling = on ? 1 : 0;
+    ws->profiling = on;              // bit p = record HIP events around phase p (FUMI_PH_*); -1 = every phase
     return FUMI_OK;
 }
 
@@ -171,6 +171,9 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
 
     size_t bytes = episode_workspace_bytes(p);
     bytes += ws_align((size_t)R * Dt * 4) + 2 * ws_align((size_t)R * Ht * 4) + 3 * ws_align((size_t)R * H1 * 4);
+    const bool hyper_lds = hyper_lds_fits(R, Dt, Ht, H1) != 0;         // LDS-resident hypernetwork kernels (hyper.hip)
+    const size_t hpart_n = hyper_lds ? hyper_bwd_workspace_floats(R, Ht, H1) : 0;
+    bytes += ws_align(hpart_n * 4);
     int rc = ws_reserve(ws, bytes);
     if (rc) return rc;
     float* c = ws_f(ws, (size_t)R * Dt);
@@ -179,6 +182,7 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
     float* h = ws_f(ws, (size_t)R * H1);
     float* hbar = ws_f(ws, (size_t)R * H1);
     float* hpb = ws_f(ws, (size_t)R * H1);
+    float* hpart = hyper_lds ? ws_f(ws, hpart_n) : nullptr;
 
     // class text rows (fumi.py:207-210), then the hypernetwork (fumi.py:70-86,104-113)
     const float* ctext = cls_text;
@@ -190,12 +194,15 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
     GemmArgs g;
     {
         ProfScope ps(ws, st, FUMI_PH_HYPER_FWD);
-        g = gemm_args(R, Ht, Dt, ctext, Dt, phi[0], Dt, u, Ht);
-        g.bias = phi[1]; g.act = 1;
-        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
-        g = gemm_args(R, H1, Ht, u, Ht, phi[2], Ht, h, H1);
-        g.bias = phi[3]; g.act = tanh_head ? 2 : 0;
-        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+        rc = hyper_lds ? launch_hyper_fwd(st, R, Dt, Ht, H1, tanh_head, ctext, phi[0], phi[1], phi[2], phi[3], u, h) : FUMI_ENOTSUP;
+        if (rc == FUMI_ENOTSUP) {                                    // shapes outside the LDS-resident kernels: plain GEMMs
+            g = gemm_args(R, Ht, Dt, ctext, Dt, phi[0], Dt, u, Ht);
+            g.bias = phi[1]; g.act = 1;
+            if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+            g = gemm_args(R, H1, Ht, u, Ht, phi[2], Ht, h, H1);
+            g.bias = phi[3]; g.act = tanh_head ? 2 : 0;
+            if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+        } else if (rc) return rc;
     }
 
     p.head = h; p.head_bar = hbar;
@@ -204,15 +211,20 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
 
     // hypernetwork backward: rows are (episode, class) pairs, weights are shared
     ProfScope ps(ws, st, FUMI_PH_HYPER_BWD);
+    if (hyper_lds) {
+        rc = launch_hyper_bwd(st, R, Dt, Ht, H1, tanh_head, grad_scale, ctext, u, h, hbar, phi[2], ub, hpart,
+                              g_phi[0], g_phi[1], g_phi[2], g_phi[3]);
+        if (rc != FUMI_ENOTSUP) return rc;
+    }
     const float* hp = hbar;
     if (tanh_head) { if ((rc = launch_tanh_bwd(st, (long)R * H1, h, hbar, hpb))) return rc; hp = hpb; }
     g = gemm_args(H1, Ht, R, hp, H1, u, Ht, g_phi[2], Ht);           // gA1 = hp^T u
     g.alpha = grad_scale;
     if ((rc = launch_gemm(st, g, 1, 1))) return rc;
     if ((rc = launch_colsum(st, hp, R, H1, H1, grad_scale, g_phi[3]))) return rc;
-    g = gemm_args(R, Ht, H1, hp, H1, phi[2], Ht, ub, Ht);            // ubar = (hp A1) * relu'(u)
+    g = gemm_args(R, Ht, H1, hp, H1, phi[2], Ht, ub, Ht);            // ubar = (hp A1) * relu'(u), mask in the epilogue
+    g.mask = u;
     if ((rc = launch_gemm(st, g, 0, 1))) return rc;
-    if ((rc = launch_relu_mask_mul(st, (long)R * Ht, u, ub))) return rc;
     g = gemm_args(Ht, Dt, R, ub, Ht, ctext, Dt, g_phi[0], Dt);       // gA0 = ubar^T c
     g.alpha = grad_scale;
     if ((rc = launch_gemm(st, g, 1, 1))) return rc;

@@ -76,6 +76,7 @@ struct GemmArgs {
     float alpha;
     int accumulate;        // C += result
     unsigned drop_thr, drop_key; float drop_scale;   // act == 1 only: dropout after the ReLU (keep iff mix(key ^ (m*N+n)) >= thr)
+    const float* mask;     // [M, ldc] or NULL: result kept where mask > 0, else 0 (a ReLU derivative fused into the product)
 };
 static inline GemmArgs gemm_args(int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                                  float* C, long ldc) {
@@ -83,7 +84,7 @@ static inline GemmArgs gemm_args(int M, int N, int K, const float* A, long lda, 
     g.M = M; g.N = N; g.K = K; g.kchunk = K; g.nsplit = 1; g.nbatch = 1;
     g.A = A; g.lda = lda; g.sA = 0; g.B = B; g.ldb = ldb; g.sB = 0;
     g.C = C; g.ldc = ldc; g.sC = 0; g.sCsplit = 0; g.bias = nullptr; g.act = 0; g.alpha = 1.f; g.accumulate = 0;
-    g.drop_thr = 0; g.drop_key = 0; g.drop_scale = 1.f;
+    g.drop_thr = 0; g.drop_key = 0; g.drop_scale = 1.f; g.mask = nullptr;
     return g;
 }
 int launch_gemm(hipStream_t st, const GemmArgs& g, int AL, int BL);
@@ -133,6 +134,15 @@ struct EpisodeProblem {
 size_t episode_workspace_bytes(const EpisodeProblem& p);
 int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p);
 
+// hypernetwork as LDS-resident kernels (hyper.hip); FUMI_ENOTSUP when the shapes do not fit (callers fall back to GEMMs)
+int hyper_lds_fits(int R, int Dt, int Ht, int H1);
+size_t hyper_bwd_workspace_floats(int R, int Ht, int H1);
+int launch_hyper_fwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_head, const float* c, const float* A0,
+                     const float* b0, const float* A1, const float* b1, float* u, float* h);
+int launch_hyper_bwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_head, float scale, const float* c,
+                     const float* u, const float* h, const float* hbar, const float* A1, float* ub, float* part,
+                     float* gA0, float* gb0, float* gA1, float* gb1);
+
 // small kernels shared by the entry points (episode.hip)
 int launch_class_text_select(hipStream_t st, int B, int N, int S, int Dt, const float* text_s, const int64_t* y_s,
                              float* out, int* status);
@@ -160,20 +170,23 @@ struct StageTab {
     short njobs, nunits;
     int bad;                   // a field did not fit its type: the caller must take the generic kernel
     void init() { njobs = 0; nunits = 0; bad = 0; }
+    // rows_: count, or -1 / -2 = the kernel's run-time nr / nr2 (at most max_rows); cols_: count, or -max = run-time nc (<= max)
     void add(const float* b_, long sb_, long st_, long sc_, long rs_, int rows_, int max_rows, int cols_, int off_, int ld_,
              int nsum_ = 1, long sstride_ = 0) {
+        const int max_cols = cols_ < 0 ? -cols_ : cols_;
+        const bool dyn_cols = cols_ < 0;
         if (njobs >= WG_MAXJOB) { bad = 1; return; }
         const int j = njobs++;
         auto fits = [](long v) { return v >= 0 && v < (1L << 31); };
-        if (!fits(sb_) || !fits(st_) || !fits(sc_) || !fits(rs_) || !fits(sstride_) || rows_ > 32767 || cols_ > 32767 ||
+        if (!fits(sb_) || !fits(st_) || !fits(sc_) || !fits(rs_) || !fits(sstride_) || rows_ > 32767 || max_cols > 32767 ||
             ld_ > 32767 || nsum_ > 255) bad = 1;
         base[j] = b_; sb[j] = (int)sb_; st[j] = (int)st_; sc[j] = (int)sc_; rs[j] = (int)rs_; off[j] = off_;
-        sstride[j] = (int)sstride_; rows[j] = (short)rows_; cols[j] = (short)cols_; ld[j] = (short)ld_; nsum[j] = (unsigned char)nsum_;
+        sstride[j] = (int)sstride_; rows[j] = (short)rows_; cols[j] = (short)(dyn_cols ? -1 : cols_); ld[j] = (short)ld_; nsum[j] = (unsigned char)nsum_;
         vec[j] = ((rs_ & 3) == 0) && ((sb_ & 3) == 0) && ((st_ & 3) == 0) && ((sc_ & 3) == 0) && ((sstride_ & 3) == 0) &&
-                 ((cols_ & 3) == 0) && ((((uintptr_t)b_) & 15) == 0);
+                 ((max_cols & 3) == 0) && ((((uintptr_t)b_) & 15) == 0);   // (run-time widths: the caller keeps them multiples of 4)
         // lanes a row needs (one float4 or one float each), rounded to a power of two: a unit is 64 / that many rows,
         // or one 64-lane segment of a row that needs more
-        const int need = vec[j] ? (cols_ + 3) / 4 : cols_;
+        const int need = vec[j] ? (max_cols + 3) / 4 : max_cols;
         int lgv = 0; while ((1 << lgv) < need && lgv < 6) ++lgv;
         lg[j] = (unsigned char)lgv;
         const int sg = (need + 63) / 64;
@@ -513,7 +526,8 @@ __device__ __forceinline__ void wg_stage_tab_to_lds(StageTab* Tl, int ntab = 1) 
 static_assert(sizeof(StageTab) % 8 == 0, "consecutive StageTab kernel arguments must be contiguous");
 // U units in flight per wave, each the sum of up to NS slabs (NS = 1: plain copy)
 template <int U, int NS = 1>
-__device__ __forceinline__ void wg_stage_rows(const StageTab* Tl, long b, long tile, long part, int nr, float* lds) {
+__device__ __forceinline__ void wg_stage_rows(const StageTab* Tl, long b, long tile, long part, int nr, float* lds,
+                                              int nr2 = 0, int nc = 0) {
     const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nunits = Tl->nunits, njobs = Tl->njobs;
@@ -526,12 +540,12 @@ __device__ __forceinline__ void wg_stage_rows(const StageTab* Tl, long b, long t
     const int ru = u - Tl->ubase[j], segs = Tl->segs[j], lgv = Tl->lg[j];
     const int r0 = segs > 1 ? ru / segs : ru << (6 - lgv);            // first row of the unit
     const int sg = segs > 1 ? ru - r0 * segs : 0;
-    const int rows = Tl->rows[j] < 0 ? nr : Tl->rows[j];
+    const int rows = Tl->rows[j] == -1 ? nr : Tl->rows[j] == -2 ? nr2 : Tl->rows[j];     // run-time row / column counts
     const bool rok = live && r0 < rows;
     const float* d_src = Tl->base[j] + b * Tl->sb[j] + tile * Tl->st[j] + part * Tl->sc[j] + (long)(rok ? r0 : 0) * Tl->rs[j];
     const int d_off = Tl->off[j] + r0 * Tl->ld[j];
     const int d_left = rok ? rows - r0 : 0;                           // rows from r0 on (a unit takes at most 64 >> lg)
-    const int d_cols = Tl->cols[j];
+    const int d_cols = Tl->cols[j] < 0 ? nc : Tl->cols[j];
     const int d_misc = (sg << 6) | (lgv << 24) | (Tl->vec[j] ? 1 << 30 : 0);
     const int d_rs = Tl->rs[j], d_ld = Tl->ld[j];
     const int d_ns = Tl->nsum[j], d_ss = Tl->sstride[j];

@@ -99,23 +99,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    f32x4 ra[2], rb[2];
-    bool oka[2], okb[2];
+    // Register staging ring, NST slabs deep: the global loads of slab s+1+NST are issued while slab s is multiplied, so a
+    // load has NST slab times (NST * 1024 matrix-pipe cycles) to come back.  The small GEMMs of the hot path (hypernetwork:
+    // 160 rows) run a dozen workgroups of ~10 slabs each; with a one-deep prefetch every slab was a full L2 round trip.
+    constexpr int NST = 3;
+    f32x4 ra[NST][2], rb[NST][2];
+    bool oka[NST][2], okb[NST][2];
     const int nslab = (kend - kbeg + BK - 1) / BK;
     if (nslab > 0) {
-        load_tile<AL, VEC>(ra, oka, A, g.lda, m0, g.M, kbeg, kbeg, kend);
-        load_tile<BL, VEC>(rb, okb, B, g.ldb, n0, g.N, kbeg, kbeg, kend);
-        store_tile<AL>(ra, oka, lds[0][0]);
-        store_tile<BL>(rb, okb, lds[0][1]);
+        load_tile<AL, VEC>(ra[0], oka[0], A, g.lda, m0, g.M, kbeg, kbeg, kend);
+        load_tile<BL, VEC>(rb[0], okb[0], B, g.ldb, n0, g.N, kbeg, kbeg, kend);
+        store_tile<AL>(ra[0], oka[0], lds[0][0]);
+        store_tile<BL>(rb[0], okb[0], lds[0][1]);
     }
+    // slab q waits in ring slot q % NST
+    if (1 < nslab) { load_tile<AL, VEC>(ra[1], oka[1], A, g.lda, m0, g.M, kbeg + 1 * BK, kbeg, kend); load_tile<BL, VEC>(rb[1], okb[1], B, g.ldb, n0, g.N, kbeg + 1 * BK, kbeg, kend); }
+    if (2 < nslab) { load_tile<AL, VEC>(ra[2], oka[2], A, g.lda, m0, g.M, kbeg + 2 * BK, kbeg, kend); load_tile<BL, VEC>(rb[2], okb[2], B, g.ldb, n0, g.N, kbeg + 2 * BK, kbeg, kend); }
+    if (3 < nslab) { load_tile<AL, VEC>(ra[0], oka[0], A, g.lda, m0, g.M, kbeg + 3 * BK, kbeg, kend); load_tile<BL, VEC>(rb[0], okb[0], B, g.ldb, n0, g.N, kbeg + 3 * BK, kbeg, kend); }
     __syncthreads();
     const int li = lane & 31, kh = lane >> 5;
-    for (int s = 0; s < nslab; ++s) {
+    // one slab: multiply LDS buffer s&1, move slab s+1 from its ring slot SL to the other buffer, refill the slot
+    auto step = [&](auto slot_c, int s) {
+        constexpr int SL = decltype(slot_c)::value;
         const int cur = s & 1;
-        if (s + 1 < nslab) {
-            load_tile<AL, VEC>(ra, oka, A, g.lda, m0, g.M, kbeg + (s + 1) * BK, kbeg, kend);
-            load_tile<BL, VEC>(rb, okb, B, g.ldb, n0, g.N, kbeg + (s + 1) * BK, kbeg, kend);
-        }
         const float* TA = lds[cur][0];
         const float* TB = lds[cur][1];
 #pragma unroll
@@ -135,10 +141,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
         }
         if (s + 1 < nslab) {
-            store_tile<AL>(ra, oka, lds[cur ^ 1][0]);
-            store_tile<BL>(rb, okb, lds[cur ^ 1][1]);
+            store_tile<AL>(ra[SL], oka[SL], lds[cur ^ 1][0]);
+            store_tile<BL>(rb[SL], okb[SL], lds[cur ^ 1][1]);
+        }
+        if (s + 1 + NST < nslab) {
+            load_tile<AL, VEC>(ra[SL], oka[SL], A, g.lda, m0, g.M, kbeg + (s + 1 + NST) * BK, kbeg, kend);
+            load_tile<BL, VEC>(rb[SL], okb[SL], B, g.ldb, n0, g.N, kbeg + (s + 1 + NST) * BK, kbeg, kend);
         }
         __syncthreads();
+    };
+    for (int s = 0; s < nslab; s += NST) {
+        step(WgInt<1>{}, s);
+        if (s + 1 < nslab) step(WgInt<2>{}, s + 1);
+        if (s + 2 < nslab) step(WgInt<0>{}, s + 2);
     }
 
     // epilogue: register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31 of the wave's 32x32 tile
@@ -161,6 +176,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 else if (g.act == 2) v = tanhf(v);
                 else if (g.act == 3) v = 1.f / (1.f + expf(-v));
                 float* c = C + (long)m * g.ldc + n;
+                if (g.mask) v = g.mask[(long)m * g.ldc + n] > 0.f ? v : 0.f;
                 if (g.accumulate) v += *c;
                 *c = v;
             }

@@ -166,9 +166,19 @@ class Workspace:
         _check(lib().fumi_hip_read_status(self._h, _stream(self.device), ctypes.byref(st)), "read_status")
         return st.value
 
-    def set_profiling(self, on):
-        """HIP-event timing of every phase inside the library (bench.py); switching it clears the records."""
-        _check(lib().fumi_hip_set_profiling(self._h, int(bool(on))), "set_profiling")
+    def set_profiling(self, on, phases=None):
+        """HIP-event timing of the library's phases (bench.py); switching it clears the records.  ``phases``: names
+        (fumi_hip_phase_name) to time -- an event pair costs stream time, so the bench times only the kernel its
+        roofline is about; None = every phase."""
+        mask = 0
+        if on:
+            if phases is None:
+                mask = -1
+            else:
+                names = {lib().fumi_hip_phase_name(i).decode(): i for i in range(32)}
+                for p in phases:
+                    mask |= 1 << names[p]
+        _check(lib().fumi_hip_set_profiling(self._h, mask), "set_profiling")
 
     def profile(self):
         """{phase name: (total ms, launches)} since profiling was switched on (synchronises the device)."""

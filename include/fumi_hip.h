@@ -75,7 +75,9 @@ int   fumi_hip_read_status(fumi_ws_t* ws, fumi_stream_t stream, int* status_out)
 #define FUMI_PH_HYPER_BWD 10   /* hypernetwork backward                                */
 #define FUMI_PH_AM3       11   /* AM3 fused head kernels                               */
 #define FUMI_PH_COUNT     12
-int          fumi_hip_set_profiling(fumi_ws_t* ws, int on);          /* also clears the records */
+/* phase_mask: bit p set = record a HIP event pair around phase p (FUMI_PH_*) on the caller's stream; -1 = every phase,
+ * 0 = off.  An event pair costs a few microseconds of stream time, so time only what is needed.  Also clears the records. */
+int          fumi_hip_set_profiling(fumi_ws_t* ws, int phase_mask);
 /* Synchronises the device; total elapsed ms and number of records of `phase` since profiling was switched on. */
 int          fumi_hip_get_profile(fumi_ws_t* ws, int phase, double* total_ms, int* count);
 const char*  fumi_hip_phase_name(int phase);

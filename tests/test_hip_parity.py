@@ -397,3 +397,20 @@ def test_am3_dropout_matches_oracle_with_same_masks(dev, ws):
     assert abs(float(out["loss"]) - float(ref["loss"])) <= LOGIT_TOL * max(1.0, abs(float(ref["loss"])))
     assert rel_to_max(out["lamda_s"].cpu(), ref["lamda_s"]) <= 1e-5
     _check_grads(list(hip.AM3_KEYS), out["grads"], None, [ref["grads"][k] for k in hip.AM3_KEYS])
+
+
+def test_generic_episode_kernels_in_subprocess(dev):
+    """The LDS-resident adapt / query / reverse kernels are taken whenever an episode fits the CU's LDS; larger problems use
+    the generic global-memory kernels.  Re-run the reference-parity cases with FUMI_EPI_GLOBAL=1 (read once per process,
+    hence the child process) so both forms stay covered."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, FUMI_EPI_GLOBAL="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-q", "-m", "gpu",
+                        "-p", "no:cacheprovider", "-k",
+                        "fumi_step_matches_reference or maml_step_matches_reference or dropout_matches_oracle or eval_mode_no_grad"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
