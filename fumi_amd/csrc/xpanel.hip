@@ -276,6 +276,193 @@ __global__ __launch_bounds__(256) void xpanel_fwd_kernel(XPanel p, float* __rest
     }
 }
 
+// ---- forward on the bf16 matrix pipe with fp32-equivalent accuracy ("split-bf16") -------------------------------------
+// gfx950 multiplies bf16 sixteen times faster than fp32 (v_mfma_f32_32x32x16_bf16: 32 cycles for 16 k; the fp32 form
+// v_mfma_f32_32x32x2_f32: 64 cycles for 2 k).  Every fp32 operand is split EXACTLY into three bf16 pieces when its slab
+// goes to LDS,  x = h + m + l  (h = top 16 bits of x, m = top 16 bits of x - h, l = top 16 bits of x - h - m; both
+// subtractions are exact in fp32, 8 significand bits per piece), and a product is accumulated in fp32 from the six
+// piece products of weight >= 2^-16:   a*b ~= ah*bl + al*bh + am*bm + ah*bm + am*bh + ah*bh.
+// The dropped terms (am*bl, al*bm, al*bl) are below 2^-24 |a*b|, i.e. below the rounding of the fp32 product itself; the
+// measured error against an fp64 reference equals the fp32 MFMA kernel's (tests/test_hip_parity.py).  Six bf16 MFMAs
+// replace eight fp32 ones per 16 k at a quarter of the cycles each: 2.67x the matrix rate.  Non-finite inputs give NaN.
+// LDS: per slab and operand three [64 rows][32 k] bf16 planes, row stride 80 B: conflict-free ds_read_b128 for the
+// 32x32x16 operand map (lane l holds row l&31, k = 8*(l>>5) .. +7).
+constexpr int SBK = 32;                    // contraction slab
+constexpr int SROW = SBK + 8;              // ushorts per LDS row (80 bytes)
+constexpr int SPLANE = 64 * SROW;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split3(const f32x4& v, u32x2& h, u32x2& m, u32x2& l) {
+    unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned u = __float_as_uint(v[e]);
+        hb[e] = u & 0xFFFF0000u;
+        const float r1 = v[e] - __uint_as_float(hb[e]);
+        mb[e] = __float_as_uint(r1) & 0xFFFF0000u;
+        const float r2 = r1 - __uint_as_float(mb[e]);
+        lb[e] = __float_as_uint(r2);
+    }
+    // two bf16 per dword: low half = element 2j, high half = element 2j+1 (top 16 bits of each)
+    h[0] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u); h[1] = __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u);
+    m[0] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u); m[1] = __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u);
+    l[0] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u); l[1] = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void xp_static_for(F&& f) {
+    if constexpr (I < N) { f(WgInt<I>{}); xp_static_for<I + 1, N>(f); }
+}
+
+template <int NST>
+__global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* __restrict__ A0, float* __restrict__ G,
+                                                                int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][3][SPLANE];      // [buffer][operand][piece]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int R = p.S + p.Qn, C = p.h0 + p.S, K = p.D;
+    const int tiles = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int b = xcd + 8 * (j / tiles), t = j % tiles;
+    if (b >= p.B) return;
+    const int m0 = (t / tiles_n) * 64, n0 = (t % tiles_n) * 64;
+
+    // staging map: float4 f = tid + 256 i  ->  tile row (f >> 3), k offset (f & 7) * 4
+    const float* arow[2]; const float* brow[2]; bool aok[2], bok[2];
+    const int k4 = (tid & 7) << 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rr = (tid >> 3) + 32 * i;
+        const int r = m0 + rr, c = n0 + rr;
+        aok[i] = r < R; bok[i] = c < C;
+        arow[i] = xrow(p, b, aok[i] ? r : 0) + k4;
+        brow[i] = (c < p.h0 ? p.W0 + (long)c * K : p.x_s + ((long)b * p.S + (bok[i] ? c - p.h0 : 0)) * K) + k4;
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ga[NST][2], gb[NST][2];
+    const int li = lane & 31, hh = lane >> 5;
+    const int aoff = (wm * 32 + li) * SROW + 8 * hh, boff = (wn * 32 + li) * SROW + 8 * hh;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int nslab = K / SBK;
+
+    auto gload = [&](auto sc, int k0) {
+        constexpr int ST = decltype(sc)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { ga[ST][i] = *(const f32x4*)(arow[i] + k0); gb[ST][i] = *(const f32x4*)(brow[i] + k0); }
+    };
+    auto lstore = [&](auto sc, int buf) {
+        constexpr int ST = decltype(sc)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int off = ((tid >> 3) + 32 * i) * SROW + k4;
+            // no masking: a row past the panel (read from a clamped, valid address) only feeds outputs that are never stored
+            u32x2 h, m, l;
+            split3(ga[ST][i], h, m, l);
+            *(u32x2*)(lds[buf][0][0] + off) = h; *(u32x2*)(lds[buf][0][1] + off) = m; *(u32x2*)(lds[buf][0][2] + off) = l;
+            split3(gb[ST][i], h, m, l);
+            *(u32x2*)(lds[buf][1][0] + off) = h; *(u32x2*)(lds[buf][1][1] + off) = m; *(u32x2*)(lds[buf][1][2] + off) = l;
+        }
+    };
+    auto mma_slab = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < SBK / 16; ++s) {
+            bf16x8 ah = __builtin_bit_cast(bf16x8, *(const f32x4*)(lds[buf][0][0] + aoff + 16 * s));
+            bf16x8 am = __builtin_bit_cast(bf16x8, *(const f32x4*)(lds[buf][0][1] + aoff + 16 * s));
+            bf16x8 al = __builtin_bit_cast(bf16x8, *(const f32x4*)(lds[buf][0][2] + aoff + 16 * s));
+            bf16x8 bh = __builtin_bit_cast(bf16x8, *(const f32x4*)(lds[buf][1][0] + boff + 16 * s));
+            bf16x8 bm = __builtin_bit_cast(bf16x8, *(const f32x4*)(lds[buf][1][1] + boff + 16 * s));
+            bf16x8 bl = __builtin_bit_cast(bf16x8, *(const f32x4*)(lds[buf][1][2] + boff + 16 * s));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);      // smallest terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        }
+    };
+    // one slab: slab s+1 sits in ring slot SL (loaded NST slabs ago); the slot is refilled with slab s+1+NST
+    auto slab = [&](auto sc, int s) {
+        const int cur = s & 1;
+        if (s + 1 < nslab) lstore(sc, cur ^ 1);
+        if (s + 1 + NST < nslab) gload(sc, (s + 1 + NST) * SBK);
+        mma_slab(cur);
+        __syncthreads();
+    };
+    // steady state (s + 1 + NST < nslab), issue order spelled out: the slab's 12 LDS fragment reads, then twelve segments
+    // of one MFMA plus a twelfth of the work that splits the NEXT slab (8 VALU operations, or 6 byte-permutes and 3 LDS
+    // writes) -- an MFMA leaves the vector ALU free for 24 of its 32 cycles.  Left alone, hipcc issues the whole split and
+    // then the whole MFMA chain and the matrix pipe idles half of the time.  sched_barrier(0) pins the segments.
+    auto slab_main = [&](auto sc, int s) {
+        constexpr int ST = decltype(sc)::value;
+        const int cur = s & 1, nxt = cur ^ 1;
+        bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                fa[st][pl] = __builtin_bit_cast(bf16x8, *(const f32x4*)(lds[cur][0][pl] + aoff + 16 * st));
+                fb[st][pl] = __builtin_bit_cast(bf16x8, *(const f32x4*)(lds[cur][1][pl] + boff + 16 * st));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        // piece pairs in accumulation order (smallest first): (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                      // float4 q of the staged slab: A0, A1, B0, B1
+            const f32x4 v = q < 2 ? ga[ST][q] : gb[ST][q - 2];
+            const int off = ((tid >> 3) + 32 * (q & 1)) * SROW + k4;
+            unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                const int u = 3 * q + part;                // MFMA number 0..11
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u / 6][PA[u % 6]], fb[u / 6][PB[u % 6]], acc, 0, 0, 0);
+                if (part < 2) {
+#pragma unroll
+                    for (int e = 2 * part; e < 2 * part + 2; ++e) {
+                        const unsigned uu = __float_as_uint(v[e]);
+                        hb[e] = uu & 0xFFFF0000u;
+                        const float r1 = v[e] - __uint_as_float(hb[e]);
+                        mb[e] = __float_as_uint(r1) & 0xFFFF0000u;
+                        lb[e] = __float_as_uint(r1 - __uint_as_float(mb[e]));
+                    }
+                } else {
+                    u32x2 h, m, l;
+                    h[0] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u); h[1] = __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u);
+                    m[0] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u); m[1] = __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u);
+                    l[0] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u); l[1] = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
+                    *(u32x2*)(lds[nxt][q >> 1][0] + off) = h; *(u32x2*)(lds[nxt][q >> 1][1] + off) = m; *(u32x2*)(lds[nxt][q >> 1][2] + off) = l;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        gload(sc, (s + 1 + NST) * SBK);
+        __syncthreads();
+    };
+    // prologue: slab 0 straight to LDS, slabs 1..NST into the ring (slot of slab q is (q-1) % NST)
+    gload(WgInt<0>{}, 0);
+    lstore(WgInt<0>{}, 0);
+    xp_static_for<0, NST>([&](auto ic) { if (decltype(ic)::value + 1 < nslab) gload(ic, (decltype(ic)::value + 1) * SBK); });
+    __syncthreads();
+    int s = 0;
+    for (; s + 2 * NST < nslab; s += NST)                // every slab of this round has s' + 1 + NST < nslab
+        xp_static_for<0, NST>([&](auto ic) { slab_main(ic, s + decltype(ic)::value); });
+    for (; s < nslab; s += NST)
+        xp_static_for<0, NST>([&](auto ic) { if (s + decltype(ic)::value < nslab) slab(ic, s + decltype(ic)::value); });
+    const int n = n0 + wn * 32 + li;
+    if (n < C) {
+        float* base; long ld; int col;
+        if (n < p.h0) { base = A0 + (long)b * R * p.h0; ld = p.h0; col = n; }
+        else          { base = G + (long)b * R * p.S;  ld = p.S;  col = n - p.h0; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (m < R) base[(long)m * ld + col] = acc[r];
+        }
+    }
+}
+
 // ---- forward, 8-wave variant: the same 64x64x64 slabs, but two waves per 32x32 output quadrant, each multiplying half
 // of every slab's k range (k-groups {0,1} / {2,3}); their accumulators are added through LDS at the end.  Two waves per
 // SIMD from the SAME workgroup share the staged data, so one wave's stalls (LDS latency after the slab barrier, the
@@ -482,7 +669,15 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
     const dim3 grid(8 * nper * tiles_m * tiles_n);
     static const int nst = getenv("FUMI_XP_NST") ? atoi(getenv("FUMI_XP_NST")) : 2;
     static const int w8 = getenv("FUMI_XP_W8") ? atoi(getenv("FUMI_XP_W8")) : 0;
-    if (aligned && D % FBK == 0 && w8) {
+    // FUMI_XP_SB=1: the split-bf16 kernel (fp32-equivalent accuracy on the bf16 matrix pipe).  Measured 65 us against the fp32
+    // kernel's 78 us at the bench shapes -- both sit on the same ~8 TB/s L2 -> CU delivery of 64x64 tiles, so it
+    // stays opt-in until the larger-tile version exists.
+    static const int use_sb = getenv("FUMI_XP_SB") ? atoi(getenv("FUMI_XP_SB")) : 0;
+    if (aligned && D % SBK == 0 && use_sb) {
+        static const int sbn = getenv("FUMI_XP_SBN") ? atoi(getenv("FUMI_XP_SBN")) : 2;          // ring depth (tuning knob)
+        if (sbn <= 2) hipLaunchKernelGGL(xpanel_fwd_sb_kernel<2>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n);
+        else hipLaunchKernelGGL(xpanel_fwd_sb_kernel<4>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n);
+    } else if (aligned && D % FBK == 0 && w8) {
         if (nst == 1) hipLaunchKernelGGL(xpanel_fwd8_kernel<1>, grid, dim3(512), 0, st, p, A0, G, tiles_m, tiles_n);
         else hipLaunchKernelGGL(xpanel_fwd8_kernel<2>, grid, dim3(512), 0, st, p, A0, G, tiles_m, tiles_n);
     } else if (aligned && D % FBK == 0) {

@@ -414,3 +414,42 @@ def test_generic_episode_kernels_in_subprocess(dev):
                        env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+_SB_SCRIPT = r"""
+import sys, json, torch
+sys.path.insert(0, %r)
+from fumi_amd import hip
+dev = torch.device("cuda:0"); ws = hip.Workspace.get(dev)
+g = torch.Generator().manual_seed(5)
+B, S, Qn, D, h0 = 3, 25, 43, 256, 96
+x_s = torch.randn(B, S, D, generator=g); x_q = torch.randn(B, Qn, D, generator=g) * 3.0
+W0 = torch.randn(h0, D, generator=g) * 0.05
+A0, G = hip.xpanel_fwd(ws, x_s.to(dev), x_q.to(dev), W0.to(dev))
+X = torch.cat([x_s, x_q], 1).double()
+A0r = X @ W0.double().T; Gr = X @ x_s.double().transpose(1, 2)
+ea = float((A0.cpu().double() - A0r).abs().max() / A0r.abs().max())
+eg = float((G.cpu().double() - Gr).abs().max() / Gr.abs().max())
+print(json.dumps({"ea": ea, "eg": eg}))
+"""
+
+
+def test_xpanel_fwd_split_bf16_has_fp32_accuracy(dev):
+    """FUMI_XP_SB=1 runs layer 0 / the Gram matrix on the bf16 matrix pipe from exact three-way bf16 splits of the fp32
+    operands (xpanel.hip).  Its error against fp64 must be of the size of the fp32 MFMA kernel's (both ~1e-7 of the
+    largest entry), far inside the 1e-4 parity tolerance.  The knob is read once per process, hence the child processes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    errs = {}
+    for sb in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", _SB_SCRIPT % root], env=dict(os.environ, FUMI_XP_SB=sb), cwd=root,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        errs[sb] = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("ea", "eg"):
+        assert errs["0"][k] < 2e-6, errs
+        assert errs["1"][k] < 2e-6, errs
+        assert errs["1"][k] < 4.0 * errs["0"][k] + 1e-7, errs
