@@ -12,17 +12,18 @@ constexpr int MAXT = 32;
 struct AdamTensors {
     float* p[MAXT]; const float* g[MAXT]; float* m[MAXT]; float* v[MAXT];
     long end[MAXT];          // cumulative element counts rounded up to 4 per tensor (in float4 units)
+    long numel[MAXT];        // element count per tensor (by value: no per-step host-to-device copy)
     int n;
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, long total4, float lr_over_bc1, float inv_sqrt_bc2,
-                                                   float b1, float b2, float eps, float wd, const long* numel) {
+                                                   float b1, float b2, float eps, float wd) {
     for (long i4 = blockIdx.x * (long)blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
         int k = 0;
         while (k + 1 < t.n && i4 >= t.end[k]) ++k;
         const long base4 = k ? t.end[k - 1] : 0;
         const long e0 = (i4 - base4) * 4;
-        const long n = numel[k];
+        const long n = t.numel[k];
         float* p = t.p[k]; const float* g = t.g[k]; float* m = t.m[k]; float* v = t.v[k];
         const bool full = e0 + 3 < n && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
         if (full) {
@@ -60,21 +61,17 @@ extern "C" int fumi_hip_adam_step(fumi_ws_t* ws, fumi_stream_t stream, int n_ten
     long tot4 = 0;
     for (int k = 0; k < n_tensors; ++k) {
         if (!params[k] || !grads[k] || !exp_avg[k] || !exp_avg_sq[k] || numel_host[k] < 0) return FUMI_EINVAL;
-        t.p[k] = params[k]; t.g[k] = grads[k]; t.m[k] = exp_avg[k]; t.v[k] = exp_avg_sq[k];
+        t.p[k] = params[k]; t.g[k] = grads[k]; t.m[k] = exp_avg[k]; t.v[k] = exp_avg_sq[k]; t.numel[k] = numel_host[k];
         tot4 += (numel_host[k] + 3) / 4;
         t.end[k] = tot4;
     }
     t.n = n_tensors;
-    // element counts live in the status allocation's tail (256 B): tiny async copy, no workspace carve
-    long* numel_dev = (long*)((char*)ws->status + 8);
-    if (n_tensors * sizeof(long) > 240) return FUMI_ENOTSUP;
-    HIP_TRY(hipMemcpyAsync(numel_dev, numel_host, n_tensors * sizeof(long), hipMemcpyHostToDevice, st));
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     int blocks = (int)((tot4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) return FUMI_OK;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, t, tot4, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)),
-                       beta1, beta2, eps, weight_decay, numel_dev);
+                       beta1, beta2, eps, weight_decay);
     LAUNCH_CHECK();
     return FUMI_OK;
 }

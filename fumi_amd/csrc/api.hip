@@ -142,7 +142,7 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
         const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
         const float* cls_text, const float* text_s,
         const float* const* theta, const float* const* phi,
-        float* logits_q, int64_t* preds_q, float* loss_b, float* acc_b, float* stats,
+        float* logits_q, int64_t* preds_q, float* preds_q_f32, float* loss_b, float* acc_b, float* stats,
         float* const* g_theta, float* const* g_phi) {
     if (!ws || !hid || !theta || !phi || !x_s || !y_s || !x_q || !y_q || !logits_q || !preds_q || !loss_b || !acc_b)
         return FUMI_EINVAL;
@@ -167,7 +167,7 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
     for (int i = 0; i < 4; ++i) if (!phi[i] || (need_grad && !g_phi[i])) return FUMI_EINVAL;
     const int H = hid[n_hidden - 1], R = B * N, H1 = H + 1;
     p.x_s = x_s; p.y_s = y_s; p.x_q = x_q; p.y_q = y_q;
-    p.logits_q = logits_q; p.preds_q = preds_q; p.loss_b = loss_b; p.acc_b = acc_b; p.stats = stats;
+    p.logits_q = logits_q; p.preds_q = preds_q; p.preds_f = preds_q_f32; p.loss_b = loss_b; p.acc_b = acc_b; p.stats = stats;
 
     size_t bytes = episode_workspace_bytes(p);
     bytes += ws_align((size_t)R * Dt * 4) + 2 * ws_align((size_t)R * Ht * 4) + 3 * ws_align((size_t)R * H1 * 4);
@@ -240,7 +240,7 @@ int fumi_hip_maml_step(fumi_ws_t* ws, fumi_stream_t stream,
         int T, float alpha, int first_order, int need_grad, float grad_scale,
         const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
         const float* const* params,
-        float* logits_q, int64_t* preds_q, float* loss_b, float* acc_b, float* stats,
+        float* logits_q, int64_t* preds_q, float* preds_q_f32, float* loss_b, float* acc_b, float* stats,
         float* const* g_params) {
     if (!ws || !params || !x_s || !y_s || !x_q || !y_q || !logits_q || !preds_q || !loss_b || !acc_b) return FUMI_EINVAL;
     if (n_hidden == 0) return FUMI_ENOTSUP;      // hidden_dims=None (a bare linear head on the embeddings)
@@ -262,7 +262,7 @@ int fumi_hip_maml_step(fumi_ws_t* ws, fumi_stream_t stream,
     if (!Wf || !bf || (need_grad && (!g_params[2 * n_hidden] || !g_params[2 * n_hidden + 1]))) return FUMI_EINVAL;
     const int H = hid[n_hidden - 1], H1 = H + 1;
     p.x_s = x_s; p.y_s = y_s; p.x_q = x_q; p.y_q = y_q;
-    p.logits_q = logits_q; p.preds_q = preds_q; p.loss_b = loss_b; p.acc_b = acc_b; p.stats = stats;
+    p.logits_q = logits_q; p.preds_q = preds_q; p.preds_f = preds_q_f32; p.loss_b = loss_b; p.acc_b = acc_b; p.stats = stats;
 
     size_t bytes = episode_workspace_bytes(p) + 2 * ws_align((size_t)B * N * H1 * 4);
     int rc = ws_reserve(ws, bytes);

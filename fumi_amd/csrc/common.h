@@ -124,7 +124,7 @@ struct EpisodeProblem {
     const float* x_s; const int64_t* y_s; const float* x_q; const int64_t* y_q;
     const float* W[FUMI_MAX_HIDDEN]; const float* b[FUMI_MAX_HIDDEN];
     const float* head;              // [B,N,H+1] initial head per episode  ([Wh | bh])
-    float* logits_q; int64_t* preds_q; float* loss_b; float* acc_b;
+    float* logits_q; int64_t* preds_q; float* preds_f /* optional */; float* loss_b; float* acc_b;
     float* gW[FUMI_MAX_HIDDEN]; float* gb[FUMI_MAX_HIDDEN];   // outputs (scaled sums over episodes)
     float* head_bar;                // [B,N,H+1] d loss_b / d head_b   (unscaled, per episode)
     float* stats;                   // optional [2]: grad_scale * (sum_b loss_b, sum_b acc_b)

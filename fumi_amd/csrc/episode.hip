@@ -462,7 +462,7 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
 // query: forward with the adapted weights, loss / argmax, first-order backward of the query loss (partial slabs)
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const float* const b0, const int64_t* y_q,
-                                                    float* logits_q, int64_t* preds_q, int* status) {
+                                                    float* logits_q, int64_t* preds_q, float* preds_f, int* status) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int sm_cap = w.lds_query;
     const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
@@ -520,6 +520,7 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
         s_loss[m] = lse - lq[m * N + y];
         s_corr[m] = (arg == y) ? 1.f : 0.f;
         preds_q[(long)b * Qn + r0 + m] = arg;
+        if (preds_f) preds_f[(long)b * Qn + r0 + m] = (float)arg;
         for (int n = 0; n < N; ++n)
             lbar[m * N + n] = (expf(lq[m * N + n] - mx) * inv - (n == y ? 1.f : 0.f)) / (float)Qn;
     }
@@ -593,7 +594,7 @@ __host__ __device__ inline void query_layout(QLay& y, int L, const int* h, int S
 }
 
 __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d, EpiBuf w, QLay y, const int64_t* y_q,
-                                                        float* logits_q, int64_t* preds_q, int* status) {
+                                                        float* logits_q, int64_t* preds_q, float* preds_f, int* status) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float s_loss[QR];
     __shared__ float s_corr[QR];
@@ -661,6 +662,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d,
         s_loss[m] = lse - row[yy];
         s_corr[m] = (arg == yy) ? 1.f : 0.f;
         preds_q[(long)b * Qn + r0 + m] = arg;
+        if (preds_f) preds_f[(long)b * Qn + r0 + m] = (float)arg;
         for (int n = 0; n < N; ++n) row[n] = (expf(row[n] - mx) * inv - (n == yy ? 1.f : 0.f)) / (float)Qn;
     }
     wg_lds_barrier(); QSTAMP()
@@ -1400,11 +1402,11 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
         if (lds_form) {
             HIP_TRY(hipFuncSetAttribute((const void*)query_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ql.total * 4));
             hipLaunchKernelGGL(query_lds_kernel, dim3(w.ntile, p.B), dim3(512), ql.total * 4, st, tb, d, w, ql, p.y_q,
-                               p.logits_q, p.preds_q, ws->status);
+                               p.logits_q, p.preds_q, p.preds_f, ws->status);
         } else {
             HIP_TRY(hipFuncSetAttribute((const void*)query_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, w.lds_query * 4));
             hipLaunchKernelGGL(query_kernel, dim3(w.ntile, p.B), dim3(512), w.lds_query * 4, st, d, w, p.b[0], p.y_q, p.logits_q,
-                               p.preds_q, ws->status);
+                               p.preds_q, p.preds_f, ws->status);
         }
         LAUNCH_CHECK();
     }

@@ -67,10 +67,10 @@ def lib():
         L.fumi_hip_fumi_step.argtypes = (
             [c_void_p, c_void_p] + [c_int] * 6 + [POINTER(c_int), c_int, c_int, c_int, c_float, c_int, c_int, c_float,
                                                  c_float, ctypes.c_uint64]
-            + [c_void_p] * 6 + [PP, PP] + [c_void_p] * 5 + [PP, PP])
+            + [c_void_p] * 6 + [PP, PP] + [c_void_p] * 6 + [PP, PP])
         L.fumi_hip_maml_step.argtypes = (
             [c_void_p, c_void_p] + [c_int] * 6 + [POINTER(c_int), c_int, c_float, c_int, c_int, c_float]
-            + [c_void_p] * 4 + [PP] + [c_void_p] * 5 + [PP])
+            + [c_void_p] * 4 + [PP] + [c_void_p] * 6 + [PP])
         L.fumi_hip_am3_step.argtypes = (
             [c_void_p, c_void_p] + [c_int] * 10 + [c_float, c_float, ctypes.c_uint64] + [c_void_p] * 5 + [PP] + [c_void_p] * 4 + [PP])
         L.fumi_hip_glove_bag.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int, c_int,
@@ -245,6 +245,7 @@ def _fumi_step(ws, dev, B, N, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, 
     L = lib()
     logits = torch.empty(B, Qn, N, device=dev, dtype=torch.float32)
     preds = torch.empty(B, Qn, device=dev, dtype=torch.int64)
+    preds_f = torch.empty(B, Qn, device=dev, dtype=torch.float32)      # the reference's float test_preds, same launch
     loss_b = torch.empty(B, device=dev, dtype=torch.float32)
     acc_b = torch.empty(B, device=dev, dtype=torch.float32)
     if need_grad:
@@ -262,11 +263,11 @@ def _fumi_step(ws, dev, B, N, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, 
         _f32(cls_text, "cls_text") if cls_text is not None else None,
         _f32(text_s, "text_s") if text_s is not None else None,
         _parr(theta, "theta"), _parr(phi, "phi"),
-        _f32(logits, "logits"), _i64(preds, "preds"), _f32(loss_b, "loss_b"), _f32(acc_b, "acc_b"),
+        _f32(logits, "logits"), _i64(preds, "preds"), _f32(preds_f, "preds_f"), _f32(loss_b, "loss_b"), _f32(acc_b, "acc_b"),
         _f32(stats, "stats") if stats is not None else None,
         _parr(g_theta, "g_theta") if need_grad else None, _parr(g_phi, "g_phi") if need_grad else None)
     _check(rc, "fumi_hip_fumi_step")
-    return dict(logits=logits, preds=preds, loss_b=loss_b, acc_b=acc_b, g_theta=g_theta, g_phi=g_phi, stats=stats)
+    return dict(logits=logits, preds=preds, preds_f=preds_f, loss_b=loss_b, acc_b=acc_b, g_theta=g_theta, g_phi=g_phi, stats=stats)
 
 
 def maml_step(ws, x_s, y_s, x_q, y_q, params, T, alpha, first_order=False, *, need_grad=True, grad_scale=None,
@@ -281,6 +282,7 @@ def maml_step(ws, x_s, y_s, x_q, y_q, params, T, alpha, first_order=False, *, ne
     N = int(params[-2].shape[0])
     logits = torch.empty(B, Qn, N, device=dev, dtype=torch.float32)
     preds = torch.empty(B, Qn, device=dev, dtype=torch.int64)
+    preds_f = torch.empty(B, Qn, device=dev, dtype=torch.float32)      # the reference's float test_preds, same launch
     loss_b = torch.empty(B, device=dev, dtype=torch.float32)
     acc_b = torch.empty(B, device=dev, dtype=torch.float32)
     if need_grad and g_params is None:
@@ -292,11 +294,11 @@ def maml_step(ws, x_s, y_s, x_q, y_q, params, T, alpha, first_order=False, *, ne
         ws.handle, _stream(dev), B, N, S, Qn, D, n_hidden, hid_arr, int(T), float(alpha), int(bool(first_order)),
         int(bool(need_grad)), float(grad_scale),
         _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"), _parr(params, "params"),
-        _f32(logits, "logits"), _i64(preds, "preds"), _f32(loss_b, "loss_b"), _f32(acc_b, "acc_b"),
+        _f32(logits, "logits"), _i64(preds, "preds"), _f32(preds_f, "preds_f"), _f32(loss_b, "loss_b"), _f32(acc_b, "acc_b"),
         _f32(stats, "stats") if stats is not None else None,
         _parr(g_params, "g_params") if need_grad else None)
     _check(rc, "fumi_hip_maml_step")
-    return dict(logits=logits, preds=preds, loss_b=loss_b, acc_b=acc_b, g_params=g_params, stats=stats)
+    return dict(logits=logits, preds=preds, preds_f=preds_f, loss_b=loss_b, acc_b=acc_b, g_params=g_params, stats=stats)
 
 
 AM3_KEYS = ["Wi", "bi", "G0", "g0", "G1", "g1", "H0", "h0", "H1", "h1"]

@@ -198,11 +198,11 @@ class FUMI(nn.Module):
             optimizer.zero_grad()
             fg.attach()
             optimizer.step()
-        preds = out["preds"]
+        preds = out["preds_f"]                                   # float, like the reference's test_preds (fumi.py:180-183)
         if fdist.world()[1] > 1 and not train:
             preds = fdist.all_gather_rows(preds)
         loss, acc = lazy.scalars(tail, 2)                        # read back asynchronously (fumi.py:195 blocks here)
-        test_preds = preds.to(torch.float32) if preds.shape[0] == B else None
+        test_preds = preds if preds.shape[0] == B else None
         return loss, acc, test_preds, q_y.to(dev)
 
 

@@ -87,7 +87,8 @@ const char*  fumi_hip_phase_name(int phase);
  * phi     : 4 pointers           A0 [Ht,Dt], a0 [Ht], A1 [H+1,Ht], a1 [H+1]           (hyper_net.0.*, hyper_net.2.*)
  * cls_text: [B,N,Dt] per-class text encodings, or NULL to select them from text_s [B,S,Dt] (first support row of
  *           each class, fumi.py:207-210)
- * outputs : logits_q [B,Qn,N], preds_q [B,Qn] (first arg-max), loss_b [B] (query CE), acc_b [B];
+ * outputs : logits_q [B,Qn,N], preds_q [B,Qn] (first arg-max), preds_q_f32 [B,Qn] or NULL (the same indices as floats:
+ *           what the reference's float `test_preds` tensor holds, fumi.py:180-183), loss_b [B] (query CE), acc_b [B];
  *           stats [2] (optional, may be NULL) = grad_scale * (sum_b loss_b, sum_b acc_b): with grad_scale = 1/B the
  *           meta-batch mean loss / accuracy that fumi.py:187-188 computes, ready for the same all-reduce as the gradients;
  *           g_theta/g_phi (same shapes as theta/phi) only when need_grad != 0.
@@ -101,7 +102,7 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
         const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
         const float* cls_text, const float* text_s,
         const float* const* theta, const float* const* phi,
-        float* logits_q, int64_t* preds_q, float* loss_b, float* acc_b, float* stats,
+        float* logits_q, int64_t* preds_q, float* preds_q_f32, float* loss_b, float* acc_b, float* stats,
         float* const* g_theta, float* const* g_phi);
 
 /* ---- MAML meta-step (replaces fumi/models/maml.py:156-191) ---------------------------------------------------
@@ -111,7 +112,7 @@ int fumi_hip_maml_step(fumi_ws_t* ws, fumi_stream_t stream,
         int T, float alpha, int first_order, int need_grad, float grad_scale,
         const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
         const float* const* params,
-        float* logits_q, int64_t* preds_q, float* loss_b, float* acc_b, float* stats,
+        float* logits_q, int64_t* preds_q, float* preds_q_f32, float* loss_b, float* acc_b, float* stats,
         float* const* g_params);
 
 /* ---- AM3 step (replaces am3.py:160-200 + utils.py:302-402, dropout 0) -----------------------------------------

@@ -31,7 +31,7 @@ class OracleEngine:
                 dst.copy_(g * (B * grad_scale))               # oracle returns mean-loss grads = (1/B) sum_b
         if stats is not None:
             stats.copy_(torch.stack([out["loss_b"].sum(), out["acc_b"].sum()]) * grad_scale)
-        return dict(logits=out["logits"], preds=out["preds"], loss_b=out["loss_b"], acc_b=out["acc_b"])
+        return dict(logits=out["logits"], preds=out["preds"], preds_f=out["preds"].float(), loss_b=out["loss_b"], acc_b=out["acc_b"])
 
     def maml_step(self, x_s, y_s, x_q, y_q, params, T, alpha, first_order, need_grad, grad_scale, g_params=None, stats=None):
         B = x_s.shape[0]
@@ -42,7 +42,7 @@ class OracleEngine:
                 dst.copy_(g * (B * grad_scale))
         if stats is not None:
             stats.copy_(torch.stack([out["loss_b"].sum(), out["acc_b"].sum()]) * grad_scale)
-        return dict(logits=out["logits"], preds=out["preds"], loss_b=out["loss_b"], acc_b=out["acc_b"])
+        return dict(logits=out["logits"], preds=out["preds"], preds_f=out["preds"].float(), loss_b=out["loss_b"], acc_b=out["acc_b"])
 
     def am3_step(self, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad, grad_scale, g_w=None, dropout_p=0.0, seed=0):
         from fumi_amd.hip import AM3_KEYS
