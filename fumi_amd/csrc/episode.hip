@@ -274,6 +274,9 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
 
     wg_stage_tab_to_lds(&s_stg);
     for (int i = tid * 4, tot = y.total; i < tot; i += nt * 4) *(f32x4*)(sm + i) = z4;
+    // labels and A0_s + b0 are loaded now: a load issued inside the step loop would wait for every older tape store
+    // (vmcnt counts loads and stores together, in order)
+    const int my_label = tid < S ? label(ys, tid, N, status) : 0;
     // A0_s + b0 of the lane's 4x4 block of the layer-0 products (block = wave)
     f32x4 preZ[4];
     {
@@ -303,11 +306,12 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
             wg_st4(dst + (long)r * cols + c, *(const f32x4*)(img + r * ld + c), min(4, cols - c));
         }
     };
-    if (d.taped) {
+    auto store_slot0 = [&]() {                 // (the images are only modified by the updates at the end of a step)
         for (int i = 1; i < L; ++i)
             store_img(w.Wslot[i] + (long)b * w.nslot * ((long)d.h[i] * d.h[i - 1]), sm + y.W[i], ldh(i - 1), d.h[i], d.h[i - 1]);
         store_img(w.Whslot + (long)b * w.nslot * N * H, Wh, ldH, N, H);
-    }
+    };
+    if (d.taped && d.T == 0) store_slot0();
 
     for (int t = 0; t < d.T; ++t) {
         const long tp = (long)b * w.ntape + (d.taped ? t : 0);
@@ -340,6 +344,7 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
                 });
             }
         }
+        if (t == 0 && d.taped) store_slot0();    // after the registers loaded at kernel start have been consumed
         wg_lds_barrier(); STAMP()
         // 2. deeper layers with the episode's fast weights
         for (int i = 1; i < L; ++i) {
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
         {
             float* tpp = w.tp + tp * S * N; float* tee = w.te + tp * S * N;
             for (int s_ = tid; s_ < S; s_ += nt) {
-                const int yy = label(ys, s_, N, status);
+                const int yy = s_ == tid ? my_label : label(ys, s_, N, status);       // (S > blockDim only)
                 float* row = e_ + s_ * ldN;
                 float mx = row[0];
                 for (int n = 1; n < N; ++n) mx = fmaxf(mx, row[n]);
@@ -610,6 +615,8 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d,
     auto a = [&](int i) { return sm + y.a[i]; };
     auto lda = [&](int i) { return wg_ld(d.h[i]); };
 
+    // the row's label is loaded now: inside the chain it would wait for every older store (vmcnt is in order)
+    const int my_label = tid < nr ? label(y_q + (long)b * Qn + r0, tid, N, status) : 0;
     // ---- zero the arena (padding must read as zero), then stage everything this tile needs in one batch (plan: host)
     wg_stage_tab_to_lds(&s_stg);
     for (int i = tid * 4, tot = y.total; i < tot; i += nt * 4) *(f32x4*)(sm + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -652,7 +659,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d,
     wg_lds_barrier(); QSTAMP()
     // per row: log-softmax loss, first arg-max (torch.max semantics, fumi.py:180), lbar = (p - onehot)/Qn in place
     for (int m = tid; m < nr; m += nt) {
-        const int yy = label(y_q + (long)b * Qn + r0, m, N, status);
+        const int yy = my_label;                                   // nr <= QR <= blockDim: m == tid
         float* row = lq + m * ldq;
         float mx = row[0]; int arg = 0;
         for (int n = 1; n < N; ++n) { const float v = row[n]; if (v > mx) { mx = v; arg = n; } }
