@@ -69,6 +69,17 @@ int fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out) {
     if (hipMalloc((void**)&ws->status, 256) != hipSuccess) { delete ws; return FUMI_ENOMEM; }
     if (hipHostMalloc((void**)&ws->status_host, 256, hipHostMallocDefault) != hipSuccess) { (void)hipFree(ws->status); delete ws; return FUMI_ENOMEM; }
     HIP_TRY(hipMemset(ws->status, 0, 256));
+    ws->side = nullptr;
+    for (auto& e : ws->ev) e = nullptr;
+    {   // high priority: the side stream carries a few small workgroups that should get CU slots as soon as they are ready
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const bool hi = getenv("FUMI_SIDE_PRIO") && atoi(getenv("FUMI_SIDE_PRIO")) != 0;
+        if (hipStreamCreateWithPriority(&ws->side, hipStreamNonBlocking, hi ? greatest : least) != hipSuccess) ws->side = nullptr;   // overlap is optional
+    }
+    for (auto& e : ws->ev) if (ws->side && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(ws->side); ws->side = nullptr;
+    }
     if (bytes_hint) {
         int rc = ws_reserve(ws, bytes_hint);
         if (rc) { fumi_hip_workspace_destroy(ws); return rc; }
@@ -86,6 +97,8 @@ void fumi_hip_workspace_destroy(fumi_ws_t* ws) {
     if (ws->status_host) (void)hipHostFree(ws->status_host);
     for (auto& r : *ws->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : *ws->pool) (void)hipEventDestroy(e);
+    for (auto e : ws->ev) if (e) (void)hipEventDestroy(e);
+    if (ws->side) (void)hipStreamDestroy(ws->side);
     delete ws->recs; delete ws->pool;
     delete ws;
 }
@@ -191,44 +204,74 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
         if ((rc = launch_class_text_select(st, B, N, S, Dt, text_s, y_s, c, ws->status))) return rc;
         ctext = c;
     }
+    // The text path (hypernetwork) and the image path (the two X-panel passes) only meet at the inner loop: the
+    // hypernetwork forward runs on the workspace's side stream beside xpanel_fwd, its backward beside xpanel_bwd.  Both
+    // are a handful of small latency-bound workgroups next to a chip-filling matrix kernel, so the overlap is nearly free.
+    static const bool no_overlap = getenv("FUMI_NO_OVERLAP") != nullptr;
+    const bool fork = ws->side && !no_overlap;
+    hipStream_t sh = fork ? ws->side : st;             // stream of the hypernetwork kernels
     GemmArgs g;
-    {
-        ProfScope ps(ws, st, FUMI_PH_HYPER_FWD);
-        rc = hyper_lds ? launch_hyper_fwd(st, R, Dt, Ht, H1, tanh_head, ctext, phi[0], phi[1], phi[2], phi[3], u, h) : FUMI_ENOTSUP;
-        if (rc == FUMI_ENOTSUP) {                                    // shapes outside the LDS-resident kernels: plain GEMMs
-            g = gemm_args(R, Ht, Dt, ctext, Dt, phi[0], Dt, u, Ht);
-            g.bias = phi[1]; g.act = 1;
-            if ((rc = launch_gemm(st, g, 0, 0))) return rc;
-            g = gemm_args(R, H1, Ht, u, Ht, phi[2], Ht, h, H1);
-            g.bias = phi[3]; g.act = tanh_head ? 2 : 0;
-            if ((rc = launch_gemm(st, g, 0, 0))) return rc;
-        } else if (rc) return rc;
-    }
+    auto hyper_forward = [&]() -> int {
+        if (fork) HIP_TRY(hipStreamWaitEvent(sh, ws->ev[0], 0));     // class text rows are ready (recorded before xpanel_fwd)
+        int r2;
+        {
+            ProfScope ps(ws, sh, FUMI_PH_HYPER_FWD);
+            r2 = hyper_lds ? launch_hyper_fwd(sh, R, Dt, Ht, H1, tanh_head, ctext, phi[0], phi[1], phi[2], phi[3], u, h) : FUMI_ENOTSUP;
+            if (r2 == FUMI_ENOTSUP) {                                // shapes outside the LDS-resident kernels: plain GEMMs
+                g = gemm_args(R, Ht, Dt, ctext, Dt, phi[0], Dt, u, Ht);
+                g.bias = phi[1]; g.act = 1;
+                if ((r2 = launch_gemm(sh, g, 0, 0))) return r2;
+                g = gemm_args(R, H1, Ht, u, Ht, phi[2], Ht, h, H1);
+                g.bias = phi[3]; g.act = tanh_head ? 2 : 0;
+                if ((r2 = launch_gemm(sh, g, 0, 0))) return r2;
+            } else if (r2) return r2;
+        }
+        if (fork) HIP_TRY(hipEventRecord(ws->ev[1], sh));
+        return FUMI_OK;
+    };
+    using HF = decltype(hyper_forward);
+    if (fork) {
+        // enqueued from inside run_episodes, right after xpanel_fwd: the matrix pass is not held up by this host work
+        p.inputs_ready = ws->ev[0];
+        p.after_xpanel_fwd = [](void* c) -> int { return (*(HF*)c)(); };
+        p.hook_ctx = &hyper_forward;
+        p.head_ready = ws->ev[1];
+        if (need_grad) p.after_reverse = ws->ev[2];
+    } else if ((rc = hyper_forward())) return rc;
 
     p.head = h; p.head_bar = hbar;
     if ((rc = run_episodes(ws, st, p))) return rc;
     if (!need_grad) return FUMI_OK;
 
     // hypernetwork backward: rows are (episode, class) pairs, weights are shared
-    ProfScope ps(ws, st, FUMI_PH_HYPER_BWD);
+    if (fork) HIP_TRY(hipStreamWaitEvent(sh, ws->ev[2], 0));       // head_bar is complete (recorded after the reverse sweep)
+    rc = [&]() -> int {
+    ProfScope ps(ws, sh, FUMI_PH_HYPER_BWD);
     if (hyper_lds) {
-        rc = launch_hyper_bwd(st, R, Dt, Ht, H1, tanh_head, grad_scale, ctext, u, h, hbar, phi[2], ub, hpart,
-                              g_phi[0], g_phi[1], g_phi[2], g_phi[3]);
-        if (rc != FUMI_ENOTSUP) return rc;
+        int rc2 = launch_hyper_bwd(sh, R, Dt, Ht, H1, tanh_head, grad_scale, ctext, u, h, hbar, phi[2], ub, hpart,
+                                   g_phi[0], g_phi[1], g_phi[2], g_phi[3]);
+        if (rc2 != FUMI_ENOTSUP) return rc2;
     }
     const float* hp = hbar;
-    if (tanh_head) { if ((rc = launch_tanh_bwd(st, (long)R * H1, h, hbar, hpb))) return rc; hp = hpb; }
+    if (tanh_head) { if ((rc = launch_tanh_bwd(sh, (long)R * H1, h, hbar, hpb))) return rc; hp = hpb; }
     g = gemm_args(H1, Ht, R, hp, H1, u, Ht, g_phi[2], Ht);           // gA1 = hp^T u
     g.alpha = grad_scale;
-    if ((rc = launch_gemm(st, g, 1, 1))) return rc;
-    if ((rc = launch_colsum(st, hp, R, H1, H1, grad_scale, g_phi[3]))) return rc;
+    if ((rc = launch_gemm(sh, g, 1, 1))) return rc;
+    if ((rc = launch_colsum(sh, hp, R, H1, H1, grad_scale, g_phi[3]))) return rc;
     g = gemm_args(R, Ht, H1, hp, H1, phi[2], Ht, ub, Ht);            // ubar = (hp A1) * relu'(u), mask in the epilogue
     g.mask = u;
-    if ((rc = launch_gemm(st, g, 0, 1))) return rc;
+    if ((rc = launch_gemm(sh, g, 0, 1))) return rc;
     g = gemm_args(Ht, Dt, R, ub, Ht, ctext, Dt, g_phi[0], Dt);       // gA0 = ubar^T c
     g.alpha = grad_scale;
-    if ((rc = launch_gemm(st, g, 1, 1))) return rc;
-    if ((rc = launch_colsum(st, ub, R, Ht, Ht, grad_scale, g_phi[1]))) return rc;
+    if ((rc = launch_gemm(sh, g, 1, 1))) return rc;
+    if ((rc = launch_colsum(sh, ub, R, Ht, Ht, grad_scale, g_phi[1]))) return rc;
+    return FUMI_OK;
+    }();
+    if (rc) return rc;
+    if (fork) {                                                      // join: the caller's stream owns every result again
+        HIP_TRY(hipEventRecord(ws->ev[3], sh));
+        HIP_TRY(hipStreamWaitEvent(st, ws->ev[3], 0));
+    }
     return FUMI_OK;
 }
 

@@ -22,7 +22,9 @@ struct fumi_ws {
     size_t off;          // bump pointer (bytes), reset at the start of each step
     int* status;         // device status word (own small allocation)
     int* status_host;    // pinned
-    int profiling;       // record HIP events around each phase (bench only)
+    int profiling;       // bit p: record HIP events around phase p (bench only)
+    hipStream_t side;    // second stream: the text path (hypernetwork fwd / bwd) runs beside the two X-panel passes
+    hipEvent_t ev[4];    // fork / join points (timing disabled)
     std::vector<ProfRec>* recs;
     std::vector<hipEvent_t>* pool;
 };
@@ -130,6 +132,12 @@ struct EpisodeProblem {
     float* stats;                   // optional [2]: grad_scale * (sum_b loss_b, sum_b acc_b)
     float dropout_p;                // inner-loop dropout probability (0 = off) and the step's 64-bit seed
     unsigned long long seed;
+    // optional cross-stream hooks (FuMI): `head` is produced on another stream -> wait for head_ready before the inner
+    // loop; record after_reverse once head_bar is complete so its consumer can start beside the layer-0 gradient pass
+    hipEvent_t head_ready, after_reverse;
+    hipEvent_t inputs_ready;                    // recorded on the caller's stream BEFORE the first launch (fork point)
+    int (*after_xpanel_fwd)(void*); void* hook_ctx;   // host callback right after xpanel_fwd is enqueued: the producer of `head`
+                                                // is launched there, so its host-side preparation does not delay the matrix pass
 };
 size_t episode_workspace_bytes(const EpisodeProblem& p);
 int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p);

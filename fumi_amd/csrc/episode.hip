@@ -1347,11 +1347,14 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     int rc;
 
     // ---- shared pass 1 over X: [A0 | G] = [Xs;Xq] [W0;Xs]^T for every episode, one launch (xpanel.hip)
+    if (p.inputs_ready) HIP_TRY(hipEventRecord(p.inputs_ready, st));
     {
         ProfScope ps(ws, st, FUMI_PH_XPANEL_FWD);
         if ((rc = launch_xpanel_fwd(st, p.B, p.S, p.Qn, p.D, h0, p.x_s, p.x_q, p.W[0], w.A0, w.G))) return rc;
     }
+    if (p.after_xpanel_fwd && (rc = p.after_xpanel_fwd(p.hook_ctx))) return rc;
     // ---- per-episode phases
+    if (p.head_ready) HIP_TRY(hipStreamWaitEvent(st, p.head_ready, 0));       // `head` was produced on another stream
     EpiParams prm;
     for (int i = 0; i < MAXL; ++i) { prm.W[i] = i < p.L ? p.W[i] : nullptr; prm.b[i] = i < p.L ? p.b[i] : nullptr; }
     {
@@ -1469,6 +1472,7 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
         }
         LAUNCH_CHECK();
     }
+    if (p.after_reverse) HIP_TRY(hipEventRecord(p.after_reverse, st));        // head_bar is complete
     // ---- sums over episodes in one launch: meta-gradients of the hidden layers, layer-0 bias, loss/accuracy totals
     {
         ProfScope pr(ws, st, FUMI_PH_REDUCE);

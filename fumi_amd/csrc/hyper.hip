@@ -4,8 +4,7 @@
 // The problem is tiny (R = B*N = 160 rows, 300|768 -> 256 -> H+1): as plain GEMM launches every product is a dozen
 // workgroups walking ~10 dependent contraction slabs.  Here each product is a grid of LDS-resident workgroups (common.h
 // "LDS-resident products"): the operands of a block are staged in ONE batch of loads and multiplied from LDS.
-//   fwd0:  u  = relu(c A0^T + b0)            grid (Ht/NC, R/16)   block: 16 rows x NC columns, K = Dt
-//   fwd1:  h  = [tanh](u A1^T + b1)          grid (R/16)          block: 16 rows x (H+1) columns, K = Ht
+//   lin:   y  = act(x W^T + b)               grid (N/NC, R/16)    block: 16 rows x NC columns, whole K; both forward layers
 //   bwd1:  hp = hbar [* tanh'], ubar = (hp A1) * relu'(u), partial slabs of hp^T u, colsum(hp), colsum(ubar)   grid (R/16)
 //   bwd0:  gA0 = scale * ubar^T c            grid (Dt/64, Ht/64)  block: 64 x 64 outputs, K = R
 // The per-row-block partial slabs of bwd1 are summed by launch_reduce_multi.
@@ -20,54 +19,35 @@ __host__ __device__ inline int h_r4(int x) { return (x + 3) & ~3; }
 __host__ __device__ inline int h_r16(int x) { return (x + 15) & ~15; }
 
 struct HyperDims { int R, Dt, Ht, H1, NC, tanh_head; float scale; };
+struct LinDims { int R, K, Nn, NC, act; };          // act: 1 relu, 2 tanh, 0 none
 
-// ---- fwd0: u[rb, nc] = relu(c[rb,:] A0[nc,:]^T + b0[nc]) -------------------------------------------------------------
-__global__ __launch_bounds__(512) void hyper_fwd0_kernel(StageTab stg, HyperDims d, float* __restrict__ u) {
+// ---- forward layer: y[rb, nc] = act(x[rb,:] W[nc,:]^T + b[nc]) -- both hypernetwork layers use it ---------------------------
+// 16 rows x NC output columns per workgroup, whole contraction staged at once.
+__global__ __launch_bounds__(512) void hyper_lin_kernel(StageTab stg, LinDims d, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ StageTab s_stg;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int cb = blockIdx.x, rb = blockIdx.y;
-    const int nr = min(HB, d.R - rb * HB), ncols = min(d.NC, d.Ht - cb * d.NC);
-    const int ldk = wg_ld(d.Dt);
-    float* ci = sm; float* Ai = sm + HB * ldk; float* bi = Ai + h_r16(d.NC) * ldk;
+    const int nr = min(HB, d.R - rb * HB), ncols = min(d.NC, d.Nn - cb * d.NC);
+    const int ldk = wg_ld(d.K);
+    float* xi = sm; float* Wi = sm + HB * ldk; float* bi = Wi + h_r16(d.NC) * ldk;
     const int tot = (HB + h_r16(d.NC)) * ldk + h_r4(d.NC);
     wg_stage_tab_to_lds(&s_stg);
     for (int i = tid * 4; i < tot; i += nt * 4) *(f32x4*)(sm + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    wg_stage_rows<20>(&s_stg, 0, rb, cb, nr, sm, ncols, ncols);
+    wg_stage_rows<16>(&s_stg, 0, rb, cb, nr, sm, ncols, ncols);
     wg_lds_barrier();
-    float* ur = u + (long)rb * HB * d.Ht + cb * d.NC;
-    wg_lmm<true, true>(nr, ncols, d.Dt, ci, ldk, Ai, ldk, [&](int m, int n, const f32x4& acc, int cnt) {
+    float* yr = y + (long)rb * HB * d.Nn + cb * d.NC;
+    wg_lmm<true, true>(nr, ncols, d.K, xi, ldk, Wi, ldk, [&](int m, int n, const f32x4& acc, int cnt) {
         f32x4 v = acc + *(const f32x4*)(bi + n);
+        if (d.act == 1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-        wg_st4(ur + (long)m * d.Ht + n, v, cnt);
-    });
-}
-
-// ---- fwd1: h[rb, :] = act(u[rb,:] A1^T + b1) -------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void hyper_fwd1_kernel(StageTab stg, HyperDims d, float* __restrict__ h) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ StageTab s_stg;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int rb = blockIdx.x;
-    const int nr = min(HB, d.R - rb * HB);
-    const int ldk = wg_ld(d.Ht);
-    float* ui = sm; float* Ai = sm + HB * ldk; float* bi = Ai + h_r16(d.H1) * ldk;
-    const int tot = (HB + h_r16(d.H1)) * ldk + h_r4(d.H1);
-    wg_stage_tab_to_lds(&s_stg);
-    for (int i = tid * 4; i < tot; i += nt * 4) *(f32x4*)(sm + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-    wg_stage_rows<12>(&s_stg, 0, rb, 0, nr, sm);
-    wg_lds_barrier();
-    float* hr = h + (long)rb * HB * d.H1;
-    wg_lmm<true, true>(nr, d.H1, d.Ht, ui, ldk, Ai, ldk, [&](int m, int n, const f32x4& acc, int cnt) {
-        f32x4 v = acc + *(const f32x4*)(bi + n);
-        if (d.tanh_head) {
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        } else if (d.act == 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
         }
-        wg_st4(hr + (long)m * d.H1 + n, v, cnt);
+        wg_st4(yr + (long)m * d.Nn + n, v, cnt);
     });
 }
 
@@ -138,50 +118,49 @@ __global__ __launch_bounds__(512) void hyper_bwd0_kernel(StageTab stg, HyperDims
 
 }  // namespace
 
-// all-or-nothing: returns 1 when the shapes do not fit the LDS-resident kernels (the caller then uses plain GEMMs)
+// column chunk of a forward layer with contraction depth K: largest of 64/32/16 whose block stays under LIN_CAP floats
+constexpr int LIN_CAP = HCAP;           // (a 76 KB cap would let a block share a CU with the X-panel kernel on the other
+                                        //  stream; measured: that slows the matrix pass by 40 % -- keep the blocks large)
+static int lin_chunk(int K) {
+    int NC = 64;
+    while (NC >= 16 && (HB + NC) * wg_ld(K) + NC > LIN_CAP) NC >>= 1;
+    return NC >= 16 ? NC : 0;
+}
+
+// all-or-nothing: 0 when the shapes do not fit the LDS-resident kernels (the caller then uses plain GEMMs)
 int hyper_lds_fits(int R, int Dt, int Ht, int H1) {
     if ((Dt & 3) || (Ht & 63) || R < 1) return 0;           // column chunks are copied as float4 / 64-wide blocks
-    int NC = 64;
-    while (NC >= 16 && (HB + NC) * wg_ld(Dt) + NC > HCAP) NC >>= 1;
-    if (NC < 16) return 0;
-    if ((HB + h_r16(H1)) * wg_ld(Ht) + h_r4(H1) > HCAP) return 0;
+    if (!lin_chunk(Dt) || !lin_chunk(Ht)) return 0;
     if (HB * wg_ld(H1) + 2 * HB * wg_ld(Ht) + h_r4(H1) * wg_ld(Ht) > HCAP) return 0;
     if (2 * h_r4(R) * wg_ld(64) > HCAP) return 0;
-    if ((Dt & 63) && ((Dt & 63) & 3)) return 0;
-    return NC;
+    return 1;
+}
+
+static int launch_lin(hipStream_t st, int R, int K, int Nn, int act, const float* x, const float* W, const float* b, float* y) {
+    const int NC = lin_chunk(K);
+    if (!NC) return FUMI_ENOTSUP;
+    LinDims d{R, K, Nn, NC, act};
+    const int ldk = wg_ld(K), nrb = (R + HB - 1) / HB;
+    StageTab tb; tb.init();
+    tb.add(x, 0, (long)HB * K, 0, K, -1, HB, K, 0, ldk);                                 // rows of this block
+    tb.add(W, 0, 0, (long)NC * K, K, -2, NC, K, HB * ldk, ldk);                          // weight rows of this column chunk
+    tb.add(b, 0, 0, NC, Nn, 1, 1, -NC, (HB + h_r16(NC)) * ldk, NC);
+    // a narrow last chunk is copied lane by lane when its width is no multiple of 4: keep the float4 path honest
+    if ((Nn % NC) & 3) tb.vec[2] = 0, tb.lg[2] = 6;
+    if (tb.bad || tb.nunits > 64 * 8) return FUMI_ENOTSUP;
+    const int tot = (HB + h_r16(NC)) * ldk + h_r4(NC);
+    HIP_TRY(hipFuncSetAttribute((const void*)hyper_lin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tot * 4));
+    hipLaunchKernelGGL(hyper_lin_kernel, dim3((Nn + NC - 1) / NC, nrb), dim3(512), tot * 4, st, tb, d, y);
+    LAUNCH_CHECK();
+    return FUMI_OK;
 }
 
 int launch_hyper_fwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_head, const float* c, const float* A0,
                      const float* b0, const float* A1, const float* b1, float* u, float* h) {
-    const int NC = hyper_lds_fits(R, Dt, Ht, H1);
-    if (!NC) return FUMI_ENOTSUP;
-    HyperDims d{R, Dt, Ht, H1, NC, tanh_head, 1.f};
-    const int nrb = (R + HB - 1) / HB;
-    {
-        const int ldk = wg_ld(Dt);
-        StageTab tb; tb.init();
-        tb.add(c, 0, (long)HB * Dt, 0, Dt, -1, HB, Dt, 0, ldk);                              // rows of this block
-        tb.add(A0, 0, 0, (long)NC * Dt, Dt, -2, NC, Dt, HB * ldk, ldk);                      // weight rows of this chunk
-        tb.add(b0, 0, 0, NC, Ht, 1, 1, -NC, (HB + h_r16(NC)) * ldk, NC);
-        if (tb.bad || tb.nunits > 64 * 8) return FUMI_ENOTSUP;
-        const int tot = (HB + h_r16(NC)) * ldk + h_r4(NC);
-        HIP_TRY(hipFuncSetAttribute((const void*)hyper_fwd0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tot * 4));
-        hipLaunchKernelGGL(hyper_fwd0_kernel, dim3((Ht + NC - 1) / NC, nrb), dim3(512), tot * 4, st, tb, d, u);
-        LAUNCH_CHECK();
-    }
-    {
-        const int ldk = wg_ld(Ht);
-        StageTab tb; tb.init();
-        tb.add(u, 0, (long)HB * Ht, 0, Ht, -1, HB, Ht, 0, ldk);
-        tb.add(A1, 0, 0, 0, Ht, H1, H1, Ht, HB * ldk, ldk);
-        tb.add(b1, 0, 0, 0, H1, 1, 1, H1, (HB + h_r16(H1)) * ldk, H1);
-        if (tb.bad || tb.nunits > 64 * 8) return FUMI_ENOTSUP;
-        const int tot = (HB + h_r16(H1)) * ldk + h_r4(H1);
-        HIP_TRY(hipFuncSetAttribute((const void*)hyper_fwd1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tot * 4));
-        hipLaunchKernelGGL(hyper_fwd1_kernel, dim3(nrb), dim3(512), tot * 4, st, tb, d, h);
-        LAUNCH_CHECK();
-    }
-    return FUMI_OK;
+    if (!hyper_lds_fits(R, Dt, Ht, H1)) return FUMI_ENOTSUP;
+    int rc = launch_lin(st, R, Dt, Ht, 1, c, A0, b0, u);
+    if (rc) return rc;
+    return launch_lin(st, R, Ht, H1, tanh_head ? 2 : 0, u, A1, b1, h);
 }
 
 size_t hyper_bwd_workspace_floats(int R, int Ht, int H1) {

@@ -453,3 +453,31 @@ def test_xpanel_fwd_split_bf16_has_fp32_accuracy(dev):
         assert errs["0"][k] < 2e-6, errs
         assert errs["1"][k] < 2e-6, errs
         assert errs["1"][k] < 4.0 * errs["0"][k] + 1e-7, errs
+
+
+def test_meta_batch_larger_than_the_chip_matches_chunks(dev, ws):
+    """72 episodes at the reference sizes: the split reverse sweep launches 8*9*4 = 288 workgroups of one CU each (> 256
+    CUs), so parts of an episode wait for partners that are dispatched later; T = 2 gives two exchange rounds.  Gradients
+    must equal the sum over chunks of 24 episodes (each chunk fits the chip), and the call must not hang."""
+    from fumi_amd import hip
+    B, N, K, Q, D, hid, Dt, Ht, T = 72, 5, 5, 32, 2048, [256, 64], 300, 256, 2
+    ep = cg.make_episodes(11, B, N, K, Q, D, Dt)
+    theta, phi = cg.make_fumi_params(11, D, hid, Dt, Ht)
+    g = lambda t: t.to(dev).contiguous()
+    th, ph = [g(t) for t in theta], [g(t) for t in phi]
+
+    def run(lo, hi):
+        o = hip.fumi_step_select(ws, N, g(ep["x_s"][lo:hi]), g(ep["y_s"][lo:hi]), g(ep["x_q"][lo:hi]), g(ep["y_q"][lo:hi]),
+                                 g(ep["text_s"][lo:hi]), th, ph, T, cg.ALPHA, False, grad_scale=1.0)
+        return [x.clone() for x in o["g_theta"] + o["g_phi"]], o["loss_b"].clone()
+
+    full, loss_full = run(0, B)
+    acc, losses = None, []
+    for lo in range(0, B, 24):
+        gs, lb = run(lo, lo + 24)
+        losses.append(lb)
+        acc = gs if acc is None else [a + b for a, b in zip(acc, gs)]
+    assert torch.allclose(loss_full, torch.cat(losses), rtol=1e-5, atol=1e-6)
+    floor = 0.05 * max(float(b.abs().max()) for b in acc)
+    for a, b in zip(full, acc):
+        assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), floor)
