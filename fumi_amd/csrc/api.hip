@@ -204,12 +204,16 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
         if ((rc = launch_class_text_select(st, B, N, S, Dt, text_s, y_s, c, ws->status))) return rc;
         ctext = c;
     }
-    // The text path (hypernetwork) and the image path (the two X-panel passes) only meet at the inner loop: the
-    // hypernetwork forward runs on the workspace's side stream beside xpanel_fwd, its backward beside xpanel_bwd.  Both
-    // are a handful of small latency-bound workgroups next to a chip-filling matrix kernel, so the overlap is nearly free.
-    static const bool no_overlap = getenv("FUMI_NO_OVERLAP") != nullptr;
-    const bool fork = ws->side && !no_overlap;
-    hipStream_t sh = fork ? ws->side : st;             // stream of the hypernetwork kernels
+    // The text path (hypernetwork) and the image path (the two X-panel passes) only meet at the inner loop, so the
+    // hypernetwork can run on the workspace's side stream beside xpanel_fwd (forward) / xpanel_bwd (backward).
+    // FUMI_OVERLAP bit 0: hypernetwork forward beside xpanel_fwd, bit 1: hypernetwork backward beside xpanel_bwd.
+    // Off by default.  Measured at the bench shapes (ms per step): 0 -> 0.3605, 1 -> 0.366, 2 -> 0.361, 3 -> 0.3533: a cross-
+    // stream fork + join costs ~15 us of event latency on this platform, about what hiding the small kernels saves, and the
+    // hypernetwork's workgroups stretch the matrix pass they run beside (80 -> 87 us).  Kept as a knob for larger text towers.
+    static const int overlap = getenv("FUMI_OVERLAP") ? atoi(getenv("FUMI_OVERLAP")) : 0;
+    const bool fork_bwd = ws->side && (overlap & 2) && need_grad;
+    const bool fork = ws->side && (overlap & 1);       // forward fork
+    hipStream_t sh = fork ? ws->side : st;             // stream of the hypernetwork forward
     GemmArgs g;
     auto hyper_forward = [&]() -> int {
         if (fork) HIP_TRY(hipStreamWaitEvent(sh, ws->ev[0], 0));     // class text rows are ready (recorded before xpanel_fwd)
@@ -236,15 +240,16 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
         p.after_xpanel_fwd = [](void* c) -> int { return (*(HF*)c)(); };
         p.hook_ctx = &hyper_forward;
         p.head_ready = ws->ev[1];
-        if (need_grad) p.after_reverse = ws->ev[2];
     } else if ((rc = hyper_forward())) return rc;
+    if (fork_bwd) p.after_reverse = ws->ev[2];
 
     p.head = h; p.head_bar = hbar;
     if ((rc = run_episodes(ws, st, p))) return rc;
     if (!need_grad) return FUMI_OK;
 
     // hypernetwork backward: rows are (episode, class) pairs, weights are shared
-    if (fork) HIP_TRY(hipStreamWaitEvent(sh, ws->ev[2], 0));       // head_bar is complete (recorded after the reverse sweep)
+    sh = fork_bwd ? ws->side : st;
+    if (fork_bwd) HIP_TRY(hipStreamWaitEvent(sh, ws->ev[2], 0));   // head_bar is complete (recorded after the reverse sweep)
     rc = [&]() -> int {
     ProfScope ps(ws, sh, FUMI_PH_HYPER_BWD);
     if (hyper_lds) {
@@ -268,7 +273,7 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
     return FUMI_OK;
     }();
     if (rc) return rc;
-    if (fork) {                                                      // join: the caller's stream owns every result again
+    if (fork_bwd) {                                                  // join: the caller's stream owns every result again
         HIP_TRY(hipEventRecord(ws->ev[3], sh));
         HIP_TRY(hipStreamWaitEvent(st, ws->ev[3], 0));
     }

@@ -50,6 +50,20 @@ void fumi_set_hip_error(hipError_t e, const char* where);
         if (_e != hipSuccess) { fumi_set_hip_error(_e, __func__); return FUMI_EHIP; } \
     } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size growth) instead of before every launch
+#define FUMI_SET_DYN_LDS(kernel, bytes)                                                                   \
+    do {                                                                                                  \
+        static int _max_set[64];                                                                          \
+        static bool _init = false;                                                                        \
+        if (!_init) { for (int& _v : _max_set) _v = -1; _init = true; }                                   \
+        int _dev = 0;                                                                                     \
+        HIP_TRY(hipGetDevice(&_dev));                                                                     \
+        if (_dev < 0 || _dev >= 64 || (int)(bytes) > _max_set[_dev]) {                                    \
+            HIP_TRY(hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+            if (_dev >= 0 && _dev < 64) _max_set[_dev] = (int)(bytes);                                    \
+        }                                                                                                 \
+    } while (0)
+
 // make sure the slab holds `bytes`; grows (synchronising) when it does not
 int ws_reserve(fumi_ws* ws, size_t bytes);
 static inline size_t ws_align(size_t b) { return (b + 255) & ~(size_t)255; }

@@ -1377,10 +1377,10 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
             lds_form = !tb.bad && tb.nunits <= 64 * 8;
         }
         if (lds_form) {
-            HIP_TRY(hipFuncSetAttribute((const void*)adapt_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, al.total * 4));
+            FUMI_SET_DYN_LDS(adapt_lds_kernel, al.total * 4);
             hipLaunchKernelGGL(adapt_lds_kernel, dim3(p.B), dim3(512), al.total * 4, st, tb, d, w, al, prm, p.y_s, ws->status);
         } else {
-            HIP_TRY(hipFuncSetAttribute((const void*)adapt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, w.lds_adapt * 4));
+            FUMI_SET_DYN_LDS(adapt_kernel, w.lds_adapt * 4);
             hipLaunchKernelGGL(adapt_kernel, dim3(p.B), dim3(512), w.lds_adapt * 4, st, d, w, prm, p.y_s, p.head, ws->status);
         }
         LAUNCH_CHECK();
@@ -1410,11 +1410,11 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
             lds_form = !tb.bad && tb.nunits <= 64 * 8;      // wg_stage_rows: one unit per lane and wave
         }
         if (lds_form) {
-            HIP_TRY(hipFuncSetAttribute((const void*)query_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ql.total * 4));
+            FUMI_SET_DYN_LDS(query_lds_kernel, ql.total * 4);
             hipLaunchKernelGGL(query_lds_kernel, dim3(w.ntile, p.B), dim3(512), ql.total * 4, st, tb, d, w, ql, p.y_q,
                                p.logits_q, p.preds_q, p.preds_f, ws->status);
         } else {
-            HIP_TRY(hipFuncSetAttribute((const void*)query_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, w.lds_query * 4));
+            FUMI_SET_DYN_LDS(query_kernel, w.lds_query * 4);
             hipLaunchKernelGGL(query_kernel, dim3(w.ntile, p.B), dim3(512), w.lds_query * 4, st, d, w, p.b[0], p.y_q, p.logits_q,
                                p.preds_q, p.preds_f, ws->status);
         }
@@ -1463,11 +1463,11 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
             lds_form = !ti.bad && !tsx.bad && ti.nunits <= 64 * 8 && tsx.nunits <= 64 * 8;
         }
         if (lds_form) {
-            HIP_TRY(hipFuncSetAttribute((const void*)reverse_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rl.total * 4));
+            FUMI_SET_DYN_LDS(reverse_lds_kernel, rl.total * 4);
             hipLaunchKernelGGL(reverse_lds_kernel, dim3(8 * ((p.B + 7) / 8) * P), dim3(512), rl.total * 4, st, ti, tsx, d, w, rl, P,
                                p.loss_b, p.acc_b, p.head_bar);
         } else {
-            HIP_TRY(hipFuncSetAttribute((const void*)reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, w.lds_reverse * 4));
+            FUMI_SET_DYN_LDS(reverse_kernel, w.lds_reverse * 4);
             hipLaunchKernelGGL(reverse_kernel, dim3(p.B), dim3(512), w.lds_reverse * 4, st, d, w, p.loss_b, p.acc_b, p.head_bar);
         }
         LAUNCH_CHECK();

@@ -149,7 +149,7 @@ static int launch_lin(hipStream_t st, int R, int K, int Nn, int act, const float
     if ((Nn % NC) & 3) tb.vec[2] = 0, tb.lg[2] = 6;
     if (tb.bad || tb.nunits > 64 * 8) return FUMI_ENOTSUP;
     const int tot = (HB + h_r16(NC)) * ldk + h_r4(NC);
-    HIP_TRY(hipFuncSetAttribute((const void*)hyper_lin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tot * 4));
+    FUMI_SET_DYN_LDS(hyper_lin_kernel, tot * 4);
     hipLaunchKernelGGL(hyper_lin_kernel, dim3((Nn + NC - 1) / NC, nrb), dim3(512), tot * 4, st, tb, d, y);
     LAUNCH_CHECK();
     return FUMI_OK;
@@ -184,7 +184,7 @@ int launch_hyper_bwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_hea
         tb.add(A1, 0, 0, 0, Ht, H1, H1, Ht, HB * ld1 + 2 * HB * ldt, ldt);
         if (tb.bad || tb.nunits > 64 * 8) return FUMI_ENOTSUP;
         const int tot = HB * ld1 + 2 * HB * ldt + h_r4(H1) * ldt;
-        HIP_TRY(hipFuncSetAttribute((const void*)hyper_bwd1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tot * 4));
+        FUMI_SET_DYN_LDS(hyper_bwd1_kernel, tot * 4);
         hipLaunchKernelGGL(hyper_bwd1_kernel, dim3(nrb), dim3(512), tot * 4, st, tb, d, h, ub, pA1, pb1, pb0);
         LAUNCH_CHECK();
     }
@@ -196,7 +196,7 @@ int launch_hyper_bwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_hea
         tb.add(c, 0, 64, 0, Dt, R, R, -64, RS * ld, ld);
         if (tb.bad || tb.nunits > 64 * 8) return FUMI_ENOTSUP;
         const int tot = 2 * RS * ld;
-        HIP_TRY(hipFuncSetAttribute((const void*)hyper_bwd0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tot * 4));
+        FUMI_SET_DYN_LDS(hyper_bwd0_kernel, tot * 4);
         hipLaunchKernelGGL(hyper_bwd0_kernel, dim3((Dt + 63) / 64, Ht / 64), dim3(512), tot * 4, st, tb, d, gA0);
         LAUNCH_CHECK();
     }

@@ -22,4 +22,5 @@ class FlatGrads:
 
     def attach(self):
         for p, v in zip(self.params, self.views):
-            p.grad = v
+            if p.grad is not v:                  # stays attached from step to step: the engine overwrites the whole buffer
+                p.grad = v

@@ -152,9 +152,9 @@ class FUMI(nn.Module):
         """One meta-batch (fumi.py:115-196).  Returns (loss np scalar, acc np scalar, preds float [B,Qn], targets)."""
         train = task == "train"
         if train:
-            self.train()
-            self.zero_grad()
-        else:
+            if not self.training:                # (nn.Module.train() walks every submodule: skip it when nothing changes)
+                self.train()
+        elif self.training:
             self.eval()
         # train-mode Dropout after each ReLU of im_net (fumi.py:93-99; CLI default --dropout 0.25): masks are drawn inside
         # the engine from a counter-based hash of a per-step seed taken from torch's CPU generator (so torch.manual_seed
@@ -195,9 +195,8 @@ class FUMI(nn.Module):
                             cls_text=cls_text, stats=tail, dropout_p=drop_p, seed=drop_seed)
         fdist.all_reduce_sum_(fg.flat if train else tail)
         if train:
-            optimizer.zero_grad()
-            fg.attach()
-            optimizer.step()
+            fg.attach()                          # .grad of every parameter IS a view of the buffer the engine just filled
+            optimizer.step()                     # (so there is nothing left for zero_grad() to clear, fumi.py:190-193)
         preds = out["preds_f"]                                   # float, like the reference's test_preds (fumi.py:180-183)
         if fdist.world()[1] > 1 and not train:
             preds = fdist.all_gather_rows(preds)

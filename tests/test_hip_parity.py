@@ -481,3 +481,17 @@ def test_meta_batch_larger_than_the_chip_matches_chunks(dev, ws):
     floor = 0.05 * max(float(b.abs().max()) for b in acc)
     for a, b in zip(full, acc):
         assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), floor)
+
+
+def test_side_stream_overlap_in_subprocess(dev):
+    """FUMI_OVERLAP=3 runs the hypernetwork forward / backward on the workspace's side stream beside the two X-panel passes
+    (fork / join with events).  Same results required; the knob is read once per process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-q", "-m", "gpu",
+                        "-p", "no:cacheprovider", "-k", "fumi_step_matches_reference or larger_than_the_chip"],
+                       env=dict(os.environ, FUMI_OVERLAP="3"), cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
