@@ -244,6 +244,8 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
     if (fork_bwd) p.after_reverse = ws->ev[2];
 
     p.head = h; p.head_bar = hbar;
+    ReduceSegs fin; fin.n = 0; fin.scale = grad_scale;          // every final sum of the step (episodes, gW0 slabs, hypernet
+    if (need_grad) p.defer_reduce = &fin;                       // row-block slabs) goes into ONE launch at the very end
     if ((rc = run_episodes(ws, st, p))) return rc;
     if (!need_grad) return FUMI_OK;
 
@@ -254,7 +256,7 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
     ProfScope ps(ws, sh, FUMI_PH_HYPER_BWD);
     if (hyper_lds) {
         int rc2 = launch_hyper_bwd(sh, R, Dt, Ht, H1, tanh_head, grad_scale, ctext, u, h, hbar, phi[2], ub, hpart,
-                                   g_phi[0], g_phi[1], g_phi[2], g_phi[3]);
+                                   g_phi[0], g_phi[1], g_phi[2], g_phi[3], &fin);
         if (rc2 != FUMI_ENOTSUP) return rc2;
     }
     const float* hp = hbar;
@@ -276,6 +278,10 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
     if (fork_bwd) {                                                  // join: the caller's stream owns every result again
         HIP_TRY(hipEventRecord(ws->ev[3], sh));
         HIP_TRY(hipStreamWaitEvent(st, ws->ev[3], 0));
+    }
+    {
+        ProfScope pr(ws, st, FUMI_PH_REDUCE);
+        if ((rc = launch_reduce_multi(st, fin))) return rc;
     }
     return FUMI_OK;
 }

@@ -149,6 +149,8 @@ struct EpisodeProblem {
     // optional cross-stream hooks (FuMI): `head` is produced on another stream -> wait for head_ready before the inner
     // loop; record after_reverse once head_bar is complete so its consumer can start beside the layer-0 gradient pass
     hipEvent_t head_ready, after_reverse;
+    struct ReduceSegs* defer_reduce;            // not NULL: the final sums over episodes / slabs are appended here and the
+                                                // caller launches them (one launch for the whole step) instead of run_episodes
     hipEvent_t inputs_ready;                    // recorded on the caller's stream BEFORE the first launch (fork point)
     int (*after_xpanel_fwd)(void*); void* hook_ctx;   // host callback right after xpanel_fwd is enqueued: the producer of `head`
                                                 // is launched there, so its host-side preparation does not delay the matrix pass
@@ -163,7 +165,7 @@ int launch_hyper_fwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_hea
                      const float* b0, const float* A1, const float* b1, float* u, float* h);
 int launch_hyper_bwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_head, float scale, const float* c,
                      const float* u, const float* h, const float* hbar, const float* A1, float* ub, float* part,
-                     float* gA0, float* gb0, float* gA1, float* gb1);
+                     float* gA0, float* gb0, float* gA1, float* gb1, ReduceSegs* defer = nullptr);
 
 // small kernels shared by the entry points (episode.hip)
 int launch_class_text_select(hipStream_t st, int B, int N, int S, int Dt, const float* text_s, const int64_t* y_s,

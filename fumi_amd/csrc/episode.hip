@@ -1476,7 +1476,10 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     // ---- sums over episodes in one launch: meta-gradients of the hidden layers, layer-0 bias, loss/accuracy totals
     {
         ProfScope pr(ws, st, FUMI_PH_REDUCE);
-        ReduceSegs sg; sg.n = 0; sg.scale = p.grad_scale;
+        ReduceSegs own; own.n = 0; own.scale = p.grad_scale;
+        const bool defer = p.defer_reduce && p.need_grad && p.defer_reduce->n + 4 + 2 * p.L <= 24;
+        ReduceSegs& sg = defer ? *p.defer_reduce : own;
+        if (defer) sg.scale = p.grad_scale;
         if (p.stats) { sg.add(p.loss_b, p.B, 1, 1, p.stats); sg.add(p.acc_b, p.B, 1, 1, p.stats + 1); }
         if (p.need_grad) {
             for (int i = 1; i < p.L; ++i) {
@@ -1486,7 +1489,7 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
             }
             sg.add(w.b0b, p.B, h0, h0, p.gb[0]);
         }
-        if ((rc = launch_reduce_multi(st, sg))) return rc;
+        if (!defer && (rc = launch_reduce_multi(st, own))) return rc;
     }
     if (!p.need_grad) return FUMI_OK;
     // ---- shared pass 2 over X: gW0 = Abar0^T [Xs;Xq], contraction over all B*R rows split into slabs (xpanel.hip)
@@ -1497,7 +1500,8 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
         const long slab = (long)h0 * p.D;
         float* slabs = ws_f(ws, (size_t)ns * slab);
         if ((rc = launch_xpanel_bwd(st, p.B, p.S, p.Qn, p.D, h0, p.x_s, p.x_q, w.A0bar, slabs, kc, ns))) return rc;
-        if ((rc = launch_reduce_slabs(st, slabs, ns, slab, slab, p.grad_scale, p.gW[0]))) return rc;
+        if (p.defer_reduce && p.defer_reduce->n < 24 && p.defer_reduce->scale == p.grad_scale) p.defer_reduce->add(slabs, ns, slab, slab, p.gW[0]);
+        else if ((rc = launch_reduce_slabs(st, slabs, ns, slab, slab, p.grad_scale, p.gW[0]))) return rc;
     }
     return FUMI_OK;
 }

@@ -171,7 +171,7 @@ size_t hyper_bwd_workspace_floats(int R, int Ht, int H1) {
 // g_phi = {gA0 [Ht,Dt], gb0 [Ht], gA1 [H1,Ht], gb1 [H1]}, all scaled by `scale`; ub [R,Ht] and `part` are workspace
 int launch_hyper_bwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_head, float scale, const float* c,
                      const float* u, const float* h, const float* hbar, const float* A1, float* ub, float* part,
-                     float* gA0, float* gb0, float* gA1, float* gb1) {
+                     float* gA0, float* gb0, float* gA1, float* gb1, ReduceSegs* defer) {
     if (!hyper_lds_fits(R, Dt, Ht, H1)) return FUMI_ENOTSUP;
     HyperDims d{R, Dt, Ht, H1, 64, tanh_head, scale};
     const int nrb = (R + HB - 1) / HB;
@@ -200,9 +200,10 @@ int launch_hyper_bwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_hea
         hipLaunchKernelGGL(hyper_bwd0_kernel, dim3((Dt + 63) / 64, Ht / 64), dim3(512), tot * 4, st, tb, d, gA0);
         LAUNCH_CHECK();
     }
-    ReduceSegs sg; sg.n = 0; sg.scale = scale;
+    ReduceSegs own; own.n = 0; own.scale = scale;
+    ReduceSegs& sg = (defer && defer->n + 3 <= 24 && defer->scale == scale) ? *defer : own;
     sg.add(pA1, nrb, (long)H1 * Ht, (long)H1 * Ht, gA1);
     sg.add(pb1, nrb, H1, H1, gb1);
     sg.add(pb0, nrb, Ht, Ht, gb0);
-    return launch_reduce_multi(st, sg);
+    return &sg == &own ? launch_reduce_multi(st, own) : FUMI_OK;
 }
