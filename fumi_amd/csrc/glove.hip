@@ -5,28 +5,30 @@
 // and, in its "select" form, also the per-class first-support-row pick of fumi/models/fumi.py:207-210 (FuMI only needs
 // the text of N class rows per episode, not of all S support rows: 5x fewer table rows gathered).
 //
-// HBM/L2-bound gather: one workgroup (4 waves) per output row.  A wave's token ids are read 64 at a time with one coalesced load and
-// handed out by cross-lane shuffles; the table rows of 8 tokens are requested back to back (8 independent 16-byte-per-
+// HBM/L2-bound gather: one workgroup (8 waves) per output row.  A wave's token ids are read 64 at a time with one coalesced load and
+// handed out by cross-lane shuffles; the table rows of 16 tokens are requested back to back (16 independent 16-byte-per-
 // lane gathers in flight) before any is accumulated -- a loop that reads a token id and then its row is two dependent
 // memory round trips per token.
 #include "common.h"
 
 namespace {
 
-// one 256-thread workgroup per output row: the row's L tokens are split over the 4 waves (4x the gathers in flight per
+// one 512-thread workgroup per output row: the row's L tokens are split over the 8 waves (8x the gathers in flight per
 // row; the whole launch is only B*N = 160 rows at the bench shape, so a wave per row left most CUs idle)
+constexpr int GW = 8;        // waves per output row
+constexpr int GU = 16;       // row gathers in flight per wave
 template <bool VEC>
-__global__ __launch_bounds__(256) void glove_bag_kernel(const int64_t* __restrict__ tok, int R, int L, int64_t pad_id,
+__global__ __launch_bounds__(512) void glove_bag_kernel(const int64_t* __restrict__ tok, int R, int L, int64_t pad_id,
                                                         const float* __restrict__ table, int V, int E, int mode,
                                                         float* __restrict__ out, int* status,
                                                         const int64_t* __restrict__ y_s, int N, int S) {
-    extern __shared__ __attribute__((aligned(16))) float part[];      // [4][Ep] partial sums / maxima, then [4] counts
+    extern __shared__ __attribute__((aligned(16))) float part[];      // [GW][Ep] partial sums / maxima, then [GW] counts
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x;
     constexpr int W = VEC ? 4 : 1;
     const int nchunk = (E / W + 63) / 64;        // chunks of 64 lanes x W floats
     const int Ep = nchunk * 64 * W;
-    float* cnts = part + 4 * Ep;
+    float* cnts = part + GW * Ep;
     long src_row = r;
     if (y_s) {                                   // select form: output row r = (episode, class); source = first support row of the class
         const int b = r / N, c = r - b * N;
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void glove_bag_kernel(const int64_t* __restric
         src_row = (long)b * S + first;
     }
     const int64_t* t = tok + src_row * L;
-    const int lw = (L + 3) / 4;                  // tokens per wave
+    const int lw = (L + GW - 1) / GW;            // tokens per wave
     const int lbeg = wave * lw, lend = min(L, lbeg + lw);
     for (int c = 0; c < nchunk; ++c) {
         const int j = (c * 64 + lane) * W;
@@ -59,16 +61,16 @@ __global__ __launch_bounds__(256) void glove_bag_kernel(const int64_t* __restric
             cnt += __popcll(__ballot(lane < nl && my != pad_id));
             if (my < 0 || my >= V) { if (lane < nl) atomicOr(status, FUMI_ST_LABEL_RANGE); my = 0; }
             const int mylo = (int)my;
-            for (int u0 = 0; u0 < nl; u0 += 8) {
-                f32x4 v[8];
+            for (int u0 = 0; u0 < nl; u0 += GU) {
+                f32x4 v[GU];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < GU; ++u) {
                     const int id = __shfl(mylo, min(u0 + u, nl - 1), 64);
                     const float* row = table + (long)id * E + jc;
                     if (VEC) v[u] = *(const f32x4*)row; else { v[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; v[u][0] = row[0]; }
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < GU; ++u) {
                     if (u0 + u < nl) {
                         if (mode == 0) acc += v[u];
                         else { acc[0] = fmaxf(acc[0], v[u][0]); acc[1] = fmaxf(acc[1], v[u][1]); acc[2] = fmaxf(acc[2], v[u][2]); acc[3] = fmaxf(acc[3], v[u][3]); }
@@ -81,20 +83,24 @@ __global__ __launch_bounds__(256) void glove_bag_kernel(const int64_t* __restric
         if (lane == 0 && c == 0) cnts[wave] = (float)cnt;
     }
     __syncthreads();
-    const float dn = cnts[0] + cnts[1] + cnts[2] + cnts[3];
+    float dn = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < GW; ++w_) dn += cnts[w_];
     for (int j = threadIdx.x; j < E; j += blockDim.x) {
-        const float a0 = part[j], a1 = part[Ep + j], a2 = part[2 * Ep + j], a3 = part[3 * Ep + j];
-        out[(long)r * E + j] = mode == 0 ? ((a0 + a1) + (a2 + a3)) / dn : fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+        float a = part[j];
+#pragma unroll
+        for (int w_ = 1; w_ < GW; ++w_) a = mode == 0 ? a + part[w_ * Ep + j] : fmaxf(a, part[w_ * Ep + j]);
+        out[(long)r * E + j] = mode == 0 ? a / dn : a;
     }
 }
 
 int launch_bag(fumi_ws_t* ws, hipStream_t st, const int64_t* tok, int R, int L, int64_t pad_id, const float* table, int V,
                int E, int mode, float* out, const int64_t* y_s, int N, int S) {
     const bool vec = E % 4 == 0 && ((uintptr_t)table & 15) == 0 && ((uintptr_t)out & 15) == 0;
-    dim3 grid(R), block(256);
+    dim3 grid(R), block(64 * GW);
     const int W = vec ? 4 : 1;
     const int Ep = ((E / W + 63) / 64) * 64 * W;
-    const size_t lds = (size_t)(4 * Ep + 4) * sizeof(float);
+    const size_t lds = (size_t)(GW * Ep + GW) * sizeof(float);
     if (lds > 64 * 1024) return FUMI_ENOTSUP;
     if (vec) hipLaunchKernelGGL(glove_bag_kernel<true>, grid, block, lds, st, tok, R, L, pad_id, table, V, E, mode, out, ws->status, y_s, N, S);
     else hipLaunchKernelGGL(glove_bag_kernel<false>, grid, block, lds, st, tok, R, L, pad_id, table, V, E, mode, out, ws->status, y_s, N, S);
