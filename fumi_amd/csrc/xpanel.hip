@@ -463,107 +463,6 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* 
     }
 }
 
-// ---- forward, 8-wave variant: the same 64x64x64 slabs, but two waves per 32x32 output quadrant, each multiplying half
-// of every slab's k range (k-groups {0,1} / {2,3}); their accumulators are added through LDS at the end.  Two waves per
-// SIMD from the SAME workgroup share the staged data, so one wave's stalls (LDS latency after the slab barrier, the
-// staging writes) are covered by its partner's MFMAs without any extra memory traffic.
-template <int NST>
-__global__ __launch_bounds__(512) void xpanel_fwd8_kernel(XPanel p, float* __restrict__ A0, float* __restrict__ G,
-                                                          int tiles_m, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][64 * FLD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wq = wave & 3, kg = wave >> 2;             // output quadrant, k-half
-    const int wm = wq >> 1, wn = wq & 1;
-    const int R = p.S + p.Qn, C = p.h0 + p.S, K = p.D;
-    const int tiles = tiles_m * tiles_n;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int b = xcd + 8 * (j / tiles), t = j % tiles;
-    if (b >= p.B) return;
-    const int m0 = (t / tiles_n) * 64, n0 = (t % tiles_n) * 64;
-
-    const float* arow[2]; const float* brow[2]; bool aok[2], bok[2];
-    const int k4 = (tid & 15) << 2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rr = (tid >> 4) + 32 * i;
-        const int r = m0 + rr, c = n0 + rr;
-        aok[i] = r < R; bok[i] = c < C;
-        arow[i] = xrow(p, b, aok[i] ? r : 0) + k4;
-        brow[i] = (c < p.h0 ? p.W0 + (long)c * K : p.x_s + ((long)b * p.S + (bok[i] ? c - p.h0 : 0)) * K) + k4;
-    }
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 ga[NST][2], gb[NST][2];
-    const int li = lane & 31, kh = lane >> 5;
-    const int aoff = (wm * 32 + li) * FLD + 4 * kh + 32 * kg, boff = (wn * 32 + li) * FLD + 4 * kh + 32 * kg;
-    f32x4 fa[2][2], fb[2][2];
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int nslab = K / FBK;
-#define XP_GLOAD(st, k0)                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
-        ga[st][i] = *(const f32x4*)(arow[i] + (k0)); gb[st][i] = *(const f32x4*)(brow[i] + (k0)); }
-#define XP_LSTORE(st, buf)                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
-        const int off = ((tid >> 4) + 32 * i) * FLD + k4;                                                    \
-        *(f32x4*)(lds[buf][0] + off) = aok[i] ? ga[st][i] : zero4;                                           \
-        *(f32x4*)(lds[buf][1] + off) = bok[i] ? gb[st][i] : zero4; }
-#define XP_FREAD(rb, buf, g)                                                                                 \
-    { fa[rb][0] = *(const f32x4*)(lds[buf][0] + aoff + 16 * (g));     fb[rb][0] = *(const f32x4*)(lds[buf][1] + boff + 16 * (g)); \
-      fa[rb][1] = *(const f32x4*)(lds[buf][0] + aoff + 16 * (g) + 8); fb[rb][1] = *(const f32x4*)(lds[buf][1] + boff + 16 * (g) + 8); }
-#define XP_MMA8(rb)                                                                                          \
-    _Pragma("unroll") for (int h = 0; h < 2; ++h) _Pragma("unroll") for (int e = 0; e < 4; ++e)              \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rb][h][e], fb[rb][h][e], acc, 0, 0, 0);
-#define XP_SLAB(ST, s)                                                                                       \
-    if ((s) < nslab) {                                                                                       \
-        const int cur = (s) & 1;                                                                             \
-        const bool more = (s) + 1 < nslab;                                                                   \
-        XP_FREAD(1, cur, 1) XP_MMA8(0)                                                                       \
-        if (more) { XP_LSTORE(ST, cur ^ 1) }                                                                 \
-        if ((s) + 1 + NST < nslab) { XP_GLOAD(ST, ((s) + 1 + NST) * FBK) }                                   \
-        XP_MMA8(1)                                                                                           \
-        __syncthreads();                                                                                     \
-        if (more) XP_FREAD(0, cur ^ 1, 0)                                                                    \
-    }
-    XP_GLOAD(0, 0)
-    XP_LSTORE(0, 0)
-    if (1 < nslab) { XP_GLOAD(0, 1 * FBK) }
-    if (NST > 1 && 2 < nslab) { XP_GLOAD(1 % NST, 2 * FBK) }
-    __syncthreads();
-    XP_FREAD(0, 0, 0)
-    for (int s = 0; s < nslab; s += NST) {
-        XP_SLAB(0, s)
-        if (NST > 1) { XP_SLAB(1 % NST, s + 1) }
-    }
-#undef XP_GLOAD
-#undef XP_LSTORE
-#undef XP_FREAD
-#undef XP_MMA8
-#undef XP_SLAB
-    // add the two k-halves: waves 4..7 park their accumulators in LDS (the staging buffers are free after the last barrier)
-    float* red = &lds[0][0][0];
-    if (kg == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[(wq * 16 + r) * 64 + lane] = acc[r];
-    }
-    __syncthreads();
-    if (kg == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += red[(wq * 16 + r) * 64 + lane];
-        const int n = n0 + wn * 32 + li;
-        if (n < C) {
-            float* base; long ld; int col;
-            if (n < p.h0) { base = A0 + (long)b * R * p.h0; ld = p.h0; col = n; }
-            else          { base = G + (long)b * R * p.S;  ld = p.S;  col = n - p.h0; }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (m < R) base[(long)m * ld + col] = acc[r];
-            }
-        }
-    }
-}
-
 // ---- backward ------------------------------------------------------------------------------------------------------
 // slab[z][i, j] = sum over global rows g in [z*kchunk, (z+1)*kchunk) of Abar0[g, i] * X(g)[j];  g = b*R + r
 template <bool FAST>     // FAST: h0 % 64 == 0, D % 64 == 0, aligned -> unconditional float4 staging loads (see forward)
@@ -667,8 +566,7 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
     const int nper = (B + 7) / 8;
     const bool aligned = al16(x_s) && al16(x_q) && al16(W0);
     const dim3 grid(8 * nper * tiles_m * tiles_n);
-    static const int nst = getenv("FUMI_XP_NST") ? atoi(getenv("FUMI_XP_NST")) : 2;
-    static const int w8 = getenv("FUMI_XP_W8") ? atoi(getenv("FUMI_XP_W8")) : 0;
+    static const int nst = getenv("FUMI_XP_NST") ? atoi(getenv("FUMI_XP_NST")) : 2;      // staging ring depth (tuning knob)
     // FUMI_XP_SB=1: the split-bf16 kernel (fp32-equivalent accuracy on the bf16 matrix pipe).  Measured 65 us against the fp32
     // kernel's 78 us at the bench shapes -- both sit on the same ~8 TB/s L2 -> CU delivery of 64x64 tiles, so it
     // stays opt-in until the larger-tile version exists.
@@ -677,9 +575,6 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
         static const int sbn = getenv("FUMI_XP_SBN") ? atoi(getenv("FUMI_XP_SBN")) : 2;          // ring depth (tuning knob)
         if (sbn <= 2) hipLaunchKernelGGL(xpanel_fwd_sb_kernel<2>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n);
         else hipLaunchKernelGGL(xpanel_fwd_sb_kernel<4>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n);
-    } else if (aligned && D % FBK == 0 && w8) {
-        if (nst == 1) hipLaunchKernelGGL(xpanel_fwd8_kernel<1>, grid, dim3(512), 0, st, p, A0, G, tiles_m, tiles_n);
-        else hipLaunchKernelGGL(xpanel_fwd8_kernel<2>, grid, dim3(512), 0, st, p, A0, G, tiles_m, tiles_n);
     } else if (aligned && D % FBK == 0) {
         if (nst == 1) hipLaunchKernelGGL(xpanel_fwd_kernel<1>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, g_trace);
         else if (nst == 2) hipLaunchKernelGGL(xpanel_fwd_kernel<2>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, g_trace);

@@ -1,0 +1,64 @@
+"""GPU-resident episode sampler.
+
+The reference builds every task on the training thread: torchmeta picks N classes, ``InatAnim.__getitem__`` reads ALL image
+embeddings of each class from HDF5 (fumi/dataset/data.py:533-549), ``ClassSplitter`` shuffles and cuts K / Q samples, and the
+collate stacks B tasks and copies them to the device (``num_workers 0``, fumi/utils/utils.py:95-98).  Once the meta-step
+takes 0.35 ms that loader is the job.  Here the embedding table ([n_images, D] fp32; iNat-Anim is ~1.6 GB of the 288 GB of
+HBM), the per-class image lists (CSR) and the per-class text rows stay on the device; a meta-batch is two launches
+(``fumi_hip_sample_episodes`` + row gathers) and has the loader's batch contract:
+
+    batch = {'train': ([idx i64 [B,S], text [B,S,Dt] f32 | [B,S,L] i64, im f32 [B,S,D]], targets i64 [B,S]),
+             'test' : same with Qn = N * num_shots_test rows}
+
+with the class-major order / categorical labels of torchmeta's ConcatTask.  Sampling is reproducible from (seed, step)."""
+import numpy as np
+import torch
+
+from .. import hip
+
+
+class GpuEpisodeSampler:
+    def __init__(self, images, class_of_image, class_text, num_ways, num_shots, num_shots_test, batch_size, seed=123,
+                 length=None):
+        """images [n_images, D] fp32 (moved to the device once), class_of_image [n_images] ints (category of every row, as
+        inat_anim.json's annotations give it), class_text [C, Dt] fp32 or [C, L] int64 tokens (one row per class: the text of
+        a sample is its class description, data.py:543-549)."""
+        self.dev = images.device if images.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        self.images = images.to(self.dev, torch.float32).contiguous()
+        coi = np.asarray(class_of_image, dtype=np.int64)
+        C = int(class_text.shape[0])
+        if coi.min() < 0 or coi.max() >= C or len(coi) != self.images.shape[0]:
+            raise ValueError("class_of_image must hold one category in [0, C) per image row")
+        order = np.argsort(coi, kind="stable")
+        counts = np.bincount(coi, minlength=C)
+        self.class_ptr_host = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        self.class_items_host = order.astype(np.int64)
+        self.class_ptr = torch.from_numpy(self.class_ptr_host).to(self.dev)
+        self.class_items = torch.from_numpy(self.class_items_host).to(self.dev)
+        self.class_text = class_text.to(self.dev).contiguous()
+        self.C, self.N, self.K, self.Q, self.B = C, int(num_ways), int(num_shots), int(num_shots_test), int(batch_size)
+        self.seed, self.length = int(seed), length
+        if counts[counts > 0].min() < self.K + self.Q and (counts >= self.K + self.Q).sum() < self.N:
+            raise ValueError("fewer than num_ways classes have num_shots + num_shots_test images")
+        S, Qn = self.N * self.K, self.N * self.Q
+        lab = torch.arange(self.N, device=self.dev, dtype=torch.int64)
+        self.y_s = lab.repeat_interleave(self.K).unsqueeze(0).expand(self.B, S).contiguous()      # ConcatTask order
+        self.y_q = lab.repeat_interleave(self.Q).unsqueeze(0).expand(self.B, Qn).contiguous()
+        self.ws = hip.Workspace.get(self.dev)
+
+    def batch(self, step):
+        B, N, K, Q = self.B, self.N, self.K, self.Q
+        cls, it_s, it_q = hip.sample_episodes(self.ws, self.seed, step, B, N, K, Q, self.class_ptr, self.class_items)
+        x_s = hip.gather_rows(self.ws, self.images, it_s.view(-1)).view(B, N * K, -1)
+        x_q = hip.gather_rows(self.ws, self.images, it_q.view(-1)).view(B, N * Q, -1)
+        t_cls = hip.gather_rows(self.ws, self.class_text, cls.view(-1)).view(B, N, -1)           # one text row per class slot
+        text_s = t_cls.repeat_interleave(K, dim=1)
+        text_q = t_cls.repeat_interleave(Q, dim=1)
+        return {'train': ([it_s.view(B, N * K), text_s, x_s], self.y_s),
+                'test': ([it_q.view(B, N * Q), text_q, x_q], self.y_q)}
+
+    def __iter__(self):
+        i = 0
+        while self.length is None or i < self.length:
+            yield self.batch(i)
+            i += 1

@@ -62,3 +62,29 @@ def get_synthetic(args):
                                             args.num_shots, q, args.batch_size, args.seed, split, tokens)
     q_eval = int(100 / args.num_ways)                      # data.py:163-166,180-183
     return mk("train", args.num_shots_test), mk("val", q_eval), mk("test", q_eval), dictionary
+
+
+def get_synthetic_resident(args, images_per_class=48):
+    """``--dataset synthetic-resident``: the same learnable task family as ``synthetic``, but as a FIXED table of image
+    embeddings per split (n_classes x images_per_class rows) that lives in HBM and is sampled by the GPU-resident episode
+    sampler (fumi_amd/dataset/gpu_sampler.py) -- the shape of the real pipeline (precomputed embeddings + class descriptions)
+    without the files.  Needs a GPU."""
+    from .gpu_sampler import GpuEpisodeSampler
+    tokens, dictionary = None, None
+    if args.text_encoder in ("glove", "w2v"):
+        V, L = args.synthetic_vocab, args.synthetic_seq_len
+        tokens = (V, L, 0)
+        dictionary = {"PAD": 0}
+        dictionary.update({f"tok{i}": i for i in range(1, V)})
+    q_eval = int(100 / args.num_ways)
+    per = max(images_per_class, args.num_shots + max(args.num_shots_test, q_eval))
+
+    def mk(split, q):
+        base = SyntheticEpisodes(args.synthetic_classes, args.im_emb_dim, args.text_emb_dim, args.num_ways, args.num_shots, q,
+                                 args.batch_size, args.seed, split, tokens)
+        rs = np.random.RandomState(args.seed * 13 + len(split))
+        coi = np.repeat(np.arange(args.synthetic_classes), per)
+        images = base.mu[coi] + 2.0 * rs.standard_normal((len(coi), args.im_emb_dim)).astype(np.float32)
+        return GpuEpisodeSampler(torch.from_numpy(images.astype(np.float32)).to(args.device), coi, torch.from_numpy(base.text),
+                                 args.num_ways, args.num_shots, q, args.batch_size, seed=args.seed + len(split))
+    return mk("train", args.num_shots_test), mk("val", q_eval), mk("test", q_eval), dictionary

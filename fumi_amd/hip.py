@@ -23,6 +23,7 @@ SYMBOLS = [
     "fumi_hip_glove_bag", "fumi_hip_glove_bag_select", "fumi_hip_class_text_select", "fumi_hip_xpanel_fwd", "fumi_hip_xpanel_bwd",
     "fumi_hip_adam_step",
     "fumi_hip_linear_fwd", "fumi_hip_linear_bwd_data", "fumi_hip_linear_bwd_weight",
+    "fumi_hip_sample_episodes", "fumi_hip_gather_rows",
 ]
 
 ST_LABEL_RANGE, ST_CLASS_MISSING = 1, 2
@@ -84,6 +85,8 @@ def lib():
         L.fumi_hip_linear_fwd.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 3 + [c_int, c_void_p]
         L.fumi_hip_linear_bwd_data.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 3
         L.fumi_hip_linear_bwd_weight.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 4
+        L.fumi_hip_sample_episodes.argtypes = [c_void_p, c_void_p, ctypes.c_uint64, ctypes.c_uint64] + [c_int] * 5 + [c_void_p] * 5
+        L.fumi_hip_gather_rows.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]
         _lib = L
     return _lib
 
@@ -440,3 +443,32 @@ def linear_bwd_weight(ws, dy, x):
     _check(lib().fumi_hip_linear_bwd_weight(ws.handle, _stream(dev), M, N, K, _f32(dy, "dy"), _f32(x, "x"),
                                             _f32(dW, "dW"), _f32(db, "db")), "fumi_hip_linear_bwd_weight")
     return dW, db
+
+
+def sample_episodes(ws, seed, step, B, N, K, Q, class_ptr, class_items):
+    """Episode indices on the device (csrc/sampler.hip): classes [B,N], items_s [B,N,K], items_q [B,N,Q] (int64)."""
+    dev = _dev(class_ptr)
+    C = int(class_ptr.numel()) - 1
+    cls = torch.empty(B, N, device=dev, dtype=torch.int64)
+    it_s = torch.empty(B, N, K, device=dev, dtype=torch.int64)
+    it_q = torch.empty(B, N, Q, device=dev, dtype=torch.int64)
+    _check(lib().fumi_hip_sample_episodes(ws.handle, _stream(dev), int(seed) & 0xFFFFFFFFFFFFFFFF, int(step) & 0xFFFFFFFFFFFFFFFF,
+                                          B, N, K, Q, C, _i64(class_ptr, "class_ptr"), _i64(class_items, "class_items"),
+                                          _i64(cls, "classes"), _i64(it_s, "items_s"), _i64(it_q, "items_q")),
+           "fumi_hip_sample_episodes")
+    return cls, it_s, it_q
+
+
+def gather_rows(ws, table, idx):
+    """out[i, :] = table[idx[i], :] for a 2-d fp32 / int64 / int32 table on the device (byte copy of whole rows)."""
+    dev = _dev(table)
+    if table.dim() != 2 or not table.is_contiguous() or table.device != idx.device or idx.dtype != torch.int64:
+        raise FumiHipError("gather_rows: table must be a contiguous 2-d device tensor and idx an int64 tensor on the same device")
+    row_bytes = table.shape[1] * table.element_size()
+    if row_bytes % 4:
+        raise FumiHipError("gather_rows: row size must be a multiple of 4 bytes")
+    idx = idx.contiguous()
+    out = torch.empty(idx.numel(), table.shape[1], device=dev, dtype=table.dtype)
+    _check(lib().fumi_hip_gather_rows(ws.handle, _stream(dev), ctypes.c_void_p(table.data_ptr()), table.shape[0], row_bytes,
+                                      _i64(idx, "idx"), idx.numel(), ctypes.c_void_p(out.data_ptr())), "fumi_hip_gather_rows")
+    return out

@@ -23,6 +23,9 @@ def get_dataset(args):
     if args.dataset == "synthetic":
         from .dataset.synthetic import get_synthetic
         return get_synthetic(args)
+    if args.dataset == "synthetic-resident":       # same task family, drawn from an HBM-resident table by the GPU sampler
+        from .dataset.synthetic import get_synthetic_resident
+        return get_synthetic_resident(args)
     raise FileNotFoundError(
         f"--dataset {args.dataset}: the iNat-Anim loader (fumi/dataset/data.py) needs the Zenodo files under "
         f"{args.data_dir} and the h5py / nltk / transformers / gensim downloads, which are unavailable here; "

@@ -18,7 +18,7 @@ from .wandb_compat import wandb
 _FLAGS = [
     ("--wandb_entity", dict(type=str, default="multimodal-image-cls", help="W&B entity")),
     ("--wandb_project", dict(type=str, default="fumi", help="W&B project")),
-    ("--dataset", dict(type=str, default="inat-anim", help="Dataset to use (inat-anim, supervised-inat-anim, synthetic)")),
+    ("--dataset", dict(type=str, default="inat-anim", help="Dataset to use (inat-anim, supervised-inat-anim, synthetic, synthetic-resident)")),
     ("--data_dir", dict(type=str, default="./data", help="Directory to use for data")),
     ("--checkpoint", dict(type=str, default=None, help="Path to pretrained model (a best.pth.tar file, or a W&B run id when wandb is installed)")),
     ("--log_dir", dict(type=str, default="./results", help="Directory to use for results")),

@@ -162,6 +162,21 @@ int fumi_hip_linear_bwd_data(fumi_ws_t* ws, fumi_stream_t stream, int M, int N, 
 int fumi_hip_linear_bwd_weight(fumi_ws_t* ws, fumi_stream_t stream, int M, int N, int K,
         const float* dy, const float* x, float* dW, float* db);
 
+
+/* ---- GPU-resident episode sampler (replaces fumi/dataset/data.py:294-581 + the torchmeta loader for
+ * precomputed embeddings held in HBM) ---------------------------------------------------------------------------------
+ * sample_episodes: for every episode b < B: N distinct classes of [0, C) and, per class, K + Q distinct members of its
+ *   item list class_items[class_ptr[c] .. class_ptr[c+1]) (CSR, device arrays), all uniformly at random from the
+ *   counter-based stream (seed, step) -- reproducible, restated in oracle/sampler_ref.py.  Outputs (device, int64):
+ *   classes [B,N], items_s [B,N,K], items_q [B,N,Q] (class-major like torchmeta's ConcatTask: label of slot n is n).
+ *   A class with fewer than K + Q items sets FUMI_ST_CLASS_MISSING (torchmeta's ClassSplitter raises) and wraps around.
+ * gather_rows: out[i, :] = table[idx[i], :] for rows of row_bytes bytes (a multiple of 4): the image rows of a meta-batch,
+ *   or the per-class text rows / token rows.  An index outside [0, n_rows) sets FUMI_ST_LABEL_RANGE and reads row 0. */
+int fumi_hip_sample_episodes(fumi_ws_t* ws, fumi_stream_t stream, uint64_t seed, uint64_t step, int B, int N, int K, int Q,
+        int C, const int64_t* class_ptr, const int64_t* class_items, int64_t* classes, int64_t* items_s, int64_t* items_q);
+int fumi_hip_gather_rows(fumi_ws_t* ws, fumi_stream_t stream, const void* table, int64_t n_rows, int64_t row_bytes,
+        const int64_t* idx, int64_t n_idx, void* out);
+
 #ifdef __cplusplus
 }
 #endif
