@@ -297,11 +297,37 @@ int fumi_hip_maml_step(fumi_ws_t* ws, fumi_stream_t stream,
         float* logits_q, int64_t* preds_q, float* preds_q_f32, float* loss_b, float* acc_b, float* stats,
         float* const* g_params) {
     if (!ws || !params || !x_s || !y_s || !x_q || !y_q || !logits_q || !preds_q || !loss_b || !acc_b) return FUMI_EINVAL;
-    if (n_hidden == 0) return FUMI_ENOTSUP;      // hidden_dims=None (a bare linear head on the embeddings)
-    if (!hid || n_hidden < 0 || n_hidden > FUMI_MAX_HIDDEN || B < 1 || N < 1 || S < 1 || Qn < 1 || D < 1 || T < 0) return FUMI_EINVAL;
+    if (n_hidden < 0 || n_hidden > FUMI_MAX_HIDDEN || (n_hidden > 0 && !hid) || B < 1 || N < 1 || S < 1 || Qn < 1 || D < 1 || T < 0)
+        return FUMI_EINVAL;
     if (need_grad && !g_params) return FUMI_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ws->device));
+    if (n_hidden == 0) {
+        // hidden_dims=None: the network is lin_final alone (maml.py:24-31).  Low-rank form with the head as "layer 0":
+        // one xpanel_fwd (h0 = N), one small per-episode kernel, one xpanel_bwd (linhead.hip).
+        const float* Wf = params[0]; const float* bf = params[1];
+        if (!Wf || !bf || (need_grad && (!g_params[0] || !g_params[1]))) return FUMI_EINVAL;
+        const size_t R = (size_t)S + Qn;
+        int kc = 0;
+        const int ns = need_grad ? xpanel_bwd_nsplit(B, S, Qn, D, N, &kc) : 0;
+        size_t bytes = ws_align(B * R * N * 4) * 2 + ws_align(B * R * S * 4) + ws_align((size_t)B * N * 4) + ws_align((size_t)ns * N * D * 4);
+        int rc = ws_reserve(ws, bytes);
+        if (rc) return rc;
+        float* A = ws_f(ws, B * R * N); float* G = ws_f(ws, B * R * S); float* Abar = ws_f(ws, B * R * N);
+        float* bbar = ws_f(ws, (size_t)B * N);
+        if ((rc = launch_xpanel_fwd(st, B, S, Qn, D, N, x_s, x_q, Wf, A, G))) return rc;
+        if ((rc = launch_linhead(st, B, N, S, Qn, T, alpha, need_grad ? 1 : 0, first_order ? 0 : 1, A, G, bf, y_s, y_q, logits_q,
+                                 preds_q, preds_q_f32, loss_b, acc_b, Abar, bbar, ws->status))) return rc;
+        ReduceSegs sg; sg.n = 0; sg.scale = grad_scale;
+        if (stats) { sg.add(loss_b, B, 1, 1, stats); sg.add(acc_b, B, 1, 1, stats + 1); }
+        if (need_grad) {
+            float* slabs = ws_f(ws, (size_t)ns * N * D);
+            if ((rc = launch_xpanel_bwd(st, B, S, Qn, D, N, x_s, x_q, Abar, slabs, kc, ns))) return rc;
+            sg.add(slabs, ns, (long)N * D, (long)N * D, g_params[0]);
+            sg.add(bbar, B, N, N, g_params[1]);
+        }
+        return launch_reduce_multi(st, sg);
+    }
 
     EpisodeProblem p;
     memset(&p, 0, sizeof(p));

@@ -158,6 +158,12 @@ struct EpisodeProblem {
 size_t episode_workspace_bytes(const EpisodeProblem& p);
 int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p);
 
+// MAML with a bare linear head (linhead.hip)
+size_t linhead_lds_floats(int N, int S, int Qn, int T, int taped);
+int launch_linhead(hipStream_t st, int B, int N, int S, int Qn, int T, float alpha, int need_grad, int second_order,
+                   const float* A, const float* G, const float* bias, const int64_t* y_s, const int64_t* y_q, float* logits_q,
+                   int64_t* preds_q, float* preds_f, float* loss_b, float* acc_b, float* Abar, float* bbar, int* status);
+
 // hypernetwork as LDS-resident kernels (hyper.hip); FUMI_ENOTSUP when the shapes do not fit (callers fall back to GEMMs)
 int hyper_lds_fits(int R, int Dt, int Ht, int H1);
 size_t hyper_bwd_workspace_floats(int R, int Ht, int H1);

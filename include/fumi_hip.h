@@ -106,7 +106,8 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
         float* const* g_theta, float* const* g_phi);
 
 /* ---- MAML meta-step (replaces fumi/models/maml.py:156-191) ---------------------------------------------------
- * params: 2*n_hidden + 2 pointers: hidden layers as above, then lin_final W [N,H], b [N].  n_hidden >= 1. */
+ * params: 2*n_hidden + 2 pointers: hidden layers as above, then lin_final W [N,H], b [N].  n_hidden = 0 is the reference's
+ * hidden_dims=None: lin_final W [N,D] alone (hid may be NULL). */
 int fumi_hip_maml_step(fumi_ws_t* ws, fumi_stream_t stream,
         int B, int N, int S, int Qn, int D, int n_hidden, const int* hid,
         int T, float alpha, int first_order, int need_grad, float grad_scale,

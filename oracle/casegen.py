@@ -154,6 +154,9 @@ MAML_CASES = {
     "maml_1st":       dict(B=4, N=5, K=1, Q=4, D=64, hid=[32, 16], T=5, first_order=True),
     "maml_5shot_t1":  dict(B=3, N=5, K=5, Q=4, D=64, hid=[32, 16], T=1, first_order=False),
     "maml_default":   dict(B=2, N=5, K=1, Q=8, D=2048, hid=[256, 64], T=5, first_order=False),
+    # hidden_dims=None: the network is lin_final alone (maml.py:24-31)
+    "maml_linear_2nd": dict(B=3, N=5, K=5, Q=6, D=128, hid=None, T=3, first_order=False),
+    "maml_linear_1st": dict(B=3, N=4, K=1, Q=5, D=128, hid=None, T=2, first_order=True),
 }
 AM3_CASES = {
     "am3_lam":        dict(B=4, N=5, K=5, Q=4, D=64, Dt=24, Ht=20, P=16, lamda_fixed=None),

@@ -80,7 +80,7 @@ def test_fumi_step_matches_reference(name, dev, ws):
     ph = [t.clone().requires_grad_(True) for t in phi]
     ref = R.fumi_meta_step(th, ph, ep["text_s"], ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], c["N"], c["T"], cg.ALPHA, c["tanh"])
     assert rel_to_max(out["loss_b"].cpu(), ref["loss_b"]) <= LOGIT_TOL
-    names = [f"im_net.linear{i}.{k}" for i in range(len(c["hid"])) for k in ("weight", "bias")]
+    names = [f"im_net.linear{i}.{k}" for i in range(len(c["hid"] or [])) for k in ("weight", "bias")]
     names += ["hyper_net.0.weight", "hyper_net.0.bias", "hyper_net.2.weight", "hyper_net.2.bias"]
     _check_grads(names, out["g_theta"] + out["g_phi"], gold, ref["g_theta"] + ref["g_phi"])
 
@@ -116,7 +116,7 @@ def test_maml_step_matches_reference(name, dev, ws):
     assert abs(float(out["loss_b"].mean()) - float(gold["loss"])) <= LOGIT_TOL * max(1.0, abs(float(gold["loss"])))
     pl = [t.clone().requires_grad_(True) for t in p]
     ref = R.maml_meta_step(pl, ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], c["T"], cg.ALPHA, c["first_order"])
-    names = [f"net.lin_{i}.{k}" for i in range(len(c["hid"])) for k in ("weight", "bias")]
+    names = [f"net.lin_{i}.{k}" for i in range(len(c["hid"] or [])) for k in ("weight", "bias")]
     names += ["net.lin_final.weight", "net.lin_final.bias"]
     _check_grads(names, out["g_params"], gold, ref["g_params"])
 

@@ -37,7 +37,7 @@ def test_fumi_oracle_matches_reference(name):
     assert abs(float(out["loss"]) - float(gold["loss"])) <= TOL * max(1.0, abs(float(gold["loss"])))
     assert np.array_equal(out["preds"].numpy(), gold["preds"])   # integer predictions: bit-exact
     assert abs(float(out["acc"]) - float(gold["acc"])) < 1e-6
-    names = [f"im_net.linear{i}.{k}" for i in range(len(c["hid"])) for k in ("weight", "bias")]
+    names = [f"im_net.linear{i}.{k}" for i in range(len(c["hid"] or [])) for k in ("weight", "bias")]
     for n, g in zip(names, out["g_theta"]):
         check_grad(gold, "grad." + n, g, 5e-5)
     for n, g in zip(["hyper_net.0.weight", "hyper_net.0.bias", "hyper_net.2.weight", "hyper_net.2.bias"], out["g_phi"]):
@@ -54,7 +54,7 @@ def test_maml_oracle_matches_reference(name):
     assert_close_max(out["logits"], gold["logits_q"], TOL, "logits")
     assert abs(float(out["loss"]) - float(gold["loss"])) <= TOL * max(1.0, abs(float(gold["loss"])))
     assert np.array_equal(out["preds"].numpy(), gold["preds"])
-    names = [f"net.lin_{i}.{k}" for i in range(len(c["hid"])) for k in ("weight", "bias")]
+    names = [f"net.lin_{i}.{k}" for i in range(len(c["hid"] or [])) for k in ("weight", "bias")]
     names += ["net.lin_final.weight", "net.lin_final.bias"]
     for n, g in zip(names, out["g_params"]):
         check_grad(gold, "grad." + n, g, 5e-5)
