@@ -284,15 +284,22 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
         const int m0 = (wave / tn) << 4, n = ((wave % tn) << 6) + 4 * (lane & 15);
         const float* A0s = w.A0 + (long)b * (S + d.Qn) * h0;
         const bool vec = ((h0 & 3) == 0) && ((((uintptr_t)A0s) & 15) == 0) && ((((uintptr_t)prm.b[0]) & 15) == 0);
+        if (vec) {                               // unconditional loads from clamped addresses: all eight in flight together
+            const int nc = n < h0 ? n : 0;
+            const f32x4 bv = *(const f32x4*)(prm.b[0] + nc);
+            f32x4 av[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = m0 + 4 * (lane >> 4) + e;
-            f32x4 v = z4;
-            if (m < S && n < h0) {
-                if (vec) v = *(const f32x4*)(A0s + (long)m * h0 + n) + *(const f32x4*)(prm.b[0] + n);
-                else for (int c = 0; c < 4 && n + c < h0; ++c) v[c] = A0s[(long)m * h0 + n + c] + prm.b[0][n + c];
+            for (int e = 0; e < 4; ++e) { const int m = m0 + 4 * (lane >> 4) + e; av[e] = *(const f32x4*)(A0s + (long)(m < S ? m : 0) * h0 + nc); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const int m = m0 + 4 * (lane >> 4) + e; preZ[e] = (m < S && n < h0) ? av[e] + bv : z4; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + 4 * (lane >> 4) + e;
+                f32x4 v = z4;
+                if (m < S && n < h0) for (int c = 0; c < 4 && n + c < h0; ++c) v[c] = A0s[(long)m * h0 + n + c] + prm.b[0][n + c];
+                preZ[e] = v;
             }
-            preZ[e] = v;
         }
     }
     wg_lds_barrier(); STAMP()                   // (LDS only: the preZ loads stay in flight behind the staging)
