@@ -108,10 +108,13 @@ int launch_gemm(hipStream_t st, const GemmArgs& g, int AL, int BL);
 int launch_reduce_slabs(hipStream_t st, const float* slabs, int nslab, long stride, long n, float scale, float* out);
 // up to 24 small slab reductions in one launch
 struct ReduceSegs {
-    const float* src[24]; float* dst[24]; long end[24]; long stride[24]; int nslab[24];
+    const float* src[24]; float* dst[24]; long end[24]; long stride[24]; int nslab[24]; int vec[24];
     int n; float scale;
+    // a segment whose rows and pointers are 16-byte aligned is processed four elements per thread (end[] counts threads)
     void add(const float* s, int ns, long st, long cnt, float* d) {
-        src[n] = s; nslab[n] = ns; stride[n] = st; dst[n] = d; end[n] = (n ? end[n - 1] : 0) + cnt; ++n;
+        const bool v4 = (cnt % 4 == 0) && (st % 4 == 0) && ((uintptr_t)s % 16 == 0) && ((uintptr_t)d % 16 == 0);
+        src[n] = s; nslab[n] = ns; stride[n] = st; dst[n] = d; vec[n] = v4 ? 1 : 0;
+        end[n] = (n ? end[n - 1] : 0) + (v4 ? cnt / 4 : cnt); ++n;
     }
 };
 int launch_reduce_multi(hipStream_t st, ReduceSegs& sg);

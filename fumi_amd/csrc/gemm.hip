@@ -193,19 +193,36 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, 
     }
 }
 
-// several small slab reductions in ONE launch: segment k: dst[i] = scale * sum_t src[t*stride + i], i < n
+// several slab reductions in ONE launch: segment k: dst[i] = scale * sum_t src[t*stride + i], i < n.  Even slabs and odd
+// slabs are summed in two chains (fixed order: bit-reproducible); aligned segments move 16 bytes per thread and slab.
 __global__ void reduce_multi_kernel(ReduceSegs sg) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= sg.end[sg.n - 1]) return;
     int k = 0;
     while (k + 1 < sg.n && i >= sg.end[k]) ++k;
-    const long e = i - (k ? sg.end[k - 1] : 0);
-    const float* src = sg.src[k] + e;
-    float s0 = 0.f, s1 = 0.f;
-    int t = 0;
-    for (; t + 1 < sg.nslab[k]; t += 2) { s0 += src[t * sg.stride[k]]; s1 += src[(t + 1) * sg.stride[k]]; }
-    if (t < sg.nslab[k]) s0 += src[t * sg.stride[k]];
-    sg.dst[k][e] = sg.scale * (s0 + s1);
+    const long u = i - (k ? sg.end[k - 1] : 0);
+    const long st = sg.stride[k];
+    const int ns = sg.nslab[k];
+    if (sg.vec[k]) {
+        const float* src = sg.src[k] + 4 * u;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        int t = 0;
+        for (; t + 3 < ns; t += 4) {                       // four independent 16-byte loads in flight
+            const f32x4 a = *(const f32x4*)(src + t * st), b = *(const f32x4*)(src + (t + 1) * st);
+            const f32x4 c = *(const f32x4*)(src + (t + 2) * st), d = *(const f32x4*)(src + (t + 3) * st);
+            s0 += a; s1 += b; s0 += c; s1 += d;
+        }
+        for (; t + 1 < ns; t += 2) { s0 += *(const f32x4*)(src + t * st); s1 += *(const f32x4*)(src + (t + 1) * st); }
+        if (t < ns) s0 += *(const f32x4*)(src + t * st);
+        *(f32x4*)(sg.dst[k] + 4 * u) = sg.scale * (s0 + s1);
+    } else {
+        const float* src = sg.src[k] + u;
+        float s0 = 0.f, s1 = 0.f;
+        int t = 0;
+        for (; t + 1 < ns; t += 2) { s0 += src[t * st]; s1 += src[(t + 1) * st]; }
+        if (t < ns) s0 += src[t * st];
+        sg.dst[k][u] = sg.scale * (s0 + s1);
+    }
 }
 
 __global__ void colsum_kernel(const float* __restrict__ X, int M, int N, long ld, float scale, float* __restrict__ out) {
