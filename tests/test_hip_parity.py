@@ -516,3 +516,26 @@ def test_cli_fumi_synthetic_end_to_end_on_gpu(dev, tmp_path, monkeypatch):
     res = cli.main(args)
     assert np.isfinite(res["test_loss"]) and 0.0 <= res["test_acc"] <= 1.0
     assert res["test_loss"] < 1.55          # below ln(5) = 1.609: the engine's gradients train the model
+
+
+def test_fumi_eval_with_100_adapt_steps_matches_oracle(dev, ws):
+    """--num_test_adapt_steps defaults to 100 (fumi/utils/utils.py:172-175): evaluation runs a long untaped inner loop.
+    Checked against the oracle in float64.  (A long loop can walk a pre-activation through zero: with step size 0.05 this
+    case has |z| = 1.8e-8 at step 85 of episode 3, where fp32 summation order decides the ReLU's side and implementations
+    legitimately part ways by 1e-3; the reference's default step size keeps every |z| well away from rounding noise.)"""
+    from fumi_amd import hip
+    c = cg.FUMI_CASES["fumi_t1"]
+    ep = cg.make_episodes(77, c["B"], c["N"], c["K"], c["Q"], c["D"], c["Dt"])
+    theta, phi = cg.make_fumi_params(77, c["D"], c["hid"], c["Dt"], c["Ht"])
+    alpha, T = cg.ALPHA, 100
+    out = hip.fumi_step_select(ws, c["N"], _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev),
+                               _g(ep["text_s"], dev), [_g(t, dev) for t in theta], [_g(t, dev) for t in phi], T, alpha, False,
+                               need_grad=False)
+    d = torch.float64
+    th = [t.clone().to(d).requires_grad_(True) for t in theta]; ph = [t.clone().to(d).requires_grad_(True) for t in phi]
+    a = (th, ph, ep["text_s"].to(d), ep["x_s"].to(d), ep["y_s"], ep["x_q"].to(d), ep["y_q"], c["N"])
+    ref = R.fumi_meta_step(*a, T, alpha, False, need_grad=False)
+    ref0 = R.fumi_meta_step(*a, 0, alpha, False, need_grad=False)
+    assert rel_to_max(ref["logits"], ref0["logits"]) > 0.02            # the adaptation is not a no-op
+    assert rel_to_max(out["logits"].cpu().double(), ref["logits"]) <= LOGIT_TOL
+    assert rel_to_max(out["loss_b"].cpu().double(), ref["loss_b"]) <= LOGIT_TOL
