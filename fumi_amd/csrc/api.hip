@@ -149,16 +149,16 @@ int fumi_hip_read_status(fumi_ws_t* ws, fumi_stream_t stream, int* status_out) {
 // ------------------------------------------------------------------------------------------------------------
 // FuMI
 // ------------------------------------------------------------------------------------------------------------
-int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
+static int fumi_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
         int B, int N, int S, int Qn, int D, int n_hidden, const int* hid, int Dt, int Ht,
         int T, float alpha, int tanh_head, int need_grad, float grad_scale, float dropout_p, uint64_t seed,
         const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
         const float* cls_text, const float* text_s,
         const float* const* theta, const float* const* phi,
         float* logits_q, int64_t* preds_q, float* preds_q_f32, float* loss_b, float* acc_b, float* stats,
-        float* const* g_theta, float* const* g_phi) {
-    if (!ws || !hid || !theta || !phi || !x_s || !y_s || !x_q || !y_q || !logits_q || !preds_q || !loss_b || !acc_b)
-        return FUMI_EINVAL;
+        float* const* g_theta, float* const* g_phi, const XRows* rows) {
+    if (!ws || !hid || !theta || !phi || !y_s || !y_q || !logits_q || !preds_q || !loss_b || !acc_b) return FUMI_EINVAL;
+    if (rows ? (!rows->table || !rows->idx_s || !rows->idx_q || rows->n_rows < 1) : (!x_s || !x_q)) return FUMI_EINVAL;
     if (!cls_text && !text_s) return FUMI_EINVAL;
     if (n_hidden < 1 || n_hidden > FUMI_MAX_HIDDEN || B < 1 || N < 1 || S < 1 || Qn < 1 || D < 1 || Dt < 1 || Ht < 1 || T < 0)
         return FUMI_EINVAL;
@@ -181,6 +181,12 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
     const int H = hid[n_hidden - 1], R = B * N, H1 = H + 1;
     p.x_s = x_s; p.y_s = y_s; p.x_q = x_q; p.y_q = y_q;
     p.logits_q = logits_q; p.preds_q = preds_q; p.preds_f = preds_q_f32; p.loss_b = loss_b; p.acc_b = acc_b; p.stats = stats;
+    if (rows) {
+        p.rows = *rows;
+        int rcx;
+        if ((rcx = launch_index_range_check(st, rows->idx_s, (long)B * S, rows->n_rows, ws->status))) return rcx;
+        if ((rcx = launch_index_range_check(st, rows->idx_q, (long)B * Qn, rows->n_rows, ws->status))) return rcx;
+    }
 
     size_t bytes = episode_workspace_bytes(p);
     bytes += ws_align((size_t)R * Dt * 4) + 2 * ws_align((size_t)R * Ht * 4) + 3 * ws_align((size_t)R * H1 * 4);
@@ -284,6 +290,33 @@ int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
         if ((rc = launch_reduce_multi(st, fin))) return rc;
     }
     return FUMI_OK;
+}
+
+int fumi_hip_fumi_step(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int D, int n_hidden, const int* hid, int Dt, int Ht,
+        int T, float alpha, int tanh_head, int need_grad, float grad_scale, float dropout_p, uint64_t seed,
+        const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
+        const float* cls_text, const float* text_s,
+        const float* const* theta, const float* const* phi,
+        float* logits_q, int64_t* preds_q, float* preds_q_f32, float* loss_b, float* acc_b, float* stats,
+        float* const* g_theta, float* const* g_phi) {
+    return fumi_step_impl(ws, stream, B, N, S, Qn, D, n_hidden, hid, Dt, Ht, T, alpha, tanh_head, need_grad, grad_scale, dropout_p,
+                          seed, x_s, y_s, x_q, y_q, cls_text, text_s, theta, phi, logits_q, preds_q, preds_q_f32, loss_b, acc_b,
+                          stats, g_theta, g_phi, nullptr);
+}
+
+int fumi_hip_fumi_step_indexed(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int D, int n_hidden, const int* hid, int Dt, int Ht,
+        int T, float alpha, int tanh_head, int need_grad, float grad_scale, float dropout_p, uint64_t seed,
+        const float* table, int64_t n_rows, const int64_t* idx_s, const int64_t* y_s, const int64_t* idx_q, const int64_t* y_q,
+        const float* cls_text, const float* text_s,
+        const float* const* theta, const float* const* phi,
+        float* logits_q, int64_t* preds_q, float* preds_q_f32, float* loss_b, float* acc_b, float* stats,
+        float* const* g_theta, float* const* g_phi) {
+    XRows rows{table, idx_s, idx_q, (long)n_rows};
+    return fumi_step_impl(ws, stream, B, N, S, Qn, D, n_hidden, hid, Dt, Ht, T, alpha, tanh_head, need_grad, grad_scale, dropout_p,
+                          seed, nullptr, y_s, nullptr, y_q, cls_text, text_s, theta, phi, logits_q, preds_q, preds_q_f32, loss_b,
+                          acc_b, stats, g_theta, g_phi, &rows);
 }
 
 // ------------------------------------------------------------------------------------------------------------

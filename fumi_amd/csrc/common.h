@@ -124,11 +124,16 @@ int launch_colsum(hipStream_t st, const float* X, int M, int N, long ld, float s
 // ------------------------------------------------------------------------------------------------------------
 // the two shared passes over the wide inputs (xpanel.hip)
 // ------------------------------------------------------------------------------------------------------------
+// zero-copy episodes: rows of the meta-batch addressed through indices into an HBM-resident table (x_s / x_q unused)
+struct XRows { const float* table; const int64_t* idx_s; const int64_t* idx_q; long n_rows; };
 int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
-                      const float* W0, float* A0 /*[B,S+Qn,h0]*/, float* G /*[B,S+Qn,S]*/);
+                      const float* W0, float* A0 /*[B,S+Qn,h0]*/, float* G /*[B,S+Qn,S]*/, const XRows* rows = nullptr);
 int xpanel_bwd_nsplit(int B, int S, int Qn, int D, int h0, int* kchunk_out);
 int launch_xpanel_bwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
-                      const float* Abar /*[B,S+Qn,h0]*/, float* slabs /*[nsplit,h0,D]*/, int kchunk, int nsplit);
+                      const float* Abar /*[B,S+Qn,h0]*/, float* slabs /*[nsplit,h0,D]*/, int kchunk, int nsplit,
+                      const XRows* rows = nullptr);
+// sets FUMI_ST_LABEL_RANGE when an index is outside [0, n_rows) (the X-panel kernels clamp such an index to row 0)
+int launch_index_range_check(hipStream_t st, const int64_t* idx, long n, long n_rows, int* status);
 
 // ------------------------------------------------------------------------------------------------------------
 // episode engine (episode.hip): inner-loop adaptation, query pass, second-order reverse sweep
@@ -143,6 +148,7 @@ struct EpisodeProblem {
     const float* x_s; const int64_t* y_s; const float* x_q; const int64_t* y_q;
     const float* W[FUMI_MAX_HIDDEN]; const float* b[FUMI_MAX_HIDDEN];
     const float* head;              // [B,N,H+1] initial head per episode  ([Wh | bh])
+    XRows rows;                     // table != NULL: x_s / x_q are not used, rows come from the table (zero-copy episodes)
     float* logits_q; int64_t* preds_q; float* preds_f /* optional */; float* loss_b; float* acc_b;
     float* gW[FUMI_MAX_HIDDEN]; float* gb[FUMI_MAX_HIDDEN];   // outputs (scaled sums over episodes)
     float* head_bar;                // [B,N,H+1] d loss_b / d head_b   (unscaled, per episode)

@@ -1357,7 +1357,7 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     if (p.inputs_ready) HIP_TRY(hipEventRecord(p.inputs_ready, st));
     {
         ProfScope ps(ws, st, FUMI_PH_XPANEL_FWD);
-        if ((rc = launch_xpanel_fwd(st, p.B, p.S, p.Qn, p.D, h0, p.x_s, p.x_q, p.W[0], w.A0, w.G))) return rc;
+        if ((rc = launch_xpanel_fwd(st, p.B, p.S, p.Qn, p.D, h0, p.x_s, p.x_q, p.W[0], w.A0, w.G, p.rows.table ? &p.rows : nullptr))) return rc;
     }
     if (p.after_xpanel_fwd && (rc = p.after_xpanel_fwd(p.hook_ctx))) return rc;
     // ---- per-episode phases
@@ -1506,7 +1506,7 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
         const int ns = xpanel_bwd_nsplit(p.B, p.S, p.Qn, p.D, h0, &kc);
         const long slab = (long)h0 * p.D;
         float* slabs = ws_f(ws, (size_t)ns * slab);
-        if ((rc = launch_xpanel_bwd(st, p.B, p.S, p.Qn, p.D, h0, p.x_s, p.x_q, w.A0bar, slabs, kc, ns))) return rc;
+        if ((rc = launch_xpanel_bwd(st, p.B, p.S, p.Qn, p.D, h0, p.x_s, p.x_q, w.A0bar, slabs, kc, ns, p.rows.table ? &p.rows : nullptr))) return rc;
         if (p.defer_reduce && p.defer_reduce->n < 24 && p.defer_reduce->scale == p.grad_scale) p.defer_reduce->add(slabs, ns, slab, slab, p.gW[0]);
         else if ((rc = launch_reduce_slabs(st, slabs, ns, slab, slab, p.grad_scale, p.gW[0]))) return rc;
     }

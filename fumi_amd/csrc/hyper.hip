@@ -26,14 +26,13 @@ struct LinDims { int R, K, Nn, NC, act; };          // act: 1 relu, 2 tanh, 0 no
 __global__ __launch_bounds__(512) void hyper_lin_kernel(StageTab stg, LinDims d, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ StageTab s_stg;
-    const int tid = threadIdx.x, nt = blockDim.x;
     const int cb = blockIdx.x, rb = blockIdx.y;
     const int nr = min(HB, d.R - rb * HB), ncols = min(d.NC, d.Nn - cb * d.NC);
     const int ldk = wg_ld(d.K);
     float* xi = sm; float* Wi = sm + HB * ldk; float* bi = Wi + h_r16(d.NC) * ldk;
-    const int tot = (HB + h_r16(d.NC)) * ldk + h_r4(d.NC);
+    // no zero-fill: K is a multiple of 4 (hyper_lds_fits), so the product never reads K padding, and rows / columns past
+    // nr / ncols only feed outputs that are not stored
     wg_stage_tab_to_lds(&s_stg);
-    for (int i = tid * 4; i < tot; i += nt * 4) *(f32x4*)(sm + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     wg_stage_rows<16>(&s_stg, 0, rb, cb, nr, sm, ncols, ncols);
     wg_lds_barrier();

@@ -92,7 +92,21 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     }
 }
 
+__global__ void index_range_check_kernel(const int64_t* __restrict__ idx, long n, long n_rows, int* status) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        if (idx[i] < 0 || idx[i] >= n_rows) atomicOr(status, FUMI_ST_LABEL_RANGE);
+}
+
 }  // namespace
+
+int launch_index_range_check(hipStream_t st, const int64_t* idx, long n, long n_rows, int* status) {
+    if (n < 1) return FUMI_OK;
+    long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(index_range_check_kernel, dim3((unsigned)blocks), dim3(256), 0, st, idx, n, n_rows, status);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
 
 extern "C" int fumi_hip_sample_episodes(fumi_ws_t* ws, fumi_stream_t stream, uint64_t seed, uint64_t step, int B, int N, int K,
         int Q, int C, const int64_t* class_ptr, const int64_t* class_items, int64_t* classes, int64_t* items_s,

@@ -27,9 +27,17 @@ constexpr int TILE_F = 64 * KC_LD;
 struct XPanel {
     const float* x_s; const float* x_q; const float* W0;
     int B, S, Qn, D, h0;
+    // zero-copy episodes (sampler.hip): when `table` is set, row r of episode b is table[idx_s[b,r]] / table[idx_q[b,r-S]]
+    // instead of x_s[b,r] / x_q[b,r-S] -- the meta-batch is never materialised
+    const float* table; const int64_t* idx_s; const int64_t* idx_q; long n_rows;
 };
 
 __device__ __forceinline__ const float* xrow(const XPanel& p, int b, int r) {
+    if (p.table) {                                   // uniform branch
+        long i = r < p.S ? p.idx_s[(long)b * p.S + r] : p.idx_q[(long)b * p.Qn + (r - p.S)];
+        if (i < 0 || i >= p.n_rows) i = 0;           // (flagged by the launcher's range check; never fault)
+        return p.table + i * p.D;
+    }
     return r < p.S ? p.x_s + ((long)b * p.S + r) * p.D : p.x_q + ((long)b * p.Qn + (r - p.S)) * p.D;
 }
 
@@ -58,7 +66,7 @@ __global__ __launch_bounds__(256) void xpanel_fwd_generic_kernel(XPanel p, float
         const int r = m0 + (f >> 3), c = n0 + (f >> 3);
         aok[i] = r < R; bok[i] = c < C;
         arow[i] = xrow(p, b, aok[i] ? r : 0);
-        brow[i] = c < p.h0 ? p.W0 + (long)c * K : p.x_s + ((long)b * p.S + (bok[i] ? c - p.h0 : 0)) * K;
+        brow[i] = c < p.h0 ? p.W0 + (long)c * K : xrow(p, b, bok[i] ? c - p.h0 : 0);
     }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto load = [&](f32x4 (&ra)[2], f32x4 (&rb)[2], int k0) {
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(256) void xpanel_fwd_kernel(XPanel p, float* __rest
         const int r = m0 + rr, c = n0 + rr;
         aok[i] = r < R; bok[i] = c < C;
         arow[i] = xrow(p, b, aok[i] ? r : 0) + k4;
-        brow[i] = (c < p.h0 ? p.W0 + (long)c * K : p.x_s + ((long)b * p.S + (bok[i] ? c - p.h0 : 0)) * K) + k4;
+        brow[i] = (c < p.h0 ? p.W0 + (long)c * K : xrow(p, b, bok[i] ? c - p.h0 : 0)) + k4;
     }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 ga[NST][4], gb[NST][4];
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* 
         const int r = m0 + rr, c = n0 + rr;
         aok[i] = r < R; bok[i] = c < C;
         arow[i] = xrow(p, b, aok[i] ? r : 0) + k4;
-        brow[i] = (c < p.h0 ? p.W0 + (long)c * K : p.x_s + ((long)b * p.S + (bok[i] ? c - p.h0 : 0)) * K) + k4;
+        brow[i] = (c < p.h0 ? p.W0 + (long)c * K : xrow(p, b, bok[i] ? c - p.h0 : 0)) + k4;
     }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 ga[NST][2], gb[NST][2];
@@ -482,10 +490,12 @@ __global__ __launch_bounds__(256) void xpanel_bwd_kernel(XPanel p, const float* 
     // thread's contraction row is tracked incrementally (+32 rows per slab) instead of dividing by R every slab.
     bool okf[2] = {true, true};
     int gb[2], gr[2];                        // episode / row-in-panel of contraction row  kbeg + s*BK + (f>>4)
+    const float* xp[2];                      // its X row, looked up one slab ahead (indexed rows: a dependent index load)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const long g = kbeg + ((tid + 256 * i) >> 4);
         gb[i] = (int)(g / R); gr[i] = (int)(g - (long)gb[i] * R);
+        xp[i] = xrow(p, g < kend ? gb[i] : 0, g < kend ? gr[i] : 0);
     }
     auto load = [&](f32x4 (&ra)[2], f32x4 (&rb)[2], long k0) {
 #pragma unroll
@@ -497,7 +507,7 @@ __global__ __launch_bounds__(256) void xpanel_bwd_kernel(XPanel p, const float* 
             const bool ok = g < kend;
             const int b = ok ? gb[i] : 0, r = ok ? gr[i] : 0;
             const float* pa = Abar + ((long)b * R + r) * M + m0 + c4;
-            const float* pb = xrow(p, b, r) + n0 + c4;
+            const float* pb = xp[i] + n0 + c4;
             if (FAST) {
                 ra[i] = *(const f32x4*)pa;                  // raw; masked when written to LDS
                 rb[i] = *(const f32x4*)pb;
@@ -510,6 +520,8 @@ __global__ __launch_bounds__(256) void xpanel_bwd_kernel(XPanel p, const float* 
             }
             gr[i] += BK;                                    // next slab's row
             while (gr[i] >= R) { gr[i] -= R; ++gb[i]; }
+            const bool okn = g + BK < kend;
+            xp[i] = xrow(p, okn ? gb[i] : 0, okn ? gr[i] : 0);
         }
     };
     auto store = [&](const f32x4 (&ra)[2], const f32x4 (&rb)[2], int buf) {
@@ -560,11 +572,12 @@ unsigned long long* g_trace = nullptr;      // dev tracing only (tools/trace_xpa
 extern "C" void fumi_dbg_set_trace(void* p) { g_trace = (unsigned long long*)p; }
 
 int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
-                      const float* W0, float* A0, float* G) {
-    XPanel p{x_s, x_q, W0, B, S, Qn, D, h0};
+                      const float* W0, float* A0, float* G, const XRows* rows) {
+    XPanel p{x_s, x_q, W0, B, S, Qn, D, h0, nullptr, nullptr, nullptr, 0};
+    if (rows && rows->table) { p.table = rows->table; p.idx_s = rows->idx_s; p.idx_q = rows->idx_q; p.n_rows = rows->n_rows; p.x_s = p.x_q = rows->table; }
     const int tiles_m = (S + Qn + 63) / 64, tiles_n = (h0 + S + 63) / 64;
     const int nper = (B + 7) / 8;
-    const bool aligned = al16(x_s) && al16(x_q) && al16(W0);
+    const bool aligned = al16(p.x_s) && al16(p.x_q) && al16(W0);
     const dim3 grid(8 * nper * tiles_m * tiles_n);
     static const int nst = getenv("FUMI_XP_NST") ? atoi(getenv("FUMI_XP_NST")) : 2;      // staging ring depth (tuning knob)
     // FUMI_XP_SB=1: the split-bf16 kernel (fp32-equivalent accuracy on the bf16 matrix pipe).  Measured 65 us against the fp32
@@ -599,9 +612,10 @@ int xpanel_bwd_nsplit(int B, int S, int Qn, int D, int h0, int* kchunk_out) {
 }
 
 int launch_xpanel_bwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
-                      const float* Abar, float* slabs, int kchunk, int nsplit) {
-    XPanel p{x_s, x_q, nullptr, B, S, Qn, D, h0};
-    const bool fast = (D % 64 == 0) && (h0 % 64 == 0) && al16(x_s) && al16(x_q) && al16(Abar);
+                      const float* Abar, float* slabs, int kchunk, int nsplit, const XRows* rows) {
+    XPanel p{x_s, x_q, nullptr, B, S, Qn, D, h0, nullptr, nullptr, nullptr, 0};
+    if (rows && rows->table) { p.table = rows->table; p.idx_s = rows->idx_s; p.idx_q = rows->idx_q; p.n_rows = rows->n_rows; p.x_s = p.x_q = rows->table; }
+    const bool fast = (D % 64 == 0) && (h0 % 64 == 0) && al16(p.x_s) && al16(p.x_q) && al16(Abar);
     const dim3 grid((D + 63) / 64, (h0 + 63) / 64, nsplit);
     if (fast) hipLaunchKernelGGL(xpanel_bwd_kernel<true>, grid, dim3(256), 0, st, p, Abar, slabs, kchunk);
     else hipLaunchKernelGGL(xpanel_bwd_kernel<false>, grid, dim3(256), 0, st, p, Abar, slabs, kchunk);

@@ -10,7 +10,9 @@ HBM), the per-class image lists (CSR) and the per-class text rows stay on the de
     batch = {'train': ([idx i64 [B,S], text [B,S,Dt] f32 | [B,S,L] i64, im f32 [B,S,D]], targets i64 [B,S]),
              'test' : same with Qn = N * num_shots_test rows}
 
-with the class-major order / categorical labels of torchmeta's ConcatTask.  Sampling is reproducible from (seed, step)."""
+with the class-major order / categorical labels of torchmeta's ConcatTask.  Sampling is reproducible from (seed, step).
+``zero_copy=True`` hands the FuMI engine ``hip.RowRef``s (table + indices) in place of the gathered image rows: the X-panel
+kernels then read the rows where they lie in the table (fumi_hip_fumi_step_indexed)."""
 import numpy as np
 import torch
 
@@ -19,7 +21,7 @@ from .. import hip
 
 class GpuEpisodeSampler:
     def __init__(self, images, class_of_image, class_text, num_ways, num_shots, num_shots_test, batch_size, seed=123,
-                 length=None):
+                 length=None, zero_copy=False):
         """images [n_images, D] fp32 (moved to the device once), class_of_image [n_images] ints (category of every row, as
         inat_anim.json's annotations give it), class_text [C, Dt] fp32 or [C, L] int64 tokens (one row per class: the text of
         a sample is its class description, data.py:543-549)."""
@@ -38,6 +40,7 @@ class GpuEpisodeSampler:
         self.class_text = class_text.to(self.dev).contiguous()
         self.C, self.N, self.K, self.Q, self.B = C, int(num_ways), int(num_shots), int(num_shots_test), int(batch_size)
         self.seed, self.length = int(seed), length
+        self.zero_copy = bool(zero_copy)       # hand out RowRefs into the table instead of gathered image rows (FuMI engine only)
         if counts[counts > 0].min() < self.K + self.Q and (counts >= self.K + self.Q).sum() < self.N:
             raise ValueError("fewer than num_ways classes have num_shots + num_shots_test images")
         S, Qn = self.N * self.K, self.N * self.Q
@@ -49,8 +52,11 @@ class GpuEpisodeSampler:
     def batch(self, step):
         B, N, K, Q = self.B, self.N, self.K, self.Q
         cls, it_s, it_q = hip.sample_episodes(self.ws, self.seed, step, B, N, K, Q, self.class_ptr, self.class_items)
-        x_s = hip.gather_rows(self.ws, self.images, it_s.view(-1)).view(B, N * K, -1)
-        x_q = hip.gather_rows(self.ws, self.images, it_q.view(-1)).view(B, N * Q, -1)
+        if self.zero_copy:
+            x_s, x_q = hip.RowRef(self.images, it_s.view(B, N * K)), hip.RowRef(self.images, it_q.view(B, N * Q))
+        else:
+            x_s = hip.gather_rows(self.ws, self.images, it_s.view(-1)).view(B, N * K, -1)
+            x_q = hip.gather_rows(self.ws, self.images, it_q.view(-1)).view(B, N * Q, -1)
         t_cls = hip.gather_rows(self.ws, self.class_text, cls.view(-1)).view(B, N, -1)           # one text row per class slot
         text_s = t_cls.repeat_interleave(K, dim=1)
         text_q = t_cls.repeat_interleave(Q, dim=1)

@@ -19,7 +19,7 @@ SYMBOLS = [
     "fumi_hip_version", "fumi_hip_strerror", "fumi_hip_last_hip_error",
     "fumi_hip_workspace_create", "fumi_hip_workspace_destroy", "fumi_hip_workspace_bytes", "fumi_hip_read_status",
     "fumi_hip_set_profiling", "fumi_hip_get_profile", "fumi_hip_phase_name",
-    "fumi_hip_fumi_step", "fumi_hip_maml_step", "fumi_hip_am3_step",
+    "fumi_hip_fumi_step", "fumi_hip_fumi_step_indexed", "fumi_hip_maml_step", "fumi_hip_am3_step",
     "fumi_hip_glove_bag", "fumi_hip_glove_bag_select", "fumi_hip_class_text_select", "fumi_hip_xpanel_fwd", "fumi_hip_xpanel_bwd",
     "fumi_hip_adam_step",
     "fumi_hip_linear_fwd", "fumi_hip_linear_bwd_data", "fumi_hip_linear_bwd_weight",
@@ -35,6 +35,36 @@ _lock = threading.Lock()
 
 class FumiHipError(RuntimeError):
     pass
+
+class RowRef:
+    """Zero-copy stand-in for an image tensor x[B, rows, D]: x[b, r] = table[idx[b, r]] with ``table`` [n_rows, D] fp32 resident
+    on the device (fumi_hip_fumi_step_indexed).  Quacks like the tensor where FUMI.evaluate touches it."""
+    __slots__ = ("table", "idx")
+
+    def __init__(self, table, idx):
+        if table.dim() != 2 or idx.dim() != 2 or idx.dtype != torch.int64 or table.dtype != torch.float32:
+            raise FumiHipError("RowRef: table must be [n_rows, D] fp32 and idx [B, rows] int64")
+        self.table, self.idx = table, idx
+
+    shape = property(lambda self: (self.idx.shape[0], self.idx.shape[1], self.table.shape[1]))
+    device = property(lambda self: self.table.device)
+    is_cuda = property(lambda self: self.table.is_cuda)
+
+    def __getitem__(self, sl):
+        return RowRef(self.table, self.idx[sl])
+
+    def to(self, *a, **k):
+        return self
+
+    def contiguous(self):
+        return RowRef(self.table, self.idx.contiguous())
+
+    def float(self):
+        return self
+
+    def materialize(self):
+        return self.table[self.idx]
+
 
 
 def lib():
@@ -69,6 +99,10 @@ def lib():
             [c_void_p, c_void_p] + [c_int] * 6 + [POINTER(c_int), c_int, c_int, c_int, c_float, c_int, c_int, c_float,
                                                  c_float, ctypes.c_uint64]
             + [c_void_p] * 6 + [PP, PP] + [c_void_p] * 6 + [PP, PP])
+        L.fumi_hip_fumi_step_indexed.argtypes = (
+            [c_void_p, c_void_p] + [c_int] * 6 + [POINTER(c_int), c_int, c_int, c_int, c_float, c_int, c_int, c_float,
+                                                 c_float, ctypes.c_uint64]
+            + [c_void_p, c_int64] + [c_void_p] * 6 + [PP, PP] + [c_void_p] * 6 + [PP, PP])
         L.fumi_hip_maml_step.argtypes = (
             [c_void_p, c_void_p] + [c_int] * 6 + [POINTER(c_int), c_int, c_float, c_int, c_int, c_float]
             + [c_void_p] * 4 + [PP] + [c_void_p] * 6 + [PP])
@@ -101,6 +135,8 @@ def _check(rc, what):
 
 
 def _dev(t):
+    if isinstance(t, RowRef):
+        t = t.table
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise FumiHipError("the MI355X engine needs GPU tensors (there is no CPU path); got "
                            f"{getattr(t, 'device', type(t))}")
@@ -259,10 +295,17 @@ def _fumi_step(ws, dev, B, N, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, 
     if grad_scale is None:
         grad_scale = 1.0 / B
     hid_arr = (c_int * len(hid))(*hid)
-    rc = L.fumi_hip_fumi_step(
-        ws.handle, _stream(dev), B, N, S, Qn, D, len(hid), hid_arr, Dt, Ht, int(T), float(alpha), int(bool(tanh_head)),
-        int(bool(need_grad)), float(grad_scale), float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
-        _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"),
+    head = (ws.handle, _stream(dev), B, N, S, Qn, D, len(hid), hid_arr, Dt, Ht, int(T), float(alpha), int(bool(tanh_head)),
+            int(bool(need_grad)), float(grad_scale), float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF)
+    if isinstance(x_s, RowRef) or isinstance(x_q, RowRef):             # zero-copy episodes: rows stay in the table
+        if not (isinstance(x_s, RowRef) and isinstance(x_q, RowRef)) or x_s.table.data_ptr() != x_q.table.data_ptr():
+            raise FumiHipError("zero-copy episodes: support and query rows must be RowRefs into the same table")
+        fn, rows = L.fumi_hip_fumi_step_indexed, (_f32(x_s.table, "table"), int(x_s.table.shape[0]), _i64(x_s.idx, "idx_s"),
+                                                  _i64(y_s, "y_s"), _i64(x_q.idx, "idx_q"), _i64(y_q, "y_q"))
+    else:
+        fn, rows = L.fumi_hip_fumi_step, (_f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"))
+    rc = fn(
+        *head, *rows,
         _f32(cls_text, "cls_text") if cls_text is not None else None,
         _f32(text_s, "text_s") if text_s is not None else None,
         _parr(theta, "theta"), _parr(phi, "phi"),

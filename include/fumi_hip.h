@@ -164,6 +164,20 @@ int fumi_hip_linear_bwd_weight(fumi_ws_t* ws, fumi_stream_t stream, int M, int N
         const float* dy, const float* x, float* dW, float* db);
 
 
+/* FuMI meta-step on ZERO-COPY episodes: identical to fumi_hip_fumi_step except that the image rows are not handed over as
+ * x_s [B,S,D] / x_q [B,Qn,D] but addressed in an HBM-resident table [n_rows, D] through idx_s [B,S] / idx_q [B,Qn] (what
+ * fumi_hip_sample_episodes produces): the two X-panel kernels read the rows where they lie, the 2*B*(S+Qn)*D*4 bytes of a
+ * gathered meta-batch are never written or re-read.  Bit-identical results to the gathered call.  An index outside
+ * [0, n_rows) sets FUMI_ST_LABEL_RANGE and is read as row 0. */
+int fumi_hip_fumi_step_indexed(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int D, int n_hidden, const int* hid, int Dt, int Ht,
+        int T, float alpha, int tanh_head, int need_grad, float grad_scale, float dropout_p, uint64_t seed,
+        const float* table, int64_t n_rows, const int64_t* idx_s, const int64_t* y_s, const int64_t* idx_q, const int64_t* y_q,
+        const float* cls_text, const float* text_s,
+        const float* const* theta, const float* const* phi,
+        float* logits_q, int64_t* preds_q, float* preds_q_f32, float* loss_b, float* acc_b, float* stats,
+        float* const* g_theta, float* const* g_phi);
+
 /* ---- GPU-resident episode sampler (replaces fumi/dataset/data.py:294-581 + the torchmeta loader for
  * precomputed embeddings held in HBM) ---------------------------------------------------------------------------------
  * sample_episodes: for every episode b < B: N distinct classes of [0, C) and, per class, K + Q distinct members of its

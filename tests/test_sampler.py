@@ -148,3 +148,56 @@ def test_cli_with_the_resident_dataset(tmp_path, monkeypatch):
     res = cli.main(args)
     # 24 fixed training classes are memorised quickly (train accuracy 1.0); held-out classes only have to beat chance (0.2)
     assert np.isfinite(res["test_loss"]) and res["test_acc"] > 0.25
+
+
+@pytest.mark.gpu
+def test_zero_copy_step_is_bit_identical_to_the_gathered_step():
+    """fumi_hip_fumi_step_indexed reads the rows where they lie in the table: same arithmetic, same bits, no gathered copy."""
+    from fumi_amd import hip
+    from oracle import casegen as cg
+    dev = torch.device("cuda:0"); ws = hip.Workspace.get(dev)
+    for (B, N, K, Q, D, hid, Dt, Ht, T) in [(4, 5, 5, 8, 256, [64, 32], 24, 20, 2), (3, 5, 5, 32, 2048, [256, 64], 300, 256, 1)]:
+        rs = np.random.RandomState(5)
+        table = torch.from_numpy(rs.standard_normal((700, D)).astype(np.float32)).to(dev)
+        S, Qn = N * K, N * Q
+        idx_s = torch.from_numpy(rs.randint(0, 700, (B, S))).to(dev); idx_q = torch.from_numpy(rs.randint(0, 700, (B, Qn))).to(dev)
+        y_s = torch.arange(N).repeat_interleave(K).expand(B, S).contiguous().to(dev)
+        y_q = torch.from_numpy(rs.randint(0, N, (B, Qn))).to(dev)
+        text = torch.from_numpy(rs.standard_normal((B, S, Dt)).astype(np.float32)).to(dev)
+        theta, phi = cg.make_fumi_params(5, D, hid, Dt, Ht)
+        th, ph = [t.to(dev) for t in theta], [t.to(dev) for t in phi]
+        a = hip.fumi_step_select(ws, N, table[idx_s].contiguous(), y_s, table[idx_q].contiguous(), y_q, text, th, ph, T, 0.01, False)
+        b = hip.fumi_step_select(ws, N, hip.RowRef(table, idx_s), y_s, hip.RowRef(table, idx_q), y_q, text, th, ph, T, 0.01, False)
+        assert ws.read_status() == 0
+        assert torch.equal(a["logits"], b["logits"]) and torch.equal(a["loss_b"], b["loss_b"]) and torch.equal(a["preds"], b["preds"])
+        for x, y in zip(a["g_theta"] + a["g_phi"], b["g_theta"] + b["g_phi"]):
+            assert torch.equal(x, y)
+    bad = idx_s.clone(); bad[0, 0] = 700
+    hip.fumi_step_select(ws, N, hip.RowRef(table, bad), y_s, hip.RowRef(table, idx_q), y_q, text, th, ph, T, 0.01, False)
+    assert ws.read_status() & hip.ST_LABEL_RANGE                      # flagged, read as row 0, no fault
+
+
+@pytest.mark.gpu
+def test_zero_copy_sampler_trains_like_the_gathering_one():
+    from fumi_amd.dataset.gpu_sampler import GpuEpisodeSampler
+    from fumi_amd.models.fumi import FUMI
+    from fumi_amd.utils import utils as U
+    from types import SimpleNamespace
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(2)
+    C, D, Dt, per = 30, 256, 64, 40
+    mu = rs.standard_normal((C, D)).astype(np.float32)
+    coi = np.repeat(np.arange(C), per); rs.shuffle(coi)
+    images = torch.from_numpy(mu[coi] + 1.5 * rs.standard_normal((C * per, D)).astype(np.float32))
+    text = torch.from_numpy(mu @ (rs.standard_normal((Dt, D)).astype(np.float32) / np.sqrt(D)).T)
+    losses = {}
+    for zc in (False, True):
+        smp = GpuEpisodeSampler(images, coi, text, num_ways=5, num_shots=5, num_shots_test=8, batch_size=8, seed=3, zero_copy=zc)
+        torch.manual_seed(0)
+        model = FUMI(n_way=5, im_emb_dim=D, im_hid_dim=[64, 32], text_encoder="BERT", text_emb_dim=Dt, text_hid_dim=32,
+                     dropout_rate=0.0).to(dev)
+        args = SimpleNamespace(device=dev, num_train_adapt_steps=2, num_test_adapt_steps=2, step_size=0.05, first_order=False,
+                               optim="adam", lr=2e-3, weight_decay=0.0, momentum=0.9, batch_size=8, num_ways=5)
+        opt = U.init_optim(args, model)
+        losses[zc] = [float(model.evaluate(args, smp.batch(i), opt, "train")[0]) for i in range(30)]
+    assert losses[True] == losses[False]                                # identical trajectories, bit for bit
