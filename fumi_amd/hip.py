@@ -157,10 +157,26 @@ def _i64(t, name):
     return c_void_p(t.data_ptr())
 
 
+_PARR_CACHE = {}
+
+
 def _parr(tensors, name):
-    arr = (c_void_p * len(tensors))()
-    for i, t in enumerate(tensors):
-        arr[i] = _f32(t, f"{name}[{i}]").value
+    """Pointer table of a parameter / gradient list.  The lists are the same tensors step after step, so a validated table is
+    kept per (name, data pointers) -- rebuilding it costs more host time than the launch it feeds."""
+    key = (name,) + tuple(t.data_ptr() for t in tensors)
+    arr = _PARR_CACHE.get(key)
+    if arr is not None:
+        for t in tensors:                         # an address can be reused by a different tensor: keep the type check
+            if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+                arr = None
+                break
+    if arr is None:
+        arr = (c_void_p * len(tensors))()
+        for i, t in enumerate(tensors):
+            arr[i] = _f32(t, f"{name}[{i}]").value
+        if len(_PARR_CACHE) > 256:
+            _PARR_CACHE.clear()
+        _PARR_CACHE[key] = arr
     return arr
 
 

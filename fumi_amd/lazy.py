@@ -13,23 +13,52 @@ import torch
 SYNC = os.environ.get("FUMI_SYNC_STATS", "0") == "1"
 
 
+_RING = {}          # (shape, dtype) -> [list of (pinned host tensor, event, owner LazyStats or None), next index]
+_RING_DEPTH = 16
+
+
 class LazyStats:
+    """Pinned staging buffers and events come from a small ring (allocating pinned memory every step costs ~15 us of host
+    time); a buffer is only reused after its previous owner has been read or is forced to materialise first."""
+
     def __init__(self, dev_tensor):
         t = dev_tensor.detach()
+        self._np = None
         if t.is_cuda:
-            self._host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            key = (tuple(t.shape), t.dtype)
+            ring = _RING.get(key)
+            if ring is None:
+                ring = _RING[key] = [[[torch.empty(t.shape, dtype=t.dtype, pin_memory=True), torch.cuda.Event(), None]
+                                      for _ in range(_RING_DEPTH)], 0]
+            slot = ring[0][ring[1]]
+            ring[1] = (ring[1] + 1) % _RING_DEPTH
+            if slot[2] is not None:
+                slot[2]._detach()                 # an unread predecessor keeps its value (copy out of the pinned buffer)
+            self._host, self._ev, self._slot = slot[0], slot[1], slot
+            slot[2] = self
             self._host.copy_(t, non_blocking=True)
-            self._ev = torch.cuda.Event()
             self._ev.record(torch.cuda.current_stream(t.device))
         else:
-            self._host, self._ev = t.clone(), None
-        self._np = None
+            self._host, self._ev, self._slot = t.clone(), None, None
+
+    def _detach(self):
+        if self._np is None:
+            self._ev.synchronize()
+            self._np = self._host.numpy().copy()
+        if self._slot is not None:
+            self._slot[2] = None
+            self._slot = None
 
     def get(self):
         if self._np is None:
             if self._ev is not None:
                 self._ev.synchronize()
-            self._np = self._host.numpy()
+                self._np = self._host.numpy().copy()
+                if self._slot is not None:
+                    self._slot[2] = None
+                    self._slot = None
+            else:
+                self._np = self._host.numpy()
         return self._np
 
 

@@ -12,6 +12,10 @@ class Adam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kw)
         self._fused_args = {}
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._fused_args = {}                     # the moment tensors were replaced: rebuild the cached pointer tables
+
     def _fusable(self, group, params):
         return (params and not group.get("amsgrad") and not group.get("maximize") and not group.get("capturable")
                 and not group.get("differentiable") and len(params) <= 32
@@ -22,28 +26,37 @@ class Adam(torch.optim.Adam):
     @torch.no_grad()
     def step(self, closure=None):
         groups = [(g, [p for p in g["params"] if p.grad is not None]) for g in self.param_groups]
-        if closure is not None or not all(self._fusable(g, ps) for g, ps in groups if ps):
+        if closure is not None:
             return super().step(closure)
+        plans = []
         for gi, (group, params) in enumerate(groups):
             if not params:
                 continue
-            for p in params:
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)        # same layout as torch.optim.Adam
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            step = int(self.state[params[0]]["step"]) + 1
-            for p in params:
-                self.state[p]["step"] += 1
-            ms = [self.state[p]["exp_avg"] for p in params]
-            vs = [self.state[p]["exp_avg_sq"] for p in params]
             grads = [p.grad for p in params]
-            key = tuple(t.data_ptr() for t in params + grads + ms + vs)
-            args = self._fused_args.get(gi)
-            if args is None or args.key != key:
-                args = self._fused_args[gi] = hip.AdamArgs(list(params), grads, ms, vs)
-            dev = params[0].device
+            cached = self._fused_args.get(gi)
+            # same tensors as last step (the usual case: parameters and the flat gradient views are stable): skip the checks
+            ident = tuple(p.data_ptr() for p in params) + tuple(g.data_ptr() for g in grads)
+            if cached is None or cached.ident != ident:
+                if not self._fusable(group, params):
+                    return super().step(closure)
+                for p in params:
+                    st = self.state[p]
+                    if len(st) == 0:
+                        st["step"] = torch.tensor(0.0, dtype=torch.float32)        # same layout as torch.optim.Adam
+                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                ms = [self.state[p]["exp_avg"] for p in params]
+                vs = [self.state[p]["exp_avg_sq"] for p in params]
+                cached = self._fused_args[gi] = hip.AdamArgs(list(params), grads, ms, vs)
+                cached.ident = ident
+                cached.steps = [self.state[p]["step"] for p in params]
+                cached.dev = params[0].device
+            elif isinstance(group["lr"], torch.Tensor) or group.get("amsgrad") or group.get("maximize"):
+                return super().step(closure)
+            plans.append((group, cached))
+        for group, args in plans:
+            step = int(args.steps[0]) + 1
+            torch._foreach_add_(args.steps, 1)                                  # the per-parameter `step` tensors stay in sync
             b1, b2 = group["betas"]
-            hip.adam_step(hip.Workspace.get(dev), args, group["lr"], b1, b2, group["eps"], group["weight_decay"], step, dev)
+            hip.adam_step(hip.Workspace.get(args.dev), args, group["lr"], b1, b2, group["eps"], group["weight_decay"], step, args.dev)
         return None
