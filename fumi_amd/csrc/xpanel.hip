@@ -290,8 +290,9 @@ __global__ __launch_bounds__(256) void xpanel_fwd_kernel(XPanel p, float* __rest
 // goes to LDS,  x = h + m + l  (h = top 16 bits of x, m = top 16 bits of x - h, l = top 16 bits of x - h - m; both
 // subtractions are exact in fp32, 8 significand bits per piece), and a product is accumulated in fp32 from the six
 // piece products of weight >= 2^-16:   a*b ~= ah*bl + al*bh + am*bm + ah*bm + am*bh + ah*bh.
-// The dropped terms (am*bl, al*bm, al*bl) are below 2^-24 |a*b|, i.e. below the rounding of the fp32 product itself; the
-// measured error against an fp64 reference equals the fp32 MFMA kernel's (tests/test_hip_parity.py).  Six bf16 MFMAs
+// The dropped terms (am*bl, al*bm, al*bl) are below 2^-24 |a*b|, i.e. below the rounding of the fp32 product itself.
+// Measured against fp64 (tools/xpanel_error.py, bench shapes): random-sign data 7e-7 rms like the fp32 MFMA kernel; the Gram
+// matrix of all-positive inputs 2.5e-6 rms vs 6e-7 (pieces are truncated, so the dropped tails have one sign).  Six bf16 MFMAs
 // replace eight fp32 ones per 16 k at a quarter of the cycles each: 2.67x the matrix rate.  Non-finite inputs give NaN.
 // LDS: per slab and operand three [64 rows][32 k] bf16 planes, row stride 80 B: conflict-free ds_read_b128 for the
 // 32x32x16 operand map (lane l holds row l&31, k = 8*(l>>5) .. +7).
