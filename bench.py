@@ -11,7 +11,8 @@ Workload (configs[1]): 5-way 5-shot, 32 query/class, D=2048 ResNet-152-style emb
 GloVe-300 token text (L=128, V=20000, mean pooling), text_hid 256, 1 inner step, 32 episodes per GPU (weak scaling:
 the global meta-batch is 32*N episodes sharded as contiguous blocks, one RCCL all-reduce of the flat gradient).
 
-Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (xpanel_fwd: [A0|G] = [Xs;Xq][W0;Xs]^T on the fp32 MFMA), timed with
+Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (xpanel_bwd: gW0 = sum_b Abar0_b^T [Xs_b;Xq_b] on the fp32 MFMA,
+the longest kernel of a step: profiles/r01), timed with
 HIP events on the launch stream inside the timed region; ``cpu_baseline`` is the oracle restatement of the reference
 path timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -75,17 +76,17 @@ def make_model(dev, seed=123):
 
 
 def flops_dominant(B):
-    """xpanel_fwd: per episode [A0|G] = [Xs;Xq] [W0;Xs]^T -> 2 (S+Qn) (h0+S) D flops."""
+    """xpanel_bwd: gW0 = sum_b Abar0_b^T [Xs_b;Xq_b] -> 2 (S+Qn) h0 D flops per episode."""
     c = CFG
     S, Qn = c["N"] * c["K"], c["N"] * c["Q"]
-    return 2.0 * B * (S + Qn) * (c["hid"][0] + S) * c["D"]
+    return 2.0 * B * (S + Qn) * c["hid"][0] * c["D"]
 
 
 def bytes_dominant(B):
-    """xpanel_fwd algorithmic HBM bytes: X and W0 read once, A0 and G written once."""
+    """xpanel_bwd algorithmic HBM bytes: X and Abar0 read once, gW0 written once."""
     c = CFG
     S, Qn, h0 = c["N"] * c["K"], c["N"] * c["Q"], c["hid"][0]
-    return 4.0 * (B * (S + Qn) * c["D"] + h0 * c["D"] + B * (S + Qn) * (h0 + S))
+    return 4.0 * (B * (S + Qn) * c["D"] + B * (S + Qn) * h0 + h0 * c["D"])
 
 
 def flops_step_algorithmic(B):
@@ -192,7 +193,7 @@ def main():
         model.evaluate(args, batches[i % NBATCH], opt, "train")
     hip.raise_on_status(ws.read_status())
     if not a.no_phase_timing:
-        ws.set_profiling(True, None if a.all_phases else ["xpanel_fwd"])
+        ws.set_profiling(True, None if a.all_phases else ["xpanel_bwd"])
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -221,21 +222,21 @@ def main():
             "final_loss": float(last[0]), "final_acc": float(last[1]),
             "step_tflops_algorithmic": round(flops_step_algorithmic(c["B_per_gpu"]) / (ms * 1e-3) / 1e12, 3),
         }
-        if "xpanel_fwd" in prof:
-            tot, n = prof["xpanel_fwd"]
+        if "xpanel_bwd" in prof:
+            tot, n = prof["xpanel_bwd"]
             dur = tot / n * 1e-3
             ach = flops_dominant(c["B_per_gpu"]) / dur / 1e12
             traffic = None       # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/<round>/pmc_traffic.json)
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))[-1:]:
                 k = json.load(open(f))["kernels"]
-                key = [x for x in k if x.startswith("xpanel_fwd_kernel")]
+                key = [x for x in k if x.startswith("xpanel_bwd_kernel")]
                 if key and "hbm_bytes_per_launch" in k[key[0]]:
                     traffic = int(k[key[0]]["hbm_bytes_per_launch"])
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                                "algorithmic_bytes": int(bytes_dominant(c["B_per_gpu"])),
-                               "kernel": "xpanel_fwd_kernel ([A0|G] = [Xs;Xq][W0;Xs]^T per episode: 32 x (185 x 281 x 2048), fp32 MFMA 32x32x2)",
+                               "kernel": "xpanel_bwd_kernel (gW0 = sum_b Abar0_b^T [Xs_b;Xq_b]: 256 x 2048 outputs, contraction over 32 x 185 rows in 8 slabs, fp32 MFMA 32x32x2)",
                                "avg_us": round(dur * 1e6, 2), "launches": n}
             out["phase_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items()}
         if not a.no_cpu_baseline and world == 1:

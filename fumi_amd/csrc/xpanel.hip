@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void xpanel_fwd_kernel(XPanel p, float* __rest
 // ---- forward on the bf16 matrix pipe with fp32-equivalent accuracy ("split-bf16") -------------------------------------
 // gfx950 multiplies bf16 sixteen times faster than fp32 (v_mfma_f32_32x32x16_bf16: 32 cycles for 16 k; the fp32 form
 // v_mfma_f32_32x32x2_f32: 64 cycles for 2 k).  Every fp32 operand is split EXACTLY into three bf16 pieces when its slab
-// goes to LDS,  x = h + m + l  (h = top 16 bits of x, m = top 16 bits of x - h, l = top 16 bits of x - h - m; both
+// goes to LDS,  x = h + m + l  (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round to nearest even; both
 // subtractions are exact in fp32, 8 significand bits per piece), and a product is accumulated in fp32 from the six
 // piece products of weight >= 2^-16:   a*b ~= ah*bl + al*bh + am*bm + ah*bm + am*bh + ah*bh.
 // The dropped terms (am*bl, al*bm, al*bl) are below 2^-24 |a*b|, i.e. below the rounding of the fp32 product itself.
@@ -302,21 +302,25 @@ constexpr int SPLANE = 64 * SROW;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// two floats -> one dword of two bf16 (low half = a), round to nearest even: v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+// exact three-way split of a pair: x = h + m + l + (a rounding residue below 2^-25 |x|, either sign: no bias in long sums)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
+    m = pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+    l = pk_bf16(s0, s1);
+}
 __device__ __forceinline__ void split3(const f32x4& v, u32x2& h, u32x2& m, u32x2& l) {
-    unsigned hb[4], mb[4], lb[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const unsigned u = __float_as_uint(v[e]);
-        hb[e] = u & 0xFFFF0000u;
-        const float r1 = v[e] - __uint_as_float(hb[e]);
-        mb[e] = __float_as_uint(r1) & 0xFFFF0000u;
-        const float r2 = r1 - __uint_as_float(mb[e]);
-        lb[e] = __float_as_uint(r2);
-    }
-    // two bf16 per dword: low half = element 2j, high half = element 2j+1 (top 16 bits of each)
-    h[0] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u); h[1] = __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u);
-    m[0] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u); m[1] = __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u);
-    l[0] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u); l[1] = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_pair(v[0], v[1], h0, m0, l0);
+    split_pair(v[2], v[3], h1, m1, l1);
+    h = (u32x2){h0, h1}; m = (u32x2){m0, m1}; l = (u32x2){l0, l1};
 }
 
 template <int I, int N, class F>
@@ -422,26 +426,17 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* 
         for (int q = 0; q < 4; ++q) {                      // float4 q of the staged slab: A0, A1, B0, B1
             const f32x4 v = q < 2 ? ga[ST][q] : gb[ST][q - 2];
             const int off = ((tid >> 3) + 32 * (q & 1)) * SROW + k4;
-            unsigned hb[4], mb[4], lb[4];
+            unsigned hp[2], mp[2], lp[2];
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
                 const int u = 3 * q + part;                // MFMA number 0..11
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u / 6][PA[u % 6]], fb[u / 6][PB[u % 6]], acc, 0, 0, 0);
                 if (part < 2) {
-#pragma unroll
-                    for (int e = 2 * part; e < 2 * part + 2; ++e) {
-                        const unsigned uu = __float_as_uint(v[e]);
-                        hb[e] = uu & 0xFFFF0000u;
-                        const float r1 = v[e] - __uint_as_float(hb[e]);
-                        mb[e] = __float_as_uint(r1) & 0xFFFF0000u;
-                        lb[e] = __float_as_uint(r1 - __uint_as_float(mb[e]));
-                    }
+                    split_pair(v[2 * part], v[2 * part + 1], hp[part], mp[part], lp[part]);
                 } else {
-                    u32x2 h, m, l;
-                    h[0] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u); h[1] = __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u);
-                    m[0] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u); m[1] = __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u);
-                    l[0] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u); l[1] = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
-                    *(u32x2*)(lds[nxt][q >> 1][0] + off) = h; *(u32x2*)(lds[nxt][q >> 1][1] + off) = m; *(u32x2*)(lds[nxt][q >> 1][2] + off) = l;
+                    *(u32x2*)(lds[nxt][q >> 1][0] + off) = (u32x2){hp[0], hp[1]};
+                    *(u32x2*)(lds[nxt][q >> 1][1] + off) = (u32x2){mp[0], mp[1]};
+                    *(u32x2*)(lds[nxt][q >> 1][2] + off) = (u32x2){lp[0], lp[1]};
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -581,10 +576,9 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
     const bool aligned = al16(p.x_s) && al16(p.x_q) && al16(W0);
     const dim3 grid(8 * nper * tiles_m * tiles_n);
     static const int nst = getenv("FUMI_XP_NST") ? atoi(getenv("FUMI_XP_NST")) : 2;      // staging ring depth (tuning knob)
-    // FUMI_XP_SB=1: the split-bf16 kernel (fp32-equivalent accuracy on the bf16 matrix pipe).  Measured 65 us against the fp32
-    // kernel's 78 us at the bench shapes -- both sit on the same ~8 TB/s L2 -> CU delivery of 64x64 tiles, so it
-    // stays opt-in until the larger-tile version exists.
-    static const int use_sb = getenv("FUMI_XP_SB") ? atoi(getenv("FUMI_XP_SB")) : 0;
+    // Default: the split-bf16 kernel (65 us at the bench shapes, error against fp64 below the fp32 MFMA kernel's: DESIGN.md).
+    // FUMI_XP_SB=0 selects the fp32 MFMA kernel (78 us).
+    static const int use_sb = getenv("FUMI_XP_SB") ? atoi(getenv("FUMI_XP_SB")) : 1;
     if (aligned && D % SBK == 0 && use_sb) {
         static const int sbn = getenv("FUMI_XP_SBN") ? atoi(getenv("FUMI_XP_SBN")) : 2;          // ring depth (tuning knob)
         if (sbn <= 2) hipLaunchKernelGGL(xpanel_fwd_sb_kernel<2>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n);

@@ -423,7 +423,7 @@ from fumi_amd import hip
 dev = torch.device("cuda:0"); ws = hip.Workspace.get(dev)
 g = torch.Generator().manual_seed(5)
 B, S, Qn, D, h0 = 3, 25, 43, 256, 96
-x_s = torch.randn(B, S, D, generator=g); x_q = torch.randn(B, Qn, D, generator=g) * 3.0
+x_s = torch.randn(B, S, D, generator=g).abs(); x_q = torch.randn(B, Qn, D, generator=g) * 3.0      # post-ReLU-like support rows
 W0 = torch.randn(h0, D, generator=g) * 0.05
 A0, G = hip.xpanel_fwd(ws, x_s.to(dev), x_q.to(dev), W0.to(dev))
 X = torch.cat([x_s, x_q], 1).double()
@@ -435,9 +435,10 @@ print(json.dumps({"ea": ea, "eg": eg}))
 
 
 def test_xpanel_fwd_split_bf16_has_fp32_accuracy(dev):
-    """FUMI_XP_SB=1 runs layer 0 / the Gram matrix on the bf16 matrix pipe from exact three-way bf16 splits of the fp32
-    operands (xpanel.hip).  Its error against fp64 must be of the size of the fp32 MFMA kernel's (both ~1e-7 of the
-    largest entry), far inside the 1e-4 parity tolerance.  The knob is read once per process, hence the child processes."""
+    """Layer 0 / the Gram matrix run on the bf16 matrix pipe from exact three-way bf16 splits of the fp32 operands (default;
+    FUMI_XP_SB=0 selects the fp32 MFMA kernel, xpanel.hip).  Its error against fp64 must not exceed the fp32 MFMA kernel's
+    (both ~1e-7..1e-6 of the largest entry, far inside the 1e-4 parity tolerance).  The knob is read once per process, hence
+    the child processes."""
     import json
     import os
     import subprocess
@@ -452,7 +453,7 @@ def test_xpanel_fwd_split_bf16_has_fp32_accuracy(dev):
     for k in ("ea", "eg"):
         assert errs["0"][k] < 2e-6, errs
         assert errs["1"][k] < 2e-6, errs
-        assert errs["1"][k] < 4.0 * errs["0"][k] + 1e-7, errs
+        assert errs["1"][k] < 1.5 * errs["0"][k] + 5e-8, errs
 
 
 def test_meta_batch_larger_than_the_chip_matches_chunks(dev, ws):
