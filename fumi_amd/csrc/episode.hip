@@ -223,6 +223,7 @@ __global__ __launch_bounds__(512) void adapt_kernel(EpiDims d, EpiBuf w, EpiPara
     }
     // colsum(D_T): every query tile needs it (b0_T = b0 - alpha * colsum(D_T))
     wg_colsum(sm, sm_cap, S, h0, D, h0, [&](int n, float s) { cs[n] = s; });
+#undef STAMP
 }
 
 // ------------------------------------------------------------------------------------------------------------
