@@ -540,3 +540,60 @@ def test_fumi_eval_with_100_adapt_steps_matches_oracle(dev, ws):
     assert rel_to_max(ref["logits"], ref0["logits"]) > 0.02            # the adaptation is not a no-op
     assert rel_to_max(out["logits"].cpu().double(), ref["logits"]) <= LOGIT_TOL
     assert rel_to_max(out["loss_b"].cpu().double(), ref["loss_b"]) <= LOGIT_TOL
+
+
+_FUZZ = [   # B  N  K  Q   D    hid              Dt  Ht  T  tanh   -- odd sizes on purpose: ragged tiles, 1-4 hidden layers, splits
+    dict(B=5, N=3, K=2, Q=7, D=72, hid=[40, 12], Dt=20, Ht=24, T=3, tanh=False),
+    dict(B=2, N=7, K=3, Q=5, D=130, hid=[36], Dt=12, Ht=16, T=2, tanh=True),
+    dict(B=9, N=2, K=4, Q=33, D=256, hid=[128, 64, 32], Dt=64, Ht=64, T=2, tanh=False),
+    dict(B=3, N=5, K=1, Q=3, D=64, hid=[16, 16, 16, 8], Dt=8, Ht=8, T=4, tanh=True),
+    dict(B=4, N=4, K=6, Q=9, D=512, hid=[256, 32], Dt=100, Ht=128, T=1, tanh=False),
+    dict(B=1, N=10, K=2, Q=4, D=96, hid=[64, 64], Dt=32, Ht=64, T=2, tanh=False),
+    dict(B=17, N=5, K=5, Q=8, D=320, hid=[192, 48], Dt=300, Ht=256, T=1, tanh=False),
+]
+
+
+@pytest.mark.parametrize("i", range(len(_FUZZ)))
+def test_fumi_step_odd_shapes_match_oracle(i, dev, ws):
+    """Shapes the golden cases do not have (ragged row / column tiles, 1-4 hidden layers, every split factor of the reverse
+    sweep, LDS-resident and generic kernels as the sizes dictate): logits, losses, predictions and all gradients vs the oracle."""
+    from fumi_amd import hip
+    c = _FUZZ[i]
+    ep = cg.make_episodes(1000 + i, c["B"], c["N"], c["K"], c["Q"], c["D"], c["Dt"], blocked=bool(i & 1))
+    theta, phi = cg.make_fumi_params(1000 + i, c["D"], c["hid"], c["Dt"], c["Ht"])
+    out = hip.fumi_step_select(ws, c["N"], _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev),
+                               _g(ep["text_s"], dev), [_g(t, dev) for t in theta], [_g(t, dev) for t in phi],
+                               c["T"], cg.ALPHA, c["tanh"])
+    assert ws.read_status() == 0
+    th = [t.clone().requires_grad_(True) for t in theta]
+    ph = [t.clone().requires_grad_(True) for t in phi]
+    ref = R.fumi_meta_step(th, ph, ep["text_s"], ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], c["N"], c["T"], cg.ALPHA, c["tanh"])
+    assert rel_to_max(out["logits"].cpu(), ref["logits"]) <= LOGIT_TOL
+    assert rel_to_max(out["loss_b"].cpu(), ref["loss_b"]) <= LOGIT_TOL
+    safe = safe_margin_mask(ref["logits"], 1e-4 * float(ref["logits"].abs().max()))
+    assert torch.equal(out["preds"].cpu()[safe], ref["preds"][safe])
+    names = [f"im_net.linear{k}.{w}" for k in range(len(c["hid"])) for w in ("weight", "bias")]
+    names += ["hyper_net.0.weight", "hyper_net.0.bias", "hyper_net.2.weight", "hyper_net.2.bias"]
+    _check_grads(names, out["g_theta"] + out["g_phi"], None, ref["g_theta"] + ref["g_phi"])
+
+
+@pytest.mark.parametrize("c", [
+    dict(B=6, N=7, K=3, Q=5, D=130, hid=None, T=4, first_order=False),          # bare linear head, unaligned D, second order
+    dict(B=33, N=5, K=5, Q=32, D=2048, hid=None, T=2, first_order=False),        # reference sizes, more episodes than 32
+    dict(B=4, N=3, K=2, Q=9, D=64, hid=None, T=3, first_order=True),
+    dict(B=5, N=6, K=2, Q=4, D=200, hid=[24, 24, 12], T=3, first_order=False),   # three hidden layers
+    dict(B=3, N=4, K=3, Q=6, D=96, hid=[20], T=2, first_order=True),             # one hidden layer, first order
+], ids=lambda c: f"hid{c['hid']}_T{c['T']}_{'fo' if c['first_order'] else 'so'}")
+def test_maml_step_odd_shapes_match_oracle(c, dev, ws):
+    from fumi_amd import hip
+    ep = cg.make_episodes(2000 + c["D"], c["B"], c["N"], c["K"], c["Q"], c["D"], 8)
+    p = cg.make_maml_params(2000 + c["D"], c["D"], c["hid"], c["N"])
+    out = hip.maml_step(ws, _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev),
+                        [_g(t, dev) for t in p], c["T"], cg.ALPHA, c["first_order"])
+    assert ws.read_status() == 0
+    pl = [t.clone().requires_grad_(True) for t in p]
+    ref = R.maml_meta_step(pl, ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], c["T"], cg.ALPHA, c["first_order"])
+    assert rel_to_max(out["logits"].cpu(), ref["logits"]) <= LOGIT_TOL
+    assert rel_to_max(out["loss_b"].cpu(), ref["loss_b"]) <= LOGIT_TOL
+    names = [f"net.lin_{i}.{k}" for i in range(len(c["hid"] or [])) for k in ("weight", "bias")] + ["net.lin_final.weight", "net.lin_final.bias"]
+    _check_grads(names, out["g_params"], None, ref["g_params"])
