@@ -560,6 +560,93 @@ __global__ __launch_bounds__(256) void xpanel_bwd_kernel(XPanel p, const float* 
     }
 }
 
+// ---- backward, 256 x 64 tiles (h0 % 256 == 0, D % 64 == 0, aligned): every X element is fetched by exactly one workgroup ----
+// The 64 x 64 kernel reads each X column block once per 64-row group of gW0 (four times at h0 = 256): 97 MB of HBM reads per
+// launch for 54.6 MB of operands.  Here a workgroup owns all 256 rows of a 64-column block, so X is streamed once and only
+// the small Abar0 panel (L2 / Infinity-Cache resident) is re-read.  8 waves as 4 (M) x 2 (N), two 32x32 accumulators each;
+// 32-deep slabs double-buffered in 80 KB of LDS (two workgroups per CU), next slab prefetched to registers.
+__global__ __launch_bounds__(512) void xpanel_bwd256_kernel(XPanel p, const float* __restrict__ Abar, float* __restrict__ slabs,
+                                                            int kchunk, int nsplit, int tiles_n, int tiles_m) {
+    extern __shared__ __attribute__((aligned(16))) float lds256[];       // [2][ A: 32 x 256 | B: 32 x 64 ]
+    constexpr int ASZ = 32 * 256, BSZ = 32 * 64, STG = ASZ + BSZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int R = p.S + p.Qn, M = p.h0, Nn = p.D;
+    const long Ktot = (long)p.B * R;
+    // XCD-aware ids (workgroup ids equal mod 8 share an XCD): all tiles of contraction slab z run on XCD z % 8, so the slab's
+    // rows of Abar0 (0.4-0.8 MB) stay in that XCD's L2 while its 32 column tiles stream their X pieces
+    const int tiles = tiles_n * tiles_m;
+    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    const int z = xcd + 8 * (jq / tiles), tl = jq % tiles;
+    if (z >= nsplit) return;
+    const int m0 = (tl / tiles_n) * 256, n0 = (tl % tiles_n) * 64;
+    const long kbeg = (long)z * kchunk;
+    const long kend = min(Ktot, kbeg + kchunk);
+    float* C = slabs + (long)z * M * Nn;
+
+    // staging map: A float4 f = tid + 512 i (i < 4) -> contraction row f >> 6, columns (f & 63) * 4;  B float4 tid -> row
+    // tid >> 4, columns (tid & 15) * 4.  Abar0 is [B*R, h0] contiguous; the X row of B goes through xrow (looked up a slab ahead).
+    const int ac4 = (tid & 63) << 2, bc4 = (tid & 15) << 2;
+    int gb, gr;
+    {
+        const long g = kbeg + (tid >> 4);
+        gb = (int)(g / R); gr = (int)(g - (long)gb * R);
+    }
+    const float* xp = xrow(p, kbeg + (tid >> 4) < kend ? gb : 0, kbeg + (tid >> 4) < kend ? gr : 0);
+    f32x4 ra[4], rb; bool oka[4], okb;
+    auto load = [&](long k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long g = k0 + (tid >> 6) + 8 * i;
+            oka[i] = g < kend;
+            ra[i] = *(const f32x4*)(Abar + (oka[i] ? g : 0) * M + m0 + ac4);      // raw; masked when written to LDS
+        }
+        const long g = k0 + (tid >> 4);
+        okb = g < kend;
+        rb = *(const f32x4*)(xp + n0 + bc4);
+        gr += 32;
+        while (gr >= R) { gr -= R; ++gb; }
+        const bool okn = g + 32 < kend;
+        xp = xrow(p, okn ? gb : 0, okn ? gr : 0);
+    };
+    auto store = [&](int buf) {
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        float* Ab = lds256 + buf * STG; float* Bb = Ab + ASZ;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(Ab + ((tid >> 6) + 8 * i) * 256 + ac4) = oka[i] ? ra[i] : zero4;
+        *(f32x4*)(Bb + (tid >> 4) * 64 + bc4) = okb ? rb : zero4;
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    const int nslab = (int)((kend - kbeg + 31) / 32);
+    if (nslab > 0) { load(kbeg); store(0); }
+    __syncthreads();
+    const int li = lane & 31, kh = lane >> 5;
+    for (int s = 0; s < nslab; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nslab) load(kbeg + (long)(s + 1) * 32);
+        const float* TA = lds256 + cur * STG + wm * 64 + li;
+        const float* TB = lds256 + cur * STG + ASZ + wn * 32 + li;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const int k = 2 * k2 + kh;
+            const float a0 = TA[k * 256], a1 = TA[k * 256 + 32], b0 = TB[k * 64];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc1, 0, 0, 0);
+        }
+        if (s + 1 < nslab) store(cur ^ 1);
+        __syncthreads();
+    }
+    const int n = n0 + wn * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        C[(long)m * Nn + n] = acc0[r];
+        C[(long)(m + 32) * Nn + n] = acc1[r];
+    }
+}
+
 inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 unsigned long long* g_trace = nullptr;      // dev tracing only (tools/trace_xpanel.py)
 
@@ -594,10 +681,18 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
     return FUMI_OK;
 }
 
+static bool xpanel_bwd_wide(int D, int h0) {
+    static const int off = getenv("FUMI_XPB_64") ? atoi(getenv("FUMI_XPB_64")) : 0;     // 1: always the 64 x 64 kernel
+    return !off && (h0 % 256 == 0) && (D % 64 == 0);
+}
+
 int xpanel_bwd_nsplit(int B, int S, int Qn, int D, int h0, int* kchunk_out) {
     const long Ktot = (long)B * (S + Qn);
-    const long tiles = (long)((h0 + 63) / 64) * ((D + 63) / 64);
-    long ns = (1024 + tiles - 1) / tiles;                // ~4 workgroups per CU
+    const bool wide = xpanel_bwd_wide(D, h0);
+    const long tiles = wide ? (long)(h0 / 256) * (D / 64) : (long)((h0 + 63) / 64) * ((D + 63) / 64);
+    static const int target = getenv("FUMI_XPB_WG") ? atoi(getenv("FUMI_XPB_WG")) : 0;
+    const long want = target > 0 ? target : (wide ? 512 : 1024);   // workgroups: two 8-wave ones or four 4-wave ones per CU
+    long ns = (want + tiles - 1) / tiles;
     if (ns < 1) ns = 1;
     if (ns > 32) ns = 32;
     long kc = ((Ktot + ns - 1) / ns + BK - 1) / BK * BK;
@@ -611,6 +706,15 @@ int launch_xpanel_bwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
     XPanel p{x_s, x_q, nullptr, B, S, Qn, D, h0, nullptr, nullptr, nullptr, 0};
     if (rows && rows->table) { p.table = rows->table; p.idx_s = rows->idx_s; p.idx_q = rows->idx_q; p.n_rows = rows->n_rows; p.x_s = p.x_q = rows->table; }
     const bool fast = (D % 64 == 0) && (h0 % 64 == 0) && al16(p.x_s) && al16(p.x_q) && al16(Abar);
+    if (fast && xpanel_bwd_wide(D, h0)) {
+        const size_t lds_bytes = 2 * (32 * 256 + 32 * 64) * sizeof(float);
+        FUMI_SET_DYN_LDS(xpanel_bwd256_kernel, lds_bytes);
+        const int tn = D / 64, tm = h0 / 256;
+        hipLaunchKernelGGL(xpanel_bwd256_kernel, dim3(8 * ((nsplit + 7) / 8) * tn * tm), dim3(512), lds_bytes, st, p, Abar, slabs,
+                           kchunk, nsplit, tn, tm);
+        LAUNCH_CHECK();
+        return FUMI_OK;
+    }
     const dim3 grid((D + 63) / 64, (h0 + 63) / 64, nsplit);
     if (fast) hipLaunchKernelGGL(xpanel_bwd_kernel<true>, grid, dim3(256), 0, st, p, Abar, slabs, kchunk);
     else hipLaunchKernelGGL(xpanel_bwd_kernel<false>, grid, dim3(256), 0, st, p, Abar, slabs, kchunk);
