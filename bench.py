@@ -230,13 +230,13 @@ def main():
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))[-1:]:
                 k = json.load(open(f))["kernels"]
-                key = [x for x in k if x.startswith("xpanel_bwd_kernel")]
+                key = [x for x in k if x.startswith("xpanel_bwd256_kernel")] or [x for x in k if x.startswith("xpanel_bwd")]
                 if key and "hbm_bytes_per_launch" in k[key[0]]:
                     traffic = int(k[key[0]]["hbm_bytes_per_launch"])
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                                "algorithmic_bytes": int(bytes_dominant(c["B_per_gpu"])),
-                               "kernel": "xpanel_bwd_kernel (gW0 = sum_b Abar0_b^T [Xs_b;Xq_b]: 256 x 2048 outputs, contraction over 32 x 185 rows in 8 slabs, fp32 MFMA 32x32x2)",
+                               "kernel": "xpanel_bwd256_kernel (gW0 = sum_b Abar0_b^T [Xs_b;Xq_b]: 256 x 2048 outputs in 256 x 64 tiles, contraction over 32 x 185 rows in 16 slabs, fp32 MFMA 32x32x2)",
                                "avg_us": round(dur * 1e6, 2), "launches": n}
             out["phase_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items()}
         if not a.no_cpu_baseline and world == 1:
