@@ -21,10 +21,11 @@ from .. import hip
 
 class GpuEpisodeSampler:
     def __init__(self, images, class_of_image, class_text, num_ways, num_shots, num_shots_test, batch_size, seed=123,
-                 length=None, zero_copy=False):
+                 length=None, zero_copy=False, row_ids=None):
         """images [n_images, D] fp32 (moved to the device once), class_of_image [n_images] ints (category of every row, as
         inat_anim.json's annotations give it), class_text [C, Dt] fp32 or [C, L] int64 tokens (one row per class: the text of
-        a sample is its class description, data.py:543-549)."""
+        a sample is its class description, data.py:543-549).  row_ids [n_images] ints: the id reported for every table row in
+        the batch's index field (the dataset's image ids, data.py:568-571); default: the row number."""
         self.dev = images.device if images.is_cuda else torch.device("cuda", torch.cuda.current_device())
         self.images = images.to(self.dev, torch.float32).contiguous()
         coi = np.asarray(class_of_image, dtype=np.int64)
@@ -47,6 +48,9 @@ class GpuEpisodeSampler:
         lab = torch.arange(self.N, device=self.dev, dtype=torch.int64)
         self.y_s = lab.repeat_interleave(self.K).unsqueeze(0).expand(self.B, S).contiguous()      # ConcatTask order
         self.y_q = lab.repeat_interleave(self.Q).unsqueeze(0).expand(self.B, Qn).contiguous()
+        self.row_ids = None if row_ids is None else torch.as_tensor(np.asarray(row_ids, dtype=np.int64)).to(self.dev)
+        if self.row_ids is not None and self.row_ids.numel() != self.images.shape[0]:
+            raise ValueError("row_ids must hold one id per image row")
         self.ws = hip.Workspace.get(self.dev)
 
     def batch(self, step):
@@ -60,8 +64,10 @@ class GpuEpisodeSampler:
         t_cls = hip.gather_rows(self.ws, self.class_text, cls.view(-1)).view(B, N, -1)           # one text row per class slot
         text_s = t_cls.repeat_interleave(K, dim=1)
         text_q = t_cls.repeat_interleave(Q, dim=1)
-        return {'train': ([it_s.view(B, N * K), text_s, x_s], self.y_s),
-                'test': ([it_q.view(B, N * Q), text_q, x_q], self.y_q)}
+        id_s, id_q = it_s.view(B, N * K), it_q.view(B, N * Q)
+        if self.row_ids is not None:
+            id_s, id_q = self.row_ids[id_s], self.row_ids[id_q]
+        return {'train': ([id_s, text_s, x_s], self.y_s), 'test': ([id_q, text_q, x_q], self.y_q)}
 
     def __iter__(self):
         i = 0

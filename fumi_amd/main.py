@@ -4,8 +4,9 @@
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m fumi_amd.main ...   (episode-sharded)
 
 Same flags (fumi_amd/utils/utils.py), same flag validation and error types, same train -> test flow and logged
-metrics.  ``--dataset inat-anim`` needs the Zenodo JSON/HDF5 files plus h5py/nltk/transformers downloads, none of
-which exist offline, so it raises with a pointer to ``--dataset synthetic`` (same batch contract)."""
+metrics.  ``--dataset inat-anim`` reads the reference's files (inat_anim.json + image_embeddings_<model>.hdf5 / .npy) into
+HBM-resident tables (fumi_amd/dataset/inat_anim.py) and raises FileNotFoundError when they are absent; ``--dataset
+synthetic`` / ``synthetic-resident`` have the same batch contract and need no files."""
 import os
 import random
 import sys
@@ -26,10 +27,10 @@ def get_dataset(args):
     if args.dataset == "synthetic-resident":       # same task family, drawn from an HBM-resident table by the GPU sampler
         from .dataset.synthetic import get_synthetic_resident
         return get_synthetic_resident(args)
-    raise FileNotFoundError(
-        f"--dataset {args.dataset}: the iNat-Anim loader (fumi/dataset/data.py) needs the Zenodo files under "
-        f"{args.data_dir} and the h5py / nltk / transformers / gensim downloads, which are unavailable here; "
-        f"use --dataset synthetic (identical batch layout)")
+    if args.dataset == "inat-anim":                # the reference's files (fumi/dataset/data.py) -> HBM-resident tables
+        from .dataset.inat_anim import get_inat_anim
+        return get_inat_anim(args)
+    raise NotImplementedError()                    # data.py:73-74 ('cub' needs a torchmeta download, 'supervised-inat-anim' is CLIP's)
 
 
 def main(args):
