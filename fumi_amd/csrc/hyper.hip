@@ -50,6 +50,161 @@ __global__ __launch_bounds__(512) void hyper_lin_kernel(StageTab stg, LinDims d,
     });
 }
 
+// ---- forward, both layers in one launch (Ht <= 256) ---------------------------------------------------------------------
+// One workgroup per 16-row block walks the whole network.  Layer 0's weights never pass through LDS: a lane of the
+// (transposed) 16x16x4 MFMA needs W[n0 + (l & 15)][k .. k+3], four consecutive floats of ONE weight row, i.e. one 16-byte
+// global load, so a wave that owns NT 16-column tiles of the hidden layer just keeps two FCH*16-deep chunks of those loads
+// in flight (a CU fetching a 300 KB weight matrix alone is latency-bound: everything is requested up front).  The block's input rows (zero-padded to a chunk multiple) and the hidden activations -- layer 1's contraction
+// operand -- are the only LDS images; layer 1's weight fragments are fetched while layer 0's epilogue runs.
+constexpr int FCH = 12;                // 16-deep steps per chunk of weight-fragment loads
+struct FwdDims { int R, Dt, Ht, H1, ldx, tanh_head; };
+__host__ __device__ inline int fwd_ldx(int Dt) { return (Dt + FCH * 16 - 1) / (FCH * 16) * (FCH * 16) + 4; }
+
+template <int NT, int NCH>              // NT tiles per wave (Ht <= 128 NT), NCH chunks of FCH*16 contraction columns
+__global__ __launch_bounds__(512) void hyper_fwd_fused_kernel(FwdDims d, const float* __restrict__ c, const float* __restrict__ A0,
+                                                              const float* __restrict__ b0, const float* __restrict__ A1,
+                                                              const float* __restrict__ b1, float* __restrict__ u,
+                                                              float* __restrict__ h) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * HB, nr = min(HB, d.R - m0);
+    const int Dt = d.Dt, Ht = d.Ht, H1 = d.H1, ldx = d.ldx, ldu = wg_ld(Ht);
+    float* xs = sm; float* us = sm + HB * ldx;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+    // layer 0 weight rows of this wave's tiles (tile t -> columns 16 t ..; waves take tiles wave, wave + 8, ...)
+    const int ntile = Ht >> 4;
+    const float* wrow[NT]; bool live[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tl = wave + 8 * t;
+        live[t] = tl < ntile;
+        wrow[t] = A0 + (long)min(tl * 16 + r, Ht - 1) * Dt;
+    }
+    struct Chunk { f32x4 w[NT][FCH]; };
+    auto wload = [&](int ci) {
+        Chunk ch;
+#pragma unroll
+        for (int s_ = 0; s_ < FCH; ++s_) {
+            const int k = min((ci * FCH + s_) * 16 + 4 * q, Dt - 4);      // past Dt: any valid address (x is zero there)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ch.w[t][s_] = *(const f32x4*)(wrow[t] + k);
+        }
+        return ch;
+    };
+    Chunk ca = wload(0);
+    Chunk cb = wload(NCH > 1 ? 1 : 0);
+
+    // stage the block's input rows, zero-padded (rows past nr, columns past Dt)
+    {
+        const int l4 = ldx >> 2, tot4 = HB * l4;
+        for (int i0 = tid; i0 < tot4; i0 += 4 * 512) {
+            f32x4 v[4]; bool ok[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int i = min(i0 + x * 512, tot4 - 1);
+                const int m = i / l4, k4 = i - m * l4;
+                ok[x] = m < nr && 4 * k4 < Dt;
+                v[x] = *(const f32x4*)(c + (long)(m0 + min(m, nr - 1)) * Dt + min(4 * k4, Dt - 4));
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) if (i0 + x * 512 < tot4) *(f32x4*)(xs + 4 * (i0 + x * 512)) = ok[x] ? v[x] : z4;
+        }
+    }
+    f32x4 bias0[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bias0[t] = *(const f32x4*)(b0 + min((wave + 8 * t) * 16 + 4 * q, Ht - 4));
+    __syncthreads();
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = z4;
+    const float* xr = xs + r * ldx + 4 * q;
+    const int nstep = (Dt + 15) >> 4;
+    auto mma = [&](const Chunk& ch, int ci) {
+#pragma unroll
+        for (int s_ = 0; s_ < FCH; ++s_) {
+            if ((ci * FCH + s_) < nstep) {                // wave-uniform: the padded steps of the last chunk are skipped
+                const f32x4 xf = *(const f32x4*)(xr + (ci * FCH + s_) * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ch.w[t][s_][e], xf[e], acc[t], 0, 0, 0);
+            }
+        }
+    };
+    // layer 1 weight fragments (tile = wave), fetched as soon as a chunk's registers are free in the last round
+    const int ntile1 = (H1 + 15) >> 4, n2 = Ht >> 4;
+    constexpr int S1 = 8 * NT;                           // 16-deep steps of layer 1 (Ht <= 128 NT)
+    f32x4 w1[S1];
+    auto w1load = [&]() {
+        const float* a1r = A1 + (long)min(wave * 16 + r, H1 - 1) * Ht + 4 * q;
+#pragma unroll
+        for (int s_ = 0; s_ < S1; ++s_) w1[s_] = *(const f32x4*)(a1r + min(s_, n2 - 1) * 16);
+    };
+    // both register sets are in flight from the start (everything, when Dt <= 2 * FCH * 16); the chunk walk is unrolled
+    // at compile time so that layer 1's fragments can take over the set that is retired first
+#pragma unroll
+    for (int ci = 0; ci < NCH; ++ci) {
+        if (ci & 1) mma(cb, ci); else mma(ca, ci);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ci + 2 < NCH) { if (ci & 1) cb = wload(ci + 2); else ca = wload(ci + 2); }
+        else if (ci + 2 == NCH || NCH == 1) w1load();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float bias1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias1[e] = b1[min(wave * 16 + 4 * q + e, H1 - 1)];
+
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (!live[t]) continue;
+        const int n = (wave + 8 * t) * 16 + 4 * q;
+        f32x4 v = acc[t] + bias0[t];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        *(f32x4*)(us + r * ldu + n) = v;
+        if (r < nr) *(f32x4*)(u + (long)(m0 + r) * Ht + n) = v;
+    }
+    wg_lds_barrier();
+
+    for (int t1 = wave; t1 < ntile1; t1 += 8) {          // (more than 8 tiles: later ones fetch their fragments here)
+        f32x4 a = z4;
+        const float* ur = us + r * ldu + 4 * q;
+        if (t1 == wave) {
+#pragma unroll
+            for (int s_ = 0; s_ < S1; ++s_) {
+                if (s_ < n2) {
+                    const f32x4 uf = *(const f32x4*)(ur + s_ * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[s_][e], uf[e], a, 0, 0, 0);
+                }
+            }
+        } else {
+            const float* a1r = A1 + (long)min(t1 * 16 + r, H1 - 1) * Ht + 4 * q;
+            for (int s_ = 0; s_ < n2; ++s_) {
+                const f32x4 wf = *(const f32x4*)(a1r + s_ * 16), uf = *(const f32x4*)(ur + s_ * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[e], uf[e], a, 0, 0, 0);
+            }
+        }
+        const int n = t1 * 16 + 4 * q;
+        if (r < nr && n < H1) {
+            const int cnt = min(4, H1 - n);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float bb = t1 == wave ? bias1[e] : b1[min(n + e, H1 - 1)];
+                v[e] = a[e] + bb;
+                if (d.tanh_head) v[e] = tanhf(v[e]);
+            }
+            wg_st4(h + (long)(m0 + r) * H1 + n, v, cnt);
+        }
+    }
+}
+
 // ---- bwd1 -------------------------------------------------------------------------------------------------------------
 // per row block: hp = hbar (* (1 - h^2)); ubar = (hp A1) * relu'(u) -> global; partial slabs pA1[rb] = hp^T u,
 // pb1[rb] = colsum(hp), pb0[rb] = colsum(ubar)
@@ -157,6 +312,27 @@ static int launch_lin(hipStream_t st, int R, int K, int Nn, int act, const float
 int launch_hyper_fwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_head, const float* c, const float* A0,
                      const float* b0, const float* A1, const float* b1, float* u, float* h) {
     if (!hyper_lds_fits(R, Dt, Ht, H1)) return FUMI_ENOTSUP;
+    static const int no_fuse = getenv("FUMI_HYPER_SPLIT") ? atoi(getenv("FUMI_HYPER_SPLIT")) : 0;     // 1: one launch per layer
+    const bool al = (((uintptr_t)c | (uintptr_t)A0 | (uintptr_t)A1 | (uintptr_t)b0 | (uintptr_t)u) & 15) == 0;
+    const int nch = (Dt + FCH * 16 - 1) / (FCH * 16);
+    if (!no_fuse && Ht <= 256 && nch <= 4 && al) {
+        FwdDims d{R, Dt, Ht, H1, fwd_ldx(Dt), tanh_head};
+        const size_t lds = (size_t)HB * (d.ldx + wg_ld(Ht)) * sizeof(float);
+        const int nrb = (R + HB - 1) / HB;
+#define FWD_LAUNCH(NT_, NCH_)                                                                                    \
+        do {                                                                                                     \
+            FUMI_SET_DYN_LDS((hyper_fwd_fused_kernel<NT_, NCH_>), lds);                                            \
+            hipLaunchKernelGGL((hyper_fwd_fused_kernel<NT_, NCH_>), dim3(nrb), dim3(512), lds, st, d, c, A0, b0, A1, b1, u, h); \
+        } while (0)
+        if (Ht <= 128) {
+            if (nch == 1) FWD_LAUNCH(1, 1); else if (nch == 2) FWD_LAUNCH(1, 2); else if (nch == 3) FWD_LAUNCH(1, 3); else FWD_LAUNCH(1, 4);
+        } else {
+            if (nch == 1) FWD_LAUNCH(2, 1); else if (nch == 2) FWD_LAUNCH(2, 2); else if (nch == 3) FWD_LAUNCH(2, 3); else FWD_LAUNCH(2, 4);
+        }
+#undef FWD_LAUNCH
+        LAUNCH_CHECK();
+        return FUMI_OK;
+    }
     int rc = launch_lin(st, R, Dt, Ht, 1, c, A0, b0, u);
     if (rc) return rc;
     return launch_lin(st, R, Ht, H1, tanh_head ? 2 : 0, u, A1, b1, h);

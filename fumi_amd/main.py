@@ -36,7 +36,7 @@ def get_dataset(args):
 def main(args):
     results_path = f"{args.log_dir}/results"
     os.makedirs(results_path, exist_ok=True)
-    os.environ.setdefault("FUMI_LOG_DIR", args.log_dir)
+    os.environ["FUMI_LOG_DIR"] = args.log_dir        # where the local W&B stand-in keeps run directories
     job_type = "eval" if args.evaluate else "train"
     os.environ['WANDB_MODE'] = 'offline' if args.wandb_offline else 'online'
     wandb.init(entity=args.wandb_entity, project=args.wandb_project, group=args.wandb_experiment, job_type=job_type,

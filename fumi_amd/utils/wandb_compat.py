@@ -25,10 +25,12 @@ class LocalWandb:
         self.run = None
         self.config = _Config()
         self._fh = None
+        self._n_runs = 0
 
     def init(self, entity=None, project=None, group=None, job_type=None, save_code=False, dir=None, **kw):
         root = dir or os.environ.get("FUMI_LOG_DIR", "./results")
-        self.run = _LocalRun(os.path.join(root, "runs"), f"{job_type or 'run'}-{int(time.time())}-{os.getpid()}")
+        self._n_runs += 1                   # two runs of one process within a second must not share a checkpoint directory
+        self.run = _LocalRun(os.path.join(root, "runs"), f"{job_type or 'run'}-{int(time.time())}-{os.getpid()}-{self._n_runs}")
         self._fh = open(os.path.join(self.run.dir, "metrics.jsonl"), "a")
         return self.run
 
