@@ -498,6 +498,20 @@ def test_side_stream_overlap_in_subprocess(dev):
     assert " passed" in r.stdout
 
 
+def test_one_launch_per_hypernet_layer_in_subprocess(dev):
+    """FUMI_HYPER_SPLIT=1: the per-layer hypernetwork forward kernels (what hypernetworks wider than 256 use) instead of the
+    fused one.  Same golden / oracle parity required."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-q", "-m", "gpu",
+                        "-p", "no:cacheprovider", "-k", "fumi_step_matches_reference"],
+                       env=dict(os.environ, FUMI_HYPER_SPLIT="1"), cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_cli_fumi_synthetic_end_to_end_on_gpu(dev, tmp_path, monkeypatch):
     """`python -m fumi_amd.main --model fumi --dataset synthetic` (BASELINE.json configs[1] wording, shortened): parse -> loaders
     -> initial validation -> meta-training on the HIP engine -> checkpoint -> test.  The task is learnable: the loss must drop."""
@@ -550,6 +564,12 @@ _FUZZ = [   # B  N  K  Q   D    hid              Dt  Ht  T  tanh   -- odd sizes 
     dict(B=4, N=4, K=6, Q=9, D=512, hid=[256, 32], Dt=100, Ht=128, T=1, tanh=False),
     dict(B=1, N=10, K=2, Q=4, D=96, hid=[64, 64], Dt=32, Ht=64, T=2, tanh=False),
     dict(B=17, N=5, K=5, Q=8, D=320, hid=[192, 48], Dt=300, Ht=256, T=1, tanh=False),
+    # hypernetwork shapes: every (tiles per wave, contraction chunks) form of the fused forward kernel, and the per-layer one
+    dict(B=3, N=5, K=2, Q=4, D=128, hid=[64, 32], Dt=768, Ht=256, T=1, tanh=True),
+    dict(B=7, N=3, K=2, Q=5, D=96, hid=[32], Dt=400, Ht=192, T=2, tanh=False),
+    dict(B=2, N=6, K=1, Q=3, D=64, hid=[48, 16], Dt=500, Ht=128, T=1, tanh=True),
+    dict(B=4, N=5, K=1, Q=2, D=64, hid=[32], Dt=768, Ht=64, T=1, tanh=False),
+    dict(B=3, N=4, K=2, Q=3, D=64, hid=[32], Dt=52, Ht=320, T=1, tanh=False),
 ]
 
 
