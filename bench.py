@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 
 CFG = dict(N=5, K=5, Q=32, D=2048, hid=[256, 64], E=300, L=128, V=20000, Ht=256, T=1, B_per_gpu=32, alpha=0.01)
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PROF_EVERY = 8                        # HIP-event timing of the roofline kernel: every 8th step
 NBATCH = 4                            # distinct pre-generated meta-batches cycled through the steps
 
 
@@ -193,7 +194,8 @@ def main():
         model.evaluate(args, batches[i % NBATCH], opt, "train")
     hip.raise_on_status(ws.read_status())
     if not a.no_phase_timing:
-        ws.set_profiling(True, None if a.all_phases else ["xpanel_bwd"])
+        # an event record is a ~6 us bubble on the stream: the roofline kernel is timed at every 8th step of the timed region
+        ws.set_profiling(True, None if a.all_phases else ["xpanel_bwd"], every=1 if a.all_phases else PROF_EVERY)
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -237,7 +239,8 @@ def main():
                                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                                "algorithmic_bytes": int(bytes_dominant(c["B_per_gpu"])),
                                "kernel": "xpanel_bwd256_kernel (gW0 = sum_b Abar0_b^T [Xs_b;Xq_b]: 256 x 2048 outputs in 256 x 64 tiles, contraction over 32 x 185 rows in 16 slabs, fp32 MFMA 32x32x2)",
-                               "avg_us": round(dur * 1e6, 2), "launches": n}
+                               "avg_us": round(dur * 1e6, 2), "launches": n,
+                               "timed": f"HIP events around every {1 if a.all_phases else PROF_EVERY}th launch of the timed region"}
             out["phase_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items()}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(table)

@@ -17,6 +17,7 @@ static hipEvent_t prof_event(fumi_ws* ws) {
 }
 
 ProfScope::ProfScope(fumi_ws* w, hipStream_t s, int phase) : ws(w), st(s), b(nullptr), on(w && ((w->profiling >> phase) & 1)) {
+    if (on && ws->prof_every > 1) on = (ws->prof_seen[phase & 15]++ % (unsigned)ws->prof_every) == 0;
     if (!on) return;
     hipEvent_t a = prof_event(ws);
     b = prof_event(ws);
@@ -65,7 +66,7 @@ int fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out) {
     HIP_TRY(hipSetDevice(device));
     fumi_ws* ws = new fumi_ws();
     ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr;
-    ws->profiling = 0; ws->recs = new std::vector<ProfRec>(); ws->pool = new std::vector<hipEvent_t>();
+    ws->profiling = 0; ws->prof_every = 1; memset(ws->prof_seen, 0, sizeof(ws->prof_seen)); ws->recs = new std::vector<ProfRec>(); ws->pool = new std::vector<hipEvent_t>();
     if (hipMalloc((void**)&ws->status, 256) != hipSuccess) { delete ws; return FUMI_ENOMEM; }
     if (hipHostMalloc((void**)&ws->status_host, 256, hipHostMallocDefault) != hipSuccess) { (void)hipFree(ws->status); delete ws; return FUMI_ENOMEM; }
     HIP_TRY(hipMemset(ws->status, 0, 256));
@@ -112,6 +113,14 @@ int fumi_hip_set_profiling(fumi_ws_t* ws, int on) {
     for (auto& r : *ws->recs) { ws->pool->push_back(r.a); ws->pool->push_back(r.b); }
     ws->recs->clear();
     ws->profiling = on;              // bit p = record HIP events around phase p (FUMI_PH_*); -1 = every phase
+    memset(ws->prof_seen, 0, sizeof(ws->prof_seen));
+    return FUMI_OK;
+}
+
+int fumi_hip_set_profiling_every(fumi_ws_t* ws, int every) {
+    if (!ws || every < 1) return FUMI_EINVAL;
+    ws->prof_every = every;
+    memset(ws->prof_seen, 0, sizeof(ws->prof_seen));
     return FUMI_OK;
 }
 

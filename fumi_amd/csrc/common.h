@@ -23,6 +23,8 @@ struct fumi_ws {
     int* status;         // device status word (own small allocation)
     int* status_host;    // pinned
     int profiling;       // bit p: record HIP events around phase p (bench only)
+    int prof_every;      // ... at every prof_every-th occurrence of the phase
+    unsigned prof_seen[16];
     hipStream_t side;    // second stream: the text path (hypernetwork fwd / bwd) runs beside the two X-panel passes
     hipEvent_t ev[4];    // fork / join points (timing disabled)
     std::vector<ProfRec>* recs;

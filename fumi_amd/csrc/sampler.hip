@@ -144,3 +144,29 @@ extern "C" int fumi_hip_gather_rows(fumi_ws_t* ws, fumi_stream_t stream, const v
     LAUNCH_CHECK();
     return FUMI_OK;
 }
+
+// ---- event-free scalar read-back --------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(64) void publish_scalars_kernel(const float* __restrict__ src, int n, float* dst, unsigned long long seq) {
+    const int i = threadIdx.x;
+    // write-through (system-scope) stores of the values, all lanes in one instruction; their completion is awaited before
+    // lane 0 raises the flag.  No release fence: that would write back every dirty L2 line the optimizer step left behind
+    // (~2 us) although nothing but these 64 bytes is read by the host.
+    if (i < n) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (i == 0) __hip_atomic_store((unsigned long long*)(dst + 14), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+extern "C" int fumi_hip_publish_scalars(fumi_ws_t* ws, fumi_stream_t stream, const float* src, int n, void* host_pinned,
+        uint64_t seq) {
+    if (!ws || !src || !host_pinned || n < 1 || n > 14 || ((uintptr_t)host_pinned & 7)) return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(ws->device));
+    void* dptr = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dptr, host_pinned, 0));          // fails for memory that is not page-locked + mapped
+    hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, n, (float*)dptr,
+                       (unsigned long long)seq);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+

@@ -18,12 +18,12 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfumi_hip.so")
 SYMBOLS = [
     "fumi_hip_version", "fumi_hip_strerror", "fumi_hip_last_hip_error",
     "fumi_hip_workspace_create", "fumi_hip_workspace_destroy", "fumi_hip_workspace_bytes", "fumi_hip_read_status",
-    "fumi_hip_set_profiling", "fumi_hip_get_profile", "fumi_hip_phase_name",
+    "fumi_hip_set_profiling", "fumi_hip_set_profiling_every", "fumi_hip_get_profile", "fumi_hip_phase_name",
     "fumi_hip_fumi_step", "fumi_hip_fumi_step_indexed", "fumi_hip_maml_step", "fumi_hip_am3_step",
     "fumi_hip_glove_bag", "fumi_hip_glove_bag_select", "fumi_hip_class_text_select", "fumi_hip_xpanel_fwd", "fumi_hip_xpanel_bwd",
     "fumi_hip_adam_step",
     "fumi_hip_linear_fwd", "fumi_hip_linear_bwd_data", "fumi_hip_linear_bwd_weight",
-    "fumi_hip_sample_episodes", "fumi_hip_gather_rows",
+    "fumi_hip_sample_episodes", "fumi_hip_gather_rows", "fumi_hip_publish_scalars",
 ]
 
 ST_LABEL_RANGE, ST_CLASS_MISSING = 1, 2
@@ -91,6 +91,7 @@ def lib():
         L.fumi_hip_workspace_bytes.restype = c_size_t
         L.fumi_hip_read_status.argtypes = [c_void_p, c_void_p, POINTER(c_int)]
         L.fumi_hip_set_profiling.argtypes = [c_void_p, c_int]
+        L.fumi_hip_set_profiling_every.argtypes = [c_void_p, c_int]
         L.fumi_hip_get_profile.argtypes = [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int)]
         L.fumi_hip_phase_name.argtypes = [c_int]
         L.fumi_hip_phase_name.restype = c_char_p
@@ -121,6 +122,7 @@ def lib():
         L.fumi_hip_linear_bwd_weight.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 4
         L.fumi_hip_sample_episodes.argtypes = [c_void_p, c_void_p, ctypes.c_uint64, ctypes.c_uint64] + [c_int] * 5 + [c_void_p] * 5
         L.fumi_hip_gather_rows.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]
+        L.fumi_hip_publish_scalars.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_uint64]
         _lib = L
     return _lib
 
@@ -221,10 +223,11 @@ class Workspace:
         _check(lib().fumi_hip_read_status(self._h, _stream(self.device), ctypes.byref(st)), "read_status")
         return st.value
 
-    def set_profiling(self, on, phases=None):
+    def set_profiling(self, on, phases=None, every=1):
         """HIP-event timing of the library's phases (bench.py); switching it clears the records.  ``phases``: names
-        (fumi_hip_phase_name) to time -- an event pair costs stream time, so the bench times only the kernel its
-        roofline is about; None = every phase."""
+        (fumi_hip_phase_name) to time -- an event pair costs stream time (two ~6 us bubbles), so the bench times only the
+        kernel its roofline is about and only at every ``every``-th step; None = every phase."""
+        _check(lib().fumi_hip_set_profiling_every(self._h, max(1, int(every))), "set_profiling_every")
         mask = 0
         if on:
             if phases is None:
@@ -531,3 +534,14 @@ def gather_rows(ws, table, idx):
     _check(lib().fumi_hip_gather_rows(ws.handle, _stream(dev), ctypes.c_void_p(table.data_ptr()), table.shape[0], row_bytes,
                                       _i64(idx, "idx"), idx.numel(), ctypes.c_void_p(out.data_ptr())), "fumi_hip_gather_rows")
     return out
+
+
+def publish_scalars(ws, src, n, host_pinned, seq):
+    """One tiny launch on the current stream writes src[:n] and then the 64-bit word ``seq`` (byte offset 56) into the pinned
+    host tensor ``host_pinned`` (>= 64 bytes) with system-scope stores: the host polls the word, no copy, no event."""
+    dev = _dev(src)
+    if src.dtype != torch.float32 or not src.is_contiguous() or not host_pinned.is_pinned() or host_pinned.numel() * host_pinned.element_size() < 64:
+        raise FumiHipError("publish_scalars: src must be contiguous fp32 on the device, host_pinned a pinned tensor of >= 64 bytes")
+    _check(lib().fumi_hip_publish_scalars(ws.handle, _stream(dev), ctypes.c_void_p(src.data_ptr()), int(n),
+                                          ctypes.c_void_p(host_pinned.data_ptr()), int(seq)), "fumi_hip_publish_scalars")
+

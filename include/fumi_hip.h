@@ -78,6 +78,8 @@ int   fumi_hip_read_status(fumi_ws_t* ws, fumi_stream_t stream, int* status_out)
 /* phase_mask: bit p set = record a HIP event pair around phase p (FUMI_PH_*) on the caller's stream; -1 = every phase,
  * 0 = off.  An event pair costs a few microseconds of stream time, so time only what is needed.  Also clears the records. */
 int          fumi_hip_set_profiling(fumi_ws_t* ws, int phase_mask);
+/* Time only every `every`-th occurrence of a selected phase (default 1): an event record is a ~6 us bubble on the stream. */
+int          fumi_hip_set_profiling_every(fumi_ws_t* ws, int every);
 /* Synchronises the device; total elapsed ms and number of records of `phase` since profiling was switched on. */
 int          fumi_hip_get_profile(fumi_ws_t* ws, int phase, double* total_ms, int* count);
 const char*  fumi_hip_phase_name(int phase);
@@ -191,6 +193,13 @@ int fumi_hip_sample_episodes(fumi_ws_t* ws, fumi_stream_t stream, uint64_t seed,
         int C, const int64_t* class_ptr, const int64_t* class_items, int64_t* classes, int64_t* items_s, int64_t* items_q);
 int fumi_hip_gather_rows(fumi_ws_t* ws, fumi_stream_t stream, const void* table, int64_t n_rows, int64_t row_bytes,
         const int64_t* idx, int64_t n_idx, void* out);
+
+/* ---- event-free read-back of a step's scalars (replaces outer_loss.detach().cpu().numpy(), fumi/models/fumi.py:195) ----
+ * One single-wave launch on `stream` stores src[0..n) (device, fp32, n <= 14) into host_pinned[0..n) and then `seq` into the
+ * 64-bit word at byte offset 56 of host_pinned, all with system-scope stores: the host polls that word instead of waiting on
+ * an event (an async copy + event record idles the stream for ~10 us per step).  host_pinned: 64 bytes of page-locked,
+ * device-accessible host memory (hipHostMalloc / a pinned torch tensor), 8-byte aligned. */
+int fumi_hip_publish_scalars(fumi_ws_t* ws, fumi_stream_t stream, const float* src, int n, void* host_pinned, uint64_t seq);
 
 #ifdef __cplusplus
 }

@@ -353,6 +353,28 @@ def test_fumi_evaluate_on_gpu_lazy_scalars(dev):
         np.testing.assert_allclose(cg.digest(p.detach().cpu())[3:], gold[f"post.{n}.digest"][3:], rtol=0, atol=3e-7)
 
 
+def test_lazy_scalars_arrive_without_events(dev, ws):
+    """fumi_hip_publish_scalars: the values and then the sequence word land in pinned host memory by system-scope stores;
+    lazy.scalars polls the word.  40 outstanding reads (> the ring of 16) read back in order, late, and out of order."""
+    from fumi_amd import hip, lazy
+    assert not lazy.USE_EVENT and not lazy.SYNC
+    host = torch.zeros(16, dtype=torch.float32, pin_memory=True)
+    src = torch.tensor([1.5, -2.25, 3.0], device=dev)
+    hip.publish_scalars(ws, src, 3, host, 0xABCDEF0123456789)
+    torch.cuda.synchronize()
+    assert host[:3].tolist() == [1.5, -2.25, 3.0] and int(host.numpy().view(np.uint64)[7]) == 0xABCDEF0123456789
+    assert host[3:14].abs().sum() == 0
+    with pytest.raises(hip.FumiHipError):
+        hip.publish_scalars(ws, src, 3, torch.zeros(16), 1)                       # not pinned
+    vals = [torch.tensor([float(i), i + 0.5], device=dev) for i in range(40)]
+    outs = [lazy.scalars(v, 2) for v in vals]
+    for i in (39, 0, 17, 5):
+        assert float(outs[i][0]) == float(i) and float(outs[i][1]) == i + 0.5
+    assert [float(a) for a, _ in outs] == [float(i) for i in range(40)]
+    big = torch.arange(20, dtype=torch.float32, device=dev)                         # more than 14 values: copy + event form
+    assert [float(x) for x in lazy.scalars(big, 20)] == list(range(20))
+
+
 @pytest.mark.parametrize("name,p", [("fumi_t5", 0.25), ("fumi_3layer", 0.5), ("fumi_1shot", 0.1)])
 def test_fumi_inner_loop_dropout_matches_oracle_with_same_masks(name, p, dev, ws):
     """Train-mode Dropout after every ReLU of im_net (fumi.py:93-99; CLI default 0.25): the engine's counter-based masks are
