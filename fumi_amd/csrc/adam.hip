@@ -17,7 +17,16 @@ struct AdamTensors {
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, long total4, float lr_over_bc1, float inv_sqrt_bc2,
-                                                   float b1, float b2, float eps, float wd) {
+                                                   float b1, float b2, float eps, float wd,
+                                                   const float* __restrict__ pub_src, int pub_n, float* pub_dst,
+                                                   unsigned long long pub_seq) {
+    // rider: a deferred publication of the step's statistics (sampler.hip: publish_scalars_kernel) saves its own launch
+    if (pub_dst && blockIdx.x == gridDim.x - 1 && threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        if (i < pub_n) __hip_atomic_store(pub_dst + i, pub_src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (i == 0) __hip_atomic_store((unsigned long long*)(pub_dst + 14), pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     for (long i4 = blockIdx.x * (long)blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
         int k = 0;
         while (k + 1 < t.n && i4 >= t.end[k]) ++k;
@@ -71,7 +80,8 @@ extern "C" int fumi_hip_adam_step(fumi_ws_t* ws, fumi_stream_t stream, int n_ten
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) return FUMI_OK;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, t, tot4, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)),
-                       beta1, beta2, eps, weight_decay);
+                       beta1, beta2, eps, weight_decay, ws->pub_src, ws->pub_n, ws->pub_dst, ws->pub_seq);
+    ws->pub_dst = nullptr; ws->pub_src = nullptr;                 // a pending publication rode along
     LAUNCH_CHECK();
     return FUMI_OK;
 }

@@ -65,11 +65,13 @@ int fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out) {
     if (device < 0 || device >= ndev) return FUMI_EINVAL;
     HIP_TRY(hipSetDevice(device));
     fumi_ws* ws = new fumi_ws();
-    ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr;
+    ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr; ws->hcnt = nullptr; ws->pub_src = nullptr; ws->pub_dst = nullptr; ws->pub_n = 0; ws->pub_seq = 0;
     ws->profiling = 0; ws->prof_every = 1; memset(ws->prof_seen, 0, sizeof(ws->prof_seen)); ws->recs = new std::vector<ProfRec>(); ws->pool = new std::vector<hipEvent_t>();
     if (hipMalloc((void**)&ws->status, 256) != hipSuccess) { delete ws; return FUMI_ENOMEM; }
     if (hipHostMalloc((void**)&ws->status_host, 256, hipHostMallocDefault) != hipSuccess) { (void)hipFree(ws->status); delete ws; return FUMI_ENOMEM; }
     HIP_TRY(hipMemset(ws->status, 0, 256));
+    if (hipMalloc((void**)&ws->hcnt, FUMI_HCNT * sizeof(int)) != hipSuccess) return FUMI_ENOMEM;
+    HIP_TRY(hipMemset(ws->hcnt, 0, FUMI_HCNT * sizeof(int)));
     ws->side = nullptr;
     for (auto& e : ws->ev) e = nullptr;
     {   // high priority: the side stream carries a few small workgroups that should get CU slots as soon as they are ready
@@ -95,6 +97,7 @@ void fumi_hip_workspace_destroy(fumi_ws_t* ws) {
     (void)hipDeviceSynchronize();
     if (ws->base) (void)hipFree(ws->base);
     if (ws->status) (void)hipFree(ws->status);
+    if (ws->hcnt) (void)hipFree(ws->hcnt);
     if (ws->status_host) (void)hipHostFree(ws->status_host);
     for (auto& r : *ws->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : *ws->pool) (void)hipEventDestroy(e);
@@ -201,7 +204,8 @@ static int fumi_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     bytes += ws_align((size_t)R * Dt * 4) + 2 * ws_align((size_t)R * Ht * 4) + 3 * ws_align((size_t)R * H1 * 4);
     const bool hyper_lds = hyper_lds_fits(R, Dt, Ht, H1) != 0;         // LDS-resident hypernetwork kernels (hyper.hip)
     const size_t hpart_n = hyper_lds ? hyper_bwd_workspace_floats(R, Ht, H1) : 0;
-    bytes += ws_align(hpart_n * 4);
+    const size_t hfp_n = hyper_lds ? hyper_fwd_workspace_floats(R, Ht, H1) : 0;     // partial layer-1 products of the split forward
+    bytes += ws_align(hpart_n * 4) + ws_align(hfp_n * 4);
     int rc = ws_reserve(ws, bytes);
     if (rc) return rc;
     float* c = ws_f(ws, (size_t)R * Dt);
@@ -211,6 +215,7 @@ static int fumi_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     float* hbar = ws_f(ws, (size_t)R * H1);
     float* hpb = ws_f(ws, (size_t)R * H1);
     float* hpart = hyper_lds ? ws_f(ws, hpart_n) : nullptr;
+    float* hfp = hyper_lds ? ws_f(ws, hfp_n) : nullptr;
 
     // class text rows (fumi.py:207-210), then the hypernetwork (fumi.py:70-86,104-113)
     const float* ctext = cls_text;
@@ -235,7 +240,7 @@ static int fumi_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
         int r2;
         {
             ProfScope ps(ws, sh, FUMI_PH_HYPER_FWD);
-            r2 = hyper_lds ? launch_hyper_fwd(sh, R, Dt, Ht, H1, tanh_head, ctext, phi[0], phi[1], phi[2], phi[3], u, h) : FUMI_ENOTSUP;
+            r2 = hyper_lds ? launch_hyper_fwd(sh, R, Dt, Ht, H1, tanh_head, ctext, phi[0], phi[1], phi[2], phi[3], u, h, hfp, ws->hcnt) : FUMI_ENOTSUP;
             if (r2 == FUMI_ENOTSUP) {                                // shapes outside the LDS-resident kernels: plain GEMMs
                 g = gemm_args(R, Ht, Dt, ctext, Dt, phi[0], Dt, u, Ht);
                 g.bias = phi[1]; g.act = 1;

@@ -22,6 +22,8 @@ struct fumi_ws {
     size_t off;          // bump pointer (bytes), reset at the start of each step
     int* status;         // device status word (own small allocation)
     int* status_host;    // pinned
+    const float* pub_src; float* pub_dst; int pub_n; unsigned long long pub_seq;   // deferred publication (api: publish_scalars_deferred)
+    int* hcnt;           // [FUMI_HCNT] arrival counters of hyper_fwd_split_kernel, zero between launches
     int profiling;       // bit p: record HIP events around phase p (bench only)
     int prof_every;      // ... at every prof_every-th occurrence of the phase
     unsigned prof_seen[16];
@@ -178,8 +180,11 @@ int launch_linhead(hipStream_t st, int B, int N, int S, int Qn, int T, float alp
 // hypernetwork as LDS-resident kernels (hyper.hip); FUMI_ENOTSUP when the shapes do not fit (callers fall back to GEMMs)
 int hyper_lds_fits(int R, int Dt, int Ht, int H1);
 size_t hyper_bwd_workspace_floats(int R, int Ht, int H1);
+constexpr int FUMI_HCNT = 1024;        // arrival counters of the split hypernetwork forward (one per 16-row block)
+size_t hyper_fwd_workspace_floats(int R, int Ht, int H1);
 int launch_hyper_fwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_head, const float* c, const float* A0,
-                     const float* b0, const float* A1, const float* b1, float* u, float* h);
+                     const float* b0, const float* A1, const float* b1, float* u, float* h, float* hpart = nullptr,
+                     int* cnt = nullptr);
 int launch_hyper_bwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_head, float scale, const float* c,
                      const float* u, const float* h, const float* hbar, const float* A1, float* ub, float* part,
                      float* gA0, float* gb0, float* gA1, float* gb1, ReduceSegs* defer = nullptr);

@@ -170,3 +170,25 @@ extern "C" int fumi_hip_publish_scalars(fumi_ws_t* ws, fumi_stream_t stream, con
     return FUMI_OK;
 }
 
+// Deferred form: the request is kept in the workspace and rides on the next fumi_hip_adam_step launch of this workspace (the
+// optimizer step that follows a training meta-step); fumi_hip_publish_flush launches it on its own if it is still pending.
+extern "C" int fumi_hip_publish_scalars_deferred(fumi_ws_t* ws, const float* src, int n, void* host_pinned, uint64_t seq) {
+    if (!ws || !src || !host_pinned || n < 1 || n > 14 || ((uintptr_t)host_pinned & 7) || ws->pub_dst) return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(ws->device));
+    void* dptr = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dptr, host_pinned, 0));
+    ws->pub_src = src; ws->pub_n = n; ws->pub_dst = (float*)dptr; ws->pub_seq = seq;
+    return FUMI_OK;
+}
+
+extern "C" int fumi_hip_publish_flush(fumi_ws_t* ws, fumi_stream_t stream) {
+    if (!ws) return FUMI_EINVAL;
+    if (!ws->pub_dst) return FUMI_OK;
+    HIP_TRY(hipSetDevice(ws->device));
+    hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws->pub_src, ws->pub_n, ws->pub_dst,
+                       ws->pub_seq);
+    ws->pub_dst = nullptr; ws->pub_src = nullptr;
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+

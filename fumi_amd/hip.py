@@ -24,6 +24,7 @@ SYMBOLS = [
     "fumi_hip_adam_step",
     "fumi_hip_linear_fwd", "fumi_hip_linear_bwd_data", "fumi_hip_linear_bwd_weight",
     "fumi_hip_sample_episodes", "fumi_hip_gather_rows", "fumi_hip_publish_scalars",
+    "fumi_hip_publish_scalars_deferred", "fumi_hip_publish_flush",
 ]
 
 ST_LABEL_RANGE, ST_CLASS_MISSING = 1, 2
@@ -123,6 +124,8 @@ def lib():
         L.fumi_hip_sample_episodes.argtypes = [c_void_p, c_void_p, ctypes.c_uint64, ctypes.c_uint64] + [c_int] * 5 + [c_void_p] * 5
         L.fumi_hip_gather_rows.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]
         L.fumi_hip_publish_scalars.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_uint64]
+        L.fumi_hip_publish_scalars_deferred.argtypes = [c_void_p, c_void_p, c_int, c_void_p, ctypes.c_uint64]
+        L.fumi_hip_publish_flush.argtypes = [c_void_p, c_void_p]
         _lib = L
     return _lib
 
@@ -536,12 +539,23 @@ def gather_rows(ws, table, idx):
     return out
 
 
-def publish_scalars(ws, src, n, host_pinned, seq):
+def publish_scalars(ws, src, n, host_pinned, seq, defer=False):
     """One tiny launch on the current stream writes src[:n] and then the 64-bit word ``seq`` (byte offset 56) into the pinned
-    host tensor ``host_pinned`` (>= 64 bytes) with system-scope stores: the host polls the word, no copy, no event."""
+    host tensor ``host_pinned`` (>= 64 bytes) with system-scope stores: the host polls the word, no copy, no event.
+    ``defer``: the stores ride on the next ``adam_step`` launch of the workspace instead (``publish_flush`` issues them if
+    none comes)."""
     dev = _dev(src)
     if src.dtype != torch.float32 or not src.is_contiguous() or not host_pinned.is_pinned() or host_pinned.numel() * host_pinned.element_size() < 64:
         raise FumiHipError("publish_scalars: src must be contiguous fp32 on the device, host_pinned a pinned tensor of >= 64 bytes")
+    if defer:
+        _check(lib().fumi_hip_publish_scalars_deferred(ws.handle, ctypes.c_void_p(src.data_ptr()), int(n),
+                                                       ctypes.c_void_p(host_pinned.data_ptr()), int(seq)),
+               "fumi_hip_publish_scalars_deferred")
+        return
     _check(lib().fumi_hip_publish_scalars(ws.handle, _stream(dev), ctypes.c_void_p(src.data_ptr()), int(n),
                                           ctypes.c_void_p(host_pinned.data_ptr()), int(seq)), "fumi_hip_publish_scalars")
+
+
+def publish_flush(ws, device):
+    _check(lib().fumi_hip_publish_flush(ws.handle, _stream(device)), "fumi_hip_publish_flush")
 

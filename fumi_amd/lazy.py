@@ -27,7 +27,7 @@ class LazyStats:
     """Pinned staging buffers and events come from a small ring (allocating pinned memory every step costs ~15 us of host
     time); a buffer is only reused after its previous owner has been read or is forced to materialise first."""
 
-    def __init__(self, dev_tensor):
+    def __init__(self, dev_tensor, defer=False):
         t = dev_tensor.detach()
         self._np = None
         self._seq = 0
@@ -47,7 +47,10 @@ class LazyStats:
             self._seq, self._n = _SEQ[0], t.numel()
             self._host, self._flag, self._slot, self._ev = slot[0], slot[1], slot, None
             slot[2] = self
-            hip.publish_scalars(hip.Workspace.get(t.device), t, self._n, self._host, self._seq)
+            self._src = t                          # (kept alive until the deferred stores have been issued)
+            if defer:
+                hip.publish_flush(hip.Workspace.get(t.device), t.device)      # (a publication stranded by an exception)
+            hip.publish_scalars(hip.Workspace.get(t.device), t, self._n, self._host, self._seq, defer=defer)
         elif t.is_cuda:
             key = (tuple(t.shape), t.dtype)
             ring = _RING.get(key)
@@ -149,10 +152,19 @@ class LazyScalar(np.lib.mixins.NDArrayOperatorsMixin):
         return format(self._v(), spec)
 
 
-def scalars(dev_tensor, n):
-    """n scalars read back from the first n elements of a device tensor (lazily unless FUMI_SYNC_STATS=1)."""
+def scalars(dev_tensor, n, defer=False):
+    """n scalars read back from the first n elements of a device tensor (lazily unless FUMI_SYNC_STATS=1).
+    ``defer``: the values ride on the optimizer step's launch that follows; the caller must call ``flush`` after it."""
     if SYNC:
         host = dev_tensor.detach().cpu().numpy()
         return tuple(host[i] for i in range(n))
-    st = LazyStats(dev_tensor)
+    st = LazyStats(dev_tensor, defer=defer and dev_tensor.is_cuda and not USE_EVENT)
     return tuple(LazyScalar(st, i) for i in range(n))
+
+
+def flush(device):
+    """Issue a deferred publication that no optimizer launch has carried (other optimizers, closures, CPU runs: no-op)."""
+    if SYNC or USE_EVENT or getattr(device, "type", "cpu") != "cuda":
+        return
+    from . import hip
+    hip.publish_flush(hip.Workspace.get(device), device)

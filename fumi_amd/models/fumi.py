@@ -194,13 +194,15 @@ class FUMI(nn.Module):
                             g_theta=fg.views[:nth] if train else None, g_phi=fg.views[nth:] if train else None,
                             cls_text=cls_text, stats=tail, dropout_p=drop_p, seed=drop_seed)
         fdist.all_reduce_sum_(fg.flat if train else tail)
+        # read back asynchronously (fumi.py:195 blocks here); in training the two stores ride on the optimizer's launch
+        loss, acc = lazy.scalars(tail, 2, defer=train)
         if train:
             fg.attach()                          # .grad of every parameter IS a view of the buffer the engine just filled
             optimizer.step()                     # (so there is nothing left for zero_grad() to clear, fumi.py:190-193)
+            lazy.flush(x_s.device)
         preds = out["preds_f"]                                   # float, like the reference's test_preds (fumi.py:180-183)
         if fdist.world()[1] > 1 and not train:
             preds = fdist.all_gather_rows(preds)
-        loss, acc = lazy.scalars(tail, 2)                        # read back asynchronously (fumi.py:195 blocks here)
         test_preds = preds if preds.shape[0] == B else None
         return loss, acc, test_preds, q_y.to(dev)
 

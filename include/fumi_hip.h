@@ -200,6 +200,11 @@ int fumi_hip_gather_rows(fumi_ws_t* ws, fumi_stream_t stream, const void* table,
  * an event (an async copy + event record idles the stream for ~10 us per step).  host_pinned: 64 bytes of page-locked,
  * device-accessible host memory (hipHostMalloc / a pinned torch tensor), 8-byte aligned. */
 int fumi_hip_publish_scalars(fumi_ws_t* ws, fumi_stream_t stream, const float* src, int n, void* host_pinned, uint64_t seq);
+/* Deferred form: the same stores ride on the next fumi_hip_adam_step launch of this workspace (the optimizer step that
+ * follows a training meta-step: one launch less); fumi_hip_publish_flush issues them on their own if none came.  At most one
+ * publication may be pending per workspace; src must stay valid and unchanged until it has been issued. */
+int fumi_hip_publish_scalars_deferred(fumi_ws_t* ws, const float* src, int n, void* host_pinned, uint64_t seq);
+int fumi_hip_publish_flush(fumi_ws_t* ws, fumi_stream_t stream);
 
 #ifdef __cplusplus
 }

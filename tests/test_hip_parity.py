@@ -371,6 +371,21 @@ def test_lazy_scalars_arrive_without_events(dev, ws):
     for i in (39, 0, 17, 5):
         assert float(outs[i][0]) == float(i) and float(outs[i][1]) == i + 0.5
     assert [float(a) for a, _ in outs] == [float(i) for i in range(40)]
+    # deferred form: nothing is issued until an optimizer launch carries it or flush() does
+    d = torch.tensor([7.0, 8.0], device=dev)
+    a, b = lazy.scalars(d, 2, defer=True)
+    torch.cuda.synchronize()
+    assert a._s._flag[0] != a._s._seq
+    lazy.flush(dev)
+    assert float(a) == 7.0 and float(b) == 8.0
+    from fumi_amd.optim import Adam
+    w = torch.nn.Parameter(torch.ones(300, device=dev)); w.grad = torch.full((300,), 0.5, device=dev)
+    opt = Adam([w], lr=1e-2)
+    a, b = lazy.scalars(d, 2, defer=True)
+    opt.step()                                                                     # the fused Adam launch carries the stores
+    torch.cuda.synchronize()
+    assert a._s._flag[0] == a._s._seq and float(b) == 8.0
+    lazy.flush(dev)                                                                 # nothing pending: no-op
     big = torch.arange(20, dtype=torch.float32, device=dev)                         # more than 14 values: copy + event form
     assert [float(x) for x in lazy.scalars(big, 20)] == list(range(20))
 
@@ -520,16 +535,17 @@ def test_side_stream_overlap_in_subprocess(dev):
     assert " passed" in r.stdout
 
 
-def test_one_launch_per_hypernet_layer_in_subprocess(dev):
-    """FUMI_HYPER_SPLIT=1: the per-layer hypernetwork forward kernels (what hypernetworks wider than 256 use) instead of the
-    fused one.  Same golden / oracle parity required."""
+@pytest.mark.parametrize("form", ["0", "1"])
+def test_other_hypernet_forward_forms_in_subprocess(form, dev):
+    """FUMI_HYPER_FWD=0: one launch per hypernetwork layer (what hypernetworks wider than 256 use); =1: one launch with a
+    workgroup per row block; the default (2) splits layer 0's columns over workgroups.  Same golden / oracle parity required."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-q", "-m", "gpu",
-                        "-p", "no:cacheprovider", "-k", "fumi_step_matches_reference"],
-                       env=dict(os.environ, FUMI_HYPER_SPLIT="1"), cwd=root, capture_output=True, text=True, timeout=600)
+                        "-p", "no:cacheprovider", "-k", "fumi_step_matches_reference or odd_shapes"],
+                       env=dict(os.environ, FUMI_HYPER_FWD=form), cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
 

@@ -1,0 +1,89 @@
+"""Per-GPU throughput of BASELINE.json's OTHER configurations at their per-rank shapes (informational; bench.py measures
+configs[1]).  One JSON line per configuration: model, shapes, ms per meta-step, episodes/s on one MI355X.
+
+    python tools/bench_configs.py [--steps 100] [--warmup 10]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from fumi_amd import hip
+from fumi_amd.models import am3 as am3_mod, maml as maml_mod
+from fumi_amd.utils import utils as U
+
+CONFIGS = {
+    # configs[0] shapes on the GPU (the reference runs it on the CPU): MAML 5-way 1-shot, meta-batch 4, 5 inner steps
+    "maml_5w1s_b4_t5": ["--model", "maml", "--num_shots", "1", "--batch_size", "4", "--num_train_adapt_steps", "5"],
+    # configs[2] per rank: FuMI 5-way 5-shot, BERT description embeddings (768-d), 5 inner steps, 32 of the 256 episodes
+    "fumi_bert_t5_b32": ["--model", "fumi", "--text_encoder", "BERT", "--text_emb_dim", "768", "--batch_size", "32",
+                         "--num_train_adapt_steps", "5"],
+    # configs[3] per rank: AM3 5-way 5-shot, 32 of the 256 episodes
+    "am3_b32": ["--model", "am3", "--text_encoder", "BERT", "--text_emb_dim", "768", "--batch_size", "32"],
+    # configs[1] with the other text path, for comparison with bench.py's GloVe line
+    "fumi_bert_t1_b32": ["--model", "fumi", "--text_encoder", "BERT", "--text_emb_dim", "768", "--batch_size", "32",
+                         "--num_train_adapt_steps", "1"],
+}
+
+
+def batches(a, dev, n=4):
+    B, N, K, Q, D, Dt = a.batch_size, a.num_ways, a.num_shots, a.num_shots_test, a.im_emb_dim, a.text_emb_dim
+    S, Qn = N * K, N * Q
+    out = []
+    for i in range(n):
+        g = torch.Generator(device=dev).manual_seed(100 + i)
+        cg = torch.Generator().manual_seed(100 + i)
+        y_s = torch.stack([torch.arange(N).repeat_interleave(K)[torch.randperm(S, generator=cg)] for _ in range(B)]).to(dev)
+        y_q = torch.stack([torch.arange(N).repeat_interleave(Q)[torch.randperm(Qn, generator=cg)] for _ in range(B)]).to(dev)
+        ct = torch.randn(B, N, Dt, device=dev, generator=g)
+        text_s = torch.gather(ct, 1, y_s[..., None].expand(-1, -1, Dt))
+        text_q = torch.gather(ct, 1, y_q[..., None].expand(-1, -1, Dt))
+        x_s = torch.randn(B, S, D, device=dev, generator=g)
+        x_q = torch.randn(B, Qn, D, device=dev, generator=g)
+        out.append({'train': ([torch.zeros(B, S, dtype=torch.int64, device=dev), text_s, x_s], y_s),
+                    'test': ([torch.zeros(B, Qn, dtype=torch.int64, device=dev), text_q, x_q], y_q)})
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    o = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    for name, argv in CONFIGS.items():
+        a = U.parser().parse_args(argv + ["--dropout", "0", "--dataset", "synthetic"])
+        a.device = dev
+        torch.manual_seed(1)
+        model = U.init_model(a, None, watch=False)
+        opt = U.init_optim(a, model)
+        bs = batches(a, dev)
+        opt_, sched = opt if type(opt) == tuple else (opt, None)
+
+        def step(b):
+            if a.model == "maml":
+                return maml_mod.evaluate(a, model, b, opt_, "train")
+            if a.model == "fumi":
+                return model.evaluate(a, b, opt_, "train")
+            return model.evaluate(b, opt_, sched, a.num_ways, dev, "train")
+        for i in range(o.warmup):
+            step(bs[i % len(bs)])
+        hip.raise_on_status(hip.Workspace.get(dev).read_status())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(o.steps):
+            last = step(bs[i % len(bs)])
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        print(json.dumps({"config": name, "argv": " ".join(argv), "episodes_per_meta_batch": a.batch_size,
+                          "ms_per_step": round(el / o.steps * 1e3, 4), "episodes_per_s": round(a.batch_size * o.steps / el, 1),
+                          "final_loss": float(last[0])}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
