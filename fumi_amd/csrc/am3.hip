@@ -21,7 +21,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // LDS layout (floats): ip[N*P] tp[N*P] pr[N*P] pb[nw][N*P] lamc[N] cnt[N] lbar[N] wl[nw] wc[nw]
-__global__ __launch_bounds__(256) void am3_head_kernel(int N, int S, int Qn, int P, int lamda_fixed, int need_grad,
+__global__ __launch_bounds__(256) void am3_head_generic_kernel(int N, int S, int Qn, int P, int lamda_fixed, int need_grad,
                                                        float dscale,
                                                        const float* __restrict__ im_s, const float* __restrict__ tx,
                                                        float* __restrict__ lam_s, const int64_t* __restrict__ y_s,
@@ -153,6 +153,167 @@ __global__ __launch_bounds__(256) void am3_head_kernel(int N, int S, int Qn, int
     }
 }
 
+
+// ---- the same head for N <= 64 classes and P <= 512 (every configuration of the reference): no global load inside a loop.
+// Labels, support embeddings and text embeddings of the episode are staged in LDS once; a query row is loaded once into
+// registers (next row prefetched), its N distances live one per LANE (lane c holds d_c), so soft-max, first arg-min and the
+// backward weights are wave-level reductions / shuffles instead of N recomputations of every distance.
+// LDS (floats): ip tp pr [N*P] | pb [nw][N*P] | ims txs [S*P] | lamc cnt lbar [N] | wl wc [nw] | ys [S] (ints) | lam [S]
+constexpr int HPJ = 8;                   // 64-lane chunks of the prototype dimension held in registers (P <= 512)
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__global__ __launch_bounds__(512) void am3_head_kernel(int N, int S, int Qn, int P, int lamda_fixed, int need_grad,
+                                                       float dscale,
+                                                       const float* __restrict__ im_s, const float* __restrict__ tx,
+                                                       float* __restrict__ lam_s, const int64_t* __restrict__ y_s,
+                                                       const float* __restrict__ im_q, const int64_t* __restrict__ y_q,
+                                                       int64_t* __restrict__ preds, float* __restrict__ loss_b,
+                                                       float* __restrict__ corr_b,
+                                                       float* __restrict__ im_s_bar, float* __restrict__ tx_bar,
+                                                       float* __restrict__ zl_bar, float* __restrict__ im_q_bar,
+                                                       int* status) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nt = blockDim.x, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NP = N * P, SP = S * P;
+    float* ip = sm; float* tp = ip + NP; float* pr = tp + NP; float* pb = pr + NP;
+    float* ims = pb + nw * NP; float* txs = ims + SP;
+    float* lamc = txs + SP; float* cnt = lamc + N; float* lbar = cnt + N; float* wl = lbar + N; float* wc = wl + nw;
+    int* ys = (int*)(wc + nw); float* lam = (float*)(ys + S);
+    im_s += (long)b * SP; tx += (long)b * SP; lam_s += (long)b * S; y_s += (long)b * S;
+    im_q += (long)b * Qn * P; y_q += (long)b * Qn; preds += (long)b * Qn;
+
+    // ---- stage the episode's support side (coalesced, all loads independent)
+    for (int i = tid; i < SP; i += nt) { ims[i] = im_s[i]; txs[i] = tx[i]; }
+    for (int s_ = tid; s_ < S; s_ += nt) {
+        long y = y_s[s_];
+        if (y < 0 || y >= N) { atomicOr(status, FUMI_ST_LABEL_RANGE); y = -1; }
+        ys[s_] = (int)y;
+        float l = lamda_fixed >= 0 ? (float)lamda_fixed : lam_s[s_];
+        if (lamda_fixed >= 0) lam_s[s_] = l;                                   // am3.py:174-177
+        lam[s_] = l;
+    }
+    for (int i = tid; i < nw * NP; i += nt) pb[i] = 0.f;
+    __syncthreads();
+    // ---- prototypes: wave per class, lanes over P; count clamped to >= 1 (utils.py:353-355)
+    for (int c = wave; c < N; c += nw) {
+        float n = 0.f, ls = 0.f;
+        for (int s_ = 0; s_ < S; ++s_) if (ys[s_] == c) { n += 1.f; ls += lam[s_]; }
+        const float nn = fmaxf(n, 1.f), lc = ls / nn;
+        for (int j = lane; j < P; j += 64) {
+            float si = 0.f, st = 0.f;
+            for (int s_ = 0; s_ < S; ++s_) if (ys[s_] == c) { si += ims[s_ * P + j]; st += txs[s_ * P + j]; }
+            si /= nn; st /= nn;
+            ip[c * P + j] = si; tp[c * P + j] = st;
+            pr[c * P + j] = lc * si + (1.f - lc) * st;
+        }
+        if (lane == 0) { lamc[c] = lc; cnt[c] = nn; }
+    }
+    __syncthreads();
+
+    // ---- queries: wave per row
+    float lsum = 0.f, csum = 0.f;
+    float* mypb = pb + wave * NP;
+    const int npj = (P + 63) >> 6;
+    float xn[HPJ];
+#pragma unroll
+    for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; xn[k] = (k < npj && j < P && wave < Qn) ? im_q[(long)wave * P + j] : 0.f; }
+    long yn = wave < Qn ? y_q[wave] : 0;
+    for (int q = wave; q < Qn; q += nw) {
+        float x[HPJ];
+#pragma unroll
+        for (int k = 0; k < HPJ; ++k) x[k] = xn[k];
+        long yq = yn;
+        const int qn = q + nw;                                                  // prefetch the wave's next row
+#pragma unroll
+        for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; xn[k] = (k < npj && j < P && qn < Qn) ? im_q[(long)qn * P + j] : 0.f; }
+        yn = qn < Qn ? y_q[qn] : 0;
+        if (yq < 0 || yq >= N) { if (lane == 0) atomicOr(status, FUMI_ST_LABEL_RANGE); yq = 0; }
+        // lane c keeps d_c = |proto_c - x|^2
+        float myd = INFINITY;
+        for (int c = 0; c < N; ++c) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; if (k < npj && j < P) { const float df = pr[c * P + j] - x[k]; v += df * df; } }
+            v = wave_sum(v);
+            if (lane == c) myd = v;
+        }
+        const float dmin = -wave_max(-myd);                                      // lanes >= N hold +inf
+        const unsigned long long at = __ballot(lane < N && myd == dmin);
+        const int amin = at ? __ffsll((long long)at) - 1 : 0;                  // first arg-min (torch.min semantics, utils.py:316)
+        const float mx = -dmin;
+        const float ex = lane < N ? expf(-myd - mx) : 0.f;
+        const float se = wave_sum(ex);
+        const float lse = mx + logf(se);
+        const float dy = __shfl(myd, (int)yq, 64);
+        lsum += lse + dy;                                                       // -log softmax(-d)[y] = lse - (-d_y)
+        csum += (amin == (int)yq) ? 1.f : 0.f;
+        if (lane == 0) preds[q] = amin;
+        if (need_grad) {
+            // dbar[c] = dL/dd[c] = -(p_c - onehot_c) * dscale ;  xbar = sum_c dbar[c] * (-2)(proto_c - x) ;  pbar_c += dbar[c]*2(proto_c - x)
+            const float mydb = lane < N ? -(expf(-myd - lse) - (lane == (int)yq ? 1.f : 0.f)) * dscale : 0.f;
+            float xb[HPJ];
+#pragma unroll
+            for (int k = 0; k < HPJ; ++k) xb[k] = 0.f;
+            for (int c = 0; c < N; ++c) {
+                const float db = __shfl(mydb, c, 64);
+#pragma unroll
+                for (int k = 0; k < HPJ; ++k) {
+                    const int j = k * 64 + lane;
+                    if (k < npj && j < P) {
+                        const float df2 = 2.f * (pr[c * P + j] - x[k]);
+                        xb[k] -= db * df2;
+                        mypb[c * P + j] += db * df2;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; if (k < npj && j < P) im_q_bar[((long)b * Qn + q) * P + j] = xb[k]; }
+        }
+    }
+    if (lane == 0) { wl[wave] = lsum; wc[wave] = csum; }
+    __syncthreads();
+    if (tid == 0) {
+        float l = 0.f, c = 0.f;
+        for (int w_ = 0; w_ < nw; ++w_) { l += wl[w_]; c += wc[w_]; }
+        loss_b[b] = l * dscale;
+        corr_b[b] = c;
+    }
+    if (!need_grad) return;
+    // ---- prototype adjoints -> per-sample gradients (utils.py:358-375 reversed)
+    for (int i = tid; i < NP; i += nt) {
+        float s_ = 0.f;
+        for (int w_ = 0; w_ < nw; ++w_) s_ += pb[w_ * NP + i];
+        pb[i] = s_;                                         // slab 0 now holds pbar (only element i of slab 0 is touched by thread i)
+    }
+    __syncthreads();
+    for (int c = wave; c < N; c += nw) {
+        float v = 0.f;
+        for (int j = lane; j < P; j += 64) v += pb[c * P + j] * (ip[c * P + j] - tp[c * P + j]);
+        v = wave_sum(v);
+        if (lane == 0) lbar[c] = v;
+    }
+    __syncthreads();
+    im_s_bar += (long)b * SP; tx_bar += (long)b * SP; zl_bar += (long)b * S;
+    for (int i = tid; i < SP; i += nt) {
+        const int s_ = i / P, j = i - s_ * P;
+        const int c = ys[s_];
+        if (c < 0) { im_s_bar[i] = 0.f; tx_bar[i] = 0.f; continue; }
+        const float g = pb[c * P + j] / cnt[c];
+        im_s_bar[i] = lamc[c] * g;
+        tx_bar[i] = (1.f - lamc[c]) * g;
+    }
+    for (int s_ = tid; s_ < S; s_ += nt) {
+        const int c = ys[s_];
+        float z = 0.f;
+        if (lamda_fixed < 0 && c >= 0) { const float l = lam[s_]; z = lbar[c] / cnt[c] * l * (1.f - l); }
+        zl_bar[s_] = z;
+    }
+}
+
 }  // namespace
 
 extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
@@ -175,8 +336,16 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     };
     const float *Wi = w[0], *bi = w[1], *G0 = w[2], *g0 = w[3], *G1 = w[4], *g1 = w[5], *H0 = w[6], *h0 = w[7], *H1 = w[8], *h1 = w[9];
     const long Rs = (long)B * S, Rq = (long)B * Qn;
-    const int nwaves = 4;
-    const size_t lds = ((size_t)(3 + nwaves) * N * P + 3 * N + 2 * nwaves) * sizeof(float);
+    // fast head: N <= 64 classes, P <= 512, and the episode's support side fits LDS next to the per-wave adjoint slabs
+    int nwaves = 8;
+    auto fast_lds = [&](int nw_) { return ((size_t)(3 + nw_) * N * P + 2 * (size_t)S * P + 3 * N + 2 * nw_ + 2 * S + 16) * sizeof(float); };
+    bool fast_head = N <= 64 && P <= 64 * HPJ;
+    if (fast_head && fast_lds(8) > 150 * 1024) nwaves = 4;
+    if (fast_head && fast_lds(nwaves) > 150 * 1024) fast_head = false;
+    static const int head_generic = getenv("FUMI_AM3_GENERIC") ? atoi(getenv("FUMI_AM3_GENERIC")) : 0;
+    if (head_generic) fast_head = false;
+    if (!fast_head) nwaves = 4;
+    const size_t lds = fast_head ? fast_lds(nwaves) : ((size_t)(3 + nwaves) * N * P + 3 * N + 2 * nwaves) * sizeof(float);
     if (lds > 160 * 1024) return FUMI_ENOTSUP;
     const int KCH = 1024;
     const int ns = (int)((Rs + KCH - 1) / KCH), nq = (int)((Rq + KCH - 1) / KCH);
@@ -184,7 +353,9 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     size_t bytes = 0;
     auto A = [&](size_t n) { bytes += ws_align(n * sizeof(float)); };
     A((Rs + Rq) * P); A(Rs * Ht); A(Rs * P); A(Rs * Ht); A(2 * B);
-    if (need_grad) { A((Rs + Rq) * P); A(Rs * P); A(Rs); A(Rs * Ht); A(Rs * Ht); A((size_t)(ns + nq) * P * D); }
+    const size_t cpart_n = (size_t)((Rs + 127) / 128) * (size_t)(2 * ((Ht + 3) & ~3) + ((P + 3) & ~3) + 4)
+                         + (size_t)((Rs + Rq + 127) / 128) * (size_t)((P + 3) & ~3) + 64;       // ColsumJobs partial sums
+    if (need_grad) { A((Rs + Rq) * P); A(Rs * P); A(Rs); A(Rs * Ht); A(Rs * Ht); A((size_t)(ns + nq) * P * D); A(cpart_n); }
     int rc = ws_reserve(ws, bytes);
     if (rc) return rc;
     float* im = ws_f(ws, (Rs + Rq) * P);          // [support rows | query rows]
@@ -220,35 +391,48 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
             if ((rc = launch_gemm(st, g, 0, 0))) return rc;
         }
     }
-    float *imb = nullptr, *txb = nullptr, *zlb = nullptr, *l1b = nullptr, *t1b = nullptr, *slabs = nullptr;
+    float *imb = nullptr, *txb = nullptr, *zlb = nullptr, *l1b = nullptr, *t1b = nullptr, *slabs = nullptr, *cpart = nullptr;
     if (need_grad) {
+        cpart = nullptr;
         imb = ws_f(ws, (Rs + Rq) * P); txb = ws_f(ws, Rs * P); zlb = ws_f(ws, Rs);
         l1b = ws_f(ws, Rs * Ht); t1b = ws_f(ws, Rs * Ht); slabs = ws_f(ws, (size_t)(ns + nq) * P * D);
+        cpart = ws_f(ws, cpart_n);
     }
     {
         ProfScope ps(ws, st, FUMI_PH_AM3);
         const float dscale = grad_scale / (float)Qn;
-        hipLaunchKernelGGL(am3_head_kernel, dim3(B), dim3(64 * nwaves), lds, st, N, S, Qn, P, lamda_fixed, need_grad ? 1 : 0,
-                           dscale, im, tx, lamda_s, y_s, imq, y_q, preds_q, lc, lc + B, imb, txb, zlb,
-                           imb ? imb + Rs * P : nullptr, ws->status);
+        if (fast_head) {
+            FUMI_SET_DYN_LDS(am3_head_kernel, lds);
+            hipLaunchKernelGGL(am3_head_kernel, dim3(B), dim3(64 * nwaves), lds, st, N, S, Qn, P, lamda_fixed, need_grad ? 1 : 0,
+                               dscale, im, tx, lamda_s, y_s, imq, y_q, preds_q, lc, lc + B, imb, txb, zlb,
+                               imb ? imb + Rs * P : nullptr, ws->status);
+        } else {
+            FUMI_SET_DYN_LDS(am3_head_generic_kernel, lds);
+            hipLaunchKernelGGL(am3_head_generic_kernel, dim3(B), dim3(64 * nwaves), lds, st, N, S, Qn, P, lamda_fixed,
+                               need_grad ? 1 : 0, dscale, im, tx, lamda_s, y_s, imq, y_q, preds_q, lc, lc + B, imb, txb, zlb,
+                               imb ? imb + Rs * P : nullptr, ws->status);
+        }
         LAUNCH_CHECK();
-        if ((rc = launch_reduce_slabs(st, lc, B, 1, 1, 1.f, loss))) return rc;
-        if ((rc = launch_reduce_slabs(st, lc + B, B, 1, 1, 1.f, correct))) return rc;
+        ReduceSegs fin; fin.n = 0; fin.scale = 1.f;              // per-episode loss / correct counts -> scalars, one launch
+        fin.add(lc, B, 1, 1, loss);
+        fin.add(lc + B, B, 1, 1, correct);
+        if ((rc = launch_reduce_multi(st, fin))) return rc;
     }
     if (!need_grad) return FUMI_OK;
 
     ProfScope pb(ws, st, FUMI_PH_HYPER_BWD);
+    ColsumJobs cj; cj.n = 0; cj.part_total = 0;
     if (lamda_fixed < 0) {
         // h network: lam = sigmoid(l1 H1^T + h1), l1 = relu(tx H0^T + h0)
         g = gemm_args(1, Ht, (int)Rs, zlb, 1, l1, Ht, g_w[8], Ht);                     // gH1 = zlbar^T l1
         if ((rc = launch_gemm(st, g, 1, 1))) return rc;
-        if ((rc = launch_colsum(st, zlb, (int)Rs, 1, 1, 1.f, g_w[9]))) return rc;
-        g = gemm_args((int)Rs, Ht, 1, zlb, 1, H1, Ht, l1b, Ht);                        // l1bar = zlbar H1, masked
+        cj.add(zlb, (int)Rs, 1, 1, g_w[9]);
+        g = gemm_args((int)Rs, Ht, 1, zlb, 1, H1, Ht, l1b, Ht);                        // l1bar = (zlbar H1) * relu'(l1) * dropout scale
+        g.mask = l1; g.alpha = dsc;
         if ((rc = launch_gemm(st, g, 0, 1))) return rc;
-        if ((rc = launch_relu_mask_mul(st, Rs * Ht, l1, l1b, dsc))) return rc;
         g = gemm_args(Ht, P, (int)Rs, l1b, Ht, tx, P, g_w[6], P);                      // gH0 = l1bar^T tx
         if ((rc = launch_gemm(st, g, 1, 1))) return rc;
-        if ((rc = launch_colsum(st, l1b, (int)Rs, Ht, Ht, 1.f, g_w[7]))) return rc;
+        cj.add(l1b, (int)Rs, Ht, Ht, g_w[7]);
         g = gemm_args((int)Rs, P, Ht, l1b, Ht, H0, P, txb, P); g.accumulate = 1;       // txbar += l1bar H0
         if ((rc = launch_gemm(st, g, 0, 1))) return rc;
     } else {
@@ -258,13 +442,13 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     // g network: tx = t1 G1^T + g1, t1 = relu(text G0^T + g0)
     g = gemm_args(P, Ht, (int)Rs, txb, P, t1, Ht, g_w[4], Ht);                         // gG1 = txbar^T t1
     if ((rc = launch_gemm(st, g, 1, 1))) return rc;
-    if ((rc = launch_colsum(st, txb, (int)Rs, P, P, 1.f, g_w[5]))) return rc;
-    g = gemm_args((int)Rs, Ht, P, txb, P, G1, Ht, t1b, Ht);                            // t1bar = txbar G1, masked
+    cj.add(txb, (int)Rs, P, P, g_w[5]);
+    g = gemm_args((int)Rs, Ht, P, txb, P, G1, Ht, t1b, Ht);                            // t1bar = (txbar G1) * relu'(t1) * dropout scale
+    g.mask = t1; g.alpha = dsc;
     if ((rc = launch_gemm(st, g, 0, 1))) return rc;
-    if ((rc = launch_relu_mask_mul(st, Rs * Ht, t1, t1b, dsc))) return rc;
     g = gemm_args(Ht, Dt, (int)Rs, t1b, Ht, text_s, Dt, g_w[2], Dt);                   // gG0 = t1bar^T text
     if ((rc = launch_gemm(st, g, 1, 1))) return rc;
-    if ((rc = launch_colsum(st, t1b, (int)Rs, Ht, Ht, 1.f, g_w[3]))) return rc;
+    cj.add(t1b, (int)Rs, Ht, Ht, g_w[3]);
     // image encoder: gWi = imbar_s^T Xs + imbar_q^T Xq (split over the contraction), gbi = colsum(imbar)
     {
         ProfScope pg(ws, st, FUMI_PH_XPANEL_BWD);
@@ -275,8 +459,11 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
         g = gemm_args(P, D, (int)Rq, imb + Rs * P, P, x_q, D, slabs + (long)ns * slab, D);
         g.kchunk = KCH; g.nsplit = nq; g.sCsplit = slab;
         if ((rc = launch_gemm(st, g, 1, 1))) return rc;
-        if ((rc = launch_reduce_slabs(st, slabs, ns + nq, slab, slab, 1.f, g_w[0]))) return rc;
-        if ((rc = launch_colsum(st, imb, (int)(Rs + Rq), P, P, 1.f, g_w[1]))) return rc;
+        cj.add(imb, (int)(Rs + Rq), P, P, g_w[1]);
+        // every bias gradient (column sums over all rows) and the image-encoder weight slabs: two launches in all
+        ReduceSegs tail_; tail_.n = 0; tail_.scale = 1.f;
+        tail_.add(slabs, ns + nq, slab, slab, g_w[0]);
+        if ((rc = launch_colsum_multi(st, cj, cpart, &tail_))) return rc;
     }
     return FUMI_OK;
 }

@@ -124,6 +124,20 @@ struct ReduceSegs {
 int launch_reduce_multi(hipStream_t st, ReduceSegs& sg);
 // out[n] = scale * sum_m X[m*ld + n]
 int launch_colsum(hipStream_t st, const float* X, int M, int N, long ld, float scale, float* out);
+// several column sums (bias gradients) in TWO launches: partial sums of 128-row chunks for every job, then one
+// reduce_multi over the chunks (fixed order: bit-reproducible)
+struct ColsumJobs {
+    const float* X[8]; float* out[8]; int M[8], N[8]; long ld[8]; int blk_end[8]; long part_off[8]; int n; long part_total;
+    void add(const float* x, int m, int nn, long l, float* o) {
+        X[n] = x; M[n] = m; N[n] = nn; ld[n] = l; out[n] = o;
+        const int blocks = ((nn + 63) / 64) * ((m + 127) / 128);
+        blk_end[n] = (n ? blk_end[n - 1] : 0) + blocks;
+        part_off[n] = part_total; part_total += (long)((m + 127) / 128) * (((long)nn + 3) & ~3L);
+        ++n;
+    }
+};
+int launch_colsum_multi(hipStream_t st, const ColsumJobs& jobs, float* part /* jobs.part_total floats */,
+                        const ReduceSegs* extra = nullptr);
 
 // ------------------------------------------------------------------------------------------------------------
 // the two shared passes over the wide inputs (xpanel.hip)

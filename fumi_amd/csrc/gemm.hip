@@ -236,6 +236,35 @@ __global__ void colsum_kernel(const float* __restrict__ X, int M, int N, long ld
     if (threadIdx.y == 0 && n < N) out[n] = scale * (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+// partial column sums: block -> (job, 64-column block, 128-row chunk); wave w of the block takes rows w, w+4, ... of the
+// chunk, four independent loads in flight; part[job][chunk][N4] (N4 = N rounded up to 4: aligned slabs for the reduction)
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumJobs jb, float* __restrict__ part) {
+    __shared__ float sh[4][64];
+    int j = 0;
+    while (j + 1 < jb.n && (int)blockIdx.x >= jb.blk_end[j]) ++j;
+    const int lb = blockIdx.x - (j ? jb.blk_end[j - 1] : 0);
+    const int M = jb.M[j], N = jb.N[j];
+    const long ld = jb.ld[j];
+    const int ncb = (N + 63) >> 6, cbk = lb % ncb, chunk = lb / ncb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = cbk * 64 + lane, r0 = chunk * 128, r1 = min(M, r0 + 128);
+    const float* X = jb.X[j] + (n < N ? n : 0);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int m = r0 + wave; m < r1; m += 16) {
+        const float a = X[(long)m * ld];
+        const float b = m + 4 < r1 ? X[(long)(m + 4) * ld] : 0.f;
+        const float c = m + 8 < r1 ? X[(long)(m + 8) * ld] : 0.f;
+        const float d = m + 12 < r1 ? X[(long)(m + 12) * ld] : 0.f;
+        s0 += a; s1 += b; s2 += c; s3 += d;
+    }
+    sh[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && n < N) {
+        const long N4 = ((long)N + 3) & ~3L;
+        part[jb.part_off[j] + chunk * N4 + n] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+    }
+}
+
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -276,6 +305,20 @@ int launch_reduce_multi(hipStream_t st, ReduceSegs& sg) {
     hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sg);
     LAUNCH_CHECK();
     return FUMI_OK;
+}
+
+int launch_colsum_multi(hipStream_t st, const ColsumJobs& jobs, float* part, const ReduceSegs* extra) {
+    ReduceSegs rs; rs.n = 0; rs.scale = 1.f;
+    if (extra) rs = *extra;                            // further slab sums of the caller ride in the same reduction launch
+    if (jobs.n < 1) return launch_reduce_multi(st, rs);
+    if (rs.n + jobs.n > 24 || rs.scale != 1.f) return FUMI_EINVAL;
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3(jobs.blk_end[jobs.n - 1]), dim3(256), 0, st, jobs, part);
+    LAUNCH_CHECK();
+    for (int j = 0; j < jobs.n; ++j) {
+        const long N4 = ((long)jobs.N[j] + 3) & ~3L;
+        rs.add(part + jobs.part_off[j], (jobs.M[j] + 127) / 128, N4, jobs.N[j], jobs.out[j]);
+    }
+    return launch_reduce_multi(st, rs);
 }
 
 int launch_colsum(hipStream_t st, const float* X, int M, int N, long ld, float scale, float* out) {

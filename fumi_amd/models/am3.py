@@ -13,6 +13,7 @@ import torch.nn as nn
 
 from .. import dist as fdist
 from .. import engine as _engine
+from .. import lazy
 from ..flatgrad import FlatGrads
 from ..utils import utils as utils
 from ..utils.average_meter import AverageMeter
@@ -132,6 +133,11 @@ class AM3(nn.Module):
                 scheduler.step()
         preds = fdist.all_gather_rows(out["preds"])
         lam_s = fdist.all_gather_rows(out["lamda_s"])
+        if task != "test" and preds.is_cuda:
+            # train / val: accuracy and the macro metrics from a confusion matrix built on the device -- the reference moves the
+            # predictions to the host and calls sklearn every meta-batch (utils.py:319-326), a blocking copy per step
+            m6 = torch.cat([tail[:1], _macro_metrics_device(q_y.to(preds.device), preds, num_ways), tail[2:3]])
+            return lazy.scalars(m6, 6)
         stats = tail.detach().cpu().numpy()
         preds_np = preds.detach().cpu().numpy()
         targets_np = q_y.detach().cpu().numpy()
@@ -140,6 +146,23 @@ class AM3(nn.Module):
             return (stats[0], acc, f1, prec, rec, stats[2], preds_np, q_y.to(device), q_idx.detach().cpu().numpy(),
                     s_idx.detach().cpu().numpy(), lam_s.detach().cpu().numpy())
         return stats[0], acc, f1, prec, rec, stats[2]
+
+
+def _macro_metrics_device(targets, preds, n_way):
+    """[acc, f1, prec, rec] (fp32, on the device) = utils.macro_metrics on the host: macro averages over the labels that occur
+    in the targets or the predictions, 0 for an undefined ratio (sklearn's zero_division), from the N x N confusion counts."""
+    t, p = targets.reshape(-1), preds.reshape(-1).to(torch.int64)
+    ones = torch.ones(t.numel(), device=t.device, dtype=torch.float32)
+    C = torch.zeros(n_way * n_way, device=t.device, dtype=torch.float32).scatter_add_(0, t * n_way + p, ones).view(n_way, n_way)
+    tp, pp, tt = C.diagonal(), C.sum(0), C.sum(1)                 # integer-valued: exact in fp32 up to 2^24 samples
+    zero = torch.zeros_like(tp)
+    prec = torch.where(pp > 0, tp / pp.clamp(min=1), zero)
+    rec = torch.where(tt > 0, tp / tt.clamp(min=1), zero)
+    f1 = torch.where(prec + rec > 0, 2 * prec * rec / (prec + rec).clamp(min=1e-30), zero)
+    present = ((pp + tt) > 0).float()
+    nl = present.sum().clamp(min=1)
+    return torch.stack([tp.sum() / max(t.numel(), 1), (f1 * present).sum() / nl, (prec * present).sum() / nl,
+                        (rec * present).sum() / nl])
 
 
 def training_run(args, model, optimizer, train_loader, val_loader, max_test_batches):

@@ -292,6 +292,20 @@ def test_am3_eval_mode_matches_train_forward(dev, ws):
     assert abs(la - float(b["loss"])) < 1e-6 and torch.equal(pa, b["preds"])
 
 
+def test_am3_device_metrics_match_host_metrics(dev):
+    """AM3.evaluate (train / val) takes accuracy and macro precision / recall / F1 from a confusion matrix on the device; the
+    host form (what sklearn returns, utils.py:319-326) is the checker, including classes that never occur."""
+    from fumi_amd.models.am3 import _macro_metrics_device
+    from fumi_amd.utils.utils import macro_metrics
+    rs = np.random.RandomState(0)
+    for N, n in [(5, 800), (5, 7), (20, 300), (3, 50)]:
+        t = rs.randint(0, N, size=n); p = rs.randint(0, N, size=n)
+        if N == 20:
+            p[p == 3] = 4; t[t == 7] = 8; p[p == 7] = 8                 # a class never predicted, a class absent everywhere
+        got = _macro_metrics_device(torch.from_numpy(t).to(dev), torch.from_numpy(p).to(dev), N).cpu().numpy()
+        np.testing.assert_allclose(got, np.array(macro_metrics(t, p)), rtol=2e-6, atol=1e-7)
+
+
 def test_fused_adam_matches_torch_adam(dev, ws):
     """fumi_hip_adam_step == torch.optim.Adam(lr, weight_decay) (utils.py:280-283) over several steps, odd sizes included."""
     from fumi_amd.optim import Adam

@@ -53,10 +53,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--only", type=str, default=None, help="run one configuration")
     o = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     for name, argv in CONFIGS.items():
+        if o.only and name != o.only:
+            continue
         a = U.parser().parse_args(argv + ["--dropout", "0", "--dataset", "synthetic"])
         a.device = dev
         torch.manual_seed(1)
