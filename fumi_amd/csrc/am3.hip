@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void am3_head_generic_kernel(int N, int S, int
                                                        float* __restrict__ lam_s, const int64_t* __restrict__ y_s,
                                                        const float* __restrict__ im_q, const int64_t* __restrict__ y_q,
                                                        int64_t* __restrict__ preds, float* __restrict__ loss_b,
-                                                       float* __restrict__ corr_b,
+                                                       float* __restrict__ corr_b, float* __restrict__ conf_b,
+                                                       float* __restrict__ lam_b, float lscale,
                                                        float* __restrict__ im_s_bar, float* __restrict__ tx_bar,
                                                        float* __restrict__ zl_bar, float* __restrict__ im_q_bar,
                                                        int* status) {
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256) void am3_head_generic_kernel(int N, int S, int
         lsum += lse + dy;                                   // -log softmax(-d)[y] = lse - (-d_y)
         csum += (amin == yq) ? 1.f : 0.f;
         if (lane == 0) preds[q] = amin;
+        if (lane == 0 && conf_b) atomicAdd(conf_b + ((long)b * N + yq) * N + amin, 1.f);   // integer-valued: exact in any order
         if (need_grad) {
             // dbar[c] = dL/dd[c] = -(p_c - onehot_c) * dscale ;  xbar = sum_c dbar[c] * (-2)(proto_c - x) ;  pbar_c += dbar[c]*2(proto_c - x)
             for (int j0 = 0; j0 < P; j0 += 64) {
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(256) void am3_head_generic_kernel(int N, int S, int
         for (int w = 0; w < nw; ++w) { l += wl[w]; c += wc[w]; }
         loss_b[b] = l * dscale;
         corr_b[b] = c;
+        if (lam_b) { float ls_ = 0.f; for (int s2 = 0; s2 < S; ++s2) ls_ += lam_s[s2]; lam_b[b] = ls_ * lscale; }
     }
     if (!need_grad) return;
     // ---- prototype adjoints -> per-sample gradients (utils.py:358-375 reversed)
@@ -171,7 +174,8 @@ __global__ __launch_bounds__(512) void am3_head_kernel(int N, int S, int Qn, int
                                                        float* __restrict__ lam_s, const int64_t* __restrict__ y_s,
                                                        const float* __restrict__ im_q, const int64_t* __restrict__ y_q,
                                                        int64_t* __restrict__ preds, float* __restrict__ loss_b,
-                                                       float* __restrict__ corr_b,
+                                                       float* __restrict__ corr_b, float* __restrict__ conf_b,
+                                                       float* __restrict__ lam_b, float lscale,
                                                        float* __restrict__ im_s_bar, float* __restrict__ tx_bar,
                                                        float* __restrict__ zl_bar, float* __restrict__ im_q_bar,
                                                        int* status) {
@@ -252,6 +256,7 @@ __global__ __launch_bounds__(512) void am3_head_kernel(int N, int S, int Qn, int
         lsum += lse + dy;                                                       // -log softmax(-d)[y] = lse - (-d_y)
         csum += (amin == (int)yq) ? 1.f : 0.f;
         if (lane == 0) preds[q] = amin;
+        if (lane == 0 && conf_b) atomicAdd(conf_b + ((long)b * N + yq) * N + amin, 1.f);   // integer-valued: exact in any order
         if (need_grad) {
             // dbar[c] = dL/dd[c] = -(p_c - onehot_c) * dscale ;  xbar = sum_c dbar[c] * (-2)(proto_c - x) ;  pbar_c += dbar[c]*2(proto_c - x)
             const float mydb = lane < N ? -(expf(-myd - lse) - (lane == (int)yq ? 1.f : 0.f)) * dscale : 0.f;
@@ -281,6 +286,7 @@ __global__ __launch_bounds__(512) void am3_head_kernel(int N, int S, int Qn, int
         for (int w_ = 0; w_ < nw; ++w_) { l += wl[w_]; c += wc[w_]; }
         loss_b[b] = l * dscale;
         corr_b[b] = c;
+        if (lam_b) { float ls_ = 0.f; for (int s2 = 0; s2 < S; ++s2) ls_ += lam_s[s2]; lam_b[b] = ls_ * lscale; }
     }
     if (!need_grad) return;
     // ---- prototype adjoints -> per-sample gradients (utils.py:358-375 reversed)
@@ -320,7 +326,8 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
         int B, int N, int S, int Qn, int D, int Dt, int Ht, int P, int lamda_fixed, int need_grad, float grad_scale,
         float dropout_p, uint64_t seed,
         const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q, const float* text_s,
-        const float* const* w, float* loss, int64_t* preds_q, float* lamda_s, float* correct, float* const* g_w) {
+        const float* const* w, float* loss, int64_t* preds_q, float* lamda_s, float* correct, float* const* g_w,
+        float* stats) {
     if (!ws || !x_s || !y_s || !x_q || !y_q || !text_s || !w || !loss || !preds_q || !lamda_s || !correct) return FUMI_EINVAL;
     if (B < 1 || N < 1 || S < 1 || Qn < 1 || D < 1 || Dt < 1 || Ht < 1 || P < 1 || lamda_fixed < -1 || lamda_fixed > 1) return FUMI_EINVAL;
     for (int i = 0; i < 10; ++i) if (!w[i] || (need_grad && (!g_w || !g_w[i]))) return FUMI_EINVAL;
@@ -352,7 +359,7 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
 
     size_t bytes = 0;
     auto A = [&](size_t n) { bytes += ws_align(n * sizeof(float)); };
-    A((Rs + Rq) * P); A(Rs * Ht); A(Rs * P); A(Rs * Ht); A(2 * B);
+    A((Rs + Rq) * P); A(Rs * Ht); A(Rs * P); A(Rs * Ht); A(2 * B); A((size_t)B * N * N + B);
     const size_t cpart_n = (size_t)((Rs + 127) / 128) * (size_t)(2 * ((Ht + 3) & ~3) + ((P + 3) & ~3) + 4)
                          + (size_t)((Rs + Rq + 127) / 128) * (size_t)((P + 3) & ~3) + 64;       // ColsumJobs partial sums
     if (need_grad) { A((Rs + Rq) * P); A(Rs * P); A(Rs); A(Rs * Ht); A(Rs * Ht); A((size_t)(ns + nq) * P * D); A(cpart_n); }
@@ -363,6 +370,10 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     float* tx = ws_f(ws, Rs * P);
     float* l1 = ws_f(ws, Rs * Ht);
     float* lc = ws_f(ws, 2 * B);                  // per-episode loss | correct
+    float* confb = ws_f(ws, (size_t)B * N * N + B);       // per-episode confusion counts | lamda sums
+    float* lamb = confb + (size_t)B * N * N;
+    if (!stats) { confb = nullptr; lamb = nullptr; }
+    else HIP_TRY(hipMemsetAsync(confb, 0, (size_t)B * N * N * sizeof(float), st));
     float* imq = im + Rs * P;
 
     GemmArgs g;
@@ -404,18 +415,24 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
         if (fast_head) {
             FUMI_SET_DYN_LDS(am3_head_kernel, lds);
             hipLaunchKernelGGL(am3_head_kernel, dim3(B), dim3(64 * nwaves), lds, st, N, S, Qn, P, lamda_fixed, need_grad ? 1 : 0,
-                               dscale, im, tx, lamda_s, y_s, imq, y_q, preds_q, lc, lc + B, imb, txb, zlb,
-                               imb ? imb + Rs * P : nullptr, ws->status);
+                               dscale, im, tx, lamda_s, y_s, imq, y_q, preds_q, lc, lc + B, confb, lamb, grad_scale / (float)S,
+                               imb, txb, zlb, imb ? imb + Rs * P : nullptr, ws->status);
         } else {
             FUMI_SET_DYN_LDS(am3_head_generic_kernel, lds);
             hipLaunchKernelGGL(am3_head_generic_kernel, dim3(B), dim3(64 * nwaves), lds, st, N, S, Qn, P, lamda_fixed,
-                               need_grad ? 1 : 0, dscale, im, tx, lamda_s, y_s, imq, y_q, preds_q, lc, lc + B, imb, txb, zlb,
-                               imb ? imb + Rs * P : nullptr, ws->status);
+                               need_grad ? 1 : 0, dscale, im, tx, lamda_s, y_s, imq, y_q, preds_q, lc, lc + B, confb, lamb,
+                               grad_scale / (float)S, imb, txb, zlb, imb ? imb + Rs * P : nullptr, ws->status);
         }
         LAUNCH_CHECK();
         ReduceSegs fin; fin.n = 0; fin.scale = 1.f;              // per-episode loss / correct counts -> scalars, one launch
         fin.add(lc, B, 1, 1, loss);
         fin.add(lc + B, B, 1, 1, correct);
+        if (stats) {        // [loss | correct count | this rank's share of the mean lamda | confusion counts]
+            fin.add(lc, B, 1, 1, stats);
+            fin.add(lc + B, B, 1, 1, stats + 1);
+            fin.add(lamb, B, 1, 1, stats + 2);
+            fin.add(confb, B, (long)N * N, (long)N * N, stats + 3);
+        }
         if ((rc = launch_reduce_multi(st, fin))) return rc;
     }
     if (!need_grad) return FUMI_OK;
@@ -467,3 +484,39 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     }
     return FUMI_OK;
 }
+
+// ---- accuracy and macro precision / recall / F1 from the confusion matrix (what the reference asks sklearn for on the host
+// every meta-batch, utils.py:319-326): lane c owns class c; averages run over the classes that occur among targets or
+// predictions, an undefined ratio counts as 0 (zero_division).  stats = [loss, -, lamda, conf[N*N]] as fumi_hip_am3_step
+// writes them (after the all-reduce over ranks, if any); out6 = [loss, acc, f1, prec, rec, lamda].
+namespace {
+__global__ __launch_bounds__(64) void am3_metrics_kernel(int N, const float* __restrict__ stats, float* __restrict__ out) {
+    const int c = threadIdx.x;
+    const float* cf = stats + 3;
+    float tp = 0.f, pp = 0.f, tt = 0.f;
+    if (c < N) {
+        tp = cf[c * N + c];
+        for (int k = 0; k < N; ++k) { pp += cf[k * N + c]; tt += cf[c * N + k]; }
+    }
+    const float prec = pp > 0.f ? tp / pp : 0.f, rec = tt > 0.f ? tp / tt : 0.f;
+    const float f1 = prec + rec > 0.f ? 2.f * prec * rec / (prec + rec) : 0.f;
+    const float present = (pp + tt) > 0.f ? 1.f : 0.f;
+    const float nl = fmaxf(wave_sum(present), 1.f);
+    const float sp = wave_sum(prec * present), sr = wave_sum(rec * present), sf = wave_sum(f1 * present);
+    const float stp = wave_sum(tp), sall = wave_sum(tt);
+    if (c == 0) {
+        out[0] = stats[0]; out[1] = sall > 0.f ? stp / sall : 0.f; out[2] = sf / nl; out[3] = sp / nl; out[4] = sr / nl;
+        out[5] = stats[2];
+    }
+}
+}  // namespace
+
+extern "C" int fumi_hip_am3_metrics(fumi_ws_t* ws, fumi_stream_t stream, int N, const float* stats, float* out6) {
+    if (!ws || !stats || !out6 || N < 1) return FUMI_EINVAL;
+    if (N > 64) return FUMI_ENOTSUP;
+    HIP_TRY(hipSetDevice(ws->device));
+    hipLaunchKernelGGL(am3_metrics_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, N, stats, out6);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+

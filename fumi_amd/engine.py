@@ -36,9 +36,12 @@ class HipEngine:
                              grad_scale=grad_scale, g_params=g_params, stats=stats)
 
     def am3_step(self, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad, grad_scale, g_w=None,
-                 dropout_p=0.0, seed=0):
+                 dropout_p=0.0, seed=0, stats=None):
         return hip.am3_step(self._ws(x_s), x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad=need_grad,
-                            grad_scale=grad_scale, g_w=g_w, dropout_p=dropout_p, seed=seed)
+                            grad_scale=grad_scale, g_w=g_w, dropout_p=dropout_p, seed=seed, stats=stats)
+
+    def am3_metrics(self, n_way, stats):
+        return hip.am3_metrics(self._ws(stats), n_way, stats)
 
     def glove_bag(self, tokens, table, pad_id, mode):
         return hip.glove_bag(self._ws(tokens), tokens, table, pad_id, mode)

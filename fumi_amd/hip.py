@@ -24,7 +24,7 @@ SYMBOLS = [
     "fumi_hip_adam_step",
     "fumi_hip_linear_fwd", "fumi_hip_linear_bwd_data", "fumi_hip_linear_bwd_weight",
     "fumi_hip_sample_episodes", "fumi_hip_gather_rows", "fumi_hip_publish_scalars",
-    "fumi_hip_publish_scalars_deferred", "fumi_hip_publish_flush",
+    "fumi_hip_publish_scalars_deferred", "fumi_hip_publish_flush", "fumi_hip_am3_metrics",
 ]
 
 ST_LABEL_RANGE, ST_CLASS_MISSING = 1, 2
@@ -109,7 +109,8 @@ def lib():
             [c_void_p, c_void_p] + [c_int] * 6 + [POINTER(c_int), c_int, c_float, c_int, c_int, c_float]
             + [c_void_p] * 4 + [PP] + [c_void_p] * 6 + [PP])
         L.fumi_hip_am3_step.argtypes = (
-            [c_void_p, c_void_p] + [c_int] * 10 + [c_float, c_float, ctypes.c_uint64] + [c_void_p] * 5 + [PP] + [c_void_p] * 4 + [PP])
+            [c_void_p, c_void_p] + [c_int] * 10 + [c_float, c_float, ctypes.c_uint64] + [c_void_p] * 5 + [PP] + [c_void_p] * 4 + [PP, c_void_p])
+        L.fumi_hip_am3_metrics.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p]
         L.fumi_hip_glove_bag.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int, c_int,
                                          c_int, c_void_p]
         L.fumi_hip_glove_bag_select.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64,
@@ -373,8 +374,10 @@ AM3_KEYS = ["Wi", "bi", "G0", "g0", "G1", "g1", "H0", "h0", "H1", "h1"]
 
 
 def am3_step(ws, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed=None, *, need_grad=True, grad_scale=None, g_w=None,
-             dropout_p=0.0, seed=0):
-    """One AM3 step (fumi/models/am3.py:160-200).  w: list of the 10 tensors in AM3_KEYS order."""
+             dropout_p=0.0, seed=0, stats=None):
+    """One AM3 step (fumi/models/am3.py:160-200).  w: list of the 10 tensors in AM3_KEYS order.  ``stats``: optional fp32
+    [3 + n_way**2] device tensor receiving [loss, correct count, grad_scale * sum of the episodes' mean lamda, confusion
+    counts] (the input of ``am3_metrics``)."""
     dev = _dev(x_s)
     L = lib()
     B, S, D = x_s.shape
@@ -394,9 +397,19 @@ def am3_step(ws, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed=None, *, need
         float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
         _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"), _f32(text_s, "text_s"),
         _parr(w, "w"), _f32(loss, "loss"), _i64(preds, "preds"), _f32(lam, "lamda_s"), _f32(correct, "correct"),
-        _parr(g_w, "g_w") if need_grad else None)
+        _parr(g_w, "g_w") if need_grad else None, _f32(stats, "stats") if stats is not None else None)
     _check(rc, "fumi_hip_am3_step")
-    return dict(loss=loss, preds=preds, lamda_s=lam, correct=correct, grads=g_w)
+    return dict(loss=loss, preds=preds, lamda_s=lam, correct=correct, grads=g_w, stats=stats)
+
+
+def am3_metrics(ws, n_way, stats):
+    """[loss, acc, macro F1, macro precision, macro recall, mean lamda] (fp32 [6] on the device) from an ``am3_step`` stats
+    tensor (summed over ranks first when sharded)."""
+    dev = _dev(stats)
+    out = torch.empty(6, device=dev, dtype=torch.float32)
+    _check(lib().fumi_hip_am3_metrics(ws.handle, _stream(dev), int(n_way), _f32(stats, "stats"), _f32(out, "out6")),
+           "fumi_hip_am3_metrics")
+    return out
 
 
 def glove_bag(ws, tokens, table, pad_id, mode="mean"):

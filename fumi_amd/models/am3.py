@@ -67,10 +67,11 @@ class AM3(nn.Module):
         return [self.image_encoder.weight, self.image_encoder.bias, self.g[0].weight, self.g[0].bias, self.g[3].weight,
                 self.g[3].bias, self.h[0].weight, self.h[0].bias, self.h[3].weight, self.h[3].bias]
 
-    def _flat_grads(self):
+    def _flat_grads(self, num_ways=0):
         params = self._w()
-        if self._flat is None or not self._flat.matches(params):
-            self._flat = FlatGrads(params, extra=3)
+        extra = 3 + num_ways * num_ways                 # [loss, correct, lamda | confusion counts] ride in the all-reduce
+        if self._flat is None or not self._flat.matches(params) or self._flat.tail.numel() != extra:
+            self._flat = FlatGrads(params, extra=extra)
         return self._flat
 
     def _encode_text(self, text):
@@ -112,14 +113,22 @@ class AM3(nn.Module):
         x_s, x_q, y_s, y_q = to(s_im).float(), to(q_im).float(), to(s_y), to(q_y)
         text = self._encode_text(to(s_text))
         need_grad = train and torch.is_grad_enabled()
-        fg = self._flat_grads() if need_grad else None
-        out = _engine.get_engine().am3_step(x_s, y_s, x_q, y_q, text, [p.detach() for p in self._w()], num_ways,
-                                            self.lamda_fixed, need_grad=need_grad, grad_scale=1.0 / B,
-                                            g_w=fg.views if need_grad else None, dropout_p=drop_p, seed=drop_seed)
-        tail = fg.tail if need_grad else torch.empty(3, device=x_s.device, dtype=torch.float32)
-        torch.stack([out["loss"].reshape(()), out["correct"].reshape(()) / (B * Qn),
-                     out["lamda_s"].sum() / (B * out["lamda_s"].shape[1])], out=tail)
+        fg = self._flat_grads(num_ways) if need_grad else None
+        eng = _engine.get_engine()
+        # train / val on the GPU: the step also leaves [loss, correct, mean lamda, confusion counts] in the buffer's tail, one
+        # all-reduce covers gradients and statistics, and accuracy / macro P / R / F1 come from one small kernel -- the reference
+        # moves the predictions to the host and calls sklearn every meta-batch (utils.py:319-326): a blocking copy per step
+        on_device = task != "test" and x_s.is_cuda and num_ways <= 64 and hasattr(eng, "am3_metrics")
+        tail = fg.tail if need_grad else torch.empty(3 + num_ways * num_ways, device=x_s.device, dtype=torch.float32)
+        out = eng.am3_step(x_s, y_s, x_q, y_q, text, [p.detach() for p in self._w()], num_ways,
+                           self.lamda_fixed, need_grad=need_grad, grad_scale=1.0 / B,
+                           g_w=fg.views if need_grad else None, dropout_p=drop_p, seed=drop_seed,
+                           **({"stats": tail} if on_device else {}))
+        if not on_device:
+            torch.stack([out["loss"].reshape(()), out["correct"].reshape(()) / (B * Qn),
+                         out["lamda_s"].sum() / (B * out["lamda_s"].shape[1])], out=tail[:3])
         fdist.all_reduce_sum_(fg.flat if need_grad else tail)
+        m6 = lazy.scalars(eng.am3_metrics(num_ways, tail), 6, defer=need_grad) if on_device else None
         if need_grad:
             optimizer.zero_grad()
             fg.attach()
@@ -131,13 +140,11 @@ class AM3(nn.Module):
             optimizer.step()
             if scheduler:
                 scheduler.step()
+            lazy.flush(x_s.device)
+        if on_device:
+            return m6
         preds = fdist.all_gather_rows(out["preds"])
         lam_s = fdist.all_gather_rows(out["lamda_s"])
-        if task != "test" and preds.is_cuda:
-            # train / val: accuracy and the macro metrics from a confusion matrix built on the device -- the reference moves the
-            # predictions to the host and calls sklearn every meta-batch (utils.py:319-326), a blocking copy per step
-            m6 = torch.cat([tail[:1], _macro_metrics_device(q_y.to(preds.device), preds, num_ways), tail[2:3]])
-            return lazy.scalars(m6, 6)
         stats = tail.detach().cpu().numpy()
         preds_np = preds.detach().cpu().numpy()
         targets_np = q_y.detach().cpu().numpy()
@@ -146,23 +153,6 @@ class AM3(nn.Module):
             return (stats[0], acc, f1, prec, rec, stats[2], preds_np, q_y.to(device), q_idx.detach().cpu().numpy(),
                     s_idx.detach().cpu().numpy(), lam_s.detach().cpu().numpy())
         return stats[0], acc, f1, prec, rec, stats[2]
-
-
-def _macro_metrics_device(targets, preds, n_way):
-    """[acc, f1, prec, rec] (fp32, on the device) = utils.macro_metrics on the host: macro averages over the labels that occur
-    in the targets or the predictions, 0 for an undefined ratio (sklearn's zero_division), from the N x N confusion counts."""
-    t, p = targets.reshape(-1), preds.reshape(-1).to(torch.int64)
-    ones = torch.ones(t.numel(), device=t.device, dtype=torch.float32)
-    C = torch.zeros(n_way * n_way, device=t.device, dtype=torch.float32).scatter_add_(0, t * n_way + p, ones).view(n_way, n_way)
-    tp, pp, tt = C.diagonal(), C.sum(0), C.sum(1)                 # integer-valued: exact in fp32 up to 2^24 samples
-    zero = torch.zeros_like(tp)
-    prec = torch.where(pp > 0, tp / pp.clamp(min=1), zero)
-    rec = torch.where(tt > 0, tp / tt.clamp(min=1), zero)
-    f1 = torch.where(prec + rec > 0, 2 * prec * rec / (prec + rec).clamp(min=1e-30), zero)
-    present = ((pp + tt) > 0).float()
-    nl = present.sum().clamp(min=1)
-    return torch.stack([tp.sum() / max(t.numel(), 1), (f1 * present).sum() / nl, (prec * present).sum() / nl,
-                        (rec * present).sum() / nl])
 
 
 def training_run(args, model, optimizer, train_loader, val_loader, max_test_batches):

@@ -123,14 +123,21 @@ int fumi_hip_maml_step(fumi_ws_t* ws, fumi_stream_t stream,
  * lamda_fixed: -1 = learned, 0 or 1 = fixed (am3.py:174-179).
  * dropout_p > 0: train-mode Dropout after the ReLU of g and of h (am3.py:82,88), counter-based masks from `seed`.
  * outputs: loss [1] (mean over B*Qn), preds_q [B,Qn] (first arg-min of the distances), lamda_s [B,S],
- *          correct [1] (number of correct query predictions, float); g_w (10 pointers) when need_grad. */
+ *          correct [1] (number of correct query predictions, float); g_w (10 pointers) when need_grad;
+ *          stats [3 + N*N] or NULL: [loss, correct count, grad_scale * sum_b mean_s lamda, confusion counts (rows = target
+ *          class, columns = predicted class)] -- with grad_scale = 1 / global meta-batch a sum over ranks gives the global
+ *          mean loss / lamda and the global counts, and fumi_hip_am3_metrics turns those into the reference's metrics. */
 int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
         int B, int N, int S, int Qn, int D, int Dt, int Ht, int P, int lamda_fixed, int need_grad, float grad_scale,
         float dropout_p, uint64_t seed,
         const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q, const float* text_s,
         const float* const* w,
         float* loss, int64_t* preds_q, float* lamda_s, float* correct,
-        float* const* g_w);
+        float* const* g_w, float* stats);
+/* out6 = [loss, accuracy, macro F1, macro precision, macro recall, mean lamda] from `stats` (fumi_hip_am3_step): what
+ * AM3.evaluate returns per meta-batch (am3.py:203-212 via sklearn on the host, utils.py:319-326), without leaving the device.
+ * N <= 64. */
+int fumi_hip_am3_metrics(fumi_ws_t* ws, fumi_stream_t stream, int N, const float* stats, float* out6);
 
 /* ---- finer-grained ops (unit parity tests; building blocks of the steps) --------------------------------------- */
 /* out[r,:] = mean (mode 0: sum / #non-PAD tokens) or max (mode 1: over ALL L positions) of table[tok[r,l],:]. */

@@ -292,18 +292,41 @@ def test_am3_eval_mode_matches_train_forward(dev, ws):
     assert abs(la - float(b["loss"])) < 1e-6 and torch.equal(pa, b["preds"])
 
 
-def test_am3_device_metrics_match_host_metrics(dev):
-    """AM3.evaluate (train / val) takes accuracy and macro precision / recall / F1 from a confusion matrix on the device; the
-    host form (what sklearn returns, utils.py:319-326) is the checker, including classes that never occur."""
-    from fumi_amd.models.am3 import _macro_metrics_device
+def test_am3_device_metrics_match_host_metrics(dev, ws):
+    """AM3.evaluate (train / val) takes accuracy and macro precision / recall / F1 from the confusion counts the step leaves on
+    the device (fumi_hip_am3_metrics); the host form (what sklearn returns, utils.py:319-326) is the checker, including classes
+    that never occur.  Then end to end: AM3.evaluate('train') on the GPU vs the host metrics of its own predictions."""
+    from fumi_amd import hip
     from fumi_amd.utils.utils import macro_metrics
     rs = np.random.RandomState(0)
-    for N, n in [(5, 800), (5, 7), (20, 300), (3, 50)]:
+    for N, n in [(5, 800), (5, 7), (20, 300), (3, 50), (64, 5000)]:
         t = rs.randint(0, N, size=n); p = rs.randint(0, N, size=n)
         if N == 20:
             p[p == 3] = 4; t[t == 7] = 8; p[p == 7] = 8                 # a class never predicted, a class absent everywhere
-        got = _macro_metrics_device(torch.from_numpy(t).to(dev), torch.from_numpy(p).to(dev), N).cpu().numpy()
-        np.testing.assert_allclose(got, np.array(macro_metrics(t, p)), rtol=2e-6, atol=1e-7)
+        conf = np.zeros((N, N), dtype=np.float32)
+        np.add.at(conf, (t, p), 1.0)
+        stats = torch.from_numpy(np.concatenate([[1.25, 0.0, 0.375], conf.ravel()]).astype(np.float32)).to(dev)
+        got = hip.am3_metrics(ws, N, stats).cpu().numpy()
+        np.testing.assert_allclose(got[1:5], np.array(macro_metrics(t, p)), rtol=3e-6, atol=1e-7)
+        assert got[0] == 1.25 and got[5] == 0.375
+    # end to end on a golden AM3 case
+    from fumi_amd.models.am3 import AM3
+    from fumi_amd.optim import Adam
+    name = "am3_default"
+    c = cg.AM3_CASES[name]
+    seed = case_seed(name)
+    ep = cg.make_episodes(seed, c["B"], c["N"], c["K"], c["Q"], c["D"], c["Dt"])
+    torch.manual_seed(3)
+    m = AM3(im_encoder="precomputed", im_emb_dim=c["D"], text_encoder="BERT", text_emb_dim=c["Dt"], text_hid_dim=c["Ht"],
+            prototype_dim=c["P"], dropout=0.0, fine_tune=False, dictionary=None, pooling_strat="mean",
+            lamda_fixed=c.get("lamda_fixed")).to(dev)
+    opt = Adam(m.parameters(), lr=1e-3)
+    batch = cg.to_batch(ep)
+    with torch.no_grad():
+        ref = m.evaluate(batch, None, None, c["N"], dev, "test")                      # host metrics of the same predictions
+    got = m.evaluate(batch, opt, None, c["N"], dev, "train")
+    assert len(got) == 6
+    np.testing.assert_allclose([float(x) for x in got], [float(x) for x in ref[:6]], rtol=2e-5, atol=1e-6)
 
 
 def test_fused_adam_matches_torch_adam(dev, ws):
