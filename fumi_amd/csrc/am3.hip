@@ -3,8 +3,10 @@
 // Replaces AM3.forward / AM3.evaluate (fumi/models/am3.py:90-126,160-200, dropout 0) and the head math of
 // fumi/utils/utils.py: get_num_samples :379-387, get_prototypes :331-376, prototypical_loss :390-402, get_preds :302-328.
 //
-// Shared-weight linears (image encoder on B*(S+Qn) rows, g / h text MLPs on B*S rows) and their backward run on the
-// GEMM family (gemm.hip).  The per-episode head is one fused kernel (am3_head_kernel, 1 workgroup / episode):
+// The image encoder (one shared Linear on all B*(S+Qn) rows) and its weight gradient run on the X-panel kernels of the FuMI
+// path (xpanel.hip: one pass over [Xs_b;Xq_b] forward, one backward, rows never copied); the g / h text MLPs on B*S rows and
+// their backward run on the GEMM family (gemm.hip), ReLU masks fused into the epilogues, every bias gradient in one batched
+// column-sum.  The per-episode head is one fused kernel (am3_head_kernel, 1 workgroup / episode):
 //   * per-class prototype sums as wavefront-level segmented reductions: one wave per class, lanes over the prototype
 //     dim, the class test is wave-uniform (no scatter atomics, unlike the reference's scatter_add_)
 //   * squared distances query x class with one wave per query row (lanes over P, shuffle reduction), softmax-CE over
@@ -31,14 +33,14 @@ __global__ __launch_bounds__(256) void am3_head_generic_kernel(int N, int S, int
                                                        float* __restrict__ lam_b, float lscale,
                                                        float* __restrict__ im_s_bar, float* __restrict__ tx_bar,
                                                        float* __restrict__ zl_bar, float* __restrict__ im_q_bar,
-                                                       int* status) {
+                                                       long im_stride, const float* __restrict__ im_bias, int* status) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int NP = N * P;
     float* ip = sm; float* tp = ip + NP; float* pr = tp + NP; float* pb = pr + NP;
     float* lamc = pb + nw * NP; float* cnt = lamc + N; float* lbar = cnt + N; float* wl = lbar + N; float* wc = wl + nw;
-    im_s += (long)b * S * P; tx += (long)b * S * P; lam_s += (long)b * S; y_s += (long)b * S;
-    im_q += (long)b * Qn * P; y_q += (long)b * Qn; preds += (long)b * Qn;
+    im_s += (long)b * im_stride; tx += (long)b * S * P; lam_s += (long)b * S; y_s += (long)b * S;
+    im_q += (long)b * im_stride; y_q += (long)b * Qn; preds += (long)b * Qn;      // (im_bias: added by the caller for this kernel)
 
     if (lamda_fixed >= 0) for (int s = tid; s < S; s += blockDim.x) lam_s[s] = (float)lamda_fixed;   // am3.py:174-177
     __syncthreads();
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void am3_head_generic_kernel(int N, int S, int
                         mypb[c * P + j] += db * df2;
                     }
                 }
-                if (j < P) im_q_bar[((long)b * Qn + q) * P + j] = xb;
+                if (j < P) im_q_bar[(long)b * im_stride + (long)q * P + j] = xb;
             }
         }
     }
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void am3_head_generic_kernel(int N, int S, int
         if (lane == 0) lbar[c] = v;
     }
     __syncthreads();
-    im_s_bar += (long)b * S * P; tx_bar += (long)b * S * P; zl_bar += (long)b * S;
+    im_s_bar += (long)b * im_stride; tx_bar += (long)b * S * P; zl_bar += (long)b * S;
     for (int i = tid; i < S * P; i += blockDim.x) {
         const int s = i / P, j = i % P;
         long c = y_s[s];
@@ -156,6 +158,10 @@ __global__ __launch_bounds__(256) void am3_head_generic_kernel(int N, int S, int
     }
 }
 
+
+__global__ void am3_bias_rows_kernel(float* __restrict__ x, const float* __restrict__ bias, long n, int P) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] += bias[i % P];
+}
 
 // ---- the same head for N <= 64 classes and P <= 512 (every configuration of the reference): no global load inside a loop.
 // Labels, support embeddings and text embeddings of the episode are staged in LDS once; a query row is loaded once into
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(512) void am3_head_kernel(int N, int S, int Qn, int
                                                        float* __restrict__ lam_b, float lscale,
                                                        float* __restrict__ im_s_bar, float* __restrict__ tx_bar,
                                                        float* __restrict__ zl_bar, float* __restrict__ im_q_bar,
-                                                       int* status) {
+                                                       long im_stride, const float* __restrict__ im_bias, int* status) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nt = blockDim.x, nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -187,11 +193,11 @@ __global__ __launch_bounds__(512) void am3_head_kernel(int N, int S, int Qn, int
     float* ims = pb + nw * NP; float* txs = ims + SP;
     float* lamc = txs + SP; float* cnt = lamc + N; float* lbar = cnt + N; float* wl = lbar + N; float* wc = wl + nw;
     int* ys = (int*)(wc + nw); float* lam = (float*)(ys + S);
-    im_s += (long)b * SP; tx += (long)b * SP; lam_s += (long)b * S; y_s += (long)b * S;
-    im_q += (long)b * Qn * P; y_q += (long)b * Qn; preds += (long)b * Qn;
+    im_s += (long)b * im_stride; tx += (long)b * SP; lam_s += (long)b * S; y_s += (long)b * S;
+    im_q += (long)b * im_stride; y_q += (long)b * Qn; preds += (long)b * Qn;
 
-    // ---- stage the episode's support side (coalesced, all loads independent)
-    for (int i = tid; i < SP; i += nt) { ims[i] = im_s[i]; txs[i] = tx[i]; }
+    // ---- stage the episode's support side (coalesced, all loads independent); the encoder's bias is added here
+    for (int i = tid; i < SP; i += nt) { ims[i] = im_s[i] + im_bias[i % P]; txs[i] = tx[i]; }
     for (int s_ = tid; s_ < S; s_ += nt) {
         long y = y_s[s_];
         if (y < 0 || y >= N) { atomicOr(status, FUMI_ST_LABEL_RANGE); y = -1; }
@@ -222,14 +228,16 @@ __global__ __launch_bounds__(512) void am3_head_kernel(int N, int S, int Qn, int
     float lsum = 0.f, csum = 0.f;
     float* mypb = pb + wave * NP;
     const int npj = (P + 63) >> 6;
-    float xn[HPJ];
+    float xn[HPJ], bq[HPJ];
+#pragma unroll
+    for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; bq[k] = (k < npj && j < P) ? im_bias[j] : 0.f; }
 #pragma unroll
     for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; xn[k] = (k < npj && j < P && wave < Qn) ? im_q[(long)wave * P + j] : 0.f; }
     long yn = wave < Qn ? y_q[wave] : 0;
     for (int q = wave; q < Qn; q += nw) {
         float x[HPJ];
 #pragma unroll
-        for (int k = 0; k < HPJ; ++k) x[k] = xn[k];
+        for (int k = 0; k < HPJ; ++k) x[k] = xn[k] + bq[k];
         long yq = yn;
         const int qn = q + nw;                                                  // prefetch the wave's next row
 #pragma unroll
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(512) void am3_head_kernel(int N, int S, int Qn, int
                 }
             }
 #pragma unroll
-            for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; if (k < npj && j < P) im_q_bar[((long)b * Qn + q) * P + j] = xb[k]; }
+            for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; if (k < npj && j < P) im_q_bar[(long)b * im_stride + (long)q * P + j] = xb[k]; }
         }
     }
     if (lane == 0) { wl[wave] = lsum; wc[wave] = csum; }
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(512) void am3_head_kernel(int N, int S, int Qn, int
         if (lane == 0) lbar[c] = v;
     }
     __syncthreads();
-    im_s_bar += (long)b * SP; tx_bar += (long)b * SP; zl_bar += (long)b * S;
+    im_s_bar += (long)b * im_stride; tx_bar += (long)b * SP; zl_bar += (long)b * S;
     for (int i = tid; i < SP; i += nt) {
         const int s_ = i / P, j = i - s_ * P;
         const int c = ys[s_];
@@ -354,18 +362,19 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     if (!fast_head) nwaves = 4;
     const size_t lds = fast_head ? fast_lds(nwaves) : ((size_t)(3 + nwaves) * N * P + 3 * N + 2 * nwaves) * sizeof(float);
     if (lds > 160 * 1024) return FUMI_ENOTSUP;
-    const int KCH = 1024;
-    const int ns = (int)((Rs + KCH - 1) / KCH), nq = (int)((Rq + KCH - 1) / KCH);
+    int xkc = 0;
+    const int xns = xpanel_bwd_nsplit(B, S, Qn, D, P, &xkc);          // contraction slabs of gWi = sum_b imbar_b^T [Xs_b;Xq_b]
 
     size_t bytes = 0;
     auto A = [&](size_t n) { bytes += ws_align(n * sizeof(float)); };
-    A((Rs + Rq) * P); A(Rs * Ht); A(Rs * P); A(Rs * Ht); A(2 * B); A((size_t)B * N * N + B);
+    A((Rs + Rq) * P); A((size_t)(Rs + Rq) * S); A(Rs * Ht); A(Rs * P); A(Rs * Ht); A(2 * B); A((size_t)B * N * N + B);
     const size_t cpart_n = (size_t)((Rs + 127) / 128) * (size_t)(2 * ((Ht + 3) & ~3) + ((P + 3) & ~3) + 4)
                          + (size_t)((Rs + Rq + 127) / 128) * (size_t)((P + 3) & ~3) + 64;       // ColsumJobs partial sums
-    if (need_grad) { A((Rs + Rq) * P); A(Rs * P); A(Rs); A(Rs * Ht); A(Rs * Ht); A((size_t)(ns + nq) * P * D); A(cpart_n); }
+    if (need_grad) { A((Rs + Rq) * P); A(Rs * P); A(Rs); A(Rs * Ht); A(Rs * Ht); A((size_t)xns * P * D); A(cpart_n); }
     int rc = ws_reserve(ws, bytes);
     if (rc) return rc;
-    float* im = ws_f(ws, (Rs + Rq) * P);          // [support rows | query rows]
+    float* im = ws_f(ws, (Rs + Rq) * P);          // image embeddings, [B, S+Qn, P]: an episode's support rows, then its query rows
+    float* gram = ws_f(ws, (size_t)(Rs + Rq) * S);
     float* t1 = ws_f(ws, Rs * Ht);
     float* tx = ws_f(ws, Rs * P);
     float* l1 = ws_f(ws, Rs * Ht);
@@ -374,18 +383,15 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     float* lamb = confb + (size_t)B * N * N;
     if (!stats) { confb = nullptr; lamb = nullptr; }
     else HIP_TRY(hipMemsetAsync(confb, 0, (size_t)B * N * N * sizeof(float), st));
-    float* imq = im + Rs * P;
+    const long imst = (long)(S + Qn) * P;         // episode stride of the panel
+    float* imq = im + (long)S * P;
 
     GemmArgs g;
     {
-        ProfScope ps(ws, st, FUMI_PH_GEMM_A0S);
-        g = gemm_args((int)Rs, P, D, x_s, D, Wi, D, im, P); g.bias = bi;
-        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
-    }
-    {
-        ProfScope ps(ws, st, FUMI_PH_GEMM_A0Q);
-        g = gemm_args((int)Rq, P, D, x_q, D, Wi, D, imq, P); g.bias = bi;
-        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+        // image encoder on every support and query row in ONE pass of the X-panel kernel (xpanel.hip: the panel [Xs_b;Xq_b]
+        // times Wi^T per episode, rows never copied); its Gram block is not used here.  The bias is added where the head reads.
+        ProfScope ps(ws, st, FUMI_PH_XPANEL_FWD);
+        if ((rc = launch_xpanel_fwd(st, B, S, Qn, D, P, x_s, x_q, Wi, im, gram))) return rc;
     }
     {
         ProfScope ps(ws, st, FUMI_PH_HYPER_FWD);
@@ -406,7 +412,7 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     if (need_grad) {
         cpart = nullptr;
         imb = ws_f(ws, (Rs + Rq) * P); txb = ws_f(ws, Rs * P); zlb = ws_f(ws, Rs);
-        l1b = ws_f(ws, Rs * Ht); t1b = ws_f(ws, Rs * Ht); slabs = ws_f(ws, (size_t)(ns + nq) * P * D);
+        l1b = ws_f(ws, Rs * Ht); t1b = ws_f(ws, Rs * Ht); slabs = ws_f(ws, (size_t)xns * P * D);
         cpart = ws_f(ws, cpart_n);
     }
     {
@@ -416,12 +422,13 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
             FUMI_SET_DYN_LDS(am3_head_kernel, lds);
             hipLaunchKernelGGL(am3_head_kernel, dim3(B), dim3(64 * nwaves), lds, st, N, S, Qn, P, lamda_fixed, need_grad ? 1 : 0,
                                dscale, im, tx, lamda_s, y_s, imq, y_q, preds_q, lc, lc + B, confb, lamb, grad_scale / (float)S,
-                               imb, txb, zlb, imb ? imb + Rs * P : nullptr, ws->status);
+                               imb, txb, zlb, imb ? imb + (long)S * P : nullptr, imst, bi, ws->status);
         } else {
+            hipLaunchKernelGGL(am3_bias_rows_kernel, dim3(256), dim3(256), 0, st, im, bi, (long)(Rs + Rq) * P, P);
             FUMI_SET_DYN_LDS(am3_head_generic_kernel, lds);
             hipLaunchKernelGGL(am3_head_generic_kernel, dim3(B), dim3(64 * nwaves), lds, st, N, S, Qn, P, lamda_fixed,
                                need_grad ? 1 : 0, dscale, im, tx, lamda_s, y_s, imq, y_q, preds_q, lc, lc + B, confb, lamb,
-                               grad_scale / (float)S, imb, txb, zlb, imb ? imb + Rs * P : nullptr, ws->status);
+                               grad_scale / (float)S, imb, txb, zlb, imb ? imb + (long)S * P : nullptr, imst, bi, ws->status);
         }
         LAUNCH_CHECK();
         ReduceSegs fin; fin.n = 0; fin.scale = 1.f;              // per-episode loss / correct counts -> scalars, one launch
@@ -470,16 +477,11 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     {
         ProfScope pg(ws, st, FUMI_PH_XPANEL_BWD);
         const long slab = (long)P * D;
-        g = gemm_args(P, D, (int)Rs, imb, P, x_s, D, slabs, D);
-        g.kchunk = KCH; g.nsplit = ns; g.sCsplit = slab;
-        if ((rc = launch_gemm(st, g, 1, 1))) return rc;
-        g = gemm_args(P, D, (int)Rq, imb + Rs * P, P, x_q, D, slabs + (long)ns * slab, D);
-        g.kchunk = KCH; g.nsplit = nq; g.sCsplit = slab;
-        if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+        if ((rc = launch_xpanel_bwd(st, B, S, Qn, D, P, x_s, x_q, imb, slabs, xkc, xns))) return rc;
         cj.add(imb, (int)(Rs + Rq), P, P, g_w[1]);
         // every bias gradient (column sums over all rows) and the image-encoder weight slabs: two launches in all
         ReduceSegs tail_; tail_.n = 0; tail_.scale = 1.f;
-        tail_.add(slabs, ns + nq, slab, slab, g_w[0]);
+        tail_.add(slabs, xns, slab, slab, g_w[0]);
         if ((rc = launch_colsum_multi(st, cj, cpart, &tail_))) return rc;
     }
     return FUMI_OK;
