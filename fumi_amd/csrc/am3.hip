@@ -244,14 +244,24 @@ __global__ __launch_bounds__(512) void am3_head_kernel(int N, int S, int Qn, int
         for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; xn[k] = (k < npj && j < P && qn < Qn) ? im_q[(long)qn * P + j] : 0.f; }
         yn = qn < Qn ? y_q[qn] : 0;
         if (yq < 0 || yq >= N) { if (lane == 0) atomicOr(status, FUMI_ST_LABEL_RANGE); yq = 0; }
-        // lane c keeps d_c = |proto_c - x|^2
+        // lane c keeps d_c = |proto_c - x|^2; eight classes are reduced together (their butterflies interleave: one
+        // dependent shuffle chain per class would cost ~600 cycles each)
         float myd = INFINITY;
-        for (int c = 0; c < N; ++c) {
-            float v = 0.f;
+        for (int c0 = 0; c0 < N; c0 += 8) {
+            float v[8];
 #pragma unroll
-            for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; if (k < npj && j < P) { const float df = pr[c * P + j] - x[k]; v += df * df; } }
-            v = wave_sum(v);
-            if (lane == c) myd = v;
+            for (int u = 0; u < 8; ++u) {
+                v[u] = 0.f;
+                const int c = min(c0 + u, N - 1);
+#pragma unroll
+                for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; if (k < npj && j < P) { const float df = pr[c * P + j] - x[k]; v[u] += df * df; } }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] += __shfl_xor(v[u], o, 64);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (c0 + u < N && lane == c0 + u) myd = v[u];
         }
         const float dmin = -wave_max(-myd);                                      // lanes >= N hold +inf
         const unsigned long long at = __ballot(lane < N && myd == dmin);
@@ -271,15 +281,24 @@ __global__ __launch_bounds__(512) void am3_head_kernel(int N, int S, int Qn, int
             float xb[HPJ];
 #pragma unroll
             for (int k = 0; k < HPJ; ++k) xb[k] = 0.f;
-            for (int c = 0; c < N; ++c) {
-                const float db = __shfl(mydb, c, 64);
+            for (int c0 = 0; c0 < N; c0 += 8) {
+                float dbv[8];
 #pragma unroll
-                for (int k = 0; k < HPJ; ++k) {
-                    const int j = k * 64 + lane;
-                    if (k < npj && j < P) {
-                        const float df2 = 2.f * (pr[c * P + j] - x[k]);
-                        xb[k] -= db * df2;
-                        mypb[c * P + j] += db * df2;
+                for (int u = 0; u < 8; ++u) dbv[u] = __shfl(mydb, min(c0 + u, N - 1), 64);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + u;
+                    if (c < N) {
+                        const float db = dbv[u];
+#pragma unroll
+                        for (int k = 0; k < HPJ; ++k) {
+                            const int j = k * 64 + lane;
+                            if (k < npj && j < P) {
+                                const float df2 = 2.f * (pr[c * P + j] - x[k]);
+                                xb[k] -= db * df2;
+                                mypb[c * P + j] += db * df2;
+                            }
+                        }
                     }
                 }
             }
@@ -367,14 +386,14 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
 
     size_t bytes = 0;
     auto A = [&](size_t n) { bytes += ws_align(n * sizeof(float)); };
-    A((Rs + Rq) * P); A((size_t)(Rs + Rq) * S); A(Rs * Ht); A(Rs * P); A(Rs * Ht); A(2 * B); A((size_t)B * N * N + B);
+    A((Rs + Rq) * P); A(Rs * Ht); A(Rs * P); A(Rs * Ht); A(2 * B); A((size_t)B * N * N + B);
+    const size_t wslab_n = (size_t)((Rs + 127) / 128) * ((size_t)Ht + 2 * (size_t)Ht * P + (size_t)Ht * Dt) + 64;   // text weight-gradient slabs
     const size_t cpart_n = (size_t)((Rs + 127) / 128) * (size_t)(2 * ((Ht + 3) & ~3) + ((P + 3) & ~3) + 4)
                          + (size_t)((Rs + Rq + 127) / 128) * (size_t)((P + 3) & ~3) + 64;       // ColsumJobs partial sums
-    if (need_grad) { A((Rs + Rq) * P); A(Rs * P); A(Rs); A(Rs * Ht); A(Rs * Ht); A((size_t)xns * P * D); A(cpart_n); }
+    if (need_grad) { A((Rs + Rq) * P); A(Rs * P); A(Rs); A(Rs * Ht); A(Rs * Ht); A((size_t)xns * P * D); A(cpart_n); A(wslab_n); }
     int rc = ws_reserve(ws, bytes);
     if (rc) return rc;
     float* im = ws_f(ws, (Rs + Rq) * P);          // image embeddings, [B, S+Qn, P]: an episode's support rows, then its query rows
-    float* gram = ws_f(ws, (size_t)(Rs + Rq) * S);
     float* t1 = ws_f(ws, Rs * Ht);
     float* tx = ws_f(ws, Rs * P);
     float* l1 = ws_f(ws, Rs * Ht);
@@ -389,9 +408,9 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     GemmArgs g;
     {
         // image encoder on every support and query row in ONE pass of the X-panel kernel (xpanel.hip: the panel [Xs_b;Xq_b]
-        // times Wi^T per episode, rows never copied); its Gram block is not used here.  The bias is added where the head reads.
+        // times Wi^T per episode, rows never copied; G = NULL: no Gram block).  The bias is added where the head reads.
         ProfScope ps(ws, st, FUMI_PH_XPANEL_FWD);
-        if ((rc = launch_xpanel_fwd(st, B, S, Qn, D, P, x_s, x_q, Wi, im, gram))) return rc;
+        if ((rc = launch_xpanel_fwd(st, B, S, Qn, D, P, x_s, x_q, Wi, im, nullptr))) return rc;
     }
     {
         ProfScope ps(ws, st, FUMI_PH_HYPER_FWD);
@@ -408,12 +427,13 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
             if ((rc = launch_gemm(st, g, 0, 0))) return rc;
         }
     }
-    float *imb = nullptr, *txb = nullptr, *zlb = nullptr, *l1b = nullptr, *t1b = nullptr, *slabs = nullptr, *cpart = nullptr;
+    float *imb = nullptr, *txb = nullptr, *zlb = nullptr, *l1b = nullptr, *t1b = nullptr, *slabs = nullptr, *cpart = nullptr, *wslabs = nullptr;
     if (need_grad) {
         cpart = nullptr;
         imb = ws_f(ws, (Rs + Rq) * P); txb = ws_f(ws, Rs * P); zlb = ws_f(ws, Rs);
         l1b = ws_f(ws, Rs * Ht); t1b = ws_f(ws, Rs * Ht); slabs = ws_f(ws, (size_t)xns * P * D);
         cpart = ws_f(ws, cpart_n);
+        wslabs = ws_f(ws, wslab_n);
     }
     {
         ProfScope ps(ws, st, FUMI_PH_AM3);
@@ -446,16 +466,28 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
 
     ProfScope pb(ws, st, FUMI_PH_HYPER_BWD);
     ColsumJobs cj; cj.n = 0; cj.part_total = 0;
+    // weight gradients of the text MLPs contract over all B*S rows with only a few output tiles: the contraction is cut into
+    // 128-row slabs (one workgroup each) that the step's final reduction sums together with everything else
+    ReduceSegs tail_; tail_.n = 0; tail_.scale = 1.f;
+    const int WKC = 128, wns = (int)((Rs + WKC - 1) / WKC);
+    float* wslab_next = wslabs;
+    auto wgrad = [&](int M_, int N_, const float* A_, long lda_, const float* B_, long ldb_, float* out) -> int {
+        GemmArgs q = gemm_args(M_, N_, (int)Rs, A_, lda_, B_, ldb_, wslab_next, N_);
+        q.kchunk = WKC; q.nsplit = wns; q.sCsplit = (long)M_ * N_;
+        int r_ = launch_gemm(st, q, 1, 1);
+        if (r_) return r_;
+        tail_.add(wslab_next, wns, (long)M_ * N_, (long)M_ * N_, out);
+        wslab_next += (size_t)wns * M_ * N_;
+        return FUMI_OK;
+    };
     if (lamda_fixed < 0) {
         // h network: lam = sigmoid(l1 H1^T + h1), l1 = relu(tx H0^T + h0)
-        g = gemm_args(1, Ht, (int)Rs, zlb, 1, l1, Ht, g_w[8], Ht);                     // gH1 = zlbar^T l1
-        if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+        if ((rc = wgrad(1, Ht, zlb, 1, l1, Ht, g_w[8]))) return rc;                    // gH1 = zlbar^T l1
         cj.add(zlb, (int)Rs, 1, 1, g_w[9]);
         g = gemm_args((int)Rs, Ht, 1, zlb, 1, H1, Ht, l1b, Ht);                        // l1bar = (zlbar H1) * relu'(l1) * dropout scale
         g.mask = l1; g.alpha = dsc;
         if ((rc = launch_gemm(st, g, 0, 1))) return rc;
-        g = gemm_args(Ht, P, (int)Rs, l1b, Ht, tx, P, g_w[6], P);                      // gH0 = l1bar^T tx
-        if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+        if ((rc = wgrad(Ht, P, l1b, Ht, tx, P, g_w[6]))) return rc;                    // gH0 = l1bar^T tx
         cj.add(l1b, (int)Rs, Ht, Ht, g_w[7]);
         g = gemm_args((int)Rs, P, Ht, l1b, Ht, H0, P, txb, P); g.accumulate = 1;       // txbar += l1bar H0
         if ((rc = launch_gemm(st, g, 0, 1))) return rc;
@@ -464,14 +496,12 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
         HIP_TRY(hipMemsetAsync(g_w[8], 0, (size_t)Ht * 4, st)); HIP_TRY(hipMemsetAsync(g_w[9], 0, 4, st));
     }
     // g network: tx = t1 G1^T + g1, t1 = relu(text G0^T + g0)
-    g = gemm_args(P, Ht, (int)Rs, txb, P, t1, Ht, g_w[4], Ht);                         // gG1 = txbar^T t1
-    if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+    if ((rc = wgrad(P, Ht, txb, P, t1, Ht, g_w[4]))) return rc;                        // gG1 = txbar^T t1
     cj.add(txb, (int)Rs, P, P, g_w[5]);
     g = gemm_args((int)Rs, Ht, P, txb, P, G1, Ht, t1b, Ht);                            // t1bar = (txbar G1) * relu'(t1) * dropout scale
     g.mask = t1; g.alpha = dsc;
     if ((rc = launch_gemm(st, g, 0, 1))) return rc;
-    g = gemm_args(Ht, Dt, (int)Rs, t1b, Ht, text_s, Dt, g_w[2], Dt);                   // gG0 = t1bar^T text
-    if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+    if ((rc = wgrad(Ht, Dt, t1b, Ht, text_s, Dt, g_w[2]))) return rc;                  // gG0 = t1bar^T text
     cj.add(t1b, (int)Rs, Ht, Ht, g_w[3]);
     // image encoder: gWi = imbar_s^T Xs + imbar_q^T Xq (split over the contraction), gbi = colsum(imbar)
     {
@@ -480,7 +510,6 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
         if ((rc = launch_xpanel_bwd(st, B, S, Qn, D, P, x_s, x_q, imb, slabs, xkc, xns))) return rc;
         cj.add(imb, (int)(Rs + Rq), P, P, g_w[1]);
         // every bias gradient (column sums over all rows) and the image-encoder weight slabs: two launches in all
-        ReduceSegs tail_; tail_.n = 0; tail_.scale = 1.f;
         tail_.add(slabs, xns, slab, slab, g_w[0]);
         if ((rc = launch_colsum_multi(st, cj, cpart, &tail_))) return rc;
     }

@@ -30,6 +30,7 @@ struct XPanel {
     // zero-copy episodes (sampler.hip): when `table` is set, row r of episode b is table[idx_s[b,r]] / table[idx_q[b,r-S]]
     // instead of x_s[b,r] / x_q[b,r-S] -- the meta-batch is never materialised
     const float* table; const int64_t* idx_s; const int64_t* idx_q; long n_rows;
+    int gcols;              // Gram columns computed: S (FuMI / MAML), or 0 when the caller passed G = NULL (AM3's image encoder)
 };
 
 __device__ __forceinline__ const float* xrow(const XPanel& p, int b, int r) {
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void xpanel_fwd_generic_kernel(XPanel p, float
     __shared__ __attribute__((aligned(16))) float lds[2][2][TILE_F];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int R = p.S + p.Qn, C = p.h0 + p.S, K = p.D;
+    const int R = p.S + p.Qn, C = p.h0 + p.gcols, K = p.D;
     // id -> (episode, tile) with id % 8 == episode % 8
     const int tiles = tiles_m * tiles_n;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void xpanel_fwd_kernel(XPanel p, float* __rest
     if (trace) { t_rt = __builtin_amdgcn_s_memrealtime(); t_ck = __builtin_amdgcn_s_memtime(); }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int R = p.S + p.Qn, C = p.h0 + p.S, K = p.D;
+    const int R = p.S + p.Qn, C = p.h0 + p.gcols, K = p.D;
     const int tiles = tiles_m * tiles_n;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int b = xcd + 8 * (j / tiles), t = j % tiles;
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* 
     __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][3][SPLANE];      // [buffer][operand][piece]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int R = p.S + p.Qn, C = p.h0 + p.S, K = p.D;
+    const int R = p.S + p.Qn, C = p.h0 + p.gcols, K = p.D;
     const int tiles = tiles_m * tiles_n;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int b = xcd + 8 * (j / tiles), t = j % tiles;
@@ -656,9 +657,9 @@ extern "C" void fumi_dbg_set_trace(void* p) { g_trace = (unsigned long long*)p; 
 
 int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
                       const float* W0, float* A0, float* G, const XRows* rows) {
-    XPanel p{x_s, x_q, W0, B, S, Qn, D, h0, nullptr, nullptr, nullptr, 0};
+    XPanel p{x_s, x_q, W0, B, S, Qn, D, h0, nullptr, nullptr, nullptr, 0, G ? S : 0};
     if (rows && rows->table) { p.table = rows->table; p.idx_s = rows->idx_s; p.idx_q = rows->idx_q; p.n_rows = rows->n_rows; p.x_s = p.x_q = rows->table; }
-    const int tiles_m = (S + Qn + 63) / 64, tiles_n = (h0 + S + 63) / 64;
+    const int tiles_m = (S + Qn + 63) / 64, tiles_n = (h0 + p.gcols + 63) / 64;
     const int nper = (B + 7) / 8;
     const bool aligned = al16(p.x_s) && al16(p.x_q) && al16(W0);
     const dim3 grid(8 * nper * tiles_m * tiles_n);
@@ -703,7 +704,7 @@ int xpanel_bwd_nsplit(int B, int S, int Qn, int D, int h0, int* kchunk_out) {
 
 int launch_xpanel_bwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
                       const float* Abar, float* slabs, int kchunk, int nsplit, const XRows* rows) {
-    XPanel p{x_s, x_q, nullptr, B, S, Qn, D, h0, nullptr, nullptr, nullptr, 0};
+    XPanel p{x_s, x_q, nullptr, B, S, Qn, D, h0, nullptr, nullptr, nullptr, 0, S};
     if (rows && rows->table) { p.table = rows->table; p.idx_s = rows->idx_s; p.idx_q = rows->idx_q; p.n_rows = rows->n_rows; p.x_s = p.x_q = rows->table; }
     const bool fast = (D % 64 == 0) && (h0 % 64 == 0) && al16(p.x_s) && al16(p.x_q) && al16(Abar);
     if (fast && xpanel_bwd_wide(D, h0)) {
