@@ -174,7 +174,7 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
-__global__ __launch_bounds__(512) void am3_head_kernel(int N, int S, int Qn, int P, int lamda_fixed, int need_grad,
+__global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, int P, int lamda_fixed, int need_grad,
                                                        float dscale,
                                                        const float* __restrict__ im_s, const float* __restrict__ tx,
                                                        float* __restrict__ lam_s, const int64_t* __restrict__ y_s,
@@ -196,8 +196,22 @@ __global__ __launch_bounds__(512) void am3_head_kernel(int N, int S, int Qn, int
     im_s += (long)b * im_stride; tx += (long)b * SP; lam_s += (long)b * S; y_s += (long)b * S;
     im_q += (long)b * im_stride; y_q += (long)b * Qn; preds += (long)b * Qn;
 
-    // ---- stage the episode's support side (coalesced, all loads independent); the encoder's bias is added here
-    for (int i = tid; i < SP; i += nt) { ims[i] = im_s[i] + im_bias[i % P]; txs[i] = tx[i]; }
+    // ---- stage the episode's support side: every load of the prologue (support + text embeddings, labels, lamda, the
+    // wave's first query row) is issued before the first one is used
+    const int npj = (P + 63) >> 6;
+    float xn[HPJ], bq[HPJ];
+#pragma unroll
+    for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; bq[k] = (k < npj && j < P) ? im_bias[j] : 0.f; }
+#pragma unroll
+    for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; xn[k] = (k < npj && j < P && wave < Qn) ? im_q[(long)wave * P + j] : 0.f; }
+    long yn = wave < Qn ? y_q[wave] : 0;
+    for (int i0 = tid; i0 < SP; i0 += 4 * nt) {
+        float a[4], t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * nt, SP - 1); a[u] = im_s[i] + im_bias[i % P]; t[u] = tx[i]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * nt; if (i < SP) { ims[i] = a[u]; txs[i] = t[u]; } }
+    }
     for (int s_ = tid; s_ < S; s_ += nt) {
         long y = y_s[s_];
         if (y < 0 || y >= N) { atomicOr(status, FUMI_ST_LABEL_RANGE); y = -1; }
@@ -208,14 +222,16 @@ __global__ __launch_bounds__(512) void am3_head_kernel(int N, int S, int Qn, int
     }
     for (int i = tid; i < nw * NP; i += nt) pb[i] = 0.f;
     __syncthreads();
-    // ---- prototypes: wave per class, lanes over P; count clamped to >= 1 (utils.py:353-355)
+    // ---- prototypes: wave per class, lanes over P; count clamped to >= 1 (utils.py:353-355).  Membership is a weight, not a
+    // branch: the LDS reads of all S rows are independent of each other
     for (int c = wave; c < N; c += nw) {
         float n = 0.f, ls = 0.f;
-        for (int s_ = 0; s_ < S; ++s_) if (ys[s_] == c) { n += 1.f; ls += lam[s_]; }
+        for (int s_ = 0; s_ < S; ++s_) { const float m_ = ys[s_] == c ? 1.f : 0.f; n += m_; ls += m_ * lam[s_]; }
         const float nn = fmaxf(n, 1.f), lc = ls / nn;
         for (int j = lane; j < P; j += 64) {
             float si = 0.f, st = 0.f;
-            for (int s_ = 0; s_ < S; ++s_) if (ys[s_] == c) { si += ims[s_ * P + j]; st += txs[s_ * P + j]; }
+#pragma unroll 5
+            for (int s_ = 0; s_ < S; ++s_) { const float m_ = ys[s_] == c ? 1.f : 0.f; si += m_ * ims[s_ * P + j]; st += m_ * txs[s_ * P + j]; }
             si /= nn; st /= nn;
             ip[c * P + j] = si; tp[c * P + j] = st;
             pr[c * P + j] = lc * si + (1.f - lc) * st;
@@ -227,13 +243,6 @@ __global__ __launch_bounds__(512) void am3_head_kernel(int N, int S, int Qn, int
     // ---- queries: wave per row
     float lsum = 0.f, csum = 0.f;
     float* mypb = pb + wave * NP;
-    const int npj = (P + 63) >> 6;
-    float xn[HPJ], bq[HPJ];
-#pragma unroll
-    for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; bq[k] = (k < npj && j < P) ? im_bias[j] : 0.f; }
-#pragma unroll
-    for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; xn[k] = (k < npj && j < P && wave < Qn) ? im_q[(long)wave * P + j] : 0.f; }
-    long yn = wave < Qn ? y_q[wave] : 0;
     for (int q = wave; q < Qn; q += nw) {
         float x[HPJ];
 #pragma unroll
@@ -371,10 +380,11 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     const float *Wi = w[0], *bi = w[1], *G0 = w[2], *g0 = w[3], *G1 = w[4], *g1 = w[5], *H0 = w[6], *h0 = w[7], *H1 = w[8], *h1 = w[9];
     const long Rs = (long)B * S, Rq = (long)B * Qn;
     // fast head: N <= 64 classes, P <= 512, and the episode's support side fits LDS next to the per-wave adjoint slabs
-    int nwaves = 8;
+    int nwaves = 16;
     auto fast_lds = [&](int nw_) { return ((size_t)(3 + nw_) * N * P + 2 * (size_t)S * P + 3 * N + 2 * nw_ + 2 * S + 16) * sizeof(float); };
     bool fast_head = N <= 64 && P <= 64 * HPJ;
-    if (fast_head && fast_lds(8) > 150 * 1024) nwaves = 4;
+    if (fast_head && fast_lds(16) > 150 * 1024) nwaves = 8;
+    if (fast_head && fast_lds(nwaves) > 150 * 1024) nwaves = 4;
     if (fast_head && fast_lds(nwaves) > 150 * 1024) fast_head = false;
     static const int head_generic = getenv("FUMI_AM3_GENERIC") ? atoi(getenv("FUMI_AM3_GENERIC")) : 0;
     if (head_generic) fast_head = false;

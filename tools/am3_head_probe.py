@@ -1,0 +1,17 @@
+import sys, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+from fumi_amd import hip
+from oracle import casegen as cg
+dev = torch.device("cuda:0"); ws = hip.Workspace.get(dev)
+B, N, K, Q, D, Dt, Ht, P = 32, 5, 5, 32, 2048, 768, 256, 64
+ep = cg.make_episodes(1, B, N, K, Q, D, Dt)
+w = cg.make_am3_params(1, D, Dt, Ht, P)
+wl = [w[k].to(dev) for k in hip.AM3_KEYS]
+g = lambda t: t.to(dev).contiguous()
+args = (ws, g(ep["x_s"]), g(ep["y_s"]), g(ep["x_q"]), g(ep["y_q"]), g(ep["text_s"]), wl, N, None)
+stats = torch.zeros(3 + N * N, device=dev)
+for ng, st in ((False, None), (True, None), (True, stats)):
+    for _ in range(30):
+        hip.am3_step(*args, need_grad=ng, stats=st)
+    torch.cuda.synchronize()
