@@ -65,13 +65,15 @@ int fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out) {
     if (device < 0 || device >= ndev) return FUMI_EINVAL;
     HIP_TRY(hipSetDevice(device));
     fumi_ws* ws = new fumi_ws();
-    ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr; ws->hcnt = nullptr; ws->pub_src = nullptr; ws->pub_dst = nullptr; ws->pub_n = 0; ws->pub_seq = 0;
+    ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr; ws->hcnt = nullptr; ws->acnt = nullptr; ws->pub_src = nullptr; ws->pub_dst = nullptr; ws->pub_n = 0; ws->pub_seq = 0;
     ws->profiling = 0; ws->prof_every = 1; memset(ws->prof_seen, 0, sizeof(ws->prof_seen)); ws->recs = new std::vector<ProfRec>(); ws->pool = new std::vector<hipEvent_t>();
     if (hipMalloc((void**)&ws->status, 256) != hipSuccess) { delete ws; return FUMI_ENOMEM; }
     if (hipHostMalloc((void**)&ws->status_host, 256, hipHostMallocDefault) != hipSuccess) { (void)hipFree(ws->status); delete ws; return FUMI_ENOMEM; }
     HIP_TRY(hipMemset(ws->status, 0, 256));
     if (hipMalloc((void**)&ws->hcnt, FUMI_HCNT * sizeof(int)) != hipSuccess) return FUMI_ENOMEM;
     HIP_TRY(hipMemset(ws->hcnt, 0, FUMI_HCNT * sizeof(int)));
+    if (hipMalloc((void**)&ws->acnt, FUMI_ACNT * sizeof(int)) != hipSuccess) return FUMI_ENOMEM;
+    HIP_TRY(hipMemset(ws->acnt, 0, FUMI_ACNT * sizeof(int)));
     ws->side = nullptr;
     for (auto& e : ws->ev) e = nullptr;
     {   // high priority: the side stream carries a few small workgroups that should get CU slots as soon as they are ready
@@ -98,6 +100,7 @@ void fumi_hip_workspace_destroy(fumi_ws_t* ws) {
     if (ws->base) (void)hipFree(ws->base);
     if (ws->status) (void)hipFree(ws->status);
     if (ws->hcnt) (void)hipFree(ws->hcnt);
+    if (ws->acnt) (void)hipFree(ws->acnt);
     if (ws->status_host) (void)hipHostFree(ws->status_host);
     for (auto& r : *ws->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : *ws->pool) (void)hipEventDestroy(e);

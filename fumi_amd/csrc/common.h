@@ -23,6 +23,7 @@ struct fumi_ws {
     int* status;         // device status word (own small allocation)
     int* status_host;    // pinned
     const float* pub_src; float* pub_dst; int pub_n; unsigned long long pub_seq;   // deferred publication (api: publish_scalars_deferred)
+    int* acnt;           // [FUMI_ACNT] arrival counters of the split adapt kernel (reset by the query kernel of the same step)
     int* hcnt;           // [FUMI_HCNT] arrival counters of hyper_fwd_split_kernel, zero between launches
     int profiling;       // bit p: record HIP events around phase p (bench only)
     int prof_every;      // ... at every prof_every-th occurrence of the phase
@@ -194,6 +195,7 @@ int launch_linhead(hipStream_t st, int B, int N, int S, int Qn, int T, float alp
 // hypernetwork as LDS-resident kernels (hyper.hip); FUMI_ENOTSUP when the shapes do not fit (callers fall back to GEMMs)
 int hyper_lds_fits(int R, int Dt, int Ht, int H1);
 size_t hyper_bwd_workspace_floats(int R, int Ht, int H1);
+constexpr int FUMI_ACNT = 16384;       // episodes per call the split adapt kernel has counters for
 constexpr int FUMI_HCNT = 1024;        // arrival counters of the split hypernetwork forward (one per 16-row block)
 size_t hyper_fwd_workspace_floats(int R, int Ht, int H1);
 int launch_hyper_fwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_head, const float* c, const float* A0,

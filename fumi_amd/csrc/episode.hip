@@ -38,6 +38,7 @@ struct EpiBuf {
     float *Wb[MAXL], *bb[MAXL], *Whb, *bhb, *b0b, *Db;                   // adjoint state per episode
     float *abar[MAXL], *X0, *X1, *eb, *lb;     // reverse scratch
     float *A0bar;                              // [B,R,h0] adjoint of A0 (support rows: sum over inner steps)
+    float *apart; int *acnt;                   // adapt_lds split over column parts: [B,2,8,S*h_1] layer-1 partial sums; [B] arrival counters (persistent, zero between steps)
     float *xpart; int *xcnt;                   // reverse_lds: [B,2,8,S*h_1] partial sums exchanged between the column parts; [B] arrival counters
     int nslot, ntape, ntile, maxh;
     unsigned long long* trace;                 // dev: per-phase wall-clock stamps of block 0 (tools/trace_adapt.py)
@@ -255,21 +256,27 @@ __host__ __device__ inline void adapt_layout(ALay& y, int L, const int* h, int S
 }
 
 __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d, EpiBuf w, ALay y, EpiParams prm,
-                                                        const int64_t* y_s, int* status) {
+                                                        const int64_t* y_s, int* status, int P) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ StageTab s_stg;
-    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    // P > 1: the episode's layer-0 columns are split over P workgroups (ids 8 apart: same XCD); c = this part
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int b = P > 1 ? (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) / P) : (int)blockIdx.x;
+    const int c = P > 1 ? (int)((blockIdx.x >> 3) % P) : 0;
+    if (b >= d.B) return;
+    const bool lead = c == 0;                    // quantities every part computes identically are written by part 0
     int stamp_i = 0;
 #define STAMP() if (w.trace && tid == 0 && blockIdx.x == 0) w.trace[stamp_i++] = __builtin_amdgcn_s_memrealtime();
     STAMP()
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int S = d.S, N = d.N, L = d.L, H = d.H, h0 = d.h[0];
+    const int S = d.S, N = d.N, L = d.L, H = d.H, h0f = d.h[0], h0 = h0f / P, c0 = c * h0;   // h0: this part's columns
     const float alpha = d.alpha;
     const int64_t* ys = y_s + (long)b * S;
     const int ldS = wg_ld(S), ldN = wg_ld(N), ld0 = wg_ld(h0), ldH = wg_ld(H);
     auto a = [&](int i) { return sm + y.a[i]; };
     auto dz = [&](int i) { return sm + y.dz[i]; };
-    auto ldh = [&](int i) { return wg_ld(d.h[i]); };
+    auto hw = [&](int i) { return i == 0 ? h0 : d.h[i]; };       // width of layer i's LDS images
+    auto ldh = [&](int i) { return wg_ld(hw(i)); };
     float* D = sm + y.D; float* cs = sm + y.cs; float* e_ = sm + y.e; float* Wh = sm + y.Wh; float* bh = sm + y.bh;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -283,14 +290,15 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
     {
         const int tn = (h0 + 63) >> 6;
         const int m0 = (wave / tn) << 4, n = ((wave % tn) << 6) + 4 * (lane & 15);
-        const float* A0s = w.A0 + (long)b * (S + d.Qn) * h0;
-        const bool vec = ((h0 & 3) == 0) && ((((uintptr_t)A0s) & 15) == 0) && ((((uintptr_t)prm.b[0]) & 15) == 0);
+        const float* A0s = w.A0 + (long)b * (S + d.Qn) * h0f + c0;
+        const float* b0p = prm.b[0] + c0;
+        const bool vec = ((h0f & 3) == 0) && ((c0 & 3) == 0) && ((((uintptr_t)A0s) & 15) == 0) && ((((uintptr_t)b0p) & 15) == 0);
         if (vec) {                               // unconditional loads from clamped addresses: all eight in flight together
             const int nc = n < h0 ? n : 0;
-            const f32x4 bv = *(const f32x4*)(prm.b[0] + nc);
+            const f32x4 bv = *(const f32x4*)(b0p + nc);
             f32x4 av[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const int m = m0 + 4 * (lane >> 4) + e; av[e] = *(const f32x4*)(A0s + (long)(m < S ? m : 0) * h0 + nc); }
+            for (int e = 0; e < 4; ++e) { const int m = m0 + 4 * (lane >> 4) + e; av[e] = *(const f32x4*)(A0s + (long)(m < S ? m : 0) * h0f + nc); }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const int m = m0 + 4 * (lane >> 4) + e; preZ[e] = (m < S && n < h0) ? av[e] + bv : z4; }
         } else {
@@ -298,26 +306,32 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
             for (int e = 0; e < 4; ++e) {
                 const int m = m0 + 4 * (lane >> 4) + e;
                 f32x4 v = z4;
-                if (m < S && n < h0) for (int c = 0; c < 4 && n + c < h0; ++c) v[c] = A0s[(long)m * h0 + n + c] + prm.b[0][n + c];
+                if (m < S && n < h0) for (int cc = 0; cc < 4 && n + cc < h0; ++cc) v[cc] = A0s[(long)m * h0f + n + cc] + b0p[n + cc];
                 preZ[e] = v;
             }
         }
     }
     wg_lds_barrier(); STAMP()                   // (LDS only: the preZ loads stay in flight behind the staging)
-    wg_stage_rows<12>(&s_stg, b, 0, 0, 0, sm);
+    wg_stage_rows<12>(&s_stg, b, 0, c, 0, sm);
     wg_lds_barrier(); STAMP()
     // slot 0 of the tape = the initial fast weights (reverse needs W_t of every step)
-    auto store_img = [&](float* dst, const float* img, int ld, int rows, int cols) {      // LDS image -> dense global
+    auto store_img = [&](float* dst, long drs, const float* img, int ld, int rows, int cols) {      // LDS image -> global rows of stride drs
         const int c4n = (cols + 3) >> 2;
         for (int i = tid; i < rows * c4n; i += nt) {
-            const int r = i / c4n, c = (i - r * c4n) << 2;
-            wg_st4(dst + (long)r * cols + c, *(const f32x4*)(img + r * ld + c), min(4, cols - c));
+            const int r = i / c4n, cc = (i - r * c4n) << 2;
+            wg_st4(dst + (long)r * drs + cc, *(const f32x4*)(img + r * ld + cc), min(4, cols - cc));
         }
     };
+    // fast weights of layer i in the tape / final slot: layer 1 holds this part's columns only
+    auto store_W = [&](int i, long slot) {
+        const long sz = (long)d.h[i] * d.h[i - 1];
+        float* dst = w.Wslot[i] + ((long)b * w.nslot + slot) * sz;
+        if (i == 1) store_img(dst + c0, h0f, sm + y.W[1], ldh(0), d.h[1], h0);
+        else if (lead) store_img(dst, d.h[i - 1], sm + y.W[i], ldh(i - 1), d.h[i], d.h[i - 1]);
+    };
     auto store_slot0 = [&]() {                 // (the images are only modified by the updates at the end of a step)
-        for (int i = 1; i < L; ++i)
-            store_img(w.Wslot[i] + (long)b * w.nslot * ((long)d.h[i] * d.h[i - 1]), sm + y.W[i], ldh(i - 1), d.h[i], d.h[i - 1]);
-        store_img(w.Whslot + (long)b * w.nslot * N * H, Wh, ldH, N, H);
+        for (int i = 1; i < L; ++i) store_W(i, 0);
+        if (lead) store_img(w.Whslot + (long)b * w.nslot * N * H, H, Wh, ldH, N, H);
     };
     if (d.taped && d.T == 0) store_slot0();
 
@@ -326,15 +340,15 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
         // 1. layer 0 through the low-rank form: a0 = relu(A0s + b0 - alpha (G D_t + colsum D_t))
         {
             float* a0 = a(0);
-            float* ta0 = w.ta[0] + tp * S * h0;
+            float* ta0 = w.ta[0] + tp * S * h0f + c0;
             const unsigned key0 = drop_key(d, b, t, 0);
             auto fin = [&](int m, int n, const f32x4& pre, int cnt) {
-                const f32x4 v = drop_relu4(d, key0, (long)m * h0 + n, pre);
+                const f32x4 v = drop_relu4(d, key0, (long)m * h0f + c0 + n, pre);
                 f32x4 o = v;
 #pragma unroll
                 for (int c = 1; c < 4; ++c) if (c >= cnt) o[c] = 0.f;
                 *(f32x4*)(a0 + m * ld0 + n) = o;
-                if (d.taped) wg_st4(ta0 + (long)m * h0 + n, o, cnt);
+                if (d.taped) wg_st4(ta0 + (long)m * h0f + n, o, cnt);
             };
             if (t == 0) {                         // D_0 = 0
                 const int tn = (h0 + 63) >> 6;
@@ -356,18 +370,53 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
         wg_lds_barrier(); STAMP()
         // 2. deeper layers with the episode's fast weights
         for (int i = 1; i < L; ++i) {
-            const int hi = d.h[i], hp = d.h[i - 1];
+            const int hi = d.h[i], hp = hw(i - 1);
             float* ai = a(i); const int ldi = ldh(i);
             const float* bi = sm + y.bi[i];
             float* tai = w.ta[i] + tp * S * hi;
             const unsigned keyi = drop_key(d, b, t, i);
-            wg_lmm<true, true>(S, hi, hp, a(i - 1), ldh(i - 1), sm + y.W[i], wg_ld(hp), [&](int m, int n, const f32x4& acc, int cnt) {
-                f32x4 o = drop_relu4(d, keyi, (long)m * hi + n, acc + *(const f32x4*)(bi + n));
+            auto act = [&](int m, int n, const f32x4& pre, int cnt) {
+                f32x4 o = drop_relu4(d, keyi, (long)m * hi + n, pre + *(const f32x4*)(bi + n));
 #pragma unroll
-                for (int c = 1; c < 4; ++c) if (c >= cnt) o[c] = 0.f;
+                for (int cc = 1; cc < 4; ++cc) if (cc >= cnt) o[cc] = 0.f;
                 *(f32x4*)(ai + m * ldi + n) = o;
-                if (d.taped) wg_st4(tai + (long)m * hi + n, o, cnt);
-            });
+                if (d.taped && lead) wg_st4(tai + (long)m * hi + n, o, cnt);
+            };
+            if (i == 1 && P > 1) {
+                // this part's share of a_0 W_1^T (contraction over its columns) -> exchange -> every part forms a_1
+                float* Xp = dz(1);                                  // free until the backward half of the step
+                wg_lmm<true, true>(S, hi, hp, a(0), ldh(0), sm + y.W[1], wg_ld(hp), [&](int m, int n, const f32x4& acc, int) {
+                    *(f32x4*)(Xp + m * ldi + n) = acc;
+                });
+                wg_lds_barrier();
+                float* xb = w.apart + (((long)b * 2 + (t & 1)) * 8) * (long)S * hi;
+                float* mine = xb + (long)c * S * hi;
+                for (int e2 = tid; e2 < S * hi; e2 += nt) {
+                    const int m = e2 / hi, n = e2 - m * hi;
+                    __hip_atomic_store(mine + e2, Xp[m * ldi + n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();                                    // every wave's stores have left (vmcnt(0)) before the signal
+                if (tid == 0) {
+                    __hip_atomic_fetch_add(w.acnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int target = P * (t + 1);
+                    // bounded: the parts of an episode are dispatched together (see reverse_lds_kernel)
+                    for (int spin = 0; spin < (1 << 22) &&
+                         __hip_atomic_load(w.acnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin) __builtin_amdgcn_s_sleep(2);
+                }
+                __syncthreads();
+                const int w4 = q_r4(hi);
+                for (int e2 = tid; e2 < S * (w4 >> 2); e2 += nt) {
+                    const int m = e2 / (w4 >> 2), n = (e2 - m * (w4 >> 2)) << 2;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    const int cnt = min(4, hi - n);
+                    for (int cc = 0; cc < P; ++cc)
+                        for (int e3 = 0; e3 < cnt; ++e3)
+                            v[e3] += __hip_atomic_load(xb + (long)cc * S * hi + m * hi + n + e3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    act(m, n, v, cnt);
+                }
+            } else {
+                wg_lmm<true, true>(S, hi, hp, a(i - 1), ldh(i - 1), sm + y.W[i], wg_ld(hp), [&](int m, int n, const f32x4& acc, int cnt) { act(m, n, acc, cnt); });
+            }
             wg_lds_barrier(); STAMP()
         }
         // 3. head logits (into e_), softmax, e = (p - onehot)/S
@@ -389,7 +438,7 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
                     const float pv = expf(row[n] - mx) * inv;
                     const float ev = (pv - (n == yy ? 1.f : 0.f)) / (float)S;
                     row[n] = ev;
-                    if (d.taped) { tpp[s_ * N + n] = pv; tee[s_ * N + n] = ev; }
+                    if (d.taped && lead) { tpp[s_ * N + n] = pv; tee[s_ * N + n] = ev; }
                 }
                 for (int n = N; n < ldN - 4; ++n) row[n] = 0.f;                  // K padding of e (logits wrote bias-free zeros anyway)
             }
@@ -408,7 +457,7 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
                 else {                                                          // single hidden layer: this is dz_0
                     float* pd = D + m * ld0 + n; *(f32x4*)pd = *(const f32x4*)pd + o;
                 }
-                if (d.taped) wg_st4(tdl + (long)m * H + n, o, cnt);
+                if (d.taped && lead) wg_st4(tdl + (long)m * H + n, o, cnt);
             };
             wg_lmm_wide<true>(S, H, N, e_, ldN, Wh, ldH, [&](int m, int n, const f32x4& acc, int cnt, auto) { put(m, n, acc, cnt); });
         }
@@ -420,15 +469,17 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
                 float* pw = Wh + m * ldH + n;
                 const f32x4 o = *(const f32x4*)pw - alpha * acc;
                 *(f32x4*)pw = o;
-                if (d.taped) wg_st4(Whn + m * H + n, o, cnt);
+                if (d.taped && lead) wg_st4(Whn + m * H + n, o, cnt);
             });
             wg_lcolsum(S, N, e_, ldN, [&](int n, float s_) { bh[n] -= alpha * s_; });
         }
         // 5. hidden layers, top down (the head update above touches neither dz_{L-1} nor W_i)
         for (int i = L - 1; i >= 1; --i) {
-            const int hi = d.h[i], hp = d.h[i - 1];
+            const int hi = d.h[i], hp = hw(i - 1);
             const float* ap = a(i - 1); const int ldp = ldh(i - 1), ldi = ldh(i);
-            float* tdp = w.tdz[i - 1] + tp * S * hp;
+            const long gst = i == 1 ? h0f : hp, gc0 = i == 1 ? c0 : 0;          // global row stride / first column of this part
+            const bool wr = i == 1 || lead;
+            float* tdp = w.tdz[i - 1] + tp * S * gst + gc0;
             wg_lmm_wide<true>(S, hp, hi, dz(i), ldi, sm + y.W[i], wg_ld(hp), [&](int m, int n, const f32x4& acc, int cnt, auto) {
                 const f32x4 act = *(const f32x4*)(ap + m * ldp + n);
                 f32x4 o;
@@ -436,16 +487,16 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
                 for (int c = 0; c < 4; ++c) o[c] = (c < cnt && act[c] > 0.f) ? acc[c] * d.mscale : 0.f;
                 if (i > 1) *(f32x4*)(dz(i - 1) + m * ldp + n) = o;
                 else { float* pd = D + m * ld0 + n; *(f32x4*)pd = *(const f32x4*)pd + o; }     // 6. D_{t+1} = D_t + dz_0
-                if (d.taped) wg_st4(tdp + (long)m * hp + n, o, cnt);
+                if (d.taped && wr) wg_st4(tdp + (long)m * gst + n, o, cnt);
             });
             wg_lds_barrier(); STAMP()
             float* Wi = sm + y.W[i]; const int ldw = wg_ld(hp);
-            float* Wn = w.Wslot[i] + ((long)b * w.nslot + (d.taped ? t + 1 : 0)) * ((long)hi * hp);
+            float* Wn = w.Wslot[i] + ((long)b * w.nslot + (d.taped ? t + 1 : 0)) * ((long)hi * gst) + gc0;
             wg_lmm_wide<false>(hi, hp, S, dz(i), ldi, ap, ldp, [&](int m, int n, const f32x4& acc, int cnt, auto) {
                 float* pw = Wi + m * ldw + n;
                 const f32x4 o = *(const f32x4*)pw - alpha * acc;
                 *(f32x4*)pw = o;
-                if (d.taped) wg_st4(Wn + (long)m * hp + n, o, cnt);
+                if (d.taped && wr) wg_st4(Wn + (long)m * gst + n, o, cnt);
             });
             float* bi = sm + y.bi[i];
             wg_lcolsum(S, hi, dz(i), ldi, [&](int n, float s_) { bi[n] -= alpha * s_; });
@@ -455,17 +506,18 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
         wg_lds_barrier(); STAMP()
     }
     // ---- final state for the query tiles / the reverse sweep
-    store_img(w.D + (long)b * S * h0, D, ld0, S, h0);
-    for (int n = tid; n < h0; n += nt) w.cs[(long)b * h0 + n] = cs[n];
-    for (int n = tid; n < N; n += nt) w.bh[(long)b * N + n] = bh[n];
-    for (int i = 1; i < L; ++i) {
-        const float* bi = sm + y.bi[i];
-        for (int n = tid; n < d.h[i]; n += nt) w.bcur[i][(long)b * d.h[i] + n] = bi[n];
+    store_img(w.D + (long)b * S * h0f + c0, h0f, D, ld0, S, h0);
+    for (int n = tid; n < h0; n += nt) w.cs[(long)b * h0f + c0 + n] = cs[n];
+    if (lead) {
+        for (int n = tid; n < N; n += nt) w.bh[(long)b * N + n] = bh[n];
+        for (int i = 1; i < L; ++i) {
+            const float* bi = sm + y.bi[i];
+            for (int n = tid; n < d.h[i]; n += nt) w.bcur[i][(long)b * d.h[i] + n] = bi[n];
+        }
     }
     if (!d.taped) {
-        for (int i = 1; i < L; ++i)
-            store_img(w.Wslot[i] + (long)b * w.nslot * ((long)d.h[i] * d.h[i - 1]), sm + y.W[i], ldh(i - 1), d.h[i], d.h[i - 1]);
-        store_img(w.Whslot + (long)b * w.nslot * N * H, Wh, ldH, N, H);
+        for (int i = 1; i < L; ++i) store_W(i, 0);
+        if (lead) store_img(w.Whslot + (long)b * w.nslot * N * H, H, Wh, ldH, N, H);
     }
     STAMP()
 #undef STAMP
@@ -544,6 +596,7 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
         w.ploss[(long)b * w.ntile + tile] = ls;
         w.pcorr[(long)b * w.ntile + tile] = cs_;
         if (tile == 0 && d.need_grad) w.xcnt[b] = 0;          // arrival counter of reverse_lds_kernel's exchanges
+        if (tile == 0 && w.acnt) w.acnt[b] = 0;               // ... and of the next step's split adapt kernel
     }
     if (!d.need_grad) return;
 
@@ -687,6 +740,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d,
         w.ploss[(long)b * w.ntile + tile] = ls;
         w.pcorr[(long)b * w.ntile + tile] = cs_;
         if (tile == 0 && d.need_grad) w.xcnt[b] = 0;          // arrival counter of reverse_lds_kernel's exchanges
+        if (tile == 0 && w.acnt) w.acnt[b] = 0;               // ... and of the next step's split adapt kernel
     }
     if (!d.need_grad) return;
 
@@ -1290,6 +1344,7 @@ void carve(Carver& c, const EpisodeProblem& p, EpiBuf& w) {
     w.lg = c.take(B * S * N);
     w.lbar = c.take(B * Qn * N); w.qcs = c.take(B * nt * h0);
     w.ploss = c.take(B * nt); w.pcorr = c.take(B * nt);
+    w.apart = c.take(B * 2 * 8 * S * (L > 1 ? (size_t)p.h[1] : 1)); w.acnt = nullptr;       // (acnt: persistent, set by run_episodes)
     for (size_t i = 0; i < L; ++i) {
         const size_t hi = p.h[i], hp = i ? p.h[i - 1] : 0;
         w.ta[i] = c.take(B * w.ntape * S * hi); w.tdz[i] = c.take(B * w.ntape * S * hi);
@@ -1339,6 +1394,7 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     Carver c{ws, 0};
     carve(c, p, w);
     w.trace = g_epi_trace;
+    w.acnt = ws->acnt;                           // persistent arrival counters of the split adapt kernel (zero between steps)
     EpiDims d;
     d.B = p.B; d.N = p.N; d.S = p.S; d.Qn = p.Qn; d.L = p.L; d.T = p.T; d.H = p.h[p.L - 1];
     for (int i = 0; i < MAXL; ++i) d.h[i] = i < p.L ? p.h[i] : 0;
@@ -1368,16 +1424,32 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     {
         ProfScope ps(ws, st, FUMI_PH_ADAPT);
         static const bool force_global_a = getenv("FUMI_EPI_GLOBAL") != nullptr;   // dev/test: take the generic kernels
-        ALay al; adapt_layout(al, p.L, p.h, p.S, p.N);
+        // column parts per episode (adapt_lds_kernel): the layer-0 columns can be split over AP workgroups that exchange the
+        // layer-1 partial sums once per inner step.  OFF by default: measured at the reference sizes (h0 = 256, AP = 4) the
+        // exchange costs what the smaller products save (phase trace: layer 1 + exchange 3.2 -> 6.0 us, the two backward
+        // products 10.3 -> 7.6 us; 0.3118 vs 0.3121 ms per step at T = 1, 0.515 vs 0.506 at T = 5): the inner loop is bound
+        // by per-phase latency, not by the CU's matrix rate.  FUMI_ADAPT_P=n enables it (wider first layers).
+        static const int ap_env = getenv("FUMI_ADAPT_P") ? atoi(getenv("FUMI_ADAPT_P")) : 1;
+        int AP = 1;
+        if (ap_env > 1 && p.L >= 2 && w.acnt && p.B <= FUMI_ACNT) {
+            AP = ap_env > 8 ? 8 : ap_env;
+            while (AP > 1 && (h0 % (64 * AP) != 0)) AP >>= 1;            // every part: a multiple of 64 columns
+        }
+        int hs[MAXL];
+        for (int i = 0; i < MAXL; ++i) hs[i] = i < p.L ? p.h[i] : 0;
+        hs[0] = h0 / AP;
+        ALay al; adapt_layout(al, p.L, hs, p.S, p.N);
         const int H = d.H;
         bool lds_form = al.total <= ALDS_CAP && 4 + 2 * (p.L - 1) <= WG_MAXJOB && !force_global_a &&
-                        ((p.S + 15) / 16) * ((h0 + 63) / 64) <= 8;         // one layer-0 block per wave (A0s + b0 in registers)
+                        ((p.S + 15) / 16) * ((hs[0] + 63) / 64) <= 8;      // one layer-0 block per wave (A0s + b0 in registers)
         StageTab tb; tb.init();
         if (lds_form) {
             const long R = p.S + p.Qn, S = p.S, N = p.N;
             tb.add(w.G, R * S, 0, 0, S, p.S, p.S, p.S, al.G, wg_ld(p.S));
             for (int i = 1; i < p.L; ++i) {
-                tb.add(p.W[i], 0, 0, 0, p.h[i - 1], p.h[i], p.h[i], p.h[i - 1], al.W[i], wg_ld(p.h[i - 1]));
+                // layer 1: this part's columns of every row (part stride hs[0]); deeper layers whole
+                const int kc = i == 1 ? hs[0] : p.h[i - 1];
+                tb.add(p.W[i], 0, 0, i == 1 ? hs[0] : 0, p.h[i - 1], p.h[i], p.h[i], kc, al.W[i], wg_ld(kc));
                 tb.add(p.b[i], 0, 0, 0, p.h[i], 1, 1, p.h[i], al.bi[i], p.h[i]);
             }
             tb.add(p.head, N * (H + 1), 0, 0, H + 1, p.N, p.N, H, al.Wh, wg_ld(H));
@@ -1386,7 +1458,8 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
         }
         if (lds_form) {
             FUMI_SET_DYN_LDS(adapt_lds_kernel, al.total * 4);
-            hipLaunchKernelGGL(adapt_lds_kernel, dim3(p.B), dim3(512), al.total * 4, st, tb, d, w, al, prm, p.y_s, ws->status);
+            const unsigned grid = AP > 1 ? 8u * ((p.B + 7) / 8) * AP : (unsigned)p.B;
+            hipLaunchKernelGGL(adapt_lds_kernel, dim3(grid), dim3(512), al.total * 4, st, tb, d, w, al, prm, p.y_s, ws->status, AP);
         } else {
             FUMI_SET_DYN_LDS(adapt_kernel, w.lds_adapt * 4);
             hipLaunchKernelGGL(adapt_kernel, dim3(p.B), dim3(512), w.lds_adapt * 4, st, d, w, prm, p.y_s, p.head, ws->status);

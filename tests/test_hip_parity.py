@@ -572,6 +572,21 @@ def test_side_stream_overlap_in_subprocess(dev):
     assert " passed" in r.stdout
 
 
+def test_adapt_split_over_column_parts_in_subprocess(dev):
+    """FUMI_ADAPT_P=4: the inner loop's layer-0 columns split over four workgroups per episode that exchange the layer-1
+    partial sums once per inner step (off by default).  Same parity required, including more episodes than the chip holds."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-q", "-m", "gpu",
+                        "-p", "no:cacheprovider", "-k",
+                        "fumi_step_matches_reference or maml_step_matches_reference or larger_than_the_chip or full_size or dropout"],
+                       env=dict(os.environ, FUMI_ADAPT_P="4"), cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 @pytest.mark.parametrize("form", ["0", "1"])
 def test_other_hypernet_forward_forms_in_subprocess(form, dev):
     """FUMI_HYPER_FWD=0: one launch per hypernetwork layer (what hypernetworks wider than 256 use); =1: one launch with a
