@@ -578,12 +578,26 @@ __host__ __device__ __forceinline__ int wg_ld(int cols) { return ((cols + 31) & 
 // loads in flight before the first LDS write, fetching each unit's descriptor from the owning lane with v_readlane;
 // loads are unconditional from clamped addresses (a guarded load is a basic block of its own with a full wait).
 // Needs nunits <= 64 * (waves per workgroup).
-__device__ __forceinline__ void wg_stage_tab_to_lds(StageTab* Tl, int ntab = 1) {
+__device__ __forceinline__ void wg_stage_tab_to_lds(StageTab* Tl, int ntab = 1, int kernarg_bytes = 0) {
     // the plans must be the kernel's FIRST arguments: they are read straight from the kernarg segment (taking the
     // address of a by-value argument would copy it to scratch)
     const int* src = (const int*)__builtin_amdgcn_kernarg_segment_ptr();
     int* dst = (int*)Tl;
     for (int i = threadIdx.x; i < ntab * (int)(sizeof(StageTab) / 4); i += blockDim.x) dst[i] = src[i];
+    // The rest of the argument block (dimension / buffer / layout structs, ~1-2 KB after the plans) is read by scalar loads
+    // scattered over the kernel's phases.  The block is a fresh piece of device memory for every launch, so each 64-byte
+    // line costs a memory round trip where it is first touched (the ISA shows 18 s_load + s_waitcnt pairs in one 4 us phase
+    // of the adapt kernel).  Touch every line now, in parallel with the plan copy: the scalar loads then hit L2.
+    if (kernarg_bytes > 0) {
+        const int first = ntab * (int)sizeof(StageTab) / 64, last = (kernarg_bytes + 63) / 64;
+        const int ln = first + (int)threadIdx.x;
+        if (ln < last) {
+            int dummy;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"((const char*)src + (long)ln * 64) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" :: "v"(dummy));
+        }
+    }
 }
 static_assert(sizeof(StageTab) % 8 == 0, "consecutive StageTab kernel arguments must be contiguous");
 // U units in flight per wave, each the sum of up to NS slabs (NS = 1: plain copy)

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
     float* D = sm + y.D; float* cs = sm + y.cs; float* e_ = sm + y.e; float* Wh = sm + y.Wh; float* bh = sm + y.bh;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
-    wg_stage_tab_to_lds(&s_stg);
+    wg_stage_tab_to_lds(&s_stg, 1, (int)(sizeof(StageTab) + sizeof(EpiDims) + sizeof(EpiBuf) + sizeof(ALay) + sizeof(EpiParams) + 64));
     for (int i = tid * 4, tot = y.total; i < tot; i += nt * 4) *(f32x4*)(sm + i) = z4;
     // labels and A0_s + b0 are loaded now: a load issued inside the step loop would wait for every older tape store
     // (vmcnt counts loads and stores together, in order)
@@ -366,7 +366,9 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
                 });
             }
         }
+        STAMP()
         if (t == 0 && d.taped) store_slot0();    // after the registers loaded at kernel start have been consumed
+        STAMP()
         wg_lds_barrier(); STAMP()
         // 2. deeper layers with the episode's fast weights
         for (int i = 1; i < L; ++i) {
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d,
     // the row's label is loaded now: inside the chain it would wait for every older store (vmcnt is in order)
     const int my_label = tid < nr ? label(y_q + (long)b * Qn + r0, tid, N, status) : 0;
     // ---- zero the arena (padding must read as zero), then stage everything this tile needs in one batch (plan: host)
-    wg_stage_tab_to_lds(&s_stg);
+    wg_stage_tab_to_lds(&s_stg, 1, (int)(sizeof(StageTab) + sizeof(EpiDims) + sizeof(EpiBuf) + sizeof(QLay) + 64));
     for (int i = tid * 4, tot = y.total; i < tot; i += nt * 4) *(f32x4*)(sm + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads(); QSTAMP()
     wg_stage_rows<20>(&s_stg, b, tile, 0, nr, sm);
@@ -1050,7 +1052,7 @@ __global__ __launch_bounds__(512) void reverse_lds_kernel(StageTab stg_init, Sta
         }
     };
 
-    wg_stage_tab_to_lds(s_stg, 2);
+    wg_stage_tab_to_lds(s_stg, 2, (int)(2 * sizeof(StageTab) + sizeof(EpiDims) + sizeof(EpiBuf) + sizeof(RLay) + 64));
     for (int i = tid * 4, tot = y.total; i < tot; i += nt * 4) *(f32x4*)(sm + i) = z4;
     __syncthreads(); RSTAMP()
     // adjoints after the query pass = sums of the tiles' partial slabs (this part's columns); G_ss

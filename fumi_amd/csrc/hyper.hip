@@ -32,7 +32,7 @@ __global__ __launch_bounds__(512) void hyper_lin_kernel(StageTab stg, LinDims d,
     float* xi = sm; float* Wi = sm + HB * ldk; float* bi = Wi + h_r16(d.NC) * ldk;
     // no zero-fill: K is a multiple of 4 (hyper_lds_fits), so the product never reads K padding, and rows / columns past
     // nr / ncols only feed outputs that are not stored
-    wg_stage_tab_to_lds(&s_stg);
+    wg_stage_tab_to_lds(&s_stg, 1, (int)sizeof(StageTab) + 128);
     __syncthreads();
     wg_stage_rows<16>(&s_stg, 0, rb, cb, nr, sm, ncols, ncols);
     wg_lds_barrier();
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(512) void hyper_bwd1_kernel(StageTab stg, HyperDims
     const int ldt = wg_ld(d.Ht), ld1 = wg_ld(d.H1);
     float* hp = sm; float* ui = hp + HB * ld1; float* ubi = ui + HB * ldt; float* A1 = ubi + HB * ldt;
     const int tot = HB * ld1 + 2 * HB * ldt + h_r4(d.H1) * ldt;
-    wg_stage_tab_to_lds(&s_stg);
+    wg_stage_tab_to_lds(&s_stg, 1, (int)sizeof(StageTab) + 128);
     for (int i = tid * 4; i < tot; i += nt * 4) *(f32x4*)(sm + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     wg_stage_rows<12>(&s_stg, 0, rb, 0, nr, sm);          // hbar rows -> hp, u rows, A1
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(512) void hyper_bwd0_kernel(StageTab stg, HyperDims
     const int ld = wg_ld(64), RS = h_r4(d.R);
     float* ubi = sm; float* ci = sm + RS * ld;
     const int tot = 2 * RS * ld;
-    wg_stage_tab_to_lds(&s_stg);
+    wg_stage_tab_to_lds(&s_stg, 1, (int)sizeof(StageTab) + 128);
     for (int i = tid * 4; i < tot; i += nt * 4) *(f32x4*)(sm + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     // job 0 (ubar columns): part = mb, width mc; job 1 (c columns): tile = nb, width nc -- two run-time widths, so the

@@ -1,3 +1,5 @@
+"""Runs fumi_hip_am3_step at the configs[3] per-rank shapes in eval / train / train+stats mode (30 calls each) so that a
+rocprofv3 --kernel-trace of this script shows what the head kernel costs in each mode (dev tool)."""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
