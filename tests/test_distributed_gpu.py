@@ -1,0 +1,80 @@
+"""GPU suite: the sharded path of bench.py / main.py with the real HIP engine -- two ranks (both on cuda:0, gloo carrying the
+all-reduce: RCCL refuses two ranks on one device and the test box has one GPU) against one process on the same meta-batch.
+Covers what the CPU twin (test_distributed_cpu.py, oracle engine) cannot: device shards, the flat gradient buffer written by
+the library, the fused Adam step and the event-free statistics on every rank."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_distributed_cpu import _build, _free_port  # noqa: E402
+
+
+def _step_gpu(kind, c, ep, m, dev):
+    from types import SimpleNamespace
+    from oracle import casegen as cg
+    from fumi_amd.models import maml
+    from fumi_amd.optim import Adam
+    m.to(dev)
+    args = SimpleNamespace(device=dev, num_train_adapt_steps=2, num_test_adapt_steps=2, step_size=cg.ALPHA, first_order=False,
+                           num_ways=c["N"], batch_size=c["B"])
+    opt = Adam(m.parameters(), lr=1e-3, weight_decay=5e-4)
+    batch = cg.to_batch(ep)
+    stats = []
+    for _ in range(3):                                   # several steps: replicas must stay together
+        if kind == "fumi":
+            tr = m.evaluate(args, batch, opt, "train")[:2]
+        elif kind == "maml":
+            tr = maml.evaluate(args, m, batch, opt, "train")
+        else:
+            tr = m.evaluate(batch, opt, None, c["N"], dev, "train")[:2]
+        stats += [float(tr[0]), float(tr[1])]
+    if kind == "fumi":
+        te = m.evaluate(args, batch, None, "test")
+        extra = te[2].cpu().numpy()
+    elif kind == "maml":
+        te = maml.evaluate(args, m, batch, None, "test")
+        extra = np.zeros(1)
+    else:
+        te = m.evaluate(batch, None, None, c["N"], dev, "test")
+        extra = np.asarray(te[6])
+    stats += [float(te[0]), float(te[1])]
+    params = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu().numpy()
+    return np.array(stats), params, extra
+
+
+def _worker(rank, world, port, kind, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c, ep, m = _build(kind)
+        stats, params, extra = _step_gpu(kind, c, ep, m, dev)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), stats=stats, params=params, extra=extra)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["fumi", "maml", "am3"])
+def test_two_rank_sharded_gpu_step_equals_single_process(kind, tmp_path):
+    dev = torch.device("cuda", 0)
+    c, ep, m = _build(kind)
+    ref_stats, ref_params, ref_extra = _step_gpu(kind, c, ep, m, dev)
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    np.testing.assert_array_equal(r0["params"], r1["params"])            # replicas stay bit-identical
+    np.testing.assert_allclose(r0["params"], ref_params, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(r0["stats"], ref_stats, rtol=0, atol=2e-5)
+    np.testing.assert_array_equal(r0["stats"], r1["stats"])
+    np.testing.assert_array_equal(r0["extra"], ref_extra)                  # gathered test-time predictions, full batch
