@@ -167,11 +167,17 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
     import torch.distributed as dist
-    dev = torch.device("cuda", local)
+    # rehearsal on a one-GPU box (the N > 1 code path, not a measurement): FUMI_BENCH_REHEARSAL=1 puts every rank on cuda:0
+    # and lets gloo carry the collectives (RCCL refuses two ranks on one device)
+    rehearsal = os.environ.get("FUMI_BENCH_REHEARSAL", "0") == "1"
+    dev = torch.device("cuda", 0 if rehearsal else local)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from fumi_amd import hip
     from fumi_amd.utils import utils as U
@@ -205,7 +211,7 @@ def main():
     el = time.perf_counter() - t0
     prof = ws.profile() if not a.no_phase_timing else {}
     ws.set_profiling(False)
-    t = torch.tensor([el], device=dev, dtype=torch.float64)
+    t = torch.tensor([el], device="cpu" if rehearsal else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
@@ -215,7 +221,7 @@ def main():
         out = {
             "metric": "episodes/sec (5-way 5-shot FuMI)", "value": round(Bg * a.steps / el, 2), "unit": "episodes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo, not a measurement)",
             "config": {"workload": "FuMI 5-way 5-shot, 32 query/class, ResNet-152-style 2048-d embeddings, im_hid [256,64], "
                                    "GloVe-300 token text (L=128, V=20000, mean pool), text_hid 256, 1 inner step, "
                                    "second-order meta-gradient + Adam step; BASELINE.json configs[1]",
