@@ -255,10 +255,20 @@ __host__ __device__ inline void adapt_layout(ALay& y, int L, const int* h, int S
     y.total = off + 64;
 }
 
-__global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d, EpiBuf w, ALay y, EpiParams prm,
+__global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d, EpiBuf w_arg, ALay y, EpiParams prm,
                                                         const int64_t* y_s, int* status, int P) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ StageTab s_stg;
+    // the buffer table (~100 pointers) is read from an LDS copy: as a kernel argument every pointer is a scalar load from the
+    // argument block at its first use, each with its own wait, scattered over the phases (2.7 us of the step loop's preheader)
+    __shared__ EpiBuf s_w;
+    {
+        constexpr int off = (int)((sizeof(StageTab) + sizeof(EpiDims) + alignof(EpiBuf) - 1) / alignof(EpiBuf) * alignof(EpiBuf));
+        const int* src = (const int*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + off);
+        int* dst = (int*)&s_w;
+        for (int i = threadIdx.x; i < (int)(sizeof(EpiBuf) / 4); i += blockDim.x) dst[i] = src[i];
+    }
+    const EpiBuf& w = s_w;
     // P > 1: the episode's layer-0 columns are split over P workgroups (ids 8 apart: same XCD); c = this part
     const int tid = threadIdx.x, nt = blockDim.x;
     const int b = P > 1 ? (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) / P) : (int)blockIdx.x;
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
     if (b >= d.B) return;
     const bool lead = c == 0;                    // quantities every part computes identically are written by part 0
     int stamp_i = 0;
-#define STAMP() if (w.trace && tid == 0 && blockIdx.x == 0) w.trace[stamp_i++] = __builtin_amdgcn_s_memrealtime();
+#define STAMP() if (w_arg.trace && tid == 0 && blockIdx.x == 0) w_arg.trace[stamp_i++] = __builtin_amdgcn_s_memrealtime();
     STAMP()
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = d.S, N = d.N, L = d.L, H = d.H, h0f = d.h[0], h0 = h0f / P, c0 = c * h0;   // h0: this part's columns
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
     {
         const int tn = (h0 + 63) >> 6;
         const int m0 = (wave / tn) << 4, n = ((wave % tn) << 6) + 4 * (lane & 15);
-        const float* A0s = w.A0 + (long)b * (S + d.Qn) * h0f + c0;
+        const float* A0s = w_arg.A0 + (long)b * (S + d.Qn) * h0f + c0;      // (before the LDS copy of the table is visible)
         const float* b0p = prm.b[0] + c0;
         const bool vec = ((h0f & 3) == 0) && ((c0 & 3) == 0) && ((((uintptr_t)A0s) & 15) == 0) && ((((uintptr_t)b0p) & 15) == 0);
         if (vec) {                               // unconditional loads from clamped addresses: all eight in flight together
@@ -350,6 +360,7 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
                 *(f32x4*)(a0 + m * ld0 + n) = o;
                 if (d.taped) wg_st4(ta0 + (long)m * h0f + n, o, cnt);
             };
+            STAMP()
             if (t == 0) {                         // D_0 = 0
                 const int tn = (h0 + 63) >> 6;
                 const int m0 = (wave / tn) << 4, n = ((wave % tn) << 6) + 4 * (lane & 15);
