@@ -33,69 +33,71 @@ def get_dataset(args):
     raise NotImplementedError()                    # data.py:73-74 ('cub' needs a torchmeta download, 'supervised-inat-anim' is CLIP's)
 
 
+# embedding width each image model produces (fumi/main.py:34-44: the three ValueErrors, same messages)
+_EMBEDDING_DIMS = {"resnet-152": ("Resnet-152", 2048), "resnet-34": ("Resnet-34", 512)}
+# names the test metrics are logged and printed under, in the order the test loops return them
+_TEST_METRICS = {"maml": ("loss", "acc"), "fumi": ("loss", "acc"), "am3": ("loss", "acc", "f1", "prec", "rec", "avg_lamda")}
+
+
+def _check_embedding_flags(args):
+    if args.image_embedding_model not in _EMBEDDING_DIMS:
+        raise ValueError("Image embedding model must be one of " + " ".join(_EMBEDDING_DIMS))
+    pretty, dim = _EMBEDDING_DIMS[args.image_embedding_model]
+    if args.im_emb_dim != dim:
+        raise ValueError(f"{pretty} outputs {dim}-dimensional embeddings, hence --im_emb_dim should be set to {dim}")
+
+
+def _restore(args, model, optimizer):
+    """--checkpoint: a file, or (like the reference, main.py:61-76) a W&B run id whose best.pth.tar is fetched first."""
+    ckpt = args.checkpoint
+    if not os.path.exists(ckpt):
+        model_path = f"./checkpoints/{args.model}/{args.checkpoint}"
+        os.makedirs(model_path, exist_ok=True)
+        ckpt = wandb.restore("best.pth.tar", run_path=f"multimodal-image-cls/{args.model}/{args.checkpoint}",
+                             root=model_path).name
+    opt = optimizer[0] if type(optimizer) == tuple else optimizer
+    return utils.load_checkpoint(model, opt, args.device, ckpt)[0]
+
+
 def main(args):
+    family = args.model if args.model in ("maml", "fumi") else "am3"      # unknown names are AM3, like utils.init_model
+    mod = {"maml": maml, "fumi": fumi, "am3": am3}[family]
     results_path = f"{args.log_dir}/results"
     os.makedirs(results_path, exist_ok=True)
     os.environ["FUMI_LOG_DIR"] = args.log_dir        # where the local W&B stand-in keeps run directories
-    job_type = "eval" if args.evaluate else "train"
-    os.environ['WANDB_MODE'] = 'offline' if args.wandb_offline else 'online'
-    wandb.init(entity=args.wandb_entity, project=args.wandb_project, group=args.wandb_experiment, job_type=job_type,
-               save_code=True)
+    os.environ["WANDB_MODE"] = "offline" if args.wandb_offline else "online"
+    wandb.init(entity=args.wandb_entity, project=args.wandb_project, group=args.wandb_experiment,
+               job_type="eval" if args.evaluate else "train", save_code=True)
     wandb.config.update(args)
-
-    if args.image_embedding_model not in ["resnet-152", "resnet-34"]:
-        raise ValueError("Image embedding model must be one of resnet-152 resnet-34")
-    if args.image_embedding_model == "resnet-152" and args.im_emb_dim != 2048:
-        raise ValueError("Resnet-152 outputs 2048-dimensional embeddings, hence --im_emb_dim should be set to 2048")
-    if args.image_embedding_model == "resnet-34" and args.im_emb_dim != 512:
-        raise ValueError("Resnet-34 outputs 512-dimensional embeddings, hence --im_emb_dim should be set to 512")
+    _check_embedding_flags(args)
 
     train_loader, val_loader, test_loader, dictionary = get_dataset(args)
     max_test_batches = int(args.num_ep_test / args.batch_size)
-
-    torch.manual_seed(args.seed)
-    np.random.seed(args.seed)
-    random.seed(args.seed)
+    for seed_fn in (torch.manual_seed, np.random.seed, random.seed):
+        seed_fn(args.seed)
 
     model = utils.init_model(args, dictionary)
     print(model)
     optimizer = utils.init_optim(args, model)
-
     if args.checkpoint:
-        ckpt = args.checkpoint
-        if not os.path.exists(ckpt):                         # a W&B run id, like the reference (main.py:61-76)
-            model_path = f"./checkpoints/{args.model}/{args.checkpoint}"
-            os.makedirs(model_path, exist_ok=True)
-            ckpt = wandb.restore("best.pth.tar", run_path=f"multimodal-image-cls/{args.model}/{args.checkpoint}",
-                                 root=model_path).name
-        opt = optimizer[0] if type(optimizer) == tuple else optimizer
-        model, _ = utils.load_checkpoint(model, opt, args.device, ckpt)
-
-    mod = {"maml": maml, "fumi": fumi}.get(args.model, am3)
+        model = _restore(args, model, optimizer)
     if not args.evaluate:
         model = mod.training_run(args, model, optimizer, train_loader, val_loader, max_test_batches // 2)
 
-    if args.model == "maml":
-        test_loss, test_acc = maml.test_loop(args, model, test_loader, max_test_batches)
-    elif args.model == "fumi":
-        test_loss, test_acc, _, _ = fumi.test_loop(args, model, test_loader, max_test_batches)
-    if args.model in ("maml", "fumi"):
-        print(f"\n TEST: \ntest loss: {test_loss}, test acc: {test_acc}")
-        wandb.log({"test/acc": test_acc, "test/loss": test_loss})
-        result = dict(test_loss=float(test_loss), test_acc=float(test_acc))
-    else:
-        (test_loss, test_acc, test_f1, test_prec, test_rec, test_avg_lamda, test_preds, test_true, query_idx,
-         support_idx, support_lamda) = am3.test_loop(args, model, test_loader, max_test_batches)
-        print(f"\n TEST: \ntest loss: {test_loss}, test acc: {test_acc},\ntest f1: {test_f1}, test prec: {test_prec}, "
-              f"test rec: {test_rec}, test avg lamda: {test_avg_lamda}")
-        wandb.log({"test/acc": test_acc, "test/f1": test_f1, "test/prec": test_prec, "test/rec": test_rec,
-                   "test/loss": test_loss, "test/avg_lamda": test_avg_lamda})
-        if fdist.world()[0] == 0:
+    out = mod.test_loop(args, model, test_loader, max_test_batches)
+    names = _TEST_METRICS[family]
+    values = dict(zip(names, out))
+    print("\n TEST: \n" + ", ".join(f"test {k.replace('_', ' ')}: {v}" for k, v in values.items()))
+    wandb.log({f"test/{k}": v for k, v in values.items()})
+    result = dict(test_loss=float(values["loss"]), test_acc=float(values["acc"]))
+    if family == "am3":
+        result["test_f1"] = float(values["f1"])
+        test_preds, test_true, query_idx, support_idx, support_lamda = out[len(names):len(names) + 5]
+        if fdist.world()[0] == 0:                                        # per-query records (main.py:126-138)
             import pandas as pd
             pd.DataFrame({"support_idx": support_idx, "support_lamda": support_lamda, "query_idx": query_idx,
                           "query_preds": test_preds, "query_targets": test_true}
                          ).to_csv(path_or_buf=f"{results_path}/run_{wandb.run.name}.csv")
-        result = dict(test_loss=float(test_loss), test_acc=float(test_acc), test_f1=float(test_f1))
     wandb.finish()
     return result
 
