@@ -41,7 +41,7 @@ struct EpiBuf {
     float *apart; int *acnt;                   // adapt_lds split over column parts: [B,2,8,S*h_1] layer-1 partial sums; [B] arrival counters (persistent, zero between steps)
     float *xpart; int *xcnt;                   // reverse_lds: [B,2,8,S*h_1] partial sums exchanged between the column parts; [B] arrival counters
     int nslot, ntape, ntile, maxh;
-    unsigned long long* trace;                 // dev: per-phase wall-clock stamps of block 0 (tools/trace_adapt.py)
+    unsigned long long* trace;                 // dev: per-phase wall-clock stamps of block 0 (tests/dev/trace_adapt.py)
     int lds_adapt, lds_query, lds_reverse;     // floats of dynamic LDS each kernel stages its products through
 };
 

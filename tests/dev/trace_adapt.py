@@ -1,5 +1,5 @@
 import os, sys, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fumi_amd import hip
 from oracle import casegen as cg
