@@ -67,15 +67,16 @@ int fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out) {
     fumi_ws* ws = new fumi_ws();
     ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr; ws->hcnt = nullptr; ws->acnt = nullptr; ws->pub_src = nullptr; ws->pub_dst = nullptr; ws->pub_n = 0; ws->pub_seq = 0;
     ws->profiling = 0; ws->prof_every = 1; memset(ws->prof_seen, 0, sizeof(ws->prof_seen)); ws->recs = new std::vector<ProfRec>(); ws->pool = new std::vector<hipEvent_t>();
-    if (hipMalloc((void**)&ws->status, 256) != hipSuccess) { delete ws; return FUMI_ENOMEM; }
-    if (hipHostMalloc((void**)&ws->status_host, 256, hipHostMallocDefault) != hipSuccess) { (void)hipFree(ws->status); delete ws; return FUMI_ENOMEM; }
-    HIP_TRY(hipMemset(ws->status, 0, 256));
-    if (hipMalloc((void**)&ws->hcnt, FUMI_HCNT * sizeof(int)) != hipSuccess) return FUMI_ENOMEM;
-    HIP_TRY(hipMemset(ws->hcnt, 0, FUMI_HCNT * sizeof(int)));
-    if (hipMalloc((void**)&ws->acnt, FUMI_ACNT * sizeof(int)) != hipSuccess) return FUMI_ENOMEM;
-    HIP_TRY(hipMemset(ws->acnt, 0, FUMI_ACNT * sizeof(int)));
     ws->side = nullptr;
     for (auto& e : ws->ev) e = nullptr;
+    // small persistent device buffers: status word, arrival counters (kept zero between launches by the kernels that use them)
+    auto fail = [&](int code) { fumi_hip_workspace_destroy(ws); return code; };
+    if (hipMalloc((void**)&ws->status, 256) != hipSuccess) return fail(FUMI_ENOMEM);
+    if (hipHostMalloc((void**)&ws->status_host, 256, hipHostMallocDefault) != hipSuccess) return fail(FUMI_ENOMEM);
+    if (hipMalloc((void**)&ws->hcnt, FUMI_HCNT * sizeof(int)) != hipSuccess) return fail(FUMI_ENOMEM);
+    if (hipMalloc((void**)&ws->acnt, FUMI_ACNT * sizeof(int)) != hipSuccess) return fail(FUMI_ENOMEM);
+    if (hipMemset(ws->status, 0, 256) != hipSuccess || hipMemset(ws->hcnt, 0, FUMI_HCNT * sizeof(int)) != hipSuccess ||
+        hipMemset(ws->acnt, 0, FUMI_ACNT * sizeof(int)) != hipSuccess) return fail(FUMI_EHIP);
     {   // high priority: the side stream carries a few small workgroups that should get CU slots as soon as they are ready
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
