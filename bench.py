@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 
 CFG = dict(N=5, K=5, Q=32, D=2048, hid=[256, 64], E=300, L=128, V=20000, Ht=256, T=1, B_per_gpu=32, alpha=0.01)
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
-PROF_EVERY = 8                        # HIP-event timing of the roofline kernel: every 8th step
+PROF_EVERY = 8                        # HIP-event timing of the roofline kernel: every 8th step (every steps//16-th of a short run)
 NBATCH = 4                            # distinct pre-generated meta-batches cycled through the steps
 
 
@@ -135,6 +135,17 @@ def cpu_baseline(table, budget_s=12.0):
         t1 = time.perf_counter(); step(batches[0]); r_ = 1.0 / (time.perf_counter() - t1)
         if r_ > best[0]:
             best = (r_, nt_)
+    def median_rate(nt_, reps=5):
+        """warm-up, then the median of >= 5 meta-batches at a fixed thread count."""
+        torch.set_num_threads(nt_)
+        step(batches[1])
+        ts = []
+        for i in range(reps):
+            t1 = time.perf_counter(); step(batches[i % 2]); ts.append(time.perf_counter() - t1)
+        ts.sort()
+        return round(B / ts[len(ts) // 2], 2)
+    ncpu = os.cpu_count() or 1
+    one_thread, all_cores = median_rate(1), median_rate(ncpu)
     torch.set_num_threads(best[1])
     n, t0 = 0, time.perf_counter()
     while True:
@@ -145,7 +156,31 @@ def cpu_baseline(table, budget_s=12.0):
             break
     return dict(value=round(n * B / el, 2), unit="episodes/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{n} meta-batches of {B} episodes ({el:.1f} s) of the same workload through oracle/fumi_ref.py "
-                       f"(eager PyTorch CPU, {os.cpu_count()} logical CPUs visible)")
+                       f"(eager PyTorch CPU, {ncpu} logical CPUs visible) at the fastest of the probed thread counts "
+                       f"(1, 8, 16, ncpu/2): the eager per-episode loop is dispatch-bound, more threads only add contention",
+                all_cores={"value": all_cores, "cores": ncpu, "how": "median of 5 meta-batches after 1 warm-up"},
+                one_thread={"value": one_thread, "cores": 1, "how": "median of 5 meta-batches after 1 warm-up"})
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start one fresh process per GPU through torch.distributed.run as a CHILD of
+    this process (which has not touched the GPU and never will), let rank 0's JSON line through and hand back the child's exit
+    code.  (Replacing this process with the launcher after a HIP call is what the pool forbids; a child process is not that.)"""
+    import socket
+    import subprocess
+    if os.environ.get("FUMI_BENCH_REHEARSAL", "0") != "1" and torch.cuda.device_count() < n:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs, found {torch.cuda.device_count()} "
+              f"(FUMI_BENCH_REHEARSAL=1 rehearses the N-rank code path on one GPU over gloo)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -160,12 +195,13 @@ def main():
                          "roofline kernel's phase")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a.gpus))             # (nothing has touched the GPU in this process)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
     # rehearsal on a one-GPU box (the N > 1 code path, not a measurement): FUMI_BENCH_REHEARSAL=1 puts every rank on cuda:0
     # and lets gloo carry the collectives (RCCL refuses two ranks on one device)
@@ -201,7 +237,8 @@ def main():
     hip.raise_on_status(ws.read_status())
     if not a.no_phase_timing:
         # an event record is a ~6 us bubble on the stream: the roofline kernel is timed at every 8th step of the timed region
-        ws.set_profiling(True, None if a.all_phases else ["xpanel_bwd"], every=1 if a.all_phases else PROF_EVERY)
+        prof_every = 1 if a.all_phases else max(1, min(PROF_EVERY, a.steps // 16))     # >= 16 samples from a short run too
+        ws.set_profiling(True, None if a.all_phases else ["xpanel_bwd"], every=prof_every)
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -212,8 +249,21 @@ def main():
     prof = ws.profile() if not a.no_phase_timing else {}
     ws.set_profiling(False)
     t = torch.tensor([el], device="cpu" if rehearsal else dev, dtype=torch.float64)
+    allreduce = None
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # the step's one collective, timed on its own after the timed region: the flat [grads | loss | acc] buffer
+        flat = model._flat_grads().flat
+        buf = flat.clone() if not rehearsal else flat.cpu()
+        for _ in range(3):
+            dist.all_reduce(buf)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(buf)
+        barrier()
+        allreduce = {"bytes": int(flat.numel() * 4), "avg_us": round((time.perf_counter() - t1) / 20 * 1e6, 1),
+                     "backend": "gloo (rehearsal)" if rehearsal else "nccl (RCCL)", "per_step": 1}
     el = float(t.item())
 
     if rank == 0:
@@ -226,6 +276,8 @@ def main():
                                    "GloVe-300 token text (L=128, V=20000, mean pool), text_hid 256, 1 inner step, "
                                    "second-order meta-gradient + Adam step; BASELINE.json configs[1]",
                        "episodes_per_gpu": c["B_per_gpu"], "global_meta_batch": Bg,
+                       "layer0_fwd": "split-bf16x3 operands on the bf16 MFMA with fp32 accumulation (fp32-equivalent: error vs "
+                                     "fp64 below the fp32-MFMA kernel's, tests/test_hip_parity.py::test_xpanel_fwd_split_bf16_has_fp32_accuracy)",
                        "parallelism": f"episode-sharded x{world}, 1 all-reduce of the flat gradient"},
             "final_loss": float(last[0]), "final_acc": float(last[1]),
             "step_tflops_algorithmic": round(flops_step_algorithmic(c["B_per_gpu"]) / (ms * 1e-3) / 1e12, 3),
@@ -243,11 +295,15 @@ def main():
                     traffic = int(k[key[0]]["hbm_bytes_per_launch"])
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                               "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this command, "
+                                                 "committed as profiles/<round>/pmc_traffic.json (not re-measured in this run)",
                                "algorithmic_bytes": int(bytes_dominant(c["B_per_gpu"])),
                                "kernel": "xpanel_bwd256_kernel (gW0 = sum_b Abar0_b^T [Xs_b;Xq_b]: 256 x 2048 outputs in 256 x 64 tiles, contraction over 32 x 185 rows in 16 slabs, fp32 MFMA 32x32x2)",
                                "avg_us": round(dur * 1e6, 2), "launches": n,
-                               "timed": f"HIP events around every {1 if a.all_phases else PROF_EVERY}th launch of the timed region"}
+                               "timed": f"HIP events around every {prof_every}th launch of the timed region"}
             out["phase_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items()}
+        if allreduce:
+            out["allreduce"] = allreduce
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(table)
         print(json.dumps(out), flush=True)

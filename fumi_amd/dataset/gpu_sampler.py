@@ -21,29 +21,50 @@ from .. import hip
 
 class GpuEpisodeSampler:
     def __init__(self, images, class_of_image, class_text, num_ways, num_shots, num_shots_test, batch_size, seed=123,
-                 length=None, zero_copy=False, row_ids=None):
+                 length=None, zero_copy=False, row_ids=None, skip_small_classes=False):
         """images [n_images, D] fp32 (moved to the device once), class_of_image [n_images] ints (category of every row, as
         inat_anim.json's annotations give it), class_text [C, Dt] fp32 or [C, L] int64 tokens (one row per class: the text of
         a sample is its class description, data.py:543-549).  row_ids [n_images] ints: the id reported for every table row in
-        the batch's index field (the dataset's image ids, data.py:568-571); default: the row number."""
-        self.dev = images.device if images.is_cuda else torch.device("cuda", torch.cuda.current_device())
-        self.images = images.to(self.dev, torch.float32).contiguous()
+        the batch's index field (the dataset's image ids, data.py:568-571); default: the row number.
+        A class with fewer than num_shots + num_shots_test images cannot fill an episode: torchmeta's ClassSplitter raises
+        ValueError when such a class is drawn, so the constructor raises it up front; ``skip_small_classes=True`` samples
+        among the classes that are large enough instead (the kernel never sees an under-populated class)."""
         coi = np.asarray(class_of_image, dtype=np.int64)
         C = int(class_text.shape[0])
-        if coi.min() < 0 or coi.max() >= C or len(coi) != self.images.shape[0]:
+        if coi.min() < 0 or coi.max() >= C or len(coi) != images.shape[0]:
             raise ValueError("class_of_image must hold one category in [0, C) per image row")
-        order = np.argsort(coi, kind="stable")
+        self.N, self.K, self.Q = int(num_ways), int(num_shots), int(num_shots_test)
         counts = np.bincount(coi, minlength=C)
+        small = np.flatnonzero(counts < self.K + self.Q)
+        self.class_ids = None                      # sampled class slot -> row of class_text (None: identity)
+        if small.size:
+            if not skip_small_classes:
+                raise ValueError(f"{small.size} of {C} classes (first: {int(small[0])} with {int(counts[small[0]])} images) have "
+                                 f"fewer than num_shots + num_shots_test = {self.K + self.Q} images; torchmeta's ClassSplitter "
+                                 f"raises for such a class -- pass skip_small_classes=True to sample among the others")
+            keep = np.flatnonzero(counts >= self.K + self.Q)
+            if keep.size < self.N:
+                raise ValueError("fewer than num_ways classes have num_shots + num_shots_test images")
+            self.class_ids = torch.from_numpy(keep.astype(np.int64))
+            rows = np.flatnonzero(np.isin(coi, keep))                      # table rows of the eligible classes, file order
+            order = rows[np.argsort(coi[rows], kind="stable")]
+            counts = counts[keep]
+        else:
+            order = np.argsort(coi, kind="stable")
+        self.C, self.B = len(counts), int(batch_size)
+        if self.C < self.N:
+            raise ValueError("fewer classes than num_ways")
         self.class_ptr_host = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         self.class_items_host = order.astype(np.int64)
+        self.dev = images.device if images.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        self.images = images.to(self.dev, torch.float32).contiguous()
         self.class_ptr = torch.from_numpy(self.class_ptr_host).to(self.dev)
         self.class_items = torch.from_numpy(self.class_items_host).to(self.dev)
         self.class_text = class_text.to(self.dev).contiguous()
-        self.C, self.N, self.K, self.Q, self.B = C, int(num_ways), int(num_shots), int(num_shots_test), int(batch_size)
+        if self.class_ids is not None:
+            self.class_ids = self.class_ids.to(self.dev)
         self.seed, self.length = int(seed), length
         self.zero_copy = bool(zero_copy)       # hand out RowRefs into the table instead of gathered image rows (FuMI engine only)
-        if counts[counts > 0].min() < self.K + self.Q and (counts >= self.K + self.Q).sum() < self.N:
-            raise ValueError("fewer than num_ways classes have num_shots + num_shots_test images")
         S, Qn = self.N * self.K, self.N * self.Q
         lab = torch.arange(self.N, device=self.dev, dtype=torch.int64)
         self.y_s = lab.repeat_interleave(self.K).unsqueeze(0).expand(self.B, S).contiguous()      # ConcatTask order
@@ -61,6 +82,8 @@ class GpuEpisodeSampler:
         else:
             x_s = hip.gather_rows(self.ws, self.images, it_s.view(-1)).view(B, N * K, -1)
             x_q = hip.gather_rows(self.ws, self.images, it_q.view(-1)).view(B, N * Q, -1)
+        if self.class_ids is not None:
+            cls = self.class_ids[cls]
         t_cls = hip.gather_rows(self.ws, self.class_text, cls.view(-1)).view(B, N, -1)           # one text row per class slot
         text_s = t_cls.repeat_interleave(K, dim=1)
         text_q = t_cls.repeat_interleave(Q, dim=1)

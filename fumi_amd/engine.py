@@ -51,7 +51,20 @@ class HipEngine:
 
     def check(self, device):
         """Synchronising validity check of the last calls (labels in range, every class has a support sample)."""
-        hip.raise_on_status(hip.Workspace.get(device).read_status())
+        device = torch.device(device)
+        if device.type == "cuda":
+            hip.raise_on_status(hip.Workspace.get(device).read_status())
+
+
+def check_status(device):
+    """Raise what the reference raises for an invalid episode.  The kernels record a label outside [0, N) or a class without
+    a support sample in the workspace's status word instead of faulting; the reference's per-class loop raises IndexError there
+    (fumi/models/fumi.py:209).  Reading the word synchronises the stream, so the loops call this where they wait for the
+    device anyway: at the end of every validation / test loop (which also covers the training steps before it) and before a
+    run ends."""
+    eng = get_engine()
+    if hasattr(eng, "check"):
+        eng.check(device)
 
 
 def get_engine():

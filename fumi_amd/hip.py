@@ -163,6 +163,24 @@ def _i64(t, name):
     return c_void_p(t.data_ptr())
 
 
+def _shape(t, shape, name):
+    """The kernels index raw pointers with the sizes they are told: a tensor of another shape would be read out of bounds (the
+    reference raises a matmul shape error there, e.g. an embedding file whose width differs from --im_emb_dim)."""
+    got = tuple(t.shape)
+    if got != tuple(shape):
+        raise FumiHipError(f"{name}: expected shape {tuple(shape)}, got {got}")
+
+
+def _mlp_shapes(params, D, name, n_layers):
+    d = D
+    for i in range(n_layers):
+        h = int(params[2 * i].shape[0])
+        _shape(params[2 * i], (h, d), f"{name}[{2 * i}] (weight of layer {i})")
+        _shape(params[2 * i + 1], (h,), f"{name}[{2 * i + 1}] (bias of layer {i})")
+        d = h
+    return d
+
+
 _PARR_CACHE = {}
 
 
@@ -305,6 +323,18 @@ def fumi_step_select(ws, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha
 def _fumi_step(ws, dev, B, N, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head,
                cls_text, text_s, need_grad, grad_scale, g_theta, g_phi, stats=None, dropout_p=0.0, seed=0):
     L = lib()
+    if len(theta) != 2 * len(hid) or len(phi) != 4 or not hid:
+        raise FumiHipError("fumi_step: theta must hold (weight, bias) per hidden layer and phi the 4 hypernetwork tensors")
+    H = _mlp_shapes(theta, D, "theta", len(hid))
+    _shape(phi[1], (Ht,), "phi[1]"); _shape(phi[2], (H + 1, Ht), "phi[2]"); _shape(phi[3], (H + 1,), "phi[3]")
+    _shape(x_q, (B, Qn, D), "x_q"); _shape(y_s, (B, S), "y_s"); _shape(y_q, (B, Qn), "y_q")
+    if cls_text is not None:
+        _shape(cls_text, (B, N, Dt), "cls_text")
+    else:
+        _shape(text_s, (B, S, Dt), "text_s")
+    if need_grad and g_theta is not None:
+        for i, (g, t) in enumerate(zip(list(g_theta) + list(g_phi or []), list(theta) + list(phi))):
+            _shape(g, t.shape, f"gradient buffer {i}")
     logits = torch.empty(B, Qn, N, device=dev, dtype=torch.float32)
     preds = torch.empty(B, Qn, device=dev, dtype=torch.int64)
     preds_f = torch.empty(B, Qn, device=dev, dtype=torch.float32)      # the reference's float test_preds, same launch
@@ -347,8 +377,16 @@ def maml_step(ws, x_s, y_s, x_q, y_q, params, T, alpha, first_order=False, *, ne
     B, S, D = x_s.shape
     Qn = x_q.shape[1]
     n_hidden = len(params) // 2 - 1
+    if n_hidden < 0 or len(params) != 2 * n_hidden + 2:
+        raise FumiHipError("maml_step: params must hold (weight, bias) per hidden layer, then lin_final's")
     hid = [int(params[2 * i].shape[0]) for i in range(n_hidden)]
     N = int(params[-2].shape[0])
+    H = _mlp_shapes(params, D, "params", n_hidden)
+    _shape(params[-2], (N, H), "params[-2] (lin_final.weight)"); _shape(params[-1], (N,), "params[-1] (lin_final.bias)")
+    _shape(x_q, (B, Qn, D), "x_q"); _shape(y_s, (B, S), "y_s"); _shape(y_q, (B, Qn), "y_q")
+    if need_grad and g_params is not None:
+        for i, (g, t) in enumerate(zip(g_params, params)):
+            _shape(g, t.shape, f"g_params[{i}]")
     logits = torch.empty(B, Qn, N, device=dev, dtype=torch.float32)
     preds = torch.empty(B, Qn, device=dev, dtype=torch.int64)
     preds_f = torch.empty(B, Qn, device=dev, dtype=torch.float32)      # the reference's float test_preds, same launch
@@ -382,7 +420,15 @@ def am3_step(ws, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed=None, *, need
     L = lib()
     B, S, D = x_s.shape
     Qn = x_q.shape[1]
+    if len(w) != 10:
+        raise FumiHipError("am3_step: w must hold the 10 tensors of AM3_KEYS")
     P, Ht, Dt = int(w[0].shape[0]), int(w[2].shape[0]), int(w[2].shape[1])
+    for t, shp, k in zip(w, [(P, D), (P,), (Ht, Dt), (Ht,), (P, Ht), (P,), (Ht, P), (Ht,), (1, Ht), (1,)], AM3_KEYS):
+        _shape(t, shp, f"w[{k}]")
+    _shape(x_q, (B, Qn, D), "x_q"); _shape(y_s, (B, S), "y_s"); _shape(y_q, (B, Qn), "y_q"); _shape(text_s, (B, S, Dt), "text_s")
+    if need_grad and g_w is not None:
+        for g, t, k in zip(g_w, w, AM3_KEYS):
+            _shape(g, t.shape, f"g_w[{k}]")
     loss = torch.empty(1, device=dev, dtype=torch.float32)
     correct = torch.empty(1, device=dev, dtype=torch.float32)
     preds = torch.empty(B, Qn, device=dev, dtype=torch.int64)

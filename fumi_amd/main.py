@@ -84,7 +84,7 @@ def main(args):
     if not args.evaluate:
         model = mod.training_run(args, model, optimizer, train_loader, val_loader, max_test_batches // 2)
 
-    out = mod.test_loop(args, model, test_loader, max_test_batches)
+    out = mod.test_loop(args, model, test_loader, max_test_batches)     # (ends with the device status check)
     names = _TEST_METRICS[family]
     values = dict(zip(names, out))
     print("\n TEST: \n" + ", ".join(f"test {k.replace('_', ' ')}: {v}" for k, v in values.items()))

@@ -205,5 +205,6 @@ def test_loop(args, model, test_dataloader, max_num_batches):
         support_lamdas += support_lamda.tolist()
         if batch_idx > max_num_batches - 1:
             break
+    _engine.check_status(args.device)
     return (m_loss.avg, m_acc.avg, m_f1.avg, m_prec.avg, m_rec.avg, m_lam.avg, test_preds, test_trues, query_idx,
             support_idx, support_lamdas)

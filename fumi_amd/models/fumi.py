@@ -253,6 +253,7 @@ def test_loop(args, model, test_loader, max_num_batches):
         test_targets.append(target)
         if batch_idx > max_num_batches - 1:
             break
+    _engine.check_status(args.device)            # IndexError for an episode the reference would have refused (fumi.py:209)
     return avg_test_loss.avg, avg_test_acc.avg, test_preds, test_targets
 
 

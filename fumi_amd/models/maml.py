@@ -113,6 +113,7 @@ def test_loop(args, model, test_loader, max_num_batches):
         avg_test_loss.update(test_loss)
         if batch_idx > max_num_batches - 1:
             break
+    _engine.check_status(args.device)            # labels outside [0, n_way) are an IndexError in the reference's cross_entropy
     return avg_test_loss.avg, avg_test_acc.avg
 
 

@@ -138,13 +138,20 @@ def init_optim(args, model):
 
 # ---- checkpoints (utils.py:406-441): same dictionary keys, same ckpt/best file names ---------------------------------
 def save_checkpoint(checkpoint_dict, is_best):
-    ckpt = os.path.join(wandb.run.dir, "ckpt.pth.tar")
-    best = os.path.join(wandb.run.dir, "best.pth.tar")
-    torch.save(checkpoint_dict, ckpt)
-    wandb.save(ckpt)
-    if is_best:
-        shutil.copyfile(ckpt, best)
-        wandb.save(best)
+    """fumi/utils/utils.py:406-419.  Episode-sharded runs keep replicated parameters, so rank 0 alone writes; the others wait
+    (the best checkpoint is reloaded by every rank at the end of training)."""
+    import torch.distributed as dist
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not sharded or dist.get_rank() == 0:
+        ckpt = os.path.join(wandb.run.dir, "ckpt.pth.tar")
+        best = os.path.join(wandb.run.dir, "best.pth.tar")
+        torch.save(checkpoint_dict, ckpt)
+        wandb.save(ckpt)
+        if is_best:
+            shutil.copyfile(ckpt, best)
+            wandb.save(best)
+    if sharded:
+        dist.barrier()
 
 
 def load_checkpoint(model, optimizer, device, checkpoint_file):

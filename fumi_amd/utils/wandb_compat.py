@@ -25,23 +25,44 @@ class LocalWandb:
         self.run = None
         self.config = _Config()
         self._fh = None
+        self._pending = None
         self._n_runs = 0
 
     def init(self, entity=None, project=None, group=None, job_type=None, save_code=False, dir=None, **kw):
         root = dir or os.environ.get("FUMI_LOG_DIR", "./results")
         self._n_runs += 1                   # two runs of one process within a second must not share a checkpoint directory
-        self.run = _LocalRun(os.path.join(root, "runs"), f"{job_type or 'run'}-{int(time.time())}-{os.getpid()}-{self._n_runs}")
-        self._fh = open(os.path.join(self.run.dir, "metrics.jsonl"), "a")
+        name = f"{job_type or 'run'}-{int(time.time())}-{os.getpid()}-{self._n_runs}"
+        rank = 0
+        try:                                # episode-sharded runs: ONE run directory, named by rank 0; only rank 0 writes metrics
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                rank = dist.get_rank()
+                box = [name]
+                dist.broadcast_object_list(box, src=0)
+                name = box[0]
+        except ImportError:                 # pragma: no cover
+            pass
+        self.run = _LocalRun(os.path.join(root, "runs"), name)
+        self._pending = None
+        self._fh = open(os.path.join(self.run.dir, "metrics.jsonl"), "a") if rank == 0 else None
         return self.run
 
-    def log(self, metrics, step=None):
-        if self._fh is None:
-            return
+    def _write(self, metrics, step):
         rec = {k: (float(v) if hasattr(v, "__float__") else str(v)) for k, v in metrics.items()}
         if step is not None:
             rec["_step"] = int(step)
         self._fh.write(json.dumps(rec) + "\n")
         self._fh.flush()
+
+    def log(self, metrics, step=None):
+        """Written one call late: the values of a training step are lazy scalars (fumi_amd/lazy.py) that wait for the GPU when
+        first read -- converting them right away would make every step host-synchronous.  By the next call the step they
+        belong to has long finished; ``finish`` writes the last record."""
+        if self._fh is None:
+            return
+        prev, self._pending = self._pending, (dict(metrics), step)
+        if prev is not None:
+            self._write(*prev)
 
     def watch(self, *a, **k):
         pass
@@ -54,6 +75,9 @@ class LocalWandb:
 
     def finish(self):
         if self._fh is not None:
+            if self._pending is not None:
+                self._write(*self._pending)
+                self._pending = None
             self._fh.close()
             self._fh = None
 

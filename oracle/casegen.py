@@ -147,6 +147,8 @@ FUMI_CASES = {
     "fumi_3layer":    dict(B=2, N=3, K=4, Q=3, D=40, hid=[24, 16, 8], Dt=16, Ht=12, T=2, tanh=False, init_bias=False, blocked=False),
     "fumi_20way":     dict(B=2, N=20, K=5, Q=3, D=96, hid=[48, 24], Dt=32, Ht=24, T=2, tanh=True, init_bias=False, blocked=False),
     "fumi_default":   dict(B=2, N=5, K=5, Q=4, D=2048, hid=[256, 64], Dt=768, Ht=256, T=5, tanh=False, init_bias=False, blocked=False),
+    # BASELINE.json configs[2] per-rank episode shape: 32 query/class, 5 inner steps, BERT-width text
+    "fumi_default_t5_q32": dict(B=2, N=5, K=5, Q=32, D=2048, hid=[256, 64], Dt=768, Ht=256, T=5, tanh=False, init_bias=False, blocked=False),
     "fumi_default_t1": dict(B=2, N=5, K=5, Q=32, D=2048, hid=[256, 64], Dt=768, Ht=256, T=1, tanh=True, init_bias=False, blocked=True),
 }
 MAML_CASES = {

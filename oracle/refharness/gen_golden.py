@@ -206,14 +206,20 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ref_fumi, ref_maml, ref_am3, ref_utils, ref_common = stubs.import_reference()
     torch.set_num_threads(1)                  # deterministic summation order for the fixtures
+    only = set(sys.argv[1:])                  # optional: names of the cases to (re)generate; default every fixture
     for name, c in cg.FUMI_CASES.items():
-        gen_fumi(ref_fumi, name, c)
+        if not only or name in only:
+            gen_fumi(ref_fumi, name, c)
     for name, c in cg.MAML_CASES.items():
-        gen_maml(ref_maml, name, c)
+        if not only or name in only:
+            gen_maml(ref_maml, name, c)
     for name, c in cg.AM3_CASES.items():
-        gen_am3(ref_am3, name, c)
-    gen_wordemb(ref_common)
-    gen_surface(ref_fumi, ref_maml, ref_am3, ref_utils)
+        if not only or name in only:
+            gen_am3(ref_am3, name, c)
+    if not only or "wordemb" in only:
+        gen_wordemb(ref_common)
+    if not only or "surface" in only:
+        gen_surface(ref_fumi, ref_maml, ref_am3, ref_utils)
 
 
 if __name__ == "__main__":

@@ -48,14 +48,18 @@ def _step_gpu(kind, c, ep, m, dev):
     return np.array(stats), params, extra
 
 
-def _worker(rank, world, port, kind, out_dir):
+def _worker(rank, world, port, kind, out_dir, backend="gloo"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)      # RCCL: one device per rank
     torch.cuda.set_device(dev)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         c, ep, m = _build(kind)
         stats, params, extra = _step_gpu(kind, c, ep, m, dev)
@@ -78,3 +82,21 @@ def test_two_rank_sharded_gpu_step_equals_single_process(kind, tmp_path):
     np.testing.assert_allclose(r0["stats"], ref_stats, rtol=0, atol=2e-5)
     np.testing.assert_array_equal(r0["stats"], r1["stats"])
     np.testing.assert_array_equal(r0["extra"], ref_extra)                  # gathered test-time predictions, full batch
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL path needs two GPUs (one rank per device)")
+@pytest.mark.parametrize("kind", ["fumi"])
+def test_two_rank_rccl_step_equals_single_process(kind, tmp_path):
+    """The production backend: `nccl` (= RCCL over xGMI), one rank per GPU, three training steps + a test step against one
+    process on the same meta-batch.  Skipped on the one-GPU test box; runs wherever two devices are visible."""
+    dev = torch.device("cuda", 0)
+    c, ep, m = _build(kind)
+    ref_stats, ref_params, ref_extra = _step_gpu(kind, c, ep, m, dev)
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, kind, str(tmp_path), "nccl"), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    np.testing.assert_array_equal(r0["params"], r1["params"])
+    np.testing.assert_allclose(r0["params"], ref_params, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(r0["stats"], ref_stats, rtol=0, atol=2e-5)
+    np.testing.assert_array_equal(r0["extra"], ref_extra)

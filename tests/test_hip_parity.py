@@ -217,6 +217,57 @@ def test_fumi_full_size_against_oracle(dev, ws):
     _check_grads([str(i) for i in range(8)], out["g_theta"] + out["g_phi"], None, ref["g_theta"] + ref["g_phi"])
 
 
+def test_fumi_configs1_glove_tokens_end_to_end_against_oracle(dev, ws):
+    """BASELINE.json configs[1] as the bench runs it, on a reduced meta-batch: token ids [B,S,L=128] -> select + GloVe bag
+    (fumi_hip_glove_bag_select) -> hypernetwork -> 1 inner step -> query loss -> all eight meta-gradients, against the oracle fed
+    the same tokens (common.py:23-41 pooling of every support row, then fumi.py:207-210)."""
+    from fumi_amd import hip
+    B, N, K, Q, D, hid, E, Ht, T, V, L = 4, 5, 5, 32, 2048, [256, 64], 300, 256, 1, 20000, 128
+    ep = cg.make_episodes(311, B, N, K, Q, D, 1, tokens=(V, L, 0))
+    theta, phi = cg.make_fumi_params(311, D, hid, E, Ht)
+    table = torch.rand(V, E, generator=torch.Generator().manual_seed(311)) * 2 - 1
+    table[0] = 0
+    cls_text = hip.glove_bag_select(ws, _g(ep["text_s"], dev), _g(ep["y_s"], dev), N, _g(table, dev), 0, "mean")
+    out = hip.fumi_step(ws, _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev),
+                        [_g(t, dev) for t in theta], [_g(t, dev) for t in phi], T, cg.ALPHA, False, cls_text=cls_text)
+    assert ws.read_status() == 0
+    th = [t.clone().requires_grad_(True) for t in theta]
+    ph = [t.clone().requires_grad_(True) for t in phi]
+    text = R.word_embedding_pool(ep["text_s"], table, 0, "mean")
+    ref = R.fumi_meta_step(th, ph, text, ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], N, T, cg.ALPHA, False)
+    assert rel_to_max(out["logits"].cpu(), ref["logits"]) <= LOGIT_TOL
+    assert rel_to_max(out["loss_b"].cpu(), ref["loss_b"]) <= LOGIT_TOL
+    mask = safe_margin_mask(ref["logits"], MARGIN)
+    assert float(mask.float().mean()) > 0.99 and torch.equal(out["preds"].cpu()[mask], ref["preds"][mask])
+    _check_grads([str(i) for i in range(8)], out["g_theta"] + out["g_phi"], None, ref["g_theta"] + ref["g_phi"])
+
+
+@pytest.mark.parametrize("which", ["label_range", "class_missing"])
+def test_invalid_episode_raises_index_error_in_the_loops(which, dev, ws):
+    """The reference raises IndexError for a class without a support sample (fumi.py:209) and for a label outside [0, N)
+    (cross_entropy).  The kernels flag such an episode in the status word; test_loop reads it where it synchronises anyway."""
+    from types import SimpleNamespace
+    from fumi_amd.models import fumi as F
+    c = cg.FUMI_CASES["fumi_t1"]
+    ep = cg.make_episodes(5, 2, c["N"], c["K"], c["Q"], c["D"], c["Dt"])
+    torch.manual_seed(0)
+    m = F.FUMI(n_way=c["N"], im_emb_dim=c["D"], im_hid_dim=c["hid"], text_emb_dim=c["Dt"], text_hid_dim=c["Ht"],
+               norm_hypernet=False).to(dev)
+    args = SimpleNamespace(device=dev, num_train_adapt_steps=1, num_test_adapt_steps=1, step_size=cg.ALPHA, first_order=False,
+                           batch_size=2, num_ways=c["N"])
+    ws.read_status()
+    loss, acc, _, _ = F.test_loop(args, m, [cg.to_batch(ep)], 1)                       # a valid batch passes
+    assert np.isfinite(float(loss))
+    bad = {k: v.clone() for k, v in ep.items()}
+    if which == "label_range":
+        bad["y_q"][1, 3] = c["N"]
+    else:
+        bad["y_s"][bad["y_s"] == 2] = 3
+    with pytest.raises(IndexError):
+        F.test_loop(args, m, [cg.to_batch(bad)], 1)
+    assert ws.read_status() == 0                                                     # the word was cleared by the check
+
+
 def test_fumi_linearity_in_grad_scale_and_episode_sum(dev, ws):
     """Size-independent properties at the bench size (B=32): (1) gradients are linear in grad_scale; (2) the
     gradient of a meta-batch is the sum of the gradients of its two halves (what the multi-GPU sharding relies on);
@@ -250,6 +301,29 @@ def test_engine_rejects_cpu_tensors(dev, ws):
     from fumi_amd import hip
     with pytest.raises(hip.FumiHipError):
         hip.linear_fwd(ws, torch.zeros(2, 2), torch.zeros(2, 2))
+
+
+def test_engine_rejects_mismatched_shapes(dev, ws):
+    """A width that does not match (an embedding file other than --im_emb_dim, a wrong --text_emb_dim) must raise on the host:
+    the kernels would read past the end of the buffers (the reference raises a matmul shape error)."""
+    from fumi_amd import hip
+    c = cg.FUMI_CASES["fumi_t1"]
+    ep = cg.make_episodes(1, 2, c["N"], c["K"], c["Q"], c["D"], c["Dt"])
+    theta, phi = cg.make_fumi_params(1, c["D"], c["hid"], c["Dt"], c["Ht"])
+    th, ph = [_g(t, dev) for t in theta], [_g(t, dev) for t in phi]
+    a = dict(x_s=_g(ep["x_s"], dev), y_s=_g(ep["y_s"], dev), x_q=_g(ep["x_q"], dev), y_q=_g(ep["y_q"], dev), text_s=_g(ep["text_s"], dev))
+    run = lambda **k: hip.fumi_step_select(ws, c["N"], k.get("x_s", a["x_s"]), k.get("y_s", a["y_s"]), k.get("x_q", a["x_q"]),
+                                           k.get("y_q", a["y_q"]), k.get("text_s", a["text_s"]), k.get("th", th), k.get("ph", ph),
+                                           1, cg.ALPHA, False)
+    run()
+    for bad in (dict(x_q=a["x_q"][..., :-1].contiguous()), dict(text_s=a["text_s"][..., :-2].contiguous()),
+                dict(y_q=a["y_q"][:, :-1].contiguous()), dict(th=[th[0], th[1], th[2][:, :-1].contiguous(), th[3]]),
+                dict(ph=[ph[0], ph[1], ph[2][:-1].contiguous(), ph[3]])):
+        with pytest.raises(hip.FumiHipError, match="expected shape"):
+            run(**bad)
+    p = [_g(t, dev) for t in cg.make_maml_params(1, c["D"], c["hid"], c["N"])]
+    with pytest.raises(hip.FumiHipError, match="expected shape"):
+        hip.maml_step(ws, a["x_s"], a["y_s"], a["x_q"][..., :-1].contiguous(), a["y_q"], p, 1, cg.ALPHA)
 
 
 @pytest.mark.parametrize("name", list(cg.AM3_CASES))

@@ -2,6 +2,7 @@
 optimizer step, checkpoints, CLI) with the oracle standing in for the GPU engine (tests/oracle_engine.py)."""
 import json
 import os
+import sys
 from types import SimpleNamespace
 
 import numpy as np
@@ -248,3 +249,31 @@ def test_fumi_glove_path_uses_class_rows_only(oracle_engine):
     ph = [p.detach().clone().requires_grad_(True) for p in m._phi()]
     ref = R.fumi_meta_step(th, ph, text, ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], c["N"], 2, cg.ALPHA, False, need_grad=False)
     assert abs(float(loss) - float(ref["loss"])) < 1e-5 and np.array_equal(preds.numpy().astype(np.int64), ref["preds"].numpy())
+
+
+def test_bench_self_launches_one_process_per_gpu(monkeypatch, capsys):
+    """`python bench.py --gpus N` (how the driver calls it) starts torch.distributed.run as a CHILD process with N ranks and
+    returns its exit code; the parent never touches the GPU.  (The child is faked here: no GPU in the CPU suite.)"""
+    import subprocess
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "5", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)          # not enough devices: refuse, exit code 2
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 2

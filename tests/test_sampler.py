@@ -201,3 +201,40 @@ def test_zero_copy_sampler_trains_like_the_gathering_one():
         opt = U.init_optim(args, model)
         losses[zc] = [float(model.evaluate(args, smp.batch(i), opt, "train")[0]) for i in range(30)]
     assert losses[True] == losses[False]                                # identical trajectories, bit for bit
+
+
+def test_gpu_sampler_refuses_underpopulated_classes():
+    """torchmeta's ClassSplitter raises ValueError for a class with fewer than K + Q images; the resident sampler raises it in
+    its constructor (before touching the GPU) instead of wrapping indices and leaking support rows into the query set."""
+    from fumi_amd.dataset.gpu_sampler import GpuEpisodeSampler
+    coi = np.concatenate([np.repeat(np.arange(6), 20), np.repeat([6], 5)])          # class 6 has 5 images, class 7 none
+    images, text = torch.zeros(len(coi), 8), torch.zeros(8, 4)
+    with pytest.raises(ValueError, match="fewer than num_shots"):
+        GpuEpisodeSampler(images, coi, text, num_ways=5, num_shots=5, num_shots_test=8, batch_size=2)
+    with pytest.raises(ValueError, match="fewer than num_ways classes"):
+        GpuEpisodeSampler(images, coi, text, num_ways=7, num_shots=5, num_shots_test=8, batch_size=2, skip_small_classes=True)
+
+
+@pytest.mark.gpu
+def test_gpu_sampler_skips_small_classes_on_request():
+    from fumi_amd import hip
+    from fumi_amd.dataset.gpu_sampler import GpuEpisodeSampler
+    rs = np.random.RandomState(5)
+    coi = np.concatenate([np.repeat(np.arange(6), 20), np.repeat([6], 5), np.repeat([8], 30)]); rs.shuffle(coi)   # 6 small, 7 empty
+    images = torch.from_numpy(rs.standard_normal((len(coi), 16)).astype(np.float32))
+    text = torch.arange(9, dtype=torch.float32)[:, None].repeat(1, 4)
+    smp = GpuEpisodeSampler(images, coi, text, num_ways=5, num_shots=5, num_shots_test=8, batch_size=16, seed=1,
+                            skip_small_classes=True)
+    seen = set()
+    for step in range(8):
+        b = smp.batch(step)
+        (idx_s, text_s, x_s), _ = b['train']
+        (idx_q, text_q, x_q), _ = b['test']
+        cls_s, cls_q = torch.from_numpy(coi)[idx_s.cpu()], torch.from_numpy(coi)[idx_q.cpu()]
+        assert torch.equal(text_s[..., 0].cpu(), cls_s.float()) and torch.equal(text_q[..., 0].cpu(), cls_q.float())
+        for e in range(16):                               # support and query never share an image
+            assert not set(idx_s[e].tolist()) & set(idx_q[e].tolist())
+            assert len(set(idx_s[e].tolist())) == 25 and len(set(idx_q[e].tolist())) == 40
+        seen |= set(cls_s.unique().tolist())
+    assert seen <= {0, 1, 2, 3, 4, 5, 8} and 8 in seen
+    assert hip.Workspace.get(torch.device("cuda:0")).read_status() == 0
