@@ -1,0 +1,655 @@
+// Meta-step with the Conv4 image encoder at the im_net seam (fumi/models/fumi.py:89-100 is the seam; the inner loop, the
+// query loss and the second-order outer gradient are fumi.py:146-192 / maml.py:156-191).  Every launch covers all B episodes
+// of the meta-batch with per-episode fast weights.  Algorithm = oracle/conv4_manual.py (forward-over-reverse second order):
+//
+//   for t < T:   forward(theta_t) -> tape_t;  backward -> g_t;  theta_{t+1} = theta_t - alpha g_t          (support set)
+//   query:       forward(theta_T) -> logits, loss;  backward -> bar_T = d loss / d theta_T
+//   for t = T-1 .. 0:  bar_t = bar_{t+1} - alpha H_t bar_{t+1}   (one tangent forward + one tangent backward over tape_t)
+//   g_theta = grad_scale * sum_b bar_0[b];   head_bar = bar_0 of the head (handed to the hypernetwork / lin_final).
+//
+// HBM is the tape: 288 GB hold every pre-activation, pooled activation and their gradients of every inner step (6.5 MB per
+// 84 x 84 image and step), nothing is recomputed except the arg-max of the pooling windows.
+#include "conv4.h"
+#include <string.h>
+#include <functional>
+
+namespace {
+
+struct Net {
+    int B, nblk, Cin, N, F;
+    CvGeom g[CV_MAXBLK];
+    int Ho[CV_MAXBLK], Wo[CV_MAXBLK];
+    long PSZ, FSZ;                                   // floats per episode: parameter slab, fragment slab
+    long offW[CV_MAXBLK], offG[CV_MAXBLK], offB[CV_MAXBLK];     // within a parameter slab
+    long fF[CV_MAXBLK], fB[CV_MAXBLK];               // within a fragment slab (forward / backward-data order)
+};
+
+static int net_init(Net& n, int B, int nblk, int Cin, int N, int H, int W) {
+    if (nblk < 1 || nblk > CV_MAXBLK || Cin < 1 || Cin > 3 || B < 1 || N < 1) return FUMI_EINVAL;
+    n.B = B; n.nblk = nblk; n.Cin = Cin; n.N = N;
+    long po = 0, fo = 0;
+    for (int l = 0; l < nblk; ++l) {
+        if (H < 2 || W < 2) return FUMI_EINVAL;
+        n.g[l] = cv_geom(H, W);
+        if ((size_t)(CV_TILE + 2 * n.g[l].halo) * 256 > 160 * 1024) return FUMI_ENOTSUP;
+        n.Ho[l] = H / 2; n.Wo[l] = W / 2;
+        n.offW[l] = po; po += l == 0 ? 2048 : 36864;
+        n.offG[l] = po; po += 64;
+        n.offB[l] = po; po += 64;
+        if (l == 0) { n.fF[0] = fo; n.fB[0] = -1; fo += (cv_frag1_floats(Cin) + 63) / 64 * 64; }
+        else { n.fF[l] = fo; fo += CV_WFRAG; n.fB[l] = fo; fo += CV_WFRAG; }
+        H /= 2; W /= 2;
+    }
+    n.PSZ = po; n.FSZ = fo;
+    n.F = 64 * n.Ho[nblk - 1] * n.Wo[nblk - 1];
+    return FUMI_OK;
+}
+
+// buffers of one pass over M images per episode (a support step's tape, or the query pass)
+struct PassBufs {
+    int M;
+    float* u[CV_MAXBLK]; float* x[CV_MAXBLK]; float* du[CV_MAXBLK]; float* dx[CV_MAXBLK]; float* coef[CV_MAXBLK];
+    float* z; float* p; float* dz;
+};
+// tangent scratch (support-sized)
+struct TanBufs { float* ud[CV_MAXBLK]; float* xd[CV_MAXBLK]; float* dud[CV_MAXBLK]; float* dxd[CV_MAXBLK]; float* dzd; };
+
+static size_t act_floats(const Net& n, int M, int l) { return (size_t)n.B * M * n.g[l].Pp * 64; }
+static size_t out_floats(const Net& n, int M, int l) {          // pooled output of block l
+    return l + 1 < n.nblk ? (size_t)n.B * M * n.g[l + 1].Pp * 64 : (size_t)n.B * M * n.F;
+}
+static size_t pass_bytes(const Net& n, int M, bool bwd) {
+    size_t b = 0;
+    for (int l = 0; l < n.nblk; ++l) {
+        b += ws_align(act_floats(n, M, l) * 4) * (bwd ? 2 : 1) + ws_align(out_floats(n, M, l) * 4) * (bwd ? 2 : 1);
+        b += ws_align((size_t)n.B * CF_N * 64 * 4);
+    }
+    return b + 3 * ws_align((size_t)n.B * M * n.N * 4);
+}
+static void pass_carve(fumi_ws* ws, const Net& n, int M, bool bwd, PassBufs& pb) {
+    pb.M = M;
+    for (int l = 0; l < n.nblk; ++l) {
+        pb.u[l] = ws_f(ws, act_floats(n, M, l));
+        pb.x[l] = ws_f(ws, out_floats(n, M, l));
+        pb.du[l] = bwd ? ws_f(ws, act_floats(n, M, l)) : nullptr;
+        pb.dx[l] = bwd ? ws_f(ws, out_floats(n, M, l)) : nullptr;
+        pb.coef[l] = ws_f(ws, (size_t)n.B * CF_N * 64);
+    }
+    pb.z = ws_f(ws, (size_t)n.B * M * n.N); pb.p = ws_f(ws, (size_t)n.B * M * n.N); pb.dz = ws_f(ws, (size_t)n.B * M * n.N);
+}
+static size_t tan_bytes(const Net& n, int M) {
+    size_t b = 0;
+    for (int l = 0; l < n.nblk; ++l) b += 2 * ws_align(act_floats(n, M, l) * 4) + 2 * ws_align(out_floats(n, M, l) * 4);
+    return b + ws_align((size_t)n.B * M * n.N * 4);
+}
+static void tan_carve(fumi_ws* ws, const Net& n, int M, TanBufs& tb) {
+    for (int l = 0; l < n.nblk; ++l) {
+        tb.ud[l] = ws_f(ws, act_floats(n, M, l)); tb.xd[l] = ws_f(ws, out_floats(n, M, l));
+        tb.dud[l] = ws_f(ws, act_floats(n, M, l)); tb.dxd[l] = ws_f(ws, out_floats(n, M, l));
+    }
+    tb.dzd = ws_f(ws, (size_t)n.B * M * n.N);
+}
+
+struct Scratch { float* cpart; float* wpart; float* rpart; size_t cpart_n, wpart_n, rpart_n; };
+
+static EwGeom ew_geom(const Net& n, int M, int l) {
+    EwGeom e; e.B = n.B; e.M = M; e.g = n.g[l]; e.Ho = n.Ho[l]; e.Wo = n.Wo[l];
+    e.last = l + 1 == n.nblk;
+    e.gn = e.last ? n.g[l] : n.g[l + 1];
+    return e;
+}
+
+#define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+// the fragment-order copies of one parameter slot (block 1's canonical weights are gathered into a dense temporary first)
+static int frags_of_slot(hipStream_t st, const Net& n, const float* params, float* frags, float* tmp1 /*[B][2048+frag1]*/) {
+    // block 1: gather the strided canonical weights into a dense temp, build, scatter back (tiny)
+    const int nf1 = cv_frag1_floats(n.Cin);
+    float* dense = tmp1; float* fdense = tmp1 + (size_t)n.B * 2048;
+    HIP_TRY(hipMemcpy2DAsync(dense, 2048 * 4, params + n.offW[0], n.PSZ * 4, 2048 * 4, n.B, hipMemcpyDeviceToDevice, st));
+    TRY(launch_wfrag1(st, n.B, n.Cin, dense, fdense));
+    HIP_TRY(hipMemcpy2DAsync(frags + n.fF[0], n.FSZ * 4, fdense, (size_t)nf1 * 4, (size_t)nf1 * 4, n.B, hipMemcpyDeviceToDevice, st));
+    for (int l = 1; l < n.nblk; ++l)
+        TRY(launch_wfrag64(st, n.B, params + n.offW[l], n.PSZ, frags + n.fF[l], frags + n.fB[l], n.FSZ));
+    return FUMI_OK;
+}
+
+struct StepCtx {
+    fumi_ws* ws; hipStream_t st; Net n; Scratch sc;
+    const float* img_s; const float* img_q; const int64_t* y_s; const int64_t* y_q;
+    int S, Qn;
+};
+
+static int forward_pass(StepCtx& c, int M, const float* img, const float* params, const float* frags, PassBufs& pb,
+                        const float* head, const int64_t* y, float scale, float* logits, int64_t* preds, float* preds_f,
+                        float* loss_b, float* acc_b) {
+    const Net& n = c.n;
+    for (int l = 0; l < n.nblk; ++l) {
+        const long npix = (long)M * n.g[l].Pp;
+        const int tiles = cv_tiles(npix);
+        if (l == 0) {
+            Conv1Args a; a.B = n.B; a.M = M; a.Cin = n.Cin; a.g = n.g[0]; a.img = img; a.frag = frags + n.fF[0]; a.frag_stride = n.FSZ;
+            a.out = pb.u[0]; a.stats = c.sc.cpart; a.dot = nullptr;
+            TRY(launch_conv1(c.st, a));
+        } else {
+            Conv64Args a; a.B = n.B; a.nsrc = 1; a.npix = npix; a.g = n.g[l];
+            a.in[0] = pb.x[l - 1]; a.frag[0] = frags + n.fF[l]; a.frag_stride[0] = n.FSZ; a.in[1] = nullptr; a.frag[1] = nullptr; a.frag_stride[1] = 0;
+            a.out = pb.u[l]; a.stats = c.sc.cpart; a.dot = nullptr;
+            TRY(launch_conv64(c.st, a));
+        }
+        CoefArgs ca; memset(&ca, 0, sizeof(ca));
+        ca.B = n.B; ca.mode = CFM_FWD; ca.nt = tiles; ca.K = 2; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
+        ca.part = c.sc.cpart; ca.coef = pb.coef[l]; ca.g = params + n.offG[l]; ca.beta = params + n.offB[l]; ca.pstride = n.PSZ;
+        TRY(launch_coef(c.st, ca));
+        PoolFwdArgs pa; pa.e = ew_geom(n, M, l); pa.u = pb.u[l]; pa.ud = nullptr; pa.coef = pb.coef[l]; pa.x = pb.x[l]; pa.xd = nullptr;
+        TRY(launch_pool_fwd(c.st, pa, 0));
+    }
+    HeadArgs h; memset(&h, 0, sizeof(h));
+    h.B = n.B; h.M = M; h.N = n.N; h.F = n.F; h.scale = scale; h.f = pb.x[n.nblk - 1]; h.head = head; h.y = y;
+    h.z = logits ? logits : pb.z; h.p = pb.p; h.dz = pb.dz; h.preds = preds; h.preds_f = preds_f; h.loss_b = loss_b; h.acc_b = acc_b;
+    h.status = c.ws->status;
+    return launch_head_logits(c.st, h);
+}
+
+// gradient of the pass's loss w.r.t. (parameter slab, head): G [B][PSZ], dh [B][N][F+1]
+static int backward_pass(StepCtx& c, int M, const float* img, const float* frags, PassBufs& pb, const float* head,
+                         float* G, float* dh) {
+    const Net& n = c.n;
+    HeadGradArgs hg; memset(&hg, 0, sizeof(hg));
+    hg.B = n.B; hg.M = M; hg.N = n.N; hg.F = n.F; hg.nsrc = 1; hg.dz[0] = pb.dz; hg.f[0] = pb.x[n.nblk - 1]; hg.head[0] = head;
+    hg.dh = dh; hg.df = pb.dx[n.nblk - 1];
+    TRY(launch_head_grad(c.st, hg));
+    for (int l = n.nblk - 1; l >= 0; --l) {
+        const EwGeom e = ew_geom(n, M, l);
+        const long npix = (long)M * n.g[l].Pp;
+        BwdRedArgs ra; ra.e = e; ra.u = pb.u[l]; ra.ud = nullptr; ra.dxo = pb.dx[l]; ra.dxod = nullptr; ra.coef = pb.coef[l];
+        ra.part = c.sc.rpart; ra.nt = ew_bwd_red_nt(e);
+        TRY(launch_bwd_reduce(c.st, ra, 0));
+        CoefArgs ca; memset(&ca, 0, sizeof(ca));
+        ca.B = n.B; ca.mode = CFM_BWD; ca.nt = ra.nt; ca.K = 2; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
+        ca.part = c.sc.rpart; ca.coef = pb.coef[l]; ca.dg = G + n.offG[l]; ca.dbeta = G + n.offB[l]; ca.gstride = n.PSZ;
+        TRY(launch_coef(c.st, ca));
+        BwdApplyArgs aa; aa.e = e; aa.u = pb.u[l]; aa.ud = nullptr; aa.dxo = pb.dx[l]; aa.dxod = nullptr; aa.coef = pb.coef[l]; aa.du = pb.du[l];
+        TRY(launch_bwd_apply(c.st, aa, 0));
+        const int ns = cv_wgrad_nsplit(n.B, npix);
+        if (l == 0) {
+            Wgrad1Args wa; wa.B = n.B; wa.M = M; wa.Cin = n.Cin; wa.nsplit = ns; wa.g = n.g[0]; wa.img = img; wa.dy = pb.du[0]; wa.part = c.sc.wpart;
+            TRY(launch_wgrad1(c.st, wa));
+            TRY(launch_reduce_batched(c.st, n.B, ns, 2048, c.sc.wpart, 1.f, G + n.offW[0], n.PSZ));
+        } else {
+            Wgrad64Args wa; wa.B = n.B; wa.nsrc = 1; wa.nsplit = ns; wa.npix = npix; wa.g = n.g[l];
+            wa.x[0] = pb.x[l - 1]; wa.dy[0] = pb.du[l]; wa.x[1] = nullptr; wa.dy[1] = nullptr; wa.part = c.sc.wpart;
+            TRY(launch_wgrad64(c.st, wa));
+            TRY(launch_reduce_batched(c.st, n.B, ns, 36864, c.sc.wpart, 1.f, G + n.offW[l], n.PSZ));
+            Conv64Args a; a.B = n.B; a.nsrc = 1; a.npix = npix; a.g = n.g[l];
+            a.in[0] = pb.du[l]; a.frag[0] = frags + n.fB[l]; a.frag_stride[0] = n.FSZ; a.in[1] = nullptr; a.frag[1] = nullptr; a.frag_stride[1] = 0;
+            a.out = pb.dx[l - 1]; a.stats = nullptr; a.dot = nullptr;
+            TRY(launch_conv64(c.st, a));
+        }
+    }
+    return FUMI_OK;
+}
+
+// HV [B][PSZ], HVh [B][N][F+1] = Hessian of the support loss at the tape's parameters times (V, Vh)
+static int hvp_pass(StepCtx& c, int M, const float* img, const float* frags, PassBufs& pb, TanBufs& tb, const float* head,
+                    const float* V, const float* Vfrags, const float* Vh, float scale, float* HV, float* HVh) {
+    const Net& n = c.n;
+    // ---- tangent forward
+    for (int l = 0; l < n.nblk; ++l) {
+        const long npix = (long)M * n.g[l].Pp;
+        const int tiles = cv_tiles(npix);
+        if (l == 0) {
+            Conv1Args a; a.B = n.B; a.M = M; a.Cin = n.Cin; a.g = n.g[0]; a.img = img; a.frag = Vfrags + n.fF[0]; a.frag_stride = n.FSZ;
+            a.out = tb.ud[0]; a.stats = c.sc.cpart; a.dot = pb.u[0];
+            TRY(launch_conv1(c.st, a));
+        } else {
+            Conv64Args a; a.B = n.B; a.nsrc = 2; a.npix = npix; a.g = n.g[l];
+            a.in[0] = pb.x[l - 1]; a.frag[0] = Vfrags + n.fF[l]; a.frag_stride[0] = n.FSZ;
+            a.in[1] = tb.xd[l - 1]; a.frag[1] = frags + n.fF[l]; a.frag_stride[1] = n.FSZ;
+            a.out = tb.ud[l]; a.stats = c.sc.cpart; a.dot = pb.u[l];
+            TRY(launch_conv64(c.st, a));
+        }
+        CoefArgs ca; memset(&ca, 0, sizeof(ca));
+        ca.B = n.B; ca.mode = CFM_TFWD; ca.nt = tiles; ca.K = 2; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
+        ca.part = c.sc.cpart; ca.coef = pb.coef[l]; ca.gd = V + n.offG[l]; ca.betad = V + n.offB[l]; ca.dstride = n.PSZ;
+        TRY(launch_coef(c.st, ca));
+        PoolFwdArgs pa; pa.e = ew_geom(n, M, l); pa.u = pb.u[l]; pa.ud = tb.ud[l]; pa.coef = pb.coef[l]; pa.x = nullptr; pa.xd = tb.xd[l];
+        TRY(launch_pool_fwd(c.st, pa, 1));
+    }
+    HeadArgs h; memset(&h, 0, sizeof(h));
+    h.B = n.B; h.M = M; h.N = n.N; h.F = n.F; h.scale = scale; h.f = pb.x[n.nblk - 1]; h.head = head; h.y = nullptr;
+    h.fd = tb.xd[n.nblk - 1]; h.headd = Vh; h.p = pb.p; h.dz = tb.dzd;
+    TRY(launch_head_logits(c.st, h));
+    // ---- tangent backward
+    HeadGradArgs hg; memset(&hg, 0, sizeof(hg));
+    hg.B = n.B; hg.M = M; hg.N = n.N; hg.F = n.F; hg.nsrc = 2;
+    hg.dz[0] = tb.dzd; hg.f[0] = pb.x[n.nblk - 1]; hg.head[0] = head;
+    hg.dz[1] = pb.dz; hg.f[1] = tb.xd[n.nblk - 1]; hg.head[1] = Vh;
+    hg.dh = HVh; hg.df = tb.dxd[n.nblk - 1];
+    TRY(launch_head_grad(c.st, hg));
+    for (int l = n.nblk - 1; l >= 0; --l) {
+        const EwGeom e = ew_geom(n, M, l);
+        const long npix = (long)M * n.g[l].Pp;
+        BwdRedArgs ra; ra.e = e; ra.u = pb.u[l]; ra.ud = tb.ud[l]; ra.dxo = pb.dx[l]; ra.dxod = tb.dxd[l]; ra.coef = pb.coef[l];
+        ra.part = c.sc.rpart; ra.nt = ew_bwd_red_nt(e);
+        TRY(launch_bwd_reduce(c.st, ra, 1));
+        CoefArgs ca; memset(&ca, 0, sizeof(ca));
+        ca.B = n.B; ca.mode = CFM_TBWD; ca.nt = ra.nt; ca.K = 3; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
+        ca.part = c.sc.rpart; ca.coef = pb.coef[l]; ca.dg = HV + n.offG[l]; ca.dbeta = HV + n.offB[l]; ca.gstride = n.PSZ;
+        TRY(launch_coef(c.st, ca));
+        BwdApplyArgs aa; aa.e = e; aa.u = pb.u[l]; aa.ud = tb.ud[l]; aa.dxo = pb.dx[l]; aa.dxod = tb.dxd[l]; aa.coef = pb.coef[l]; aa.du = tb.dud[l];
+        TRY(launch_bwd_apply(c.st, aa, 1));
+        const int ns = cv_wgrad_nsplit(n.B, npix);
+        if (l == 0) {
+            Wgrad1Args wa; wa.B = n.B; wa.M = M; wa.Cin = n.Cin; wa.nsplit = ns; wa.g = n.g[0]; wa.img = img; wa.dy = tb.dud[0]; wa.part = c.sc.wpart;
+            TRY(launch_wgrad1(c.st, wa));
+            TRY(launch_reduce_batched(c.st, n.B, ns, 2048, c.sc.wpart, 1.f, HV + n.offW[0], n.PSZ));
+        } else {
+            Wgrad64Args wa; wa.B = n.B; wa.nsrc = 2; wa.nsplit = ns; wa.npix = npix; wa.g = n.g[l];
+            wa.x[0] = pb.x[l - 1]; wa.dy[0] = tb.dud[l]; wa.x[1] = tb.xd[l - 1]; wa.dy[1] = pb.du[l]; wa.part = c.sc.wpart;
+            TRY(launch_wgrad64(c.st, wa));
+            TRY(launch_reduce_batched(c.st, n.B, ns, 36864, c.sc.wpart, 1.f, HV + n.offW[l], n.PSZ));
+            Conv64Args a; a.B = n.B; a.nsrc = 2; a.npix = npix; a.g = n.g[l];
+            a.in[0] = tb.dud[l]; a.frag[0] = frags + n.fB[l]; a.frag_stride[0] = n.FSZ;
+            a.in[1] = pb.du[l]; a.frag[1] = Vfrags + n.fB[l]; a.frag_stride[1] = n.FSZ;
+            a.out = tb.dxd[l - 1]; a.stats = nullptr; a.dot = nullptr;
+            TRY(launch_conv64(c.st, a));
+        }
+    }
+    return FUMI_OK;
+}
+
+// last step's buffer table, for fumi_hip_conv4_probe (tests compare every intermediate with oracle/conv4_manual.py)
+struct ProbeTab {
+    bool valid; Net n; int T, S, Qn; int ntape;
+    PassBufs tape[8]; PassBufs query; TanBufs tan;
+    float* params; float* heads; float* G; float* dh; float* bar; float* barh; float* HV; float* HVh;
+};
+static ProbeTab g_probe;
+
+}  // namespace
+
+struct Conv4Problem {
+    int B, N, S, Qn, Cin, H, W, nblk, T;
+    float alpha, grad_scale;
+    int need_grad, second_order;
+    const float* x_s; const int64_t* y_s; const float* x_q; const int64_t* y_q;
+    const float* theta[3 * CV_MAXBLK];      // W [64][Cin|64][3][3], BN weight [64], BN bias [64] per block
+    const float* head;                      // [B][N][F+1]
+    float* logits_q; int64_t* preds_q; float* preds_f; float* loss_b; float* acc_b; float* stats;
+    float* g_theta[3 * CV_MAXBLK];
+    float* head_bar;                        // [B][N][F+1] d loss_b / d head_b (unscaled)
+};
+
+int conv4_feature_dim(int nblk, int H, int W) {
+    for (int l = 0; l < nblk; ++l) { H /= 2; W /= 2; }
+    return 64 * H * W;
+}
+
+static size_t conv4_scratch_sizes(const Net& n, int S, int Qn, Scratch& sc) {
+    size_t cp = 0, wp = 0, rp = 0;
+    const int Ms[2] = {S, Qn};
+    for (int mi = 0; mi < 2; ++mi)
+        for (int l = 0; l < n.nblk; ++l) {
+            const long npix = (long)Ms[mi] * n.g[l].Pp;
+            const size_t c1 = (size_t)n.B * cv_tiles(npix) * 128;
+            if (c1 > cp) cp = c1;
+            const size_t w1 = (size_t)n.B * cv_wgrad_nsplit(n.B, npix) * (l == 0 ? 2048 : 36864);
+            if (w1 > wp) wp = w1;
+            const size_t r1 = (size_t)n.B * ew_bwd_red_nt(ew_geom(n, Ms[mi], l)) * 3 * 64;
+            if (r1 > rp) rp = r1;
+        }
+    sc.cpart_n = cp; sc.wpart_n = wp; sc.rpart_n = rp;
+    return ws_align(cp * 4) + ws_align(wp * 4) + ws_align(rp * 4);
+}
+
+// `prepare(extra)` runs once the slab is reserved: the caller carves its own buffers (head, head_bar, the head's producer's
+// activations) from the `extra_bytes` region, launches the producer of the head and returns the two pointers.
+struct Conv4Hooks {
+    size_t extra_bytes;
+    std::function<int(char* extra, const float** head, float** head_bar)> prepare;
+};
+
+int run_conv4_episodes(fumi_ws* ws, hipStream_t st, Conv4Problem p, const Conv4Hooks& hooks) {
+    const size_t extra_bytes = ws_align(hooks.extra_bytes);
+    StepCtx c; c.ws = ws; c.st = st;
+    int rc = net_init(c.n, p.B, p.nblk, p.Cin, p.N, p.H, p.W);
+    if (rc) return rc;
+    const Net& n = c.n;
+    if (p.T < 0 || p.S < 1 || p.Qn < 1) return FUMI_EINVAL;
+    const bool grad = p.need_grad != 0, second = grad && p.second_order && p.T > 0;
+    if (second && p.T > 8) return FUMI_ENOTSUP;                      // taped inner steps (the probe table holds 8)
+    c.S = p.S; c.Qn = p.Qn; c.img_s = p.x_s; c.img_q = p.x_q; c.y_s = p.y_s; c.y_q = p.y_q;
+    const int ntape = second ? p.T : 1;
+    const int nslot = second ? p.T + 1 : 2;
+    const size_t hsz = (size_t)n.B * n.N * (n.F + 1);
+    // ---- workspace
+    size_t bytes = extra_bytes + conv4_scratch_sizes(n, p.S, p.Qn, c.sc);
+    bytes += (size_t)ntape * pass_bytes(n, p.S, true) + pass_bytes(n, p.Qn, grad);
+    if (second) bytes += tan_bytes(n, p.S);
+    bytes += (size_t)nslot * (ws_align((size_t)n.B * n.PSZ * 4) + ws_align((size_t)n.B * n.FSZ * 4) + ws_align(hsz * 4));
+    bytes += 4 * ws_align((size_t)n.B * n.PSZ * 4) + 4 * ws_align(hsz * 4) + ws_align((size_t)n.B * n.FSZ * 4);   // G, bar, HV, tmp | dh, barh, HVh | Vfrags
+    bytes += ws_align((size_t)n.B * (2048 + 4096) * 4) + ws_align((size_t)(n.nblk) * 36864 * 4) + ws_align((size_t)n.PSZ * 4);
+    if ((rc = ws_reserve(ws, bytes))) return rc;
+    char* extra = ws->base + ws->off;
+    ws->off += extra_bytes;                                           // (the caller's buffers: head, hypernetwork activations)
+    TRY(hooks.prepare(extra, &p.head, &p.head_bar));
+    c.sc.cpart = ws_f(ws, c.sc.cpart_n); c.sc.wpart = ws_f(ws, c.sc.wpart_n); c.sc.rpart = ws_f(ws, c.sc.rpart_n);
+    ProbeTab& pt = g_probe;
+    pt.valid = false;
+    for (int t = 0; t < ntape; ++t) pass_carve(ws, n, p.S, true, pt.tape[t]);
+    pass_carve(ws, n, p.Qn, grad, pt.query);
+    if (second) tan_carve(ws, n, p.S, pt.tan);
+    float* params = ws_f(ws, (size_t)nslot * n.B * n.PSZ);
+    float* frags = ws_f(ws, (size_t)nslot * n.B * n.FSZ);
+    float* heads = ws_f(ws, (size_t)nslot * hsz);
+    float* G = ws_f(ws, (size_t)n.B * n.PSZ); float* bar = ws_f(ws, (size_t)n.B * n.PSZ); float* HV = ws_f(ws, (size_t)n.B * n.PSZ);
+    float* dh = ws_f(ws, hsz); float* barh = ws_f(ws, hsz); float* HVh = ws_f(ws, hsz);
+    float* Vfrags = ws_f(ws, (size_t)n.B * n.FSZ);
+    float* tmp1 = ws_f(ws, (size_t)n.B * (2048 + 4096));
+    float* toi_tmp = ws_f(ws, (size_t)n.nblk * 36864);
+    float* gsum = ws_f(ws, (size_t)n.PSZ);
+    auto P = [&](int s) { return params + (size_t)s * n.B * n.PSZ; };
+    auto Fr = [&](int s) { return frags + (size_t)s * n.B * n.FSZ; };
+    auto Hd = [&](int s) { return heads + (size_t)s * hsz; };
+
+    // ---- slot 0: the meta-parameters, one copy per episode (canonical layouts), and the caller's head
+    TRY(launch_w1_to_canon(st, n.B, n.Cin, p.theta[0], 0, P(0) + n.offW[0], n.PSZ));
+    for (int l = 0; l < n.nblk; ++l) {
+        if (l) {
+            TRY(launch_oihw_to_toi(st, 1, p.theta[3 * l], toi_tmp + (size_t)l * 36864));
+            TRY(launch_broadcast(st, n.B, 36864, toi_tmp + (size_t)l * 36864, P(0) + n.offW[l], n.PSZ));
+        }
+        TRY(launch_broadcast(st, n.B, 64, p.theta[3 * l + 1], P(0) + n.offG[l], n.PSZ));
+        TRY(launch_broadcast(st, n.B, 64, p.theta[3 * l + 2], P(0) + n.offB[l], n.PSZ));
+    }
+    TRY(frags_of_slot(st, n, P(0), Fr(0), tmp1));
+    HIP_TRY(hipMemcpyAsync(Hd(0), p.head, hsz * 4, hipMemcpyDeviceToDevice, st));
+
+    // ---- inner loop on the support set
+    int cur = 0;
+    for (int t = 0; t < p.T; ++t) {
+        PassBufs& pb = pt.tape[second ? t : 0];
+        const int nxt = second ? t + 1 : cur ^ 1;
+        TRY(forward_pass(c, p.S, p.x_s, P(cur), Fr(cur), pb, Hd(cur), p.y_s, 1.f / p.S, nullptr, nullptr, nullptr, nullptr, nullptr));
+        TRY(backward_pass(c, p.S, p.x_s, Fr(cur), pb, Hd(cur), G, dh));
+        TRY(launch_axpy(st, (long)n.B * n.PSZ, P(cur), -p.alpha, G, P(nxt)));
+        TRY(launch_axpy(st, (long)hsz, Hd(cur), -p.alpha, dh, Hd(nxt)));
+        TRY(frags_of_slot(st, n, P(nxt), Fr(nxt), tmp1));
+        cur = nxt;
+    }
+    // ---- query pass with the adapted parameters
+    TRY(forward_pass(c, p.Qn, p.x_q, P(cur), Fr(cur), pt.query, Hd(cur), p.y_q, 1.f / p.Qn, p.logits_q, p.preds_q, p.preds_f,
+                     p.loss_b, p.acc_b));
+    if (p.stats) {
+        ReduceSegs sg; sg.n = 0; sg.scale = p.grad_scale;
+        sg.add(p.loss_b, n.B, 1, 1, p.stats); sg.add(p.acc_b, n.B, 1, 1, p.stats + 1);
+        TRY(launch_reduce_multi(st, sg));
+    }
+    pt.n = n; pt.T = p.T; pt.S = p.S; pt.Qn = p.Qn; pt.ntape = ntape; pt.params = params; pt.heads = heads; pt.G = G; pt.dh = dh;
+    pt.bar = bar; pt.barh = barh; pt.HV = HV; pt.HVh = HVh; pt.valid = true;
+    if (!grad) return FUMI_OK;
+    TRY(backward_pass(c, p.Qn, p.x_q, Fr(cur), pt.query, Hd(cur), bar, barh));
+    // ---- second-order reverse sweep
+    if (second) {
+        for (int t = p.T - 1; t >= 0; --t) {
+            TRY(frags_of_slot(st, n, bar, Vfrags, tmp1));
+            TRY(hvp_pass(c, p.S, p.x_s, Fr(t), pt.tape[t], pt.tan, Hd(t), bar, Vfrags, barh, 1.f / p.S, HV, HVh));
+            TRY(launch_axpy(st, (long)n.B * n.PSZ, bar, -p.alpha, HV, bar));
+            TRY(launch_axpy(st, (long)hsz, barh, -p.alpha, HVh, barh));
+        }
+    }
+    // ---- meta-gradients: scaled sum over the episodes, back to the parameters' own layouts
+    TRY(launch_reduce_batched(st, 1, n.B, n.PSZ, bar, p.grad_scale, gsum, 0));
+    TRY(launch_w1_from_canon(st, n.Cin, gsum + n.offW[0], p.g_theta[0], 1.f));
+    for (int l = 0; l < n.nblk; ++l) {
+        if (l) TRY(launch_toi_to_oihw(st, 1, gsum + n.offW[l], p.g_theta[3 * l], 1.f));
+        HIP_TRY(hipMemcpyAsync(p.g_theta[3 * l + 1], gsum + n.offG[l], 64 * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(p.g_theta[3 * l + 2], gsum + n.offB[l], 64 * 4, hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(hipMemcpyAsync(p.head_bar, barh, hsz * 4, hipMemcpyDeviceToDevice, st));
+    return FUMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------
+static int fill_problem(Conv4Problem& p, int B, int N, int S, int Qn, int Cin, int H, int W, int nblk, int T, float alpha,
+                        int need_grad, int second_order, float grad_scale, const float* x_s, const int64_t* y_s,
+                        const float* x_q, const int64_t* y_q, const float* const* theta, float* logits_q, int64_t* preds_q,
+                        float* preds_f, float* loss_b, float* acc_b, float* stats, float* const* g_theta) {
+    memset(&p, 0, sizeof(p));
+    if (!x_s || !y_s || !x_q || !y_q || !theta || !logits_q || !preds_q || !loss_b || !acc_b) return FUMI_EINVAL;
+    if (nblk < 1 || nblk > CV_MAXBLK || (need_grad && !g_theta)) return FUMI_EINVAL;
+    p.B = B; p.N = N; p.S = S; p.Qn = Qn; p.Cin = Cin; p.H = H; p.W = W; p.nblk = nblk; p.T = T; p.alpha = alpha;
+    p.grad_scale = grad_scale; p.need_grad = need_grad ? 1 : 0; p.second_order = second_order ? 1 : 0;
+    p.x_s = x_s; p.y_s = y_s; p.x_q = x_q; p.y_q = y_q;
+    for (int i = 0; i < 3 * nblk; ++i) {
+        if (!theta[i] || (need_grad && !g_theta[i])) return FUMI_EINVAL;
+        p.theta[i] = theta[i]; p.g_theta[i] = need_grad ? g_theta[i] : nullptr;
+    }
+    p.logits_q = logits_q; p.preds_q = preds_q; p.preds_f = preds_f; p.loss_b = loss_b; p.acc_b = acc_b; p.stats = stats;
+    return FUMI_OK;
+}
+
+extern "C" {
+
+int fumi_hip_conv4_feature_dim(int nblk, int H, int W) { return (nblk < 1 || nblk > CV_MAXBLK) ? FUMI_EINVAL : conv4_feature_dim(nblk, H, W); }
+
+int fumi_hip_maml_conv4_step(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int Cin, int H, int W, int nblk,
+        int T, float alpha, int first_order, int need_grad, float grad_scale,
+        const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
+        const float* const* params,
+        float* logits_q, int64_t* preds_q, float* preds_q_f32, float* loss_b, float* acc_b, float* stats,
+        float* const* g_params) {
+    if (!ws || !params) return FUMI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ws->device));
+    Conv4Problem p;
+    int rc = fill_problem(p, B, N, S, Qn, Cin, H, W, nblk, T, alpha, need_grad, !first_order, grad_scale, x_s, y_s, x_q, y_q, params,
+                          logits_q, preds_q, preds_q_f32, loss_b, acc_b, stats, g_params);
+    if (rc) return rc;
+    const float* Wf = params[3 * nblk]; const float* bf = params[3 * nblk + 1];
+    if (!Wf || !bf || (need_grad && (!g_params[3 * nblk] || !g_params[3 * nblk + 1]))) return FUMI_EINVAL;
+    const int F = conv4_feature_dim(nblk, H, W);
+    if (F < 64) return FUMI_EINVAL;
+    const size_t hsz = (size_t)B * N * (F + 1);
+    float* hbar = nullptr;
+    Conv4Hooks hk;
+    hk.extra_bytes = 2 * ws_align(hsz * 4);
+    hk.prepare = [&](char* extra, const float** head, float** head_bar) -> int {
+        float* h = (float*)extra;
+        hbar = (float*)(extra + ws_align(hsz * 4));
+        *head = h; *head_bar = hbar;
+        return launch_broadcast_head(st, B, N, F, Wf, bf, h);            // every episode starts from lin_final (maml.py:24-31)
+    };
+    if ((rc = run_conv4_episodes(ws, st, p, hk))) return rc;
+    if (!need_grad) return FUMI_OK;
+    return launch_split_head_grad(st, B, N, F, hbar, grad_scale, g_params[3 * nblk], g_params[3 * nblk + 1]);
+}
+
+int fumi_hip_fumi_conv4_step(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int Cin, int H, int W, int nblk, int Dt, int Ht,
+        int T, float alpha, int tanh_head, int need_grad, float grad_scale,
+        const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
+        const float* cls_text, const float* text_s,
+        const float* const* theta, const float* const* phi,
+        float* logits_q, int64_t* preds_q, float* preds_q_f32, float* loss_b, float* acc_b, float* stats,
+        float* const* g_theta, float* const* g_phi) {
+    if (!ws || !theta || !phi || (!cls_text && !text_s) || Dt < 1 || Ht < 1) return FUMI_EINVAL;
+    if (need_grad && !g_phi) return FUMI_EINVAL;
+    for (int i = 0; i < 4; ++i) if (!phi[i] || (need_grad && !g_phi[i])) return FUMI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ws->device));
+    Conv4Problem p;
+    int rc = fill_problem(p, B, N, S, Qn, Cin, H, W, nblk, T, alpha, need_grad, 1, grad_scale, x_s, y_s, x_q, y_q, theta,
+                          logits_q, preds_q, preds_q_f32, loss_b, acc_b, stats, g_theta);       // fumi.py:176: second order always
+    if (rc) return rc;
+    const int F = conv4_feature_dim(nblk, H, W);
+    if (F < 64) return FUMI_EINVAL;
+    const int R = B * N, H1 = F + 1;
+    // hypernetwork rows are (episode, class) pairs: Linear(Dt, Ht) . ReLU . Linear(Ht, F+1) [. Tanh]  (fumi.py:70-86,104-113)
+    float *c = nullptr, *u = nullptr, *ub = nullptr, *h = nullptr, *hbar = nullptr, *hpb = nullptr;
+    const float* ctext = cls_text;
+    Conv4Hooks hk;
+    hk.extra_bytes = ws_align((size_t)R * Dt * 4) + 2 * ws_align((size_t)R * Ht * 4) + 3 * ws_align((size_t)R * H1 * 4);
+    hk.prepare = [&](char* extra, const float** head, float** head_bar) -> int {
+        auto take = [&](size_t nfl) { float* q = (float*)extra; extra += ws_align(nfl * 4); return q; };
+        c = take((size_t)R * Dt); u = take((size_t)R * Ht); ub = take((size_t)R * Ht);
+        h = take((size_t)R * H1); hbar = take((size_t)R * H1); hpb = take((size_t)R * H1);
+        int r2;
+        if (!ctext) {                                                    // first support row of each class (fumi.py:207-210)
+            if ((r2 = launch_class_text_select(st, B, N, S, Dt, text_s, y_s, c, ws->status))) return r2;
+            ctext = c;
+        }
+        GemmArgs g = gemm_args(R, Ht, Dt, ctext, Dt, phi[0], Dt, u, Ht);
+        g.bias = phi[1]; g.act = 1;
+        if ((r2 = launch_gemm(st, g, 0, 0))) return r2;
+        g = gemm_args(R, H1, Ht, u, Ht, phi[2], Ht, h, H1);
+        g.bias = phi[3]; g.act = tanh_head ? 2 : 0;
+        if ((r2 = launch_gemm(st, g, 0, 0))) return r2;
+        *head = h; *head_bar = hbar;
+        return FUMI_OK;
+    };
+    if ((rc = run_conv4_episodes(ws, st, p, hk))) return rc;
+    if (!need_grad) return FUMI_OK;
+    const float* hp = hbar;
+    if (tanh_head) { if ((rc = launch_tanh_bwd(st, (long)R * H1, h, hbar, hpb))) return rc; hp = hpb; }
+    GemmArgs g = gemm_args(H1, Ht, R, hp, H1, u, Ht, g_phi[2], Ht);    // gA1 = hp^T u
+    g.alpha = grad_scale;
+    if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+    if ((rc = launch_colsum(st, hp, R, H1, H1, grad_scale, g_phi[3]))) return rc;
+    g = gemm_args(R, Ht, H1, hp, H1, phi[2], Ht, ub, Ht);              // ubar = (hp A1) * relu'(u)
+    g.mask = u;
+    if ((rc = launch_gemm(st, g, 0, 1))) return rc;
+    g = gemm_args(Ht, Dt, R, ub, Ht, ctext, Dt, g_phi[0], Dt);         // gA0 = ubar^T c
+    g.alpha = grad_scale;
+    if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+    return launch_colsum(st, ub, R, Ht, Ht, grad_scale, g_phi[1]);
+}
+
+// Copies one intermediate of the LAST conv4 step of this process out of the workspace (tests compare every tensor of the
+// sweep with oracle/conv4_manual.py).  pass: 0..T-1 = support step t, T = query pass, T+1 = tangent scratch of the last HVP
+// (inner step 0).  kind: 0 u, 1 x (pooled output / features), 2 du, 3 dx, 4 coef [B][16][64], 5 p, 6 dz;  tangent pass: 0 u',
+// 1 x', 2 du', 3 dx', 6 dz'.  pass = -1: kind 0 parameter slabs [slot=block][B][PSZ], 1 heads [slot][B][N][F+1], 2 G, 3 dh,
+// 4 bar, 5 bar_h, 6 HV, 7 HV_h  (block = slot for kinds 0 / 1).  Returns the number of floats in *n_out (copies min(n, max)).
+int fumi_hip_conv4_probe(fumi_ws_t* ws, fumi_stream_t stream, int pass, int kind, int block, float* out, size_t max_floats,
+                         size_t* n_out) {
+    if (!ws || !out || !n_out || !g_probe.valid) return FUMI_EINVAL;
+    const ProbeTab& pt = g_probe;
+    const Net& n = pt.n;
+    const float* src = nullptr; size_t cnt = 0;
+    const size_t hsz = (size_t)n.B * n.N * (n.F + 1);
+    if (pass == -1) {
+        switch (kind) {
+            case 0: src = pt.params + (size_t)block * n.B * n.PSZ; cnt = (size_t)n.B * n.PSZ; break;
+            case 1: src = pt.heads + (size_t)block * hsz; cnt = hsz; break;
+            case 2: src = pt.G; cnt = (size_t)n.B * n.PSZ; break;
+            case 3: src = pt.dh; cnt = hsz; break;
+            case 4: src = pt.bar; cnt = (size_t)n.B * n.PSZ; break;
+            case 5: src = pt.barh; cnt = hsz; break;
+            case 6: src = pt.HV; cnt = (size_t)n.B * n.PSZ; break;
+            case 7: src = pt.HVh; cnt = hsz; break;
+            default: return FUMI_EINVAL;
+        }
+    } else if (pass == pt.T + 1) {
+        if (block < 0 || block >= n.nblk) return FUMI_EINVAL;
+        const int M = pt.S;
+        switch (kind) {
+            case 0: src = pt.tan.ud[block]; cnt = act_floats(n, M, block); break;
+            case 1: src = pt.tan.xd[block]; cnt = out_floats(n, M, block); break;
+            case 2: src = pt.tan.dud[block]; cnt = act_floats(n, M, block); break;
+            case 3: src = pt.tan.dxd[block]; cnt = out_floats(n, M, block); break;
+            case 6: src = pt.tan.dzd; cnt = (size_t)n.B * M * n.N; break;
+            default: return FUMI_EINVAL;
+        }
+    } else {
+        if (pass < 0 || pass > pt.T || block < 0 || block >= n.nblk) return FUMI_EINVAL;
+        const PassBufs& pb = pass == pt.T ? pt.query : pt.tape[pass < pt.ntape ? pass : 0];
+        const int M = pb.M;
+        switch (kind) {
+            case 0: src = pb.u[block]; cnt = act_floats(n, M, block); break;
+            case 1: src = pb.x[block]; cnt = out_floats(n, M, block); break;
+            case 2: src = pb.du[block]; cnt = act_floats(n, M, block); break;
+            case 3: src = pb.dx[block]; cnt = out_floats(n, M, block); break;
+            case 4: src = pb.coef[block]; cnt = (size_t)n.B * CF_N * 64; break;
+            case 5: src = pb.p; cnt = (size_t)n.B * M * n.N; break;
+            case 6: src = pb.dz; cnt = (size_t)n.B * M * n.N; break;
+            default: return FUMI_EINVAL;
+        }
+    }
+    if (!src) return FUMI_EINVAL;
+    *n_out = cnt;
+    const size_t k = cnt < max_floats ? cnt : max_floats;
+    HIP_TRY(hipMemcpyAsync(out, src, k * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return FUMI_OK;
+}
+
+// ---- finer-grained ops --------------------------------------------------------------------------------------------------
+static int conv3x3_common(fumi_ws_t* ws, hipStream_t st, int M, int H, int W, const float* x, const float* Wt, float* y, bool data_grad) {
+    if (!ws || !x || !Wt || !y || M < 1 || H < 1 || W < 1) return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(ws->device));
+    const CvGeom g = cv_geom(H, W);
+    const size_t act = (size_t)M * g.Pp * 64;
+    int rc = ws_reserve(ws, 2 * ws_align(act * 4) + 3 * ws_align((size_t)CV_WFRAG * 4));
+    if (rc) return rc;
+    float* xp = ws_f(ws, act); float* yp = ws_f(ws, act);
+    float* toi = ws_f(ws, CV_WFRAG); float* ff = ws_f(ws, CV_WFRAG); float* fb = ws_f(ws, CV_WFRAG);
+    TRY(launch_pad_cl(st, M, g, x, xp));
+    TRY(launch_oihw_to_toi(st, 1, Wt, toi));
+    TRY(launch_wfrag64(st, 1, toi, 0, ff, fb, 0));
+    Conv64Args a; a.B = 1; a.nsrc = 1; a.npix = (long)M * g.Pp; a.g = g;
+    a.in[0] = xp; a.frag[0] = data_grad ? fb : ff; a.frag_stride[0] = 0; a.in[1] = nullptr; a.frag[1] = nullptr; a.frag_stride[1] = 0;
+    a.out = yp; a.stats = nullptr; a.dot = nullptr;
+    TRY(launch_conv64(st, a));
+    return launch_unpad_cl(st, M, g, yp, y);
+}
+
+int fumi_hip_conv3x3_fwd(fumi_ws_t* ws, fumi_stream_t stream, int M, int H, int W, const float* x, const float* Wt, float* y) {
+    return conv3x3_common(ws, (hipStream_t)stream, M, H, W, x, Wt, y, false);
+}
+int fumi_hip_conv3x3_bwd_data(fumi_ws_t* ws, fumi_stream_t stream, int M, int H, int W, const float* dy, const float* Wt, float* dx) {
+    return conv3x3_common(ws, (hipStream_t)stream, M, H, W, dy, Wt, dx, true);
+}
+int fumi_hip_conv3x3_bwd_weight(fumi_ws_t* ws, fumi_stream_t stream, int M, int H, int W, const float* x, const float* dy, float* dW) {
+    if (!ws || !x || !dy || !dW || M < 1 || H < 1 || W < 1) return FUMI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ws->device));
+    const CvGeom g = cv_geom(H, W);
+    const size_t act = (size_t)M * g.Pp * 64;
+    const long npix = (long)M * g.Pp;
+    const int ns = cv_wgrad_nsplit(1, npix);
+    int rc = ws_reserve(ws, 2 * ws_align(act * 4) + ws_align((size_t)(ns + 1) * CV_WFRAG * 4));
+    if (rc) return rc;
+    float* xp = ws_f(ws, act); float* dp = ws_f(ws, act); float* part = ws_f(ws, (size_t)(ns + 1) * CV_WFRAG);
+    float* toi = part + (size_t)ns * CV_WFRAG;
+    TRY(launch_pad_cl(st, M, g, x, xp));
+    TRY(launch_pad_cl(st, M, g, dy, dp));
+    Wgrad64Args wa; wa.B = 1; wa.nsrc = 1; wa.nsplit = ns; wa.npix = npix; wa.g = g;
+    wa.x[0] = xp; wa.dy[0] = dp; wa.x[1] = nullptr; wa.dy[1] = nullptr; wa.part = part;
+    TRY(launch_wgrad64(st, wa));
+    TRY(launch_reduce_batched(st, 1, ns, CV_WFRAG, part, 1.f, toi, 0));
+    return launch_toi_to_oihw(st, 1, toi, dW, 1.f);
+}
+
+int fumi_hip_sgd_axpy(fumi_ws_t* ws, fumi_stream_t stream, long n, const float* p, float step_size, const float* g, float* out) {
+    if (!ws || !p || !g || !out || n < 1) return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(ws->device));
+    return launch_axpy((hipStream_t)stream, n, p, -step_size, g, out);
+}
+
+int fumi_hip_ce_fwd_bwd(fumi_ws_t* ws, fumi_stream_t stream, int M, int N, const float* z, const int64_t* y, float* loss, float* dz,
+        int64_t* preds) {
+    if (!ws || !z || !y || !loss || M < 1 || N < 1) return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(ws->device));
+    return launch_ce((hipStream_t)stream, M, N, z, y, loss, dz, preds, ws->status);
+}
+
+int fumi_hip_proto_reduce(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int N, int P, const float* x, const int64_t* y, float* out) {
+    if (!ws || !x || !y || !out || B < 1 || S < 1 || N < 1 || P < 1) return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(ws->device));
+    return launch_proto((hipStream_t)stream, B, S, N, P, x, y, out, ws->status);
+}
+
+}  // extern "C"

@@ -25,6 +25,9 @@ SYMBOLS = [
     "fumi_hip_linear_fwd", "fumi_hip_linear_bwd_data", "fumi_hip_linear_bwd_weight",
     "fumi_hip_sample_episodes", "fumi_hip_gather_rows", "fumi_hip_publish_scalars",
     "fumi_hip_publish_scalars_deferred", "fumi_hip_publish_flush", "fumi_hip_am3_metrics",
+    "fumi_hip_conv4_feature_dim", "fumi_hip_fumi_conv4_step", "fumi_hip_maml_conv4_step", "fumi_hip_conv4_probe",
+    "fumi_hip_conv3x3_fwd", "fumi_hip_conv3x3_bwd_data", "fumi_hip_conv3x3_bwd_weight",
+    "fumi_hip_sgd_axpy", "fumi_hip_ce_fwd_bwd", "fumi_hip_proto_reduce",
 ]
 
 ST_LABEL_RANGE, ST_CLASS_MISSING = 1, 2
@@ -127,6 +130,19 @@ def lib():
         L.fumi_hip_publish_scalars.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_uint64]
         L.fumi_hip_publish_scalars_deferred.argtypes = [c_void_p, c_void_p, c_int, c_void_p, ctypes.c_uint64]
         L.fumi_hip_publish_flush.argtypes = [c_void_p, c_void_p]
+        L.fumi_hip_conv4_feature_dim.argtypes = [c_int] * 3
+        L.fumi_hip_fumi_conv4_step.argtypes = (
+            [c_void_p, c_void_p] + [c_int] * 10 + [c_int, c_float, c_int, c_int, c_float]
+            + [c_void_p] * 6 + [PP, PP] + [c_void_p] * 6 + [PP, PP])
+        L.fumi_hip_maml_conv4_step.argtypes = (
+            [c_void_p, c_void_p] + [c_int] * 8 + [c_int, c_float, c_int, c_int, c_float]
+            + [c_void_p] * 4 + [PP] + [c_void_p] * 6 + [PP])
+        L.fumi_hip_conv4_probe.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, POINTER(c_size_t)]
+        for fn in (L.fumi_hip_conv3x3_fwd, L.fumi_hip_conv3x3_bwd_data, L.fumi_hip_conv3x3_bwd_weight):
+            fn.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+        L.fumi_hip_sgd_axpy.argtypes = [c_void_p, c_void_p, ctypes.c_long, c_void_p, c_float, c_void_p, c_void_p]
+        L.fumi_hip_ce_fwd_bwd.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.fumi_hip_proto_reduce.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p] * 3
         _lib = L
     return _lib
 
@@ -618,3 +634,149 @@ def publish_scalars(ws, src, n, host_pinned, seq, defer=False):
 def publish_flush(ws, device):
     _check(lib().fumi_hip_publish_flush(ws.handle, _stream(device)), "fumi_hip_publish_flush")
 
+
+
+# ---- Conv4 image encoder at the im_net seam (include/fumi_hip.h; csrc/conv4.hip) -------------------------------------------
+def conv4_feature_dim(nblk, H, W):
+    return int(lib().fumi_hip_conv4_feature_dim(int(nblk), int(H), int(W)))
+
+
+def _conv4_shapes(x_s, y_s, x_q, y_q, theta):
+    if x_s.dim() != 5 or x_q.dim() != 5:
+        raise FumiHipError("conv4: images must be [B, rows, Cin, H, W]")
+    B, S, Cin, H, W = x_s.shape
+    Qn = x_q.shape[1]
+    if len(theta) % 3 or not theta:
+        raise FumiHipError("conv4: theta must hold (conv weight, BN weight, BN bias) per block")
+    nblk = len(theta) // 3
+    _shape(x_q, (B, Qn, Cin, H, W), "x_q"); _shape(y_s, (B, S), "y_s"); _shape(y_q, (B, Qn), "y_q")
+    for l in range(nblk):
+        _shape(theta[3 * l], (64, Cin if l == 0 else 64, 3, 3), f"theta[{3 * l}] (conv weight of block {l})")
+        _shape(theta[3 * l + 1], (64,), f"theta[{3 * l + 1}]"); _shape(theta[3 * l + 2], (64,), f"theta[{3 * l + 2}]")
+    F = conv4_feature_dim(nblk, H, W)
+    if F < 64:
+        raise FumiHipError(f"conv4: {H}x{W} images are too small for {nblk} blocks")
+    return B, S, Qn, Cin, H, W, nblk, F
+
+
+def _step_outputs(dev, B, Qn, N):
+    return (torch.empty(B, Qn, N, device=dev, dtype=torch.float32), torch.empty(B, Qn, device=dev, dtype=torch.int64),
+            torch.empty(B, Qn, device=dev, dtype=torch.float32), torch.empty(B, device=dev, dtype=torch.float32),
+            torch.empty(B, device=dev, dtype=torch.float32))
+
+
+def fumi_conv4_step(ws, n_way, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head, *, cls_text=None, text_s=None,
+                    need_grad=True, grad_scale=None, g_theta=None, g_phi=None, stats=None):
+    """FuMI meta-step with the Conv4 encoder (fumi/models/fumi.py:146-192 with im_net = Conv4)."""
+    dev = _dev(x_s)
+    B, S, Qn, Cin, H, W, nblk, F = _conv4_shapes(x_s, y_s, x_q, y_q, theta)
+    N = int(n_way)
+    Ht, Dt = int(phi[0].shape[0]), int(phi[0].shape[1])
+    _shape(phi[1], (Ht,), "phi[1]"); _shape(phi[2], (F + 1, Ht), "phi[2]"); _shape(phi[3], (F + 1,), "phi[3]")
+    if cls_text is not None:
+        _shape(cls_text, (B, N, Dt), "cls_text")
+    else:
+        _shape(text_s, (B, S, Dt), "text_s")
+    logits, preds, preds_f, loss_b, acc_b = _step_outputs(dev, B, Qn, N)
+    if need_grad:
+        g_theta = [torch.empty_like(t) for t in theta] if g_theta is None else g_theta
+        g_phi = [torch.empty_like(t) for t in phi] if g_phi is None else g_phi
+    rc = lib().fumi_hip_fumi_conv4_step(
+        ws.handle, _stream(dev), B, N, S, Qn, Cin, H, W, nblk, Dt, Ht, int(T), float(alpha), int(bool(tanh_head)),
+        int(bool(need_grad)), float(1.0 / B if grad_scale is None else grad_scale),
+        _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"),
+        _f32(cls_text, "cls_text") if cls_text is not None else None, _f32(text_s, "text_s") if text_s is not None else None,
+        _parr(theta, "theta"), _parr(phi, "phi"),
+        _f32(logits, "logits"), _i64(preds, "preds"), _f32(preds_f, "preds_f"), _f32(loss_b, "loss_b"), _f32(acc_b, "acc_b"),
+        _f32(stats, "stats") if stats is not None else None,
+        _parr(g_theta, "g_theta") if need_grad else None, _parr(g_phi, "g_phi") if need_grad else None)
+    _check(rc, "fumi_hip_fumi_conv4_step")
+    return dict(logits=logits, preds=preds, preds_f=preds_f, loss_b=loss_b, acc_b=acc_b, g_theta=g_theta, g_phi=g_phi, stats=stats)
+
+
+def maml_conv4_step(ws, x_s, y_s, x_q, y_q, params, T, alpha, first_order=False, *, need_grad=True, grad_scale=None,
+                    g_params=None, stats=None):
+    """MAML meta-step with the Conv4 encoder: params = theta (3 per block) + [lin_final W [N,F], b [N]]."""
+    dev = _dev(x_s)
+    B, S, Qn, Cin, H, W, nblk, F = _conv4_shapes(x_s, y_s, x_q, y_q, params[:-2])
+    N = int(params[-2].shape[0])
+    _shape(params[-2], (N, F), "lin_final.weight"); _shape(params[-1], (N,), "lin_final.bias")
+    logits, preds, preds_f, loss_b, acc_b = _step_outputs(dev, B, Qn, N)
+    if need_grad and g_params is None:
+        g_params = [torch.empty_like(t) for t in params]
+    rc = lib().fumi_hip_maml_conv4_step(
+        ws.handle, _stream(dev), B, N, S, Qn, Cin, H, W, nblk, int(T), float(alpha), int(bool(first_order)),
+        int(bool(need_grad)), float(1.0 / B if grad_scale is None else grad_scale),
+        _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"), _parr(params, "params"),
+        _f32(logits, "logits"), _i64(preds, "preds"), _f32(preds_f, "preds_f"), _f32(loss_b, "loss_b"), _f32(acc_b, "acc_b"),
+        _f32(stats, "stats") if stats is not None else None, _parr(g_params, "g_params") if need_grad else None)
+    _check(rc, "fumi_hip_maml_conv4_step")
+    return dict(logits=logits, preds=preds, preds_f=preds_f, loss_b=loss_b, acc_b=acc_b, g_params=g_params, stats=stats)
+
+
+def conv4_probe(ws, device, pass_, kind, block=0):
+    """Test hook: one intermediate tensor of the last conv4 step as a flat fp32 tensor (fumi_hip_conv4_probe)."""
+    n = c_size_t(0)
+    dummy = torch.empty(1, device=device, dtype=torch.float32)
+    _check(lib().fumi_hip_conv4_probe(ws.handle, _stream(device), int(pass_), int(kind), int(block), _f32(dummy, "out"), 0,
+                                      ctypes.byref(n)), "fumi_hip_conv4_probe")
+    out = torch.empty(n.value, device=device, dtype=torch.float32)
+    _check(lib().fumi_hip_conv4_probe(ws.handle, _stream(device), int(pass_), int(kind), int(block), _f32(out, "out"), n.value,
+                                      ctypes.byref(n)), "fumi_hip_conv4_probe")
+    return out
+
+
+def _conv3x3(fn, name, ws, a, b, out_shape):
+    dev = _dev(a)
+    M, H, W, C = a.shape
+    if C != 64:
+        raise FumiHipError(f"{name}: channels-last tensors with 64 channels expected")
+    out = torch.empty(out_shape, device=dev, dtype=torch.float32)
+    _check(fn(ws.handle, _stream(dev), M, H, W, _f32(a, "a"), _f32(b, "b"), _f32(out, "out")), name)
+    return out
+
+
+def conv3x3_fwd(ws, x, Wt):
+    """y [M,H,W,64] = conv3x3(x [M,H,W,64], Wt [64,64,3,3]), pad 1 (channels-last)."""
+    _shape(Wt, (64, 64, 3, 3), "Wt")
+    return _conv3x3(lib().fumi_hip_conv3x3_fwd, "fumi_hip_conv3x3_fwd", ws, x, Wt, x.shape)
+
+
+def conv3x3_bwd_data(ws, dy, Wt):
+    _shape(Wt, (64, 64, 3, 3), "Wt")
+    return _conv3x3(lib().fumi_hip_conv3x3_bwd_data, "fumi_hip_conv3x3_bwd_data", ws, dy, Wt, dy.shape)
+
+
+def conv3x3_bwd_weight(ws, x, dy):
+    _shape(dy, x.shape, "dy")
+    return _conv3x3(lib().fumi_hip_conv3x3_bwd_weight, "fumi_hip_conv3x3_bwd_weight", ws, x, dy, (64, 64, 3, 3))
+
+
+def sgd_axpy(ws, p, step_size, g, out=None):
+    dev = _dev(p)
+    out = torch.empty_like(p) if out is None else out
+    _check(lib().fumi_hip_sgd_axpy(ws.handle, _stream(dev), p.numel(), _f32(p, "p"), float(step_size), _f32(g, "g"), _f32(out, "out")),
+           "fumi_hip_sgd_axpy")
+    return out
+
+
+def ce_fwd_bwd(ws, z, y):
+    """(mean cross-entropy [1], dz [M,N], first arg-max [M]) of logits z [M,N] and labels y [M]."""
+    dev = _dev(z)
+    M, N = z.shape
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    dz = torch.empty_like(z)
+    preds = torch.empty(M, device=dev, dtype=torch.int64)
+    _check(lib().fumi_hip_ce_fwd_bwd(ws.handle, _stream(dev), M, N, _f32(z, "z"), _i64(y, "y"), _f32(loss, "loss"), _f32(dz, "dz"),
+                                     _i64(preds, "preds")), "fumi_hip_ce_fwd_bwd")
+    return loss, dz, preds
+
+
+def proto_reduce(ws, x, y, n_way):
+    """Per-class means [B,N,P] of x [B,S,P] (fumi/utils/utils.py:331-376, counts clamped to >= 1)."""
+    dev = _dev(x)
+    B, S, P = x.shape
+    out = torch.empty(B, n_way, P, device=dev, dtype=torch.float32)
+    _check(lib().fumi_hip_proto_reduce(ws.handle, _stream(dev), B, S, int(n_way), P, _f32(x, "x"), _i64(y, "y"), _f32(out, "out")),
+           "fumi_hip_proto_reduce")
+    return out

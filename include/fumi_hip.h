@@ -173,6 +173,53 @@ int fumi_hip_linear_bwd_weight(fumi_ws_t* ws, fumi_stream_t stream, int M, int N
         const float* dy, const float* x, float* dW, float* db);
 
 
+/* ---- Conv4 image encoder at the im_net seam ---------------------------------------------------------------------------
+ * The reference adapts an MLP over pre-computed embeddings; `im_net` is "any module with forward(x, params) and
+ * meta_named_parameters()" (fumi/models/fumi.py:89-100, `--im_encoder resnet` is a TODO at fumi/models/am3.py:41-46).
+ * BASELINE.json words its configurations with a Conv4 encoder on 84x84 images: nblk blocks of conv3x3(64, pad 1, no bias) .
+ * BatchNorm2d with BATCH statistics (training and evaluation alike) . ReLU . MaxPool2d(2), flattened like PyTorch's
+ * x.view(M, -1) of NCHW.  PARITY UNPINNED for the convolutional part (nothing to import); oracle = oracle/conv4_ref.py.
+ * Everything after the feature vector is the reference's algorithm (fumi.py:146-192 / maml.py:156-191).
+ *   x_s [B,S,Cin,H,W], x_q [B,Qn,Cin,H,W] fp32 NCHW (Cin <= 3);  theta: 3*nblk pointers  W_l [64,Cin|64,3,3], BN weight [64],
+ *   BN bias [64];  F = fumi_hip_conv4_feature_dim(nblk, H, W) = 64 * (H >> nblk) * (W >> nblk).
+ *   fumi: phi = A0 [Ht,Dt], a0, A1 [F+1,Ht], a1 [F+1];  maml: params = theta then lin_final W [N,F], b [N].
+ * Outputs / gradient conventions as fumi_hip_fumi_step / fumi_hip_maml_step.  Second order needs T <= 8 taped inner steps. */
+int fumi_hip_conv4_feature_dim(int nblk, int H, int W);
+int fumi_hip_fumi_conv4_step(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int Cin, int H, int W, int nblk, int Dt, int Ht,
+        int T, float alpha, int tanh_head, int need_grad, float grad_scale,
+        const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
+        const float* cls_text, const float* text_s,
+        const float* const* theta, const float* const* phi,
+        float* logits_q, int64_t* preds_q, float* preds_q_f32, float* loss_b, float* acc_b, float* stats,
+        float* const* g_theta, float* const* g_phi);
+int fumi_hip_maml_conv4_step(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int Cin, int H, int W, int nblk,
+        int T, float alpha, int first_order, int need_grad, float grad_scale,
+        const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
+        const float* const* params,
+        float* logits_q, int64_t* preds_q, float* preds_q_f32, float* loss_b, float* acc_b, float* stats,
+        float* const* g_params);
+/* Test hook: copies one intermediate tensor of the LAST conv4 step of this process out of the workspace (layouts:
+ * fumi_amd/csrc/conv4.hip, fumi_hip_conv4_probe).  *n_out = its size in floats; at most max_floats are copied. */
+int fumi_hip_conv4_probe(fumi_ws_t* ws, fumi_stream_t stream, int pass, int kind, int block, float* out, size_t max_floats,
+        size_t* n_out);
+/* The three 3x3 / pad 1 / stride 1 convolution products on 64 -> 64 channels (the set is closed under differentiation: the
+ * second-order sweep uses nothing else).  Dense channels-last tensors x, y, dy [M,H,W,64]; weights W, dW [64,64,3,3] (OIHW). */
+int fumi_hip_conv3x3_fwd(fumi_ws_t* ws, fumi_stream_t stream, int M, int H, int W, const float* x, const float* Wt, float* y);
+int fumi_hip_conv3x3_bwd_data(fumi_ws_t* ws, fumi_stream_t stream, int M, int H, int W, const float* dy, const float* Wt, float* dx);
+int fumi_hip_conv3x3_bwd_weight(fumi_ws_t* ws, fumi_stream_t stream, int M, int H, int W, const float* x, const float* dy, float* dW);
+/* torchmeta gradient_update_parameters / the reference's in-place `hyper_params -= step_size * grad` (fumi.py:165-176):
+ * out[i] = p[i] - step_size * g[i], n floats (out may alias p). */
+int fumi_hip_sgd_axpy(fumi_ws_t* ws, fumi_stream_t stream, long n, const float* p, float step_size, const float* g, float* out);
+/* F.cross_entropy forward + backward of M rows of N logits (fumi.py:162,182): loss [1] = mean NLL, dz [M,N] = (softmax - onehot)/M,
+ * preds [M] = first arg-max (fumi.py:180).  A label outside [0,N) sets FUMI_ST_LABEL_RANGE. */
+int fumi_hip_ce_fwd_bwd(fumi_ws_t* ws, fumi_stream_t stream, int M, int N, const float* z, const int64_t* y, float* loss, float* dz,
+        int64_t* preds);
+/* get_prototypes (fumi/utils/utils.py:331-376): out[b,n,:] = sum_{s: y[b,s]==n} x[b,s,:] / max(count, 1)  -> [B,N,P] */
+int fumi_hip_proto_reduce(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int N, int P, const float* x, const int64_t* y, float* out);
+
+
 /* FuMI meta-step on ZERO-COPY episodes: identical to fumi_hip_fumi_step except that the image rows are not handed over as
  * x_s [B,S,D] / x_q [B,Qn,D] but addressed in an HBM-resident table [n_rows, D] through idx_s [B,S] / idx_q [B,Qn] (what
  * fumi_hip_sample_episodes produces): the two X-panel kernels read the rows where they lie, the 2*B*(S+Qn)*D*4 bytes of a

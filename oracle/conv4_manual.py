@@ -72,7 +72,8 @@ def block_fwd(x, W, g, b):
     first = ((vw == mx[..., None]).to(torch.int8).cumsum(-1) == 1) & (vw == mx[..., None])     # FIRST maximum of the window
     arg = first.to(torch.int8).argmax(-1)
     mask = (mx > 0).to(x.dtype)
-    return torch.relu(mx), dict(x=x, W=W, g=g.view(1, -1, 1, 1), r=r, xh=xh, arg=arg, mask=mask, shape=u.shape)
+    return torch.relu(mx), dict(x=x, W=W, g=g.view(1, -1, 1, 1), r=r, xh=xh, arg=arg, mask=mask, shape=u.shape, u=u, mu=mu,
+                                xo=torch.relu(mx))
 
 
 def _scatter(dxo, tp):
@@ -95,7 +96,7 @@ def block_bwd(dxo, tp, need_dx=True):
     dv = _scatter(dxo, tp)
     d1, d2 = _mean(dv), _mean(dv * tp["xh"])
     du = tp["g"] * tp["r"] * (dv - d1 - tp["xh"] * d2)
-    tp.update(dv=dv, d1=d1, d2=d2, du=du)
+    tp.update(dv=dv, d1=d1, d2=d2, du=du, dxo=dxo)
     dg, db = (dv * tp["xh"]).sum((0, 2, 3)), dv.sum((0, 2, 3))
     return (conv_bwd_data(du, tp["W"]) if need_dx else None), conv_bwd_weight(tp["x"], du), dg, db
 
@@ -108,8 +109,9 @@ def block_tan_fwd(xd, Wd, gd, bd, tp):
     m1, m2 = _mean(ud), _mean(tp["xh"] * ud)
     xhd = tp["r"] * (ud - m1 - tp["xh"] * m2)
     vd = gd.view(1, -1, 1, 1) * tp["xh"] + tp["g"] * xhd + bd.view(1, -1, 1, 1)
-    tp.update(xd=xd, Wd=Wd, gd=gd.view(1, -1, 1, 1), xhd=xhd, m2=m2)
-    return _gather(vd, tp)
+    tp.update(xd=xd, Wd=Wd, gd=gd.view(1, -1, 1, 1), xhd=xhd, m2=m2, ud=ud)
+    tp["xod"] = _gather(vd, tp)
+    return tp["xod"]
 
 
 def block_tan_bwd(dxod, tp, need_dx=True):
@@ -125,6 +127,7 @@ def block_tan_bwd(dxod, tp, need_dx=True):
     if tp["xd"] is not None:
         dWd = dWd + conv_bwd_weight(tp["xd"], tp["du"])
     dxd = (conv_bwd_data(dud, tp["W"]) + conv_bwd_data(tp["du"], tp["Wd"])) if need_dx else None
+    tp.update(dud=dud, dxod=dxod)
     return dxd, dWd, dgd, dbd
 
 
@@ -171,9 +174,12 @@ def net_hvp(tape, vth, vh, scale):
     return out, dhd
 
 
-def episode_grads(theta, h0, x_s, y_s, x_q, y_q, T, alpha, first_order=False):
-    """(query logits, query loss, d loss / d theta, d loss / d h0) of one episode, no autograd anywhere."""
+def episode_grads(theta, h0, x_s, y_s, x_q, y_q, T, alpha, first_order=False, trace=None):
+    """(query logits, query loss, d loss / d theta, d loss / d h0) of one episode, no autograd anywhere.
+    trace (dict): receives every intermediate (tapes of the inner steps, the query pass, gradients, adjoints, H v)."""
     th, h, tapes = [t for t in theta], h0, []
+    if trace is not None:
+        trace.update(tapes=tapes, params=[list(th)], heads=[h], grads=[], dh=[], hv=[])
     S = x_s.shape[0]
     for _ in range(T):
         z, tape = net_fwd(x_s, th, h)
@@ -181,12 +187,18 @@ def episode_grads(theta, h0, x_s, y_s, x_q, y_q, T, alpha, first_order=False):
         tapes.append(tape)
         th = [p - alpha * gi for p, gi in zip(th, g)]
         h = h - alpha * dh
+        if trace is not None:
+            trace["grads"].append(g); trace["dh"].append(dh); trace["params"].append(list(th)); trace["heads"].append(h)
     zq, tq = net_fwd(x_q, th, h)
     loss = F.cross_entropy(zq, y_q)
     bar_th, bar_h = net_bwd(zq, y_q, tq, 1.0 / x_q.shape[0])
+    if trace is not None:
+        trace.update(query=tq, bar_T=(list(bar_th), bar_h))
     if not first_order:
         for tape in reversed(tapes):
             hv_th, hv_h = net_hvp(tape, bar_th, bar_h, 1.0 / S)
+            if trace is not None:
+                trace["hv"].append((hv_th, hv_h))
             bar_th = [b - alpha * v for b, v in zip(bar_th, hv_th)]
             bar_h = bar_h - alpha * hv_h
     return zq, loss, bar_th, bar_h

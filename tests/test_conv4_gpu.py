@@ -1,0 +1,251 @@
+"""GPU parity of the Conv4 image encoder at the im_net seam (csrc/conv_gemm.hip, conv_ew.hip, conv4.hip), through the C ABI.
+
+PARITY UNPINNED for the convolutional part (the reference has no such encoder: oracle/conv4_ref.py's header).  Checkers:
+  * the three convolution products against torch.nn.functional on the host;
+  * EVERY intermediate tensor of a meta-step (fumi_hip_conv4_probe) against the autograd-free sweep oracle/conv4_manual.py,
+    which tests/test_conv4_manual.py ties to autograd at 1e-9 in float64 -- so a failure names the kernel;
+  * whole meta-steps (FuMI and MAML heads, T = 0..3, first order, evaluation mode) against autograd through
+    oracle/conv4_ref.py: logits 1e-4 of max|logit|, integer predictions bit-exact outside the 1e-5 margin, every meta-gradient
+    1e-3 of the tensor's scale; one full-size 84 x 84 5-way episode pair.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import casegen as cg
+from oracle import conv4_manual as M
+from oracle import conv4_ref as C
+from oracle import fumi_ref as R
+from helpers import rel_to_max, safe_margin_mask
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL, GRAD_TOL, MARGIN = 1e-4, 1e-3, 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ws(dev):
+    from fumi_amd import hip
+    return hip.Workspace.get(dev)
+
+
+def _g(t, dev):
+    return t.to(dev).contiguous()
+
+
+# ---- the three convolution products ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Mi,H,W", [(3, 10, 10), (2, 21, 21), (5, 42, 42), (1, 7, 13), (40, 5, 5)])
+def test_conv3x3_products_match_torch(Mi, H, W, dev, ws):
+    from fumi_amd import hip
+    g = torch.Generator().manual_seed(Mi * 100 + H)
+    x = torch.randn(Mi, 64, H, W, generator=g)
+    Wt = torch.randn(64, 64, 3, 3, generator=g) / 24
+    dy = torch.randn(Mi, 64, H, W, generator=g)
+    cl = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    y = hip.conv3x3_fwd(ws, _g(cl(x), dev), _g(Wt, dev)).cpu().permute(0, 3, 1, 2)
+    assert rel_to_max(y, F.conv2d(x.double(), Wt.double(), padding=1)) <= 2e-6
+    dx = hip.conv3x3_bwd_data(ws, _g(cl(dy), dev), _g(Wt, dev)).cpu().permute(0, 3, 1, 2)
+    assert rel_to_max(dx, M.conv_bwd_data(dy.double(), Wt.double())) <= 2e-6
+    dW = hip.conv3x3_bwd_weight(ws, _g(cl(x), dev), _g(cl(dy), dev)).cpu()
+    assert rel_to_max(dW, M.conv_bwd_weight(x.double(), dy.double())) <= 5e-6
+
+
+def test_conv3x3_asymmetric_identity(dev, ws):
+    """A one-hot kernel (output channel o copies input channel pi(o) shifted by one tap) catches a transposed channel map, a
+    flipped tap order and a swapped row / column shift."""
+    from fumi_amd import hip
+    H, W = 9, 12
+    x = torch.arange(2 * 64 * H * W, dtype=torch.float32).reshape(2, 64, H, W) % 251 - 100.0
+    Wt = torch.zeros(64, 64, 3, 3)
+    for o in range(64):
+        Wt[o, (o * 7 + 3) % 64, o % 3, (o // 3) % 3] = 1.0
+    y = hip.conv3x3_fwd(ws, _g(x.permute(0, 2, 3, 1), dev), _g(Wt, dev)).cpu().permute(0, 3, 1, 2)
+    assert torch.equal(y, F.conv2d(x, Wt, padding=1))
+
+
+def test_small_exported_ops(dev, ws):
+    from fumi_amd import hip
+    g = torch.Generator().manual_seed(3)
+    z, y = torch.randn(37, 5, generator=g), torch.randint(0, 5, (37,), generator=g)
+    loss, dz, preds = hip.ce_fwd_bwd(ws, _g(z, dev), _g(y, dev))
+    zz = z.clone().requires_grad_(True)
+    ref = F.cross_entropy(zz, y)
+    assert abs(float(loss) - float(ref)) < 1e-6 and rel_to_max(dz.cpu(), torch.autograd.grad(ref, zz)[0]) < 1e-5
+    assert torch.equal(preds.cpu(), z.max(-1)[1])
+    p, gr = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    assert torch.allclose(hip.sgd_axpy(ws, _g(p, dev), 0.01, _g(gr, dev)).cpu(), p - 0.01 * gr, atol=1e-7)
+    x, ys = torch.randn(3, 12, 20, generator=g), torch.randint(0, 4, (3, 12), generator=g)
+    ys[0][ys[0] == 2] = 1                                               # an empty class -> count clamped to 1 -> zeros
+    out = hip.proto_reduce(ws, _g(x, dev), _g(ys, dev), 4).cpu()
+    ref = torch.stack([torch.stack([x[b][ys[b] == n].sum(0) / max(int((ys[b] == n).sum()), 1) for n in range(4)]) for b in range(3)])
+    assert torch.allclose(out, ref, atol=1e-6)
+    assert ws.read_status() == 0
+
+
+# ---- every intermediate of a meta-step ------------------------------------------------------------------------------------
+def _unpad(flat, B, Mi, H, W):
+    """padded channels-last [B*M][(H+2)(W+2)][64] -> NCHW [B, M, 64, H, W]; also returns the largest |border| value."""
+    t = flat.reshape(B, Mi, H + 2, W + 2, 64)
+    inner = t[:, :, 1:-1, 1:-1, :]
+    border = t.abs().sum() - inner.abs().sum()
+    return inner.permute(0, 1, 4, 2, 3), float(border)
+
+
+def _case(seed, B, N, K, Q, Cin, H, W, nblk):
+    ep = C.make_image_episodes(seed, B, N, K, Q, Cin, H, W, 12)
+    theta = C.make_conv4_params(seed, Cin, 64, nblk)
+    Fd = C.feature_dim(H, W, 64, nblk)
+    return ep, theta, Fd
+
+
+def _cmp(name, got, ref, tol=2e-4):
+    e = rel_to_max(got, ref, floor=1e-6)
+    assert e <= tol, f"{name}: rel-to-max error {e:.3e}"
+
+
+@pytest.mark.parametrize("shape", [(3, 12, 12, 2), (1, 20, 20, 3)])
+def test_every_intermediate_matches_the_manual_sweep(shape, dev, ws):
+    from fumi_amd import hip
+    Cin, H, W, nblk = shape
+    B, N, K, Q, T, alpha = 2, 3, 2, 3, 2, 0.05
+    ep, theta, Fd = _case(11, B, N, K, Q, Cin, H, W, nblk)
+    S, Qn = N * K, N * Q
+    p = theta + [torch.randn(N, Fd, generator=torch.Generator().manual_seed(5)) * 0.2, torch.zeros(N).uniform_(-0.1, 0.1)]
+    out = hip.maml_conv4_step(ws, _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev),
+                              [_g(t, dev) for t in p], T, alpha)
+    assert ws.read_status() == 0
+    probe = lambda pa, kind, blk=0: hip.conv4_probe(ws, dev, pa, kind, blk).cpu()
+    head = torch.cat([p[-2], p[-1][:, None]], 1)
+    traces = []
+    for b in range(B):
+        tr = {}
+        M.episode_grads(theta, head, ep["x_s"][b], ep["y_s"][b], ep["x_q"][b], ep["y_q"][b], T, alpha, trace=tr)
+        traces.append(tr)
+    geo = [(H >> l, W >> l) for l in range(nblk + 1)]
+    for t in range(T + 1):                                              # support steps, then the query pass
+        Mi = S if t < T else Qn
+        tapes = [tr["tapes"][t] if t < T else tr["query"] for tr in traces]
+        for l in range(nblk):
+            Hl, Wl = geo[l]
+            u, bu = _unpad(probe(t, 0, l), B, Mi, Hl, Wl)
+            _cmp(f"pass {t} block {l} u", u, torch.stack([tp["blocks"][l]["u"] for tp in tapes]))
+            assert bu == 0.0, f"pass {t} block {l}: conv output border not zero"
+            xo = probe(t, 1, l)
+            ref_xo = torch.stack([tp["blocks"][l]["xo"] for tp in tapes])
+            if l + 1 < nblk:
+                xo, bx = _unpad(xo, B, Mi, *geo[l + 1])
+                assert bx == 0.0
+            else:
+                xo = xo.reshape(B, Mi, -1); ref_xo = ref_xo.reshape(B, Mi, -1)
+            _cmp(f"pass {t} block {l} pooled", xo, ref_xo)
+        _cmp(f"pass {t} p", probe(t, 5).reshape(B, Mi, N), torch.stack([tp["p"] for tp in tapes]))
+        _cmp(f"pass {t} dz", probe(t, 6).reshape(B, Mi, N), torch.stack([tp["dz"] for tp in tapes]))
+        for l in reversed(range(nblk)):
+            Hl, Wl = geo[l]
+            dxo = probe(t, 3, l)
+            ref = torch.stack([tp["blocks"][l]["dxo"] for tp in tapes])
+            if l + 1 < nblk:
+                dxo, _ = _unpad(dxo, B, Mi, *geo[l + 1])
+            else:
+                dxo = dxo.reshape(ref.shape)
+            _cmp(f"pass {t} block {l} dxo", dxo, ref)
+            du, bd = _unpad(probe(t, 2, l), B, Mi, Hl, Wl)
+            _cmp(f"pass {t} block {l} du", du, torch.stack([tp["blocks"][l]["du"] for tp in tapes]))
+            assert bd == 0.0, f"pass {t} block {l}: du border not zero"
+    # tangent scratch of the last Hessian-vector product (inner step 0)
+    tp0 = [tr["tapes"][0] for tr in traces]
+    for l in range(nblk):
+        Hl, Wl = geo[l]
+        ud, _ = _unpad(probe(T + 1, 0, l), B, S, Hl, Wl)
+        _cmp(f"tangent block {l} u'", ud, torch.stack([tp["blocks"][l]["ud"] for tp in tp0]))
+        xod = probe(T + 1, 1, l)
+        ref = torch.stack([tp["blocks"][l]["xod"] for tp in tp0])
+        xod = _unpad(xod, B, S, *geo[l + 1])[0] if l + 1 < nblk else xod.reshape(ref.shape)
+        _cmp(f"tangent block {l} x'", xod, ref)
+    for l in reversed(range(nblk)):
+        Hl, Wl = geo[l]
+        dxod = probe(T + 1, 3, l)
+        ref = torch.stack([tp["blocks"][l]["dxod"] for tp in tp0])
+        dxod = _unpad(dxod, B, S, *geo[l + 1])[0] if l + 1 < nblk else dxod.reshape(ref.shape)
+        _cmp(f"tangent block {l} dxo'", dxod, ref)
+        dud, bd = _unpad(probe(T + 1, 2, l), B, S, Hl, Wl)
+        _cmp(f"tangent block {l} du'", dud, torch.stack([tp["blocks"][l]["dud"] for tp in tp0]))
+        assert bd == 0.0
+
+
+# ---- whole meta-steps against autograd --------------------------------------------------------------------------------------
+def _check_grads(names, got, ref):
+    floor = max(0.02 * max(float(r.abs().max()) for r in ref), 1e-7)
+    for n, a, r in zip(names, got, ref):
+        e = rel_to_max(a.cpu(), r, floor)
+        assert e <= GRAD_TOL, f"grad {n}: rel-to-max error {e:.3e}"
+
+
+@pytest.mark.parametrize("T,first_order,need_grad", [(1, False, True), (3, False, True), (2, True, True), (0, False, True), (2, False, False)])
+def test_maml_conv4_step_matches_autograd(T, first_order, need_grad, dev, ws):
+    from fumi_amd import hip
+    B, N, K, Q, Cin, H, W, nblk, alpha = 3, 5, 1, 3, 3, 16, 16, 4, 0.05
+    ep, theta, Fd = _case(21 + T, B, N, K, Q, Cin, H, W, nblk)
+    g = torch.Generator().manual_seed(9)
+    p = theta + [torch.randn(N, Fd, generator=g) * 0.2, torch.randn(N, generator=g) * 0.1]
+    out = hip.maml_conv4_step(ws, _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev),
+                              [_g(t, dev) for t in p], T, alpha, first_order, need_grad=need_grad)
+    assert ws.read_status() == 0
+    pl = [t.clone().requires_grad_(True) for t in p]
+    ref = C.maml_conv4_meta_step(pl, ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], T, alpha, first_order, need_grad=need_grad)
+    assert rel_to_max(out["logits"].cpu(), ref["logits"]) <= LOGIT_TOL
+    assert rel_to_max(out["loss_b"].cpu(), ref["loss_b"]) <= LOGIT_TOL
+    mask = safe_margin_mask(ref["logits"], MARGIN)
+    assert torch.equal(out["preds"].cpu()[mask], ref["preds"][mask]) and float(mask.float().mean()) > 0.9
+    assert torch.allclose(out["acc_b"].cpu(), ref["acc_b"], atol=1e-6) or not bool(mask.all())
+    if need_grad:
+        _check_grads([str(i) for i in range(len(p))], out["g_params"], ref["g_params"])
+
+
+@pytest.mark.parametrize("T,tanh", [(1, False), (2, True)])
+def test_fumi_conv4_step_matches_autograd(T, tanh, dev, ws):
+    from fumi_amd import hip
+    B, N, K, Q, Cin, H, W, nblk, Dt, Ht, alpha = 2, 5, 2, 3, 3, 20, 20, 4, 12, 16, 0.05
+    ep, theta, Fd = _case(31 + T, B, N, K, Q, Cin, H, W, nblk)
+    _, phi = cg.make_fumi_params(31, 8, [Fd], Dt, Ht, head_scale=0.3)
+    stats = torch.zeros(2, device=dev)
+    out = hip.fumi_conv4_step(ws, N, _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev),
+                              [_g(t, dev) for t in theta], [_g(t, dev) for t in phi], T, alpha, tanh, text_s=_g(ep["text_s"], dev),
+                              stats=stats)
+    assert ws.read_status() == 0
+    th = [t.clone().requires_grad_(True) for t in theta]
+    ph = [t.clone().requires_grad_(True) for t in phi]
+    ref = C.fumi_conv4_meta_step(th, ph, ep["text_s"], ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], N, T, alpha, tanh)
+    assert rel_to_max(out["logits"].cpu(), ref["logits"]) <= LOGIT_TOL
+    mask = safe_margin_mask(ref["logits"], MARGIN)
+    assert torch.equal(out["preds"].cpu()[mask], ref["preds"][mask])
+    assert abs(float(stats[0]) - float(ref["loss"])) <= LOGIT_TOL * max(1.0, float(ref["loss"]))
+    _check_grads([f"theta{i}" for i in range(len(theta))] + [f"phi{i}" for i in range(4)], out["g_theta"] + out["g_phi"],
+                 ref["g_theta"] + ref["g_phi"])
+
+
+def test_conv4_full_size_episode_84x84(dev, ws):
+    """BASELINE.json configs[1] as worded, one episode pair: 5-way 5-shot, 3 x 84 x 84 images, Conv4 (1600 features), 1 inner
+    step, second-order meta-gradients (15 query images per class keep the host-side autograd oracle to a few seconds)."""
+    from fumi_amd import hip
+    B, N, K, Q, Cin, H, W, nblk, Dt, Ht, alpha, T = 2, 5, 5, 3, 3, 84, 84, 4, 32, 24, 0.01, 1
+    ep, theta, Fd = _case(77, B, N, K, Q, Cin, H, W, nblk)
+    assert Fd == 1600
+    _, phi = cg.make_fumi_params(77, 8, [Fd], Dt, Ht, head_scale=0.5)
+    out = hip.fumi_conv4_step(ws, N, _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev),
+                              [_g(t, dev) for t in theta], [_g(t, dev) for t in phi], T, alpha, False, text_s=_g(ep["text_s"], dev))
+    assert ws.read_status() == 0
+    th = [t.clone().requires_grad_(True) for t in theta]
+    ph = [t.clone().requires_grad_(True) for t in phi]
+    ref = C.fumi_conv4_meta_step(th, ph, ep["text_s"], ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], N, T, alpha, False)
+    assert rel_to_max(out["logits"].cpu(), ref["logits"]) <= LOGIT_TOL
+    mask = safe_margin_mask(ref["logits"], MARGIN)
+    assert torch.equal(out["preds"].cpu()[mask], ref["preds"][mask])
+    _check_grads([f"theta{i}" for i in range(len(theta))] + [f"phi{i}" for i in range(4)], out["g_theta"] + out["g_phi"],
+                 ref["g_theta"] + ref["g_phi"])
