@@ -76,7 +76,7 @@ def test_small_exported_ops(dev, ws):
     loss, dz, preds = hip.ce_fwd_bwd(ws, _g(z, dev), _g(y, dev))
     zz = z.clone().requires_grad_(True)
     ref = F.cross_entropy(zz, y)
-    assert abs(float(loss) - float(ref)) < 1e-6 and rel_to_max(dz.cpu(), torch.autograd.grad(ref, zz)[0]) < 1e-5
+    assert abs(float(loss) - float(ref.detach())) < 1e-6 and rel_to_max(dz.cpu(), torch.autograd.grad(ref, zz)[0]) < 1e-5
     assert torch.equal(preds.cpu(), z.max(-1)[1])
     p, gr = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
     assert torch.allclose(hip.sgd_axpy(ws, _g(p, dev), 0.01, _g(gr, dev)).cpu(), p - 0.01 * gr, atol=1e-7)
@@ -93,8 +93,9 @@ def _unpad(flat, B, Mi, H, W):
     """padded channels-last [B*M][(H+2)(W+2)][64] -> NCHW [B, M, 64, H, W]; also returns the largest |border| value."""
     t = flat.reshape(B, Mi, H + 2, W + 2, 64)
     inner = t[:, :, 1:-1, 1:-1, :]
-    border = t.abs().sum() - inner.abs().sum()
-    return inner.permute(0, 1, 4, 2, 3), float(border)
+    frame = t.clone()
+    frame[:, :, 1:-1, 1:-1, :] = 0
+    return inner.permute(0, 1, 4, 2, 3), float(frame.abs().max())
 
 
 def _case(seed, B, N, K, Q, Cin, H, W, nblk):
@@ -234,7 +235,7 @@ def test_conv4_full_size_episode_84x84(dev, ws):
     """BASELINE.json configs[1] as worded, one episode pair: 5-way 5-shot, 3 x 84 x 84 images, Conv4 (1600 features), 1 inner
     step, second-order meta-gradients (15 query images per class keep the host-side autograd oracle to a few seconds)."""
     from fumi_amd import hip
-    B, N, K, Q, Cin, H, W, nblk, Dt, Ht, alpha, T = 2, 5, 5, 3, 3, 84, 84, 4, 32, 24, 0.01, 1
+    B, N, K, Q, Cin, H, W, nblk, Dt, Ht, alpha, T = 2, 5, 5, 3, 3, 84, 84, 4, 12, 24, 0.01, 1
     ep, theta, Fd = _case(77, B, N, K, Q, Cin, H, W, nblk)
     assert Fd == 1600
     _, phi = cg.make_fumi_params(77, 8, [Fd], Dt, Ht, head_scale=0.5)
