@@ -114,6 +114,20 @@ static int frags_of_slot(hipStream_t st, const Net& n, const float* params, floa
     return FUMI_OK;
 }
 
+// meta-parameters (torch layouts) -> one canonical copy per episode
+static int slot0_from_theta(hipStream_t st, const Net& n, const float* const* theta, float* P0, float* toi_tmp) {
+    TRY(launch_w1_to_canon(st, n.B, n.Cin, theta[0], 0, P0 + n.offW[0], n.PSZ));
+    for (int l = 0; l < n.nblk; ++l) {
+        if (l) {
+            TRY(launch_oihw_to_toi(st, 1, theta[3 * l], toi_tmp + (size_t)l * 36864));
+            TRY(launch_broadcast(st, n.B, 36864, toi_tmp + (size_t)l * 36864, P0 + n.offW[l], n.PSZ));
+        }
+        TRY(launch_broadcast(st, n.B, 64, theta[3 * l + 1], P0 + n.offG[l], n.PSZ));
+        TRY(launch_broadcast(st, n.B, 64, theta[3 * l + 2], P0 + n.offB[l], n.PSZ));
+    }
+    return FUMI_OK;
+}
+
 struct StepCtx {
     fumi_ws* ws; hipStream_t st; Net n; Scratch sc;
     const float* img_s; const float* img_q; const int64_t* y_s; const int64_t* y_q;
@@ -144,6 +158,7 @@ static int forward_pass(StepCtx& c, int M, const float* img, const float* params
         PoolFwdArgs pa; pa.e = ew_geom(n, M, l); pa.u = pb.u[l]; pa.ud = nullptr; pa.coef = pb.coef[l]; pa.x = pb.x[l]; pa.xd = nullptr;
         TRY(launch_pool_fwd(c.st, pa, 0));
     }
+    if (!head) return FUMI_OK;                                        // features only (fumi_hip_conv4_features)
     HeadArgs h; memset(&h, 0, sizeof(h));
     h.B = n.B; h.M = M; h.N = n.N; h.F = n.F; h.scale = scale; h.f = pb.x[n.nblk - 1]; h.head = head; h.y = y;
     h.z = logits ? logits : pb.z; h.p = pb.p; h.dz = pb.dz; h.preds = preds; h.preds_f = preds_f; h.loss_b = loss_b; h.acc_b = acc_b;
@@ -354,15 +369,7 @@ int run_conv4_episodes(fumi_ws* ws, hipStream_t st, Conv4Problem p, const Conv4H
     auto Hd = [&](int s) { return heads + (size_t)s * hsz; };
 
     // ---- slot 0: the meta-parameters, one copy per episode (canonical layouts), and the caller's head
-    TRY(launch_w1_to_canon(st, n.B, n.Cin, p.theta[0], 0, P(0) + n.offW[0], n.PSZ));
-    for (int l = 0; l < n.nblk; ++l) {
-        if (l) {
-            TRY(launch_oihw_to_toi(st, 1, p.theta[3 * l], toi_tmp + (size_t)l * 36864));
-            TRY(launch_broadcast(st, n.B, 36864, toi_tmp + (size_t)l * 36864, P(0) + n.offW[l], n.PSZ));
-        }
-        TRY(launch_broadcast(st, n.B, 64, p.theta[3 * l + 1], P(0) + n.offG[l], n.PSZ));
-        TRY(launch_broadcast(st, n.B, 64, p.theta[3 * l + 2], P(0) + n.offB[l], n.PSZ));
-    }
+    TRY(slot0_from_theta(st, n, p.theta, P(0), toi_tmp));
     TRY(frags_of_slot(st, n, P(0), Fr(0), tmp1));
     HIP_TRY(hipMemcpyAsync(Hd(0), p.head, hsz * 4, hipMemcpyDeviceToDevice, st));
 
@@ -583,6 +590,34 @@ int fumi_hip_conv4_probe(fumi_ws_t* ws, fumi_stream_t stream, int pass, int kind
     *n_out = cnt;
     const size_t k = cnt < max_floats ? cnt : max_floats;
     HIP_TRY(hipMemcpyAsync(out, src, k * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return FUMI_OK;
+}
+
+// Forward only: feats [G*M, F] = Conv4(x [G, M, Cin, H, W]) with the batch statistics of every group of M images taken
+// separately (a support set or a query set is one group, as in the meta-step).  Serves Conv4.forward / FUMI.im_forward.
+int fumi_hip_conv4_features(fumi_ws_t* ws, fumi_stream_t stream, int G, int M, int Cin, int H, int W, int nblk,
+        const float* x, const float* const* theta, float* feats) {
+    if (!ws || !x || !theta || !feats || G < 1 || M < 1) return FUMI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ws->device));
+    StepCtx c; c.ws = ws; c.st = st;
+    int rc = net_init(c.n, G, nblk, Cin, 1, H, W);
+    if (rc) return rc;
+    const Net& n = c.n;
+    for (int i = 0; i < 3 * nblk; ++i) if (!theta[i]) return FUMI_EINVAL;
+    size_t bytes = conv4_scratch_sizes(n, M, M, c.sc) + pass_bytes(n, M, false);
+    bytes += ws_align((size_t)n.B * n.PSZ * 4) + ws_align((size_t)n.B * n.FSZ * 4) + ws_align((size_t)n.B * (2048 + 4096) * 4) +
+             ws_align((size_t)n.nblk * 36864 * 4);
+    if ((rc = ws_reserve(ws, bytes))) return rc;
+    g_probe.valid = false;
+    c.sc.cpart = ws_f(ws, c.sc.cpart_n); c.sc.wpart = ws_f(ws, c.sc.wpart_n); c.sc.rpart = ws_f(ws, c.sc.rpart_n);
+    PassBufs pb; pass_carve(ws, n, M, false, pb);
+    float* params = ws_f(ws, (size_t)n.B * n.PSZ); float* frags = ws_f(ws, (size_t)n.B * n.FSZ);
+    float* tmp1 = ws_f(ws, (size_t)n.B * (2048 + 4096)); float* toi_tmp = ws_f(ws, (size_t)n.nblk * 36864);
+    TRY(slot0_from_theta(st, n, theta, params, toi_tmp));
+    TRY(frags_of_slot(st, n, params, frags, tmp1));
+    TRY(forward_pass(c, M, x, params, frags, pb, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr));
+    HIP_TRY(hipMemcpyAsync(feats, pb.x[n.nblk - 1], (size_t)G * M * n.F * 4, hipMemcpyDeviceToDevice, st));
     return FUMI_OK;
 }
 

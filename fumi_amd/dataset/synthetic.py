@@ -13,8 +13,13 @@ import torch
 
 
 class SyntheticEpisodes:
-    def __init__(self, n_classes, D, Dt, N, K, Q, batch_size, seed, split, tokens=None, length=None):
+    def __init__(self, n_classes, D, Dt, N, K, Q, batch_size, seed, split, tokens=None, length=None, image_shape=None):
+        """image_shape=(C, H, W): the samples are raw images (--im_encoder conv4) -- the class prototype is a D = C*H*W pattern
+        and a sample is prototype + noise, reshaped to [C, H, W]."""
         rs = np.random.RandomState(seed * 7 + {"train": 0, "val": 1, "test": 2}[split])
+        self.image_shape = image_shape
+        if image_shape is not None:
+            D = int(np.prod(image_shape))
         self.mu = rs.standard_normal((n_classes, D)).astype(np.float32)
         proj = np.random.RandomState(seed + 99).standard_normal((Dt if tokens is None else 16, D)).astype(np.float32) / np.sqrt(D)
         self.N, self.K, self.Q, self.B, self.D = N, K, Q, batch_size, D
@@ -39,6 +44,8 @@ class SyntheticEpisodes:
         cs, cq = np.take_along_axis(cls, y_s, 1), np.take_along_axis(cls, y_q, 1)
         x_s = self.mu[cs] + 2.0 * rs.standard_normal((B, S, self.D)).astype(np.float32)
         x_q = self.mu[cq] + 2.0 * rs.standard_normal((B, Qn, self.D)).astype(np.float32)
+        if self.image_shape is not None:
+            x_s, x_q = x_s.reshape(B, S, *self.image_shape), x_q.reshape(B, Qn, *self.image_shape)
         t = torch.from_numpy
         return {'train': ([t(cs.astype(np.int64)), t(self.text[cs]), t(x_s.astype(np.float32))], t(y_s.astype(np.int64))),
                 'test': ([t(cq.astype(np.int64)), t(self.text[cq]), t(x_q.astype(np.float32))], t(y_q.astype(np.int64)))}
@@ -58,8 +65,9 @@ def get_synthetic(args):
         tokens = (V, L, 0)
         dictionary = {"PAD": 0}
         dictionary.update({f"tok{i}": i for i in range(1, V)})
+    shape = (args.image_channels, args.image_size, args.image_size) if getattr(args, "im_encoder", "") == "conv4" else None
     mk = lambda split, q: SyntheticEpisodes(args.synthetic_classes, args.im_emb_dim, args.text_emb_dim, args.num_ways,
-                                            args.num_shots, q, args.batch_size, args.seed, split, tokens)
+                                            args.num_shots, q, args.batch_size, args.seed, split, tokens, image_shape=shape)
     q_eval = int(100 / args.num_ways)                      # data.py:163-166,180-183
     return mk("train", args.num_shots_test), mk("val", q_eval), mk("test", q_eval), dictionary
 

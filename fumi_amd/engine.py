@@ -40,6 +40,21 @@ class HipEngine:
         return hip.am3_step(self._ws(x_s), x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad=need_grad,
                             grad_scale=grad_scale, g_w=g_w, dropout_p=dropout_p, seed=seed, stats=stats)
 
+    def fumi_conv4_step(self, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head, need_grad, grad_scale,
+                        g_theta=None, g_phi=None, cls_text=None, stats=None):
+        """FuMI with the Conv4 encoder at the im_net seam: x_s [B,S,C,H,W], x_q [B,Qn,C,H,W]."""
+        return hip.fumi_conv4_step(self._ws(x_s), n_way, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head, cls_text=cls_text,
+                                   text_s=text_s, need_grad=need_grad, grad_scale=grad_scale, g_theta=g_theta, g_phi=g_phi,
+                                   stats=stats)
+
+    def maml_conv4_step(self, x_s, y_s, x_q, y_q, params, T, alpha, first_order, need_grad, grad_scale, g_params=None,
+                        stats=None):
+        return hip.maml_conv4_step(self._ws(x_s), x_s, y_s, x_q, y_q, params, T, alpha, first_order, need_grad=need_grad,
+                                   grad_scale=grad_scale, g_params=g_params, stats=stats)
+
+    def conv4_features(self, x, theta):
+        return hip.conv4_features(self._ws(x), x, theta)
+
     def am3_metrics(self, n_way, stats):
         return hip.am3_metrics(self._ws(stats), n_way, stats)
 

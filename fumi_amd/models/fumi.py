@@ -34,8 +34,14 @@ except Exception:          # pragma: no cover
 class FUMI(nn.Module):
     def __init__(self, n_way=5, im_emb_dim=2048, im_hid_dim=[64], text_encoder="BERT", text_emb_dim=300,
                  text_hid_dim=1024, dropout_rate=0.0, dictionary=None, pooling_strat="mean", init_all_layers=False,
-                 norm_hypernet=True, fine_tune=False, init_bias=False):
+                 norm_hypernet=True, fine_tune=False, init_bias=False, im_encoder="precomputed", image_size=84,
+                 image_channels=3):
         super().__init__()
+        # im_encoder (additive): "precomputed" / "resnet" = the reference's MLP over embeddings (fumi.py:89-100);
+        # "conv4" = the Conv4 encoder on raw images at the same seam (fumi_amd/models/conv4.py), im_hid_dim is then unused
+        if im_encoder not in ("precomputed", "resnet", "conv4"):
+            raise NameError(f"{im_encoder} not allowed as image encoder")
+        self.im_encoder = im_encoder
         self.n_way = n_way
         self.im_emb_dim = im_emb_dim
         self.im_hid_dim = list(im_hid_dim)
@@ -71,6 +77,11 @@ class FUMI(nn.Module):
             raise NotImplementedError("Entire model hypernet initialisation removed")
         if len(self.im_hid_dim) < 1:
             raise IndexError("im_hid_dim needs at least one hidden layer (the reference indexes im_hid_dim[-1])")
+        conv = None
+        if im_encoder == "conv4":
+            from .conv4 import Conv4
+            conv = Conv4(image_channels, 64, 4, image_size)
+            self.im_hid_dim = [conv.feature_dim]          # the head the hypernetwork emits is [N, feature_dim + 1]
 
         # hypernetwork: Linear . ReLU . Linear(H+1) [. Tanh]  (fumi.py:70-86,104-107)
         head = nn.Linear(self.text_hid_dim, self.im_hid_dim[-1] + 1)
@@ -91,11 +102,13 @@ class FUMI(nn.Module):
             if dropout_rate > 0:
                 im[f'dropout{i}'] = nn.Dropout(dropout_rate)
             d = h
-        self.im_net = MetaSequential(im)
+        self.im_net = conv if conv is not None else MetaSequential(im)
         self._flat = None
 
     # ---- parameter views handed to the engine --------------------------------------------------------------------
     def _theta(self):
+        if self.im_encoder == "conv4":
+            return self.im_net.theta()
         out = []
         for i in range(len(self.im_hid_dim)):
             lin = getattr(self.im_net, f'linear{i}')
@@ -141,6 +154,10 @@ class FUMI(nn.Module):
     def im_forward(self, im_embeds, im_params, hyper_params):
         """logits [rows, N] = im_net(x; params) @ h[:, :-1].T + h[:, -1]  (fumi.py:214-218); inference helper."""
         eng = _engine.get_engine()
+        if self.im_encoder == "conv4":
+            x = self.im_net(im_embeds, params=im_params)
+            h = hyper_params.detach()
+            return eng.linear(x.reshape(-1, x.shape[-1]).contiguous(), h[:, :-1].contiguous(), h[:, -1].contiguous(), act=0)
         x = im_embeds.contiguous()
         names = [f'linear{i}' for i in range(len(self.im_hid_dim))]
         for n in names:
@@ -189,10 +206,16 @@ class FUMI(nn.Module):
         nth = len(theta)
         # [.. grads .. | sum loss / B | sum acc / B], written by the engine -> one all-reduce(sum) -> global means everywhere
         tail = fg.tail if train else torch.empty(2, device=x_s.device, dtype=torch.float32)
-        out = eng.fumi_step(self.n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, args.step_size, self.norm_hypernet,
-                            need_grad=train, grad_scale=1.0 / B,
-                            g_theta=fg.views[:nth] if train else None, g_phi=fg.views[nth:] if train else None,
-                            cls_text=cls_text, stats=tail, dropout_p=drop_p, seed=drop_seed)
+        if self.im_encoder == "conv4":
+            out = eng.fumi_conv4_step(self.n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, args.step_size, self.norm_hypernet,
+                                      need_grad=train, grad_scale=1.0 / B,
+                                      g_theta=fg.views[:nth] if train else None, g_phi=fg.views[nth:] if train else None,
+                                      cls_text=cls_text, stats=tail)
+        else:
+            out = eng.fumi_step(self.n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, args.step_size, self.norm_hypernet,
+                                need_grad=train, grad_scale=1.0 / B,
+                                g_theta=fg.views[:nth] if train else None, g_phi=fg.views[nth:] if train else None,
+                                cls_text=cls_text, stats=tail, dropout_p=drop_p, seed=drop_seed)
         fdist.all_reduce_sum_(fg.flat if train else tail)
         # read back asynchronously (fumi.py:195 blocks here); in training the two stores ride on the optimizer's launch
         loss, acc = lazy.scalars(tail, 2, defer=train)

@@ -19,12 +19,19 @@ from ..utils.wandb_compat import wandb
 
 
 class PureImageNetwork(MetaModule):
-    def __init__(self, im_embed_dim=2048, n_way=5, hidden_dims=None):
+    def __init__(self, im_embed_dim=2048, n_way=5, hidden_dims=None, im_encoder="precomputed", image_size=84,
+                 image_channels=3):
         super().__init__()
         self.im_embed_dim = im_embed_dim
         self.n_way = n_way
         self.hidden_dims = list(hidden_dims) if hidden_dims is not None else None
+        self.im_encoder = im_encoder              # additive: "conv4" = Conv4 on raw images in front of lin_final
         layers, d = OrderedDict(), im_embed_dim
+        if im_encoder == "conv4":
+            from .conv4 import Conv4
+            self.hidden_dims = None
+            layers['features'] = Conv4(image_channels, 64, 4, image_size)
+            d = layers['features'].feature_dim
         for i, h in enumerate(self.hidden_dims or []):
             layers[f'lin_{i}'] = MetaLinear(d, h)
             layers[f'relu_{i}'] = nn.ReLU()
@@ -37,6 +44,8 @@ class PureImageNetwork(MetaModule):
         return self.net(inputs, params=self.get_subdict(params, 'net'))
 
     def _params(self):
+        if self.im_encoder == "conv4":
+            return self.net.features.theta() + [self.net.lin_final.weight, self.net.lin_final.bias]
         out = []
         for i in range(len(self.hidden_dims or [])):
             lin = getattr(self.net, f'lin_{i}')
@@ -66,9 +75,9 @@ def evaluate(args, model, batch, optimizer, task="train"):
     T = args.num_train_adapt_steps if train else args.num_test_adapt_steps
     fg = model._flat_grads() if train else None
     tail = fg.tail if train else torch.empty(2, device=x_s.device, dtype=torch.float32)
-    _engine.get_engine().maml_step(x_s, y_s, x_q, y_q, [p.detach() for p in model._params()], T, args.step_size,
-                                   bool(args.first_order), need_grad=train, grad_scale=1.0 / B,
-                                   g_params=fg.views if train else None, stats=tail)
+    step = _engine.get_engine().maml_conv4_step if getattr(model, "im_encoder", "") == "conv4" else _engine.get_engine().maml_step
+    step(x_s, y_s, x_q, y_q, [p.detach() for p in model._params()], T, args.step_size,
+         bool(args.first_order), need_grad=train, grad_scale=1.0 / B, g_params=fg.views if train else None, stats=tail)
     fdist.all_reduce_sum_(fg.flat if train else tail)
     if train:
         optimizer.zero_grad()

@@ -42,7 +42,7 @@ _FLAGS = [
     # model
     ("--model", dict(type=str, default="fumi", help="Model to be trained")),
     ("--prototype_dim", dict(type=int, default=64, help="Dimension of latent space")),
-    ("--im_encoder", dict(type=str, default="precomputed", help="Type of vision feature extractor (resnet, precomputed)")),
+    ("--im_encoder", dict(type=str, default="precomputed", help="Type of vision feature extractor (resnet, precomputed; conv4 = Conv4 on raw images, this engine's extension at the im_net seam)")),
     ("--im_emb_dim", dict(type=int, default=2048, help="Dimension of image embedding (if precomputed)")),
     ("--im_hid_dim", dict(type=int, nargs="+", default=[256, 64], help="Hidden dimension of image model")),
     ("--text_encoder", dict(type=str, choices=["glove", "w2v", "RNN", "RNNhid", "BERT", "rand"], default="BERT",
@@ -76,6 +76,8 @@ _ENGINE_FLAGS = [     # additive, not in the reference
     ("--synthetic_classes", dict(type=int, default=64, help="[synthetic dataset] number of classes per split")),
     ("--synthetic_vocab", dict(type=int, default=2000, help="[synthetic dataset] vocabulary size for token text")),
     ("--synthetic_seq_len", dict(type=int, default=32, help="[synthetic dataset] token sequence length")),
+    ("--image_size", dict(type=int, default=84, help="[--im_encoder conv4] height = width of the input images")),
+    ("--image_channels", dict(type=int, default=3, help="[--im_encoder conv4] input channels (1-3)")),
 ]
 
 
@@ -90,13 +92,16 @@ def init_model(args, dictionary, watch=True):
     """Model factory (utils.py:232-274).  Unknown names fall through to AM3 exactly like the reference."""
     from ..models import am3, fumi, maml
     if args.model == "maml":
-        model = maml.PureImageNetwork(im_embed_dim=args.im_emb_dim, n_way=args.num_ways, hidden_dims=args.im_hid_dim)
+        conv = dict(im_encoder="conv4", image_size=args.image_size, image_channels=args.image_channels) if args.im_encoder == "conv4" else {}
+        model = maml.PureImageNetwork(im_embed_dim=args.im_emb_dim, n_way=args.num_ways, hidden_dims=args.im_hid_dim, **conv)
     elif args.model == "fumi":
         model = fumi.FUMI(n_way=args.num_ways, im_emb_dim=args.im_emb_dim, im_hid_dim=args.im_hid_dim,
                           text_encoder=args.text_encoder, text_emb_dim=args.text_emb_dim,
                           text_hid_dim=args.text_hid_dim, dropout_rate=args.dropout, dictionary=dictionary,
                           pooling_strat=args.pooling_strat, init_all_layers=args.init_all_layers,
-                          norm_hypernet=args.norm_hypernet, fine_tune=args.fine_tune, init_bias=args.hypernet_bias_init)
+                          norm_hypernet=args.norm_hypernet, fine_tune=args.fine_tune, init_bias=args.hypernet_bias_init,
+                          **(dict(im_encoder="conv4", image_size=args.image_size, image_channels=args.image_channels)
+                             if args.im_encoder == "conv4" else {}))
     elif args.model == "clip":
         raise NotImplementedError("the supervised CLIP baseline (fumi/models/clip.py) is outside the episodic hot path")
     else:

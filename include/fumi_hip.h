@@ -200,6 +200,9 @@ int fumi_hip_maml_conv4_step(fumi_ws_t* ws, fumi_stream_t stream,
         const float* const* params,
         float* logits_q, int64_t* preds_q, float* preds_q_f32, float* loss_b, float* acc_b, float* stats,
         float* const* g_params);
+/* Forward only: feats [G*M, F] = Conv4(x [G,M,Cin,H,W]); batch statistics per group of M images (one support or query set). */
+int fumi_hip_conv4_features(fumi_ws_t* ws, fumi_stream_t stream, int G, int M, int Cin, int H, int W, int nblk,
+        const float* x, const float* const* theta, float* feats);
 /* Test hook: copies one intermediate tensor of the LAST conv4 step of this process out of the workspace (layouts:
  * fumi_amd/csrc/conv4.hip, fumi_hip_conv4_probe).  *n_out = its size in floats; at most max_floats are copied. */
 int fumi_hip_conv4_probe(fumi_ws_t* ws, fumi_stream_t stream, int pass, int kind, int block, float* out, size_t max_floats,

@@ -250,3 +250,59 @@ def test_conv4_full_size_episode_84x84(dev, ws):
     assert torch.equal(out["preds"].cpu()[mask], ref["preds"][mask])
     _check_grads([f"theta{i}" for i in range(len(theta))] + [f"phi{i}" for i in range(4)], out["g_theta"] + out["g_phi"],
                  ref["g_theta"] + ref["g_phi"])
+
+
+# ---- the module surface (--im_encoder conv4) on the GPU -------------------------------------------------------------------
+def test_conv4_features_op(dev, ws):
+    from fumi_amd import hip
+    ep, theta, Fd = _case(5, 3, 4, 2, 3, 3, 28, 28, 4)
+    f = hip.conv4_features(ws, _g(ep["x_q"], dev), [_g(t, dev) for t in theta]).cpu()
+    ref = torch.stack([C.conv4_features(ep["x_q"][b], theta) for b in range(3)])
+    assert f.shape == (3, 12, Fd) and rel_to_max(f, ref) <= 1e-5
+
+
+def test_fumi_conv4_evaluate_on_gpu_equals_the_cpu_oracle_engine(dev):
+    """FUMI(im_encoder='conv4').evaluate: three training steps + a test step on the HIP engine against the same model driven by
+    the autograd oracle on the host (tests/oracle_engine.py): losses and parameters stay together."""
+    from types import SimpleNamespace
+    from fumi_amd import engine
+    from fumi_amd.models.fumi import FUMI
+    from oracle_engine import OracleEngine
+    ep = C.make_image_episodes(8, 4, 5, 2, 3, 3, 20, 20, 12)
+    batch = cg.to_batch(ep)
+
+    def run(device, eng):
+        old = engine.set_engine(eng)
+        try:
+            torch.manual_seed(1)
+            m = FUMI(n_way=5, im_encoder="conv4", image_size=20, text_emb_dim=12, text_hid_dim=16, norm_hypernet=True).to(device)
+            args = SimpleNamespace(device=device, num_train_adapt_steps=2, num_test_adapt_steps=2, step_size=0.05,
+                                   first_order=False, num_ways=5, batch_size=4)
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+            losses = [float(m.evaluate(args, batch, opt, "train")[0]) for _ in range(3)]
+            te = m.evaluate(args, batch, None, "test")
+            return losses + [float(te[0])], torch.cat([p.detach().reshape(-1).cpu() for p in m.parameters()]), te[2].cpu()
+        finally:
+            engine.set_engine(old)
+    l_gpu, p_gpu, pr_gpu = run(dev, None)
+    l_cpu, p_cpu, pr_cpu = run(torch.device("cpu"), OracleEngine())
+    assert np.allclose(l_gpu, l_cpu, rtol=0, atol=2e-4), (l_gpu, l_cpu)
+    assert float((p_gpu - p_cpu).abs().max()) < 2e-4                   # Adam's sign-like first steps amplify 1e-7 differences
+    assert float((pr_gpu == pr_cpu).float().mean()) > 0.9
+
+
+def test_cli_fumi_conv4_end_to_end_on_gpu(dev, tmp_path, monkeypatch):
+    """`python -m fumi_amd.main --model fumi --im_encoder conv4 --dataset synthetic` (BASELINE.json configs[1] as worded, shortened):
+    image loader -> Conv4 + hypernetwork -> meta-training on the HIP engine -> checkpoint -> test."""
+    from fumi_amd import main as cli
+    monkeypatch.chdir(tmp_path)
+    argv = ["--model", "fumi", "--dataset", "synthetic", "--im_encoder", "conv4", "--image_size", "28", "--text_encoder", "BERT",
+            "--text_emb_dim", "32", "--batch_size", "8", "--num_shots", "5", "--num_ways", "5", "--num_shots_test", "5",
+            "--epochs", "30", "--eval_freq", "15", "--num_ep_test", "16", "--num_train_adapt_steps", "1",
+            "--num_test_adapt_steps", "1", "--lr", "1e-3", "--step_size", "0.05", "--dropout", "0", "--log_dir", str(tmp_path / "res"),
+            "--synthetic_classes", "16", "--wandb_offline"]
+    args = cli.parse_args(argv)
+    assert args.device.type == "cuda"
+    res = cli.main(args)
+    assert np.isfinite(res["test_loss"]) and 0.0 <= res["test_acc"] <= 1.0
+    assert res["test_acc"] > 0.3                                        # chance = 0.2: the engine's gradients train the encoder

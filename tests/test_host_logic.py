@@ -277,3 +277,49 @@ def test_bench_self_launches_one_process_per_gpu(monkeypatch, capsys):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 2
+
+
+def test_cli_maml_conv4_plumbing_on_cpu(oracle_engine, tmp_path, monkeypatch):
+    """BASELINE.json configs[0] as worded: `main.py --model maml` 5-way 1-shot with the Conv4 encoder, meta-batch 4, on CPU
+    (plumbing: flags -> image loader -> Conv4 module -> inner loop -> checkpoint -> test; tiny images keep it to seconds)."""
+    from fumi_amd import main as cli
+    monkeypatch.chdir(tmp_path)
+    argv = ["--model", "maml", "--dataset", "synthetic", "--disable_cuda", "--im_encoder", "conv4", "--image_size", "16",
+            "--num_shots", "1", "--num_shots_test", "2", "--batch_size", "4", "--epochs", "1", "--eval_freq", "1",
+            "--num_ep_test", "4", "--num_train_adapt_steps", "1", "--num_test_adapt_steps", "1",
+            "--log_dir", str(tmp_path / "res"), "--synthetic_classes", "10"]
+    args = cli.parse_args(argv)
+    res = cli.main(args)
+    assert np.isfinite(res["test_loss"]) and 0.0 <= res["test_acc"] <= 1.0
+    runs = os.listdir(tmp_path / "res" / "runs")
+    ck = torch.load(tmp_path / "res" / "runs" / runs[0] / "ckpt.pth.tar", weights_only=False)
+    keys = set(ck["state_dict"])
+    assert {"net.features.block0.conv.weight", "net.features.block3.norm.bias", "net.lin_final.weight"} <= keys
+    assert ck["state_dict"]["net.features.block0.conv.weight"].shape == (64, 3, 3, 3)
+    assert ck["state_dict"]["net.lin_final.weight"].shape == (5, 64)            # 16 -> 8 -> 4 -> 2 -> 1: 64 features
+
+
+def test_fumi_conv4_module_trains_through_evaluate(oracle_engine):
+    """FUMI(im_encoder='conv4'): the hypernetwork emits [N, F+1] rows for the Conv4 features, evaluate() fills .grad of the 12
+    encoder tensors + 4 hypernetwork tensors and steps the optimizer; Conv4.forward / im_forward run on the feature op."""
+    from fumi_amd.models.fumi import FUMI
+    from oracle import conv4_ref as C
+    torch.manual_seed(0)
+    m = FUMI(n_way=3, im_encoder="conv4", image_size=16, image_channels=3, text_emb_dim=12, text_hid_dim=8, norm_hypernet=False)
+    assert m.im_net.feature_dim == 64 and m.hyper_net[2].weight.shape == (65, 8)
+    assert [k for k in m.state_dict() if k.startswith("im_net.")][:3] == ["im_net.block0.conv.weight", "im_net.block0.norm.weight",
+                                                                           "im_net.block0.norm.bias"]
+    ep = C.make_image_episodes(3, 2, 3, 2, 2, 3, 16, 16, 12)
+    args = SimpleNamespace(device=torch.device("cpu"), num_train_adapt_steps=1, num_test_adapt_steps=1, step_size=0.05,
+                           first_order=False, num_ways=3, batch_size=2)
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    before = [p.detach().clone() for p in m.parameters()]
+    loss, acc, _, _ = m.evaluate(args, cg.to_batch(ep), opt, "train")
+    assert np.isfinite(float(loss)) and 0.0 <= float(acc) <= 1.0
+    changed = [not torch.equal(a, b.detach()) for a, b in zip(before, m.parameters())]
+    assert all(changed), "every meta-parameter receives a gradient (Conv4 weights, BN weight / bias, hypernetwork)"
+    loss2, _, preds, tgt = m.evaluate(args, cg.to_batch(ep), None, "test")
+    assert preds.shape == tgt.shape == (2, 6)
+    feats = m.im_net(ep["x_q"])                                         # [B, Qn, F]: batch statistics per query set
+    assert feats.shape == (2, 6, 64)
+    assert torch.allclose(feats[1], C.conv4_features(ep["x_q"][1], [t.detach() for t in m.im_net.theta()]), atol=1e-6)
