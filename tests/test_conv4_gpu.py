@@ -233,7 +233,10 @@ def test_fumi_conv4_step_matches_autograd(T, tanh, dev, ws):
 
 def test_conv4_full_size_episode_84x84(dev, ws):
     """BASELINE.json configs[1] as worded, one episode pair: 5-way 5-shot, 3 x 84 x 84 images, Conv4 (1600 features), 1 inner
-    step, second-order meta-gradients (15 query images per class keep the host-side autograd oracle to a few seconds)."""
+    step, second-order meta-gradients (3 query images per class keep the host-side autograd oracle to a few seconds).
+    The checker runs in FLOAT64: at this depth (four K = 576 convolutions with batch statistics over 176 400 values, differentiated
+    twice) the fp32 host oracle is itself 2.6e-4 of max|logit| away from the float64 result while the engine is 5e-5 away
+    (tests/dev/probe_conv4_precision.py), so fp32-vs-fp32 would measure the oracle's noise (tolerance semantics)."""
     from fumi_amd import hip
     B, N, K, Q, Cin, H, W, nblk, Dt, Ht, alpha, T = 2, 5, 5, 3, 3, 84, 84, 4, 12, 24, 0.01, 1
     ep, theta, Fd = _case(77, B, N, K, Q, Cin, H, W, nblk)
@@ -242,11 +245,12 @@ def test_conv4_full_size_episode_84x84(dev, ws):
     out = hip.fumi_conv4_step(ws, N, _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev),
                               [_g(t, dev) for t in theta], [_g(t, dev) for t in phi], T, alpha, False, text_s=_g(ep["text_s"], dev))
     assert ws.read_status() == 0
-    th = [t.clone().requires_grad_(True) for t in theta]
-    ph = [t.clone().requires_grad_(True) for t in phi]
-    ref = C.fumi_conv4_meta_step(th, ph, ep["text_s"], ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], N, T, alpha, False)
+    th = [t.double().requires_grad_(True) for t in theta]
+    ph = [t.double().requires_grad_(True) for t in phi]
+    ref = C.fumi_conv4_meta_step(th, ph, ep["text_s"].double(), ep["x_s"].double(), ep["y_s"], ep["x_q"].double(), ep["y_q"], N, T,
+                                 alpha, False)
     assert rel_to_max(out["logits"].cpu(), ref["logits"]) <= LOGIT_TOL
-    mask = safe_margin_mask(ref["logits"], MARGIN)
+    mask = safe_margin_mask(ref["logits"], 1e-3)
     assert torch.equal(out["preds"].cpu()[mask], ref["preds"][mask])
     _check_grads([f"theta{i}" for i in range(len(theta))] + [f"phi{i}" for i in range(4)], out["g_theta"] + out["g_phi"],
                  ref["g_theta"] + ref["g_phi"])
