@@ -171,6 +171,119 @@ def cpu_baseline(table, budget_s=12.0):
                 all_cores=all_cores, one_thread=one_thread)
 
 
+# ---- BASELINE.json configs[1] AS WORDED: the same FuMI meta-step with the Conv4 encoder on 3 x 84 x 84 images ------------------
+CW = dict(N=5, K=5, Q=32, C=3, H=84, E=300, L=128, V=20000, Ht=256, T=1, B_per_gpu=32, alpha=0.01)
+
+
+def conv_unit_flops():
+    """2 * H_l * W_l * 576 * 64 per image for the three 64 -> 64 blocks (42, 21, 10) and 2 * 84^2 * 27 * 64 for block 1."""
+    return [2.0 * 84 * 84 * 27 * 64] + [2.0 * h * h * 576 * 64 for h in (42, 21, 10)]
+
+
+def conv4_flops_per_episode(T, S, Qn):
+    """F_img = sum of the four blocks' forward products; support images cost 9 products per inner step
+    (forward, 2 backward, 2 + 4 tangent; block 1 has no input gradient: 4), query images 3 (block 1: 2)."""
+    u = conv_unit_flops()
+    return S * T * (4 * u[0] + 9 * sum(u[1:])) + Qn * (2 * u[0] + 3 * sum(u[1:]))
+
+
+def as_worded(dev, steps, warmup, cpu_budget_s, with_cpu):
+    from fumi_amd import hip
+    from fumi_amd.models import common
+    from fumi_amd.models.fumi import FUMI
+    from fumi_amd.utils import utils as U
+    c = CW
+    B, S, Qn = c["B_per_gpu"], c["N"] * c["K"], c["N"] * c["Q"]
+    torch.manual_seed(7)
+    g = torch.Generator().manual_seed(7)
+    words = [f"w{i}" for i in range(c["V"])]
+    common.register_word_vectors("glove", common.ArrayKeyedVectors(words, (torch.rand(c["V"], c["E"], generator=g) * 2 - 1).numpy()))
+    dictionary = {"PAD": 0, **{w: i for i, w in enumerate(words) if i > 0}}
+    model = FUMI(n_way=c["N"], im_encoder="conv4", image_size=c["H"], image_channels=c["C"], text_encoder="glove",
+                 text_emb_dim=c["E"], text_hid_dim=c["Ht"], dropout_rate=0.0, dictionary=dictionary, pooling_strat="mean",
+                 norm_hypernet=False).to(dev)
+    args = SimpleNamespace(device=dev, num_train_adapt_steps=c["T"], num_test_adapt_steps=c["T"], step_size=c["alpha"],
+                           first_order=False, optim="adam", lr=3e-5, weight_decay=5e-4, momentum=0.9, batch_size=B, num_ways=c["N"])
+    opt = U.init_optim(args, model)
+
+    def batch(seed, device, nb):
+        gg = torch.Generator(device=device).manual_seed(seed)
+        cg_ = torch.Generator().manual_seed(seed)
+        y_s = torch.stack([torch.arange(c["N"]).repeat_interleave(c["K"])[torch.randperm(S, generator=cg_)] for _ in range(nb)])
+        y_q = torch.stack([torch.arange(c["N"]).repeat_interleave(c["Q"])[torch.randperm(Qn, generator=cg_)] for _ in range(nb)])
+        lens = torch.randint(8, c["L"] + 1, (nb, c["N"]), generator=cg_)
+        tok = torch.randint(1, c["V"], (nb, c["N"], c["L"]), generator=cg_) * (torch.arange(c["L"])[None, None, :] < lens[..., None])
+        text_s = torch.gather(tok, 1, y_s[..., None].expand(-1, -1, c["L"]))
+        text_q = torch.gather(tok, 1, y_q[..., None].expand(-1, -1, c["L"]))
+        x_s = torch.randn(nb, S, c["C"], c["H"], c["H"], device=device, generator=gg)
+        x_q = torch.randn(nb, Qn, c["C"], c["H"], c["H"], device=device, generator=gg)
+        to = lambda t: t.to(device)
+        return {'train': ([to(torch.arange(nb * S).view(nb, S)), to(text_s), x_s], to(y_s)),
+                'test': ([to(torch.arange(nb * Qn).view(nb, Qn)), to(text_q), x_q], to(y_q))}
+    batches = [batch(2000 + i, dev, B) for i in range(2)]
+    ws = hip.Workspace.get(dev)
+    for i in range(warmup):
+        model.evaluate(args, batches[i % 2], opt, "train")
+    hip.raise_on_status(ws.read_status())
+    ws.set_profiling(True, ["conv_gemm", "conv_first", "conv_ew"], every=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(steps):
+        last = model.evaluate(args, batches[i % 2], opt, "train")
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    prof = ws.profile()
+    ws.set_profiling(False)
+    ms = el / steps * 1e3
+    f_ep = conv4_flops_per_episode(c["T"], S, Qn)
+    u = conv_unit_flops()
+    gemm_flops = B * sum(u[1:]) * (S * c["T"] * 9 + Qn * 3)
+    out = {"workload": "FuMI 5-way 5-shot, 32 query/class, Conv4 (4 x [conv3x3(64) . BN(batch stats) . ReLU . maxpool2]) on 3x84x84 "
+                       "images -> 1600 features, hypernetwork head [5,1601] from GloVe-300 token text, 1 inner step over encoder + "
+                       "head, second-order meta-gradient + Adam step; BASELINE.json configs[1] as worded (the reference has no "
+                       "convolutional encoder: parity unpinned, oracle = oracle/conv4_ref.py)",
+           "value": round(B * steps / el, 2), "unit": "episodes/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+           "episodes_per_gpu": B, "dtype": "f32", "data": "synthetic",
+           "gflop_per_episode_algorithmic": round(f_ep / 1e9, 2),
+           "step_tflops_algorithmic": round(B * f_ep / (ms * 1e-3) / 1e12, 2),
+           "final_loss": float(last[0]), "final_acc": float(last[1]), "workspace_GiB": round(ws.bytes() / 2 ** 30, 1)}
+    if "conv_gemm" in prof:
+        tot, n = prof["conv_gemm"]
+        per_step = tot / steps * 1e-3
+        ach = gemm_flops / per_step / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "kernel": "conv64_kernel + wgrad64_kernel: the 64 -> 64 channel 3x3 products (forward, input-gradient, "
+                                     "weight-gradient and their tangents) as implicit GEMMs on v_mfma_f32_32x32x2_f32",
+                           "flops_per_step": gemm_flops, "ms_per_step": round(per_step * 1e3, 3), "launches_per_step": n // steps,
+                           "timed": "HIP events around every launch of the timed region"}
+        out["phase_ms_per_step"] = {k: round(v[0] / steps, 3) for k, v in prof.items()}
+    if with_cpu:
+        from oracle import casegen as cg
+        from oracle import conv4_ref as C
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        theta = [p.detach().cpu().clone().requires_grad_(True) for p in model._theta()]
+        phi = [p.detach().cpu().clone().requires_grad_(True) for p in model._phi()]
+        cb = batch(3000, torch.device("cpu"), 1)
+        (_, tok, x_s), y_s = cb['train']
+        (_, _, x_q), y_q = cb['test']
+        from oracle import fumi_ref as R
+        text = R.word_embedding_pool(tok, model.text_encoder.embed.weight.detach().cpu(), 0, "mean")
+        n, t0 = 0, time.perf_counter()
+        while True:
+            C.fumi_conv4_meta_step(theta, phi, text, x_s, y_s, x_q, y_q, c["N"], c["T"], c["alpha"], False)
+            n += 1
+            el2 = time.perf_counter() - t0
+            print(f"[bench] as-worded cpu baseline: {n} episode(s) in {el2:.1f} s", file=sys.stderr, flush=True)
+            if el2 >= cpu_budget_s or n >= 8:
+                break
+        out["cpu_baseline"] = {"value": round(n / el2, 4), "unit": "episodes/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{n} episode(s) of the same shape ({el2:.1f} s) through oracle/conv4_ref.py (eager PyTorch "
+                                         f"CPU, autograd second order)"}
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start one fresh process per GPU through torch.distributed.run as a CHILD of
     this process (which has not touched the GPU and never will), let rank 0's JSON line through and hand back the child's exit
@@ -198,6 +311,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-as-worded", action="store_true", help="skip the Conv4-as-worded leg (runs at N = 1 only)")
+    ap.add_argument("--as-worded-steps", type=int, default=10)
     ap.add_argument("--no-phase-timing", action="store_true", help="do not record HIP events around the library's phases")
     ap.add_argument("--all-phases", action="store_true",
                     help="time every phase of the library (adds ~10 us of stream time per phase and step); default: only the "
@@ -316,6 +431,11 @@ def main():
             out["allreduce"] = allreduce
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(table)
+        if not a.no_as_worded and world == 1:
+            print("[bench] as-worded (Conv4, 84x84) leg", file=sys.stderr, flush=True)
+            del batches
+            torch.cuda.empty_cache()
+            out["as_worded"] = as_worded(dev, a.as_worded_steps, 2, 20.0, not a.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

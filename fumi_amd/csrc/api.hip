@@ -148,7 +148,7 @@ int fumi_hip_get_profile(fumi_ws_t* ws, int phase, double* total_ms, int* count)
 
 const char* fumi_hip_phase_name(int phase) {
     static const char* names[FUMI_PH_COUNT] = {"class_text_select", "hyper_fwd", "enc_gemm_s", "enc_gemm_q", "xpanel_fwd",
-        "adapt", "query", "reverse", "reduce", "xpanel_bwd", "hyper_bwd", "am3_head"};
+        "adapt", "query", "reverse", "reduce", "xpanel_bwd", "hyper_bwd", "am3_head", "conv_gemm", "conv_first", "conv_ew"};
     return (phase >= 0 && phase < FUMI_PH_COUNT) ? names[phase] : "?";
 }
 

@@ -100,6 +100,8 @@ static EwGeom ew_geom(const Net& n, int M, int l) {
 }
 
 #define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+// a launch inside a profiling phase (HIP events on the stream only when bench.py switched the phase on)
+#define TRYP(phase, expr) do { ProfScope _ps(c.ws, c.st, phase); int _rc = (expr); if (_rc) return _rc; } while (0)
 
 // the fragment-order copies of one parameter slot (block 1's canonical weights are gathered into a dense temporary first)
 static int frags_of_slot(hipStream_t st, const Net& n, const float* params, float* frags, float* tmp1 /*[B][2048+frag1]*/) {
@@ -144,26 +146,27 @@ static int forward_pass(StepCtx& c, int M, const float* img, const float* params
         if (l == 0) {
             Conv1Args a; a.B = n.B; a.M = M; a.Cin = n.Cin; a.g = n.g[0]; a.img = img; a.frag = frags + n.fF[0]; a.frag_stride = n.FSZ;
             a.out = pb.u[0]; a.stats = c.sc.cpart; a.dot = nullptr;
-            TRY(launch_conv1(c.st, a));
+            TRYP(FUMI_PH_CONV_FIRST, launch_conv1(c.st, a));
         } else {
             Conv64Args a; a.B = n.B; a.nsrc = 1; a.npix = npix; a.g = n.g[l];
             a.in[0] = pb.x[l - 1]; a.frag[0] = frags + n.fF[l]; a.frag_stride[0] = n.FSZ; a.in[1] = nullptr; a.frag[1] = nullptr; a.frag_stride[1] = 0;
             a.out = pb.u[l]; a.stats = c.sc.cpart; a.dot = nullptr;
-            TRY(launch_conv64(c.st, a));
+            TRYP(FUMI_PH_CONV_GEMM, launch_conv64(c.st, a));
         }
         CoefArgs ca; memset(&ca, 0, sizeof(ca));
         ca.B = n.B; ca.mode = CFM_FWD; ca.nt = tiles; ca.K = 2; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
         ca.part = c.sc.cpart; ca.coef = pb.coef[l]; ca.g = params + n.offG[l]; ca.beta = params + n.offB[l]; ca.pstride = n.PSZ;
-        TRY(launch_coef(c.st, ca));
+        TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca));
         PoolFwdArgs pa; pa.e = ew_geom(n, M, l); pa.u = pb.u[l]; pa.ud = nullptr; pa.coef = pb.coef[l]; pa.x = pb.x[l]; pa.xd = nullptr;
-        TRY(launch_pool_fwd(c.st, pa, 0));
+        TRYP(FUMI_PH_CONV_EW, launch_pool_fwd(c.st, pa, 0));
     }
     if (!head) return FUMI_OK;                                        // features only (fumi_hip_conv4_features)
     HeadArgs h; memset(&h, 0, sizeof(h));
     h.B = n.B; h.M = M; h.N = n.N; h.F = n.F; h.scale = scale; h.f = pb.x[n.nblk - 1]; h.head = head; h.y = y;
     h.z = logits ? logits : pb.z; h.p = pb.p; h.dz = pb.dz; h.preds = preds; h.preds_f = preds_f; h.loss_b = loss_b; h.acc_b = acc_b;
     h.status = c.ws->status;
-    return launch_head_logits(c.st, h);
+    TRYP(FUMI_PH_CONV_EW, launch_head_logits(c.st, h));
+    return FUMI_OK;
 }
 
 // gradient of the pass's loss w.r.t. (parameter slab, head): G [B][PSZ], dh [B][N][F+1]
@@ -173,33 +176,33 @@ static int backward_pass(StepCtx& c, int M, const float* img, const float* frags
     HeadGradArgs hg; memset(&hg, 0, sizeof(hg));
     hg.B = n.B; hg.M = M; hg.N = n.N; hg.F = n.F; hg.nsrc = 1; hg.dz[0] = pb.dz; hg.f[0] = pb.x[n.nblk - 1]; hg.head[0] = head;
     hg.dh = dh; hg.df = pb.dx[n.nblk - 1];
-    TRY(launch_head_grad(c.st, hg));
+    TRYP(FUMI_PH_CONV_EW, launch_head_grad(c.st, hg));
     for (int l = n.nblk - 1; l >= 0; --l) {
         const EwGeom e = ew_geom(n, M, l);
         const long npix = (long)M * n.g[l].Pp;
         BwdRedArgs ra; ra.e = e; ra.u = pb.u[l]; ra.ud = nullptr; ra.dxo = pb.dx[l]; ra.dxod = nullptr; ra.coef = pb.coef[l];
         ra.part = c.sc.rpart; ra.nt = ew_bwd_red_nt(e);
-        TRY(launch_bwd_reduce(c.st, ra, 0));
+        TRYP(FUMI_PH_CONV_EW, launch_bwd_reduce(c.st, ra, 0));
         CoefArgs ca; memset(&ca, 0, sizeof(ca));
         ca.B = n.B; ca.mode = CFM_BWD; ca.nt = ra.nt; ca.K = 2; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
         ca.part = c.sc.rpart; ca.coef = pb.coef[l]; ca.dg = G + n.offG[l]; ca.dbeta = G + n.offB[l]; ca.gstride = n.PSZ;
-        TRY(launch_coef(c.st, ca));
+        TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca));
         BwdApplyArgs aa; aa.e = e; aa.u = pb.u[l]; aa.ud = nullptr; aa.dxo = pb.dx[l]; aa.dxod = nullptr; aa.coef = pb.coef[l]; aa.du = pb.du[l];
-        TRY(launch_bwd_apply(c.st, aa, 0));
+        TRYP(FUMI_PH_CONV_EW, launch_bwd_apply(c.st, aa, 0));
         const int ns = cv_wgrad_nsplit(n.B, npix);
         if (l == 0) {
             Wgrad1Args wa; wa.B = n.B; wa.M = M; wa.Cin = n.Cin; wa.nsplit = ns; wa.g = n.g[0]; wa.img = img; wa.dy = pb.du[0]; wa.part = c.sc.wpart;
-            TRY(launch_wgrad1(c.st, wa));
+            TRYP(FUMI_PH_CONV_FIRST, launch_wgrad1(c.st, wa));
             TRY(launch_reduce_batched(c.st, n.B, ns, 2048, c.sc.wpart, 1.f, G + n.offW[0], n.PSZ));
         } else {
             Wgrad64Args wa; wa.B = n.B; wa.nsrc = 1; wa.nsplit = ns; wa.npix = npix; wa.g = n.g[l];
             wa.x[0] = pb.x[l - 1]; wa.dy[0] = pb.du[l]; wa.x[1] = nullptr; wa.dy[1] = nullptr; wa.part = c.sc.wpart;
-            TRY(launch_wgrad64(c.st, wa));
+            TRYP(FUMI_PH_CONV_GEMM, launch_wgrad64(c.st, wa));
             TRY(launch_reduce_batched(c.st, n.B, ns, 36864, c.sc.wpart, 1.f, G + n.offW[l], n.PSZ));
             Conv64Args a; a.B = n.B; a.nsrc = 1; a.npix = npix; a.g = n.g[l];
             a.in[0] = pb.du[l]; a.frag[0] = frags + n.fB[l]; a.frag_stride[0] = n.FSZ; a.in[1] = nullptr; a.frag[1] = nullptr; a.frag_stride[1] = 0;
             a.out = pb.dx[l - 1]; a.stats = nullptr; a.dot = nullptr;
-            TRY(launch_conv64(c.st, a));
+            TRYP(FUMI_PH_CONV_GEMM, launch_conv64(c.st, a));
         }
     }
     return FUMI_OK;
@@ -216,59 +219,59 @@ static int hvp_pass(StepCtx& c, int M, const float* img, const float* frags, Pas
         if (l == 0) {
             Conv1Args a; a.B = n.B; a.M = M; a.Cin = n.Cin; a.g = n.g[0]; a.img = img; a.frag = Vfrags + n.fF[0]; a.frag_stride = n.FSZ;
             a.out = tb.ud[0]; a.stats = c.sc.cpart; a.dot = pb.u[0];
-            TRY(launch_conv1(c.st, a));
+            TRYP(FUMI_PH_CONV_FIRST, launch_conv1(c.st, a));
         } else {
             Conv64Args a; a.B = n.B; a.nsrc = 2; a.npix = npix; a.g = n.g[l];
             a.in[0] = pb.x[l - 1]; a.frag[0] = Vfrags + n.fF[l]; a.frag_stride[0] = n.FSZ;
             a.in[1] = tb.xd[l - 1]; a.frag[1] = frags + n.fF[l]; a.frag_stride[1] = n.FSZ;
             a.out = tb.ud[l]; a.stats = c.sc.cpart; a.dot = pb.u[l];
-            TRY(launch_conv64(c.st, a));
+            TRYP(FUMI_PH_CONV_GEMM, launch_conv64(c.st, a));
         }
         CoefArgs ca; memset(&ca, 0, sizeof(ca));
         ca.B = n.B; ca.mode = CFM_TFWD; ca.nt = tiles; ca.K = 2; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
         ca.part = c.sc.cpart; ca.coef = pb.coef[l]; ca.gd = V + n.offG[l]; ca.betad = V + n.offB[l]; ca.dstride = n.PSZ;
-        TRY(launch_coef(c.st, ca));
+        TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca));
         PoolFwdArgs pa; pa.e = ew_geom(n, M, l); pa.u = pb.u[l]; pa.ud = tb.ud[l]; pa.coef = pb.coef[l]; pa.x = nullptr; pa.xd = tb.xd[l];
-        TRY(launch_pool_fwd(c.st, pa, 1));
+        TRYP(FUMI_PH_CONV_EW, launch_pool_fwd(c.st, pa, 1));
     }
     HeadArgs h; memset(&h, 0, sizeof(h));
     h.B = n.B; h.M = M; h.N = n.N; h.F = n.F; h.scale = scale; h.f = pb.x[n.nblk - 1]; h.head = head; h.y = nullptr;
     h.fd = tb.xd[n.nblk - 1]; h.headd = Vh; h.p = pb.p; h.dz = tb.dzd;
-    TRY(launch_head_logits(c.st, h));
+    TRYP(FUMI_PH_CONV_EW, launch_head_logits(c.st, h));
     // ---- tangent backward
     HeadGradArgs hg; memset(&hg, 0, sizeof(hg));
     hg.B = n.B; hg.M = M; hg.N = n.N; hg.F = n.F; hg.nsrc = 2;
     hg.dz[0] = tb.dzd; hg.f[0] = pb.x[n.nblk - 1]; hg.head[0] = head;
     hg.dz[1] = pb.dz; hg.f[1] = tb.xd[n.nblk - 1]; hg.head[1] = Vh;
     hg.dh = HVh; hg.df = tb.dxd[n.nblk - 1];
-    TRY(launch_head_grad(c.st, hg));
+    TRYP(FUMI_PH_CONV_EW, launch_head_grad(c.st, hg));
     for (int l = n.nblk - 1; l >= 0; --l) {
         const EwGeom e = ew_geom(n, M, l);
         const long npix = (long)M * n.g[l].Pp;
         BwdRedArgs ra; ra.e = e; ra.u = pb.u[l]; ra.ud = tb.ud[l]; ra.dxo = pb.dx[l]; ra.dxod = tb.dxd[l]; ra.coef = pb.coef[l];
         ra.part = c.sc.rpart; ra.nt = ew_bwd_red_nt(e);
-        TRY(launch_bwd_reduce(c.st, ra, 1));
+        TRYP(FUMI_PH_CONV_EW, launch_bwd_reduce(c.st, ra, 1));
         CoefArgs ca; memset(&ca, 0, sizeof(ca));
         ca.B = n.B; ca.mode = CFM_TBWD; ca.nt = ra.nt; ca.K = 3; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
         ca.part = c.sc.rpart; ca.coef = pb.coef[l]; ca.dg = HV + n.offG[l]; ca.dbeta = HV + n.offB[l]; ca.gstride = n.PSZ;
-        TRY(launch_coef(c.st, ca));
+        TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca));
         BwdApplyArgs aa; aa.e = e; aa.u = pb.u[l]; aa.ud = tb.ud[l]; aa.dxo = pb.dx[l]; aa.dxod = tb.dxd[l]; aa.coef = pb.coef[l]; aa.du = tb.dud[l];
-        TRY(launch_bwd_apply(c.st, aa, 1));
+        TRYP(FUMI_PH_CONV_EW, launch_bwd_apply(c.st, aa, 1));
         const int ns = cv_wgrad_nsplit(n.B, npix);
         if (l == 0) {
             Wgrad1Args wa; wa.B = n.B; wa.M = M; wa.Cin = n.Cin; wa.nsplit = ns; wa.g = n.g[0]; wa.img = img; wa.dy = tb.dud[0]; wa.part = c.sc.wpart;
-            TRY(launch_wgrad1(c.st, wa));
+            TRYP(FUMI_PH_CONV_FIRST, launch_wgrad1(c.st, wa));
             TRY(launch_reduce_batched(c.st, n.B, ns, 2048, c.sc.wpart, 1.f, HV + n.offW[0], n.PSZ));
         } else {
             Wgrad64Args wa; wa.B = n.B; wa.nsrc = 2; wa.nsplit = ns; wa.npix = npix; wa.g = n.g[l];
             wa.x[0] = pb.x[l - 1]; wa.dy[0] = tb.dud[l]; wa.x[1] = tb.xd[l - 1]; wa.dy[1] = pb.du[l]; wa.part = c.sc.wpart;
-            TRY(launch_wgrad64(c.st, wa));
+            TRYP(FUMI_PH_CONV_GEMM, launch_wgrad64(c.st, wa));
             TRY(launch_reduce_batched(c.st, n.B, ns, 36864, c.sc.wpart, 1.f, HV + n.offW[l], n.PSZ));
             Conv64Args a; a.B = n.B; a.nsrc = 2; a.npix = npix; a.g = n.g[l];
             a.in[0] = tb.dud[l]; a.frag[0] = frags + n.fB[l]; a.frag_stride[0] = n.FSZ;
             a.in[1] = pb.du[l]; a.frag[1] = Vfrags + n.fB[l]; a.frag_stride[1] = n.FSZ;
             a.out = tb.dxd[l - 1]; a.stats = nullptr; a.dot = nullptr;
-            TRY(launch_conv64(c.st, a));
+            TRYP(FUMI_PH_CONV_GEMM, launch_conv64(c.st, a));
         }
     }
     return FUMI_OK;

@@ -31,7 +31,7 @@ SYMBOLS = [
 ]
 
 ST_LABEL_RANGE, ST_CLASS_MISSING = 1, 2
-N_PHASES = 12
+N_PHASES = 15
 
 _lib = None
 _lock = threading.Lock()

@@ -74,7 +74,10 @@ int   fumi_hip_read_status(fumi_ws_t* ws, fumi_stream_t stream, int* status_out)
 #define FUMI_PH_XPANEL_BWD 9   /* gW0 = Abar0^T X (split-K slabs + slab reduce)        */
 #define FUMI_PH_HYPER_BWD 10   /* hypernetwork backward                                */
 #define FUMI_PH_AM3       11   /* AM3 fused head kernels                               */
-#define FUMI_PH_COUNT     12
+#define FUMI_PH_CONV_GEMM 12   /* Conv4: the 64 -> 64 channel products (forward, input-gradient, weight-gradient) on the MFMA */
+#define FUMI_PH_CONV_FIRST 13  /* Conv4: block 1 (Cin <= 3 -> 64: K = 27, bound by writing / reading its 84x84x64 maps)   */
+#define FUMI_PH_CONV_EW   14   /* Conv4: batch-norm / ReLU / max-pool passes, head, updates                               */
+#define FUMI_PH_COUNT     15
 /* phase_mask: bit p set = record a HIP event pair around phase p (FUMI_PH_*) on the caller's stream; -1 = every phase,
  * 0 = off.  An event pair costs a few microseconds of stream time, so time only what is needed.  Also clears the records. */
 int          fumi_hip_set_profiling(fumi_ws_t* ws, int phase_mask);
