@@ -141,8 +141,8 @@ def cpu_baseline(table, budget_s=12.0):
         """warm-up, then the median of 5 meta-batches at a fixed thread count -- fewer when the box has
         so many cores that the dispatch-bound loop crawls under thread contention (the sample is bounded in time)."""
         torch.set_num_threads(nt_)
-        nb = 8                                   # meta-batches of 8 episodes: bounded even when thread contention is severe
-        t1 = time.perf_counter(); step(batches[1], nb); warm = time.perf_counter() - t1
+        t1 = time.perf_counter(); step(batches[1], 1); warm = time.perf_counter() - t1     # one episode: how slow is this setting?
+        nb = max(1, min(8, int(1.0 / max(warm, 1e-3))))     # ~1 s per sample: bounded even when thread contention is severe
         ts, t_all = [], time.perf_counter()
         for i in range(reps):
             if ts and time.perf_counter() - t_all + ts[-1] > budget:

@@ -96,7 +96,8 @@ struct CoefArgs {
     const float* gd; const float* betad; long dstride;    // tangent direction (CFM_TFWD / CFM_TBWD)
     float* dg; float* dbeta; long gstride;       // CFM_BWD / CFM_TBWD: gradients (or their tangents) of BN weight / bias
 };
-int launch_coef(hipStream_t st, const CoefArgs& a);
+size_t coef_scratch_doubles(int B, int nt);
+int launch_coef(hipStream_t st, const CoefArgs& a, double* scratch /* coef_scratch_doubles(B, nt) */);
 
 // max-pool(ReLU(BN(u))) -> next block's padded input (or the feature matrix); TAN: also the tangent x' from u'
 struct PoolFwdArgs { EwGeom e; const float* u; const float* ud; const float* coef; float* x; float* xd; };
@@ -118,6 +119,7 @@ struct HeadArgs {
     float* z;                                    // [B][M][N] logits (plain) -- may be NULL in the tangent pass
     float* p; float* dz;                         // [B][M][N] soft-max (plain: written, tangent: read); dz (plain) / dz' (tangent) written
     int64_t* preds; float* preds_f; float* loss_b; float* acc_b; int* status;    // plain pass outputs (may be NULL)
+    float* row_loss; float* row_hit;             // [B][M] scratch, needed when loss_b / acc_b are asked for
 };
 int launch_head_logits(hipStream_t st, const HeadArgs& a);
 // dh[b][n][F+1] = sum_s dz_s^T f_s | colsum dz_0 ;  df[b][m][F] = sum_s dz_s head_s   (s over 1 or 2 source pairs)

@@ -90,7 +90,7 @@ static void tan_carve(fumi_ws* ws, const Net& n, int M, TanBufs& tb) {
     tb.dzd = ws_f(ws, (size_t)n.B * M * n.N);
 }
 
-struct Scratch { float* cpart; float* wpart; float* rpart; size_t cpart_n, wpart_n, rpart_n; };
+struct Scratch { float* cpart; float* wpart; float* rpart; double* dsum; float* rowl; size_t cpart_n, wpart_n, rpart_n, dsum_n, rowl_n; };
 
 static EwGeom ew_geom(const Net& n, int M, int l) {
     EwGeom e; e.B = n.B; e.M = M; e.g = n.g[l]; e.Ho = n.Ho[l]; e.Wo = n.Wo[l];
@@ -156,7 +156,7 @@ static int forward_pass(StepCtx& c, int M, const float* img, const float* params
         CoefArgs ca; memset(&ca, 0, sizeof(ca));
         ca.B = n.B; ca.mode = CFM_FWD; ca.nt = tiles; ca.K = 2; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
         ca.part = c.sc.cpart; ca.coef = pb.coef[l]; ca.g = params + n.offG[l]; ca.beta = params + n.offB[l]; ca.pstride = n.PSZ;
-        TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca));
+        TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca, c.sc.dsum));
         PoolFwdArgs pa; pa.e = ew_geom(n, M, l); pa.u = pb.u[l]; pa.ud = nullptr; pa.coef = pb.coef[l]; pa.x = pb.x[l]; pa.xd = nullptr;
         TRYP(FUMI_PH_CONV_EW, launch_pool_fwd(c.st, pa, 0));
     }
@@ -164,7 +164,7 @@ static int forward_pass(StepCtx& c, int M, const float* img, const float* params
     HeadArgs h; memset(&h, 0, sizeof(h));
     h.B = n.B; h.M = M; h.N = n.N; h.F = n.F; h.scale = scale; h.f = pb.x[n.nblk - 1]; h.head = head; h.y = y;
     h.z = logits ? logits : pb.z; h.p = pb.p; h.dz = pb.dz; h.preds = preds; h.preds_f = preds_f; h.loss_b = loss_b; h.acc_b = acc_b;
-    h.status = c.ws->status;
+    h.status = c.ws->status; h.row_loss = c.sc.rowl; h.row_hit = c.sc.rowl + (size_t)n.B * M;
     TRYP(FUMI_PH_CONV_EW, launch_head_logits(c.st, h));
     return FUMI_OK;
 }
@@ -186,7 +186,7 @@ static int backward_pass(StepCtx& c, int M, const float* img, const float* frags
         CoefArgs ca; memset(&ca, 0, sizeof(ca));
         ca.B = n.B; ca.mode = CFM_BWD; ca.nt = ra.nt; ca.K = 2; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
         ca.part = c.sc.rpart; ca.coef = pb.coef[l]; ca.dg = G + n.offG[l]; ca.dbeta = G + n.offB[l]; ca.gstride = n.PSZ;
-        TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca));
+        TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca, c.sc.dsum));
         BwdApplyArgs aa; aa.e = e; aa.u = pb.u[l]; aa.ud = nullptr; aa.dxo = pb.dx[l]; aa.dxod = nullptr; aa.coef = pb.coef[l]; aa.du = pb.du[l];
         TRYP(FUMI_PH_CONV_EW, launch_bwd_apply(c.st, aa, 0));
         const int ns = cv_wgrad_nsplit(n.B, npix);
@@ -230,7 +230,7 @@ static int hvp_pass(StepCtx& c, int M, const float* img, const float* frags, Pas
         CoefArgs ca; memset(&ca, 0, sizeof(ca));
         ca.B = n.B; ca.mode = CFM_TFWD; ca.nt = tiles; ca.K = 2; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
         ca.part = c.sc.cpart; ca.coef = pb.coef[l]; ca.gd = V + n.offG[l]; ca.betad = V + n.offB[l]; ca.dstride = n.PSZ;
-        TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca));
+        TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca, c.sc.dsum));
         PoolFwdArgs pa; pa.e = ew_geom(n, M, l); pa.u = pb.u[l]; pa.ud = tb.ud[l]; pa.coef = pb.coef[l]; pa.x = nullptr; pa.xd = tb.xd[l];
         TRYP(FUMI_PH_CONV_EW, launch_pool_fwd(c.st, pa, 1));
     }
@@ -254,7 +254,7 @@ static int hvp_pass(StepCtx& c, int M, const float* img, const float* frags, Pas
         CoefArgs ca; memset(&ca, 0, sizeof(ca));
         ca.B = n.B; ca.mode = CFM_TBWD; ca.nt = ra.nt; ca.K = 3; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
         ca.part = c.sc.rpart; ca.coef = pb.coef[l]; ca.dg = HV + n.offG[l]; ca.dbeta = HV + n.offB[l]; ca.gstride = n.PSZ;
-        TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca));
+        TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca, c.sc.dsum));
         BwdApplyArgs aa; aa.e = e; aa.u = pb.u[l]; aa.ud = tb.ud[l]; aa.dxo = pb.dx[l]; aa.dxod = tb.dxd[l]; aa.coef = pb.coef[l]; aa.du = tb.dud[l];
         TRYP(FUMI_PH_CONV_EW, launch_bwd_apply(c.st, aa, 1));
         const int ns = cv_wgrad_nsplit(n.B, npix);
@@ -318,7 +318,9 @@ static size_t conv4_scratch_sizes(const Net& n, int S, int Qn, Scratch& sc) {
             if (r1 > rp) rp = r1;
         }
     sc.cpart_n = cp; sc.wpart_n = wp; sc.rpart_n = rp;
-    return ws_align(cp * 4) + ws_align(wp * 4) + ws_align(rp * 4);
+    sc.dsum_n = coef_scratch_doubles(n.B, (int)(cp / ((size_t)n.B * 128)) + 1) + coef_scratch_doubles(n.B, (int)(rp / ((size_t)n.B * 192)) + 1);
+    sc.rowl_n = 2 * (size_t)n.B * (S > Qn ? S : Qn);
+    return ws_align(cp * 4) + ws_align(wp * 4) + ws_align(rp * 4) + ws_align(sc.dsum_n * 8) + ws_align(sc.rowl_n * 4);
 }
 
 // `prepare(extra)` runs once the slab is reserved: the caller carves its own buffers (head, head_bar, the head's producer's
@@ -353,6 +355,7 @@ int run_conv4_episodes(fumi_ws* ws, hipStream_t st, Conv4Problem p, const Conv4H
     ws->off += extra_bytes;                                           // (the caller's buffers: head, hypernetwork activations)
     TRY(hooks.prepare(extra, &p.head, &p.head_bar));
     c.sc.cpart = ws_f(ws, c.sc.cpart_n); c.sc.wpart = ws_f(ws, c.sc.wpart_n); c.sc.rpart = ws_f(ws, c.sc.rpart_n);
+    c.sc.dsum = (double*)ws_f(ws, c.sc.dsum_n * 2); c.sc.rowl = ws_f(ws, c.sc.rowl_n);
     ProbeTab& pt = g_probe;
     pt.valid = false;
     for (int t = 0; t < ntape; ++t) pass_carve(ws, n, p.S, true, pt.tape[t]);
@@ -614,6 +617,7 @@ int fumi_hip_conv4_features(fumi_ws_t* ws, fumi_stream_t stream, int G, int M, i
     if ((rc = ws_reserve(ws, bytes))) return rc;
     g_probe.valid = false;
     c.sc.cpart = ws_f(ws, c.sc.cpart_n); c.sc.wpart = ws_f(ws, c.sc.wpart_n); c.sc.rpart = ws_f(ws, c.sc.rpart_n);
+    c.sc.dsum = (double*)ws_f(ws, c.sc.dsum_n * 2); c.sc.rowl = ws_f(ws, c.sc.rowl_n);
     PassBufs pb; pass_carve(ws, n, M, false, pb);
     float* params = ws_f(ws, (size_t)n.B * n.PSZ); float* frags = ws_f(ws, (size_t)n.B * n.FSZ);
     float* tmp1 = ws_f(ws, (size_t)n.B * (2048 + 4096)); float* toi_tmp = ws_f(ws, (size_t)n.nblk * 36864);

@@ -50,13 +50,43 @@ __device__ __forceinline__ f32x4 load_dxo(const float* dxo, const EwGeom& e, lon
 // ------------------------------------------------------------------------------------------------------------
 // coefficients
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void coef_kernel(CoefArgs a) {
+// level 1 of the fixed-order sum over an episode's partial slabs: workgroup (chunk, b) adds COEF_CHUNK slabs per channel in
+// double (4 row groups x 4 independent loads in flight) -> one double slab per chunk
+constexpr int COEF_CHUNK = 64;
+__global__ __launch_bounds__(256) void coef_sum_kernel(int nt, int K, const float* part_all, double* out) {
+    __shared__ double red[4][3][64];
+    const int b = blockIdx.y, ch = blockIdx.x, c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int nch = gridDim.x;
+    const float* part = part_all + (long)b * nt * K * 64;
+    const int t0 = ch * COEF_CHUNK, t1 = min(nt, t0 + COEF_CHUNK);
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int t = t0 + grp; t < t1; t += 16) {
+        float v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int tt = min(t + 4 * u, t1 - 1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[u][k] = k < K ? part[((long)tt * K + k) * 64 + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t + 4 * u < t1)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) s[k] += (double)v[u][k];
+    }
+    for (int k = 0; k < 3; ++k) red[grp][k][c] = s[k];
+    __syncthreads();
+    if (grp) return;
+    for (int k = 0; k < K; ++k)
+        out[(((long)b * nch + ch) * 3 + k) * 64 + c] = (red[0][k][c] + red[1][k][c]) + (red[2][k][c] + red[3][k][c]);
+}
+
+__global__ __launch_bounds__(1024) void coef_kernel(CoefArgs a, const double* sums, int nch) {
     __shared__ double red[16][3][64];
     const int b = blockIdx.x, c = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const float* part = a.part + (long)b * a.nt * a.K * 64;
     double s[3] = {0.0, 0.0, 0.0};
-    for (int t = grp; t < a.nt; t += 16)
-        for (int k = 0; k < a.K; ++k) s[k] += (double)part[((long)t * a.K + k) * 64 + c];
+    for (int t = grp; t < nch; t += 16)
+        for (int k = 0; k < a.K; ++k) s[k] += sums[(((long)b * nch + t) * 3 + k) * 64 + c];
     for (int k = 0; k < 3; ++k) red[grp][k][c] = s[k];
     __syncthreads();
     if (grp) return;
@@ -287,14 +317,13 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(BwdApplyArgs a, long nth
 // ------------------------------------------------------------------------------------------------------------
 constexpr int HEAD_MAXN = 32;
 __global__ __launch_bounds__(256) void head_logits_kernel(HeadArgs a) {
-    __shared__ float sred[2][4];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.y * 4 + wave, rstep = gridDim.y * 4;
     const int N = a.N, F = a.F, F1 = F + 1;
     const float* head = a.head + (long)b * N * F1;
     const bool tan = a.fd != nullptr;
     const float* headd = tan ? a.headd + (long)b * N * F1 : nullptr;
-    float loss_acc = 0.f, hit_acc = 0.f;
-    for (int m = wave; m < a.M; m += 4) {
+    for (int m = row0; m < a.M; m += rstep) {
         const long row = (long)b * a.M + m;
         const float* f = a.f + row * F;
         const float* fd = tan ? a.fd + row * F : nullptr;
@@ -337,7 +366,7 @@ __global__ __launch_bounds__(256) void head_logits_kernel(HeadArgs a) {
                     if (a.z) a.z[row * N + n] = s[n];
                     if (n == (int)y) sy = s[n];
                 }
-                loss_acc += lse - sy; hit_acc += arg == (int)y ? 1.f : 0.f;
+                if (a.row_loss) { a.row_loss[row] = lse - sy; a.row_hit[row] = arg == (int)y ? 1.f : 0.f; }
                 if (a.preds) a.preds[row] = arg;
                 if (a.preds_f) a.preds_f[row] = (float)arg;
             }
@@ -350,16 +379,16 @@ __global__ __launch_bounds__(256) void head_logits_kernel(HeadArgs a) {
             for (int n = 0; n < HEAD_MAXN; ++n) if (n < N) dz[n] = p[n] * (s[n] - dot) * a.scale;
         }
     }
-    if (!tan && (a.loss_b || a.acc_b)) {
-        if (lane == 0) { sred[0][wave] = loss_acc; sred[1][wave] = hit_acc; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float l = (sred[0][0] + sred[0][1]) + (sred[0][2] + sred[0][3]);
-            const float h = (sred[1][0] + sred[1][1]) + (sred[1][2] + sred[1][3]);
-            if (a.loss_b) a.loss_b[b] = l / a.M;
-            if (a.acc_b) a.acc_b[b] = h / a.M;
-        }
-    }
+}
+
+// loss_b / acc_b of an episode = mean over its rows (fixed order)
+__global__ __launch_bounds__(64) void head_finish_kernel(int M, const float* row_loss, const float* row_hit, float* loss_b, float* acc_b) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float l = 0.f, h = 0.f;
+    for (int m = lane; m < M; m += 64) { l += row_loss[(long)b * M + m]; h += row_hit[(long)b * M + m]; }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { l += __shfl_xor(l, o); h += __shfl_xor(h, o); }
+    if (lane == 0) { if (loss_b) loss_b[b] = l / M; if (acc_b) acc_b[b] = h / M; }
 }
 
 // thread = feature column k of episode b: dh[n][k] = sum_s sum_m dz_s[m][n] f_s[m][k];  df[m][k] = sum_s sum_n dz_s[m][n] head_s[n][k]
@@ -507,9 +536,14 @@ __global__ void proto_kernel(int S, int N, int P, const float* x, const int64_t*
 
 }  // namespace
 
-int launch_coef(hipStream_t st, const CoefArgs& a) {
-    if (a.K < 1 || a.K > 3 || a.nt < 1) return FUMI_EINVAL;
-    hipLaunchKernelGGL(coef_kernel, dim3(a.B), dim3(1024), 0, st, a);
+size_t coef_scratch_doubles(int B, int nt) { return (size_t)B * ((nt + COEF_CHUNK - 1) / COEF_CHUNK) * 3 * 64; }
+
+int launch_coef(hipStream_t st, const CoefArgs& a, double* scratch) {
+    if (a.K < 1 || a.K > 3 || a.nt < 1 || !scratch) return FUMI_EINVAL;
+    const int nch = (a.nt + COEF_CHUNK - 1) / COEF_CHUNK;
+    hipLaunchKernelGGL(coef_sum_kernel, dim3(nch, a.B), dim3(256), 0, st, a.nt, a.K, a.part, scratch);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(coef_kernel, dim3(a.B), dim3(1024), 0, st, a, (const double*)scratch, nch);
     LAUNCH_CHECK();
     return FUMI_OK;
 }
@@ -554,8 +588,15 @@ int launch_bwd_apply(hipStream_t st, const BwdApplyArgs& a, int tangent) {
 
 int launch_head_logits(hipStream_t st, const HeadArgs& a) {
     if (a.N < 1 || a.N > HEAD_MAXN) return FUMI_ENOTSUP;
-    hipLaunchKernelGGL(head_logits_kernel, dim3(a.B), dim3(256), 0, st, a);
+    if ((a.loss_b || a.acc_b) && (!a.row_loss || !a.row_hit)) return FUMI_EINVAL;
+    int gy = (a.M + 3) / 4;
+    if (gy > 16) gy = 16;
+    hipLaunchKernelGGL(head_logits_kernel, dim3(a.B, gy), dim3(256), 0, st, a);
     LAUNCH_CHECK();
+    if (!a.fd && (a.loss_b || a.acc_b)) {
+        hipLaunchKernelGGL(head_finish_kernel, dim3(a.B), dim3(64), 0, st, a.M, a.row_loss, a.row_hit, a.loss_b, a.acc_b);
+        LAUNCH_CHECK();
+    }
     return FUMI_OK;
 }
 

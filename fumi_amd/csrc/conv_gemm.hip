@@ -108,19 +108,31 @@ __global__ __launch_bounds__(256, 2) void conv64_kernel(Conv64Args a, int tiles)
         __syncthreads();
         const float* fr = a.frag[s] + (long)b * a.frag_stride[s] + lane * 4;
         const int pbase = halo + wave * 32 + r;
-        for (int tap = 0; tap < 9; ++tap) {
+        // 72 steps (tap, j) of 8 MFMAs.  hipcc left to itself issues each weight load right before its use and waits for
+        // it (vmcnt(0) every 4 MFMAs: 55 % of the matrix rate); here the weight fragments of the next CV_DB steps are always
+        // in flight in a register ring and the activation fragment of the next step is read from LDS one step ahead.
+        constexpr int NIT = 72, CV_DB = 4;
+        auto ldB = [&](int it, int ct) { return *(const f32x4*)(fr + (it * 2 + ct) * 256); };
+        auto ldA = [&](int it) {
+            const int tap = it >> 3, j = it & 7;
             const int pi = pbase + (tap / 3 - 1) * Wp + (tap % 3 - 1);
-            const float* arow = lds + pi * 64;
-            const int key = pi & 15;
-            const float* ft = fr + tap * (8 * 2 * 256);
+            return *(const f32x4*)(lds + pi * 64 + (((2 * j + h) ^ (pi & 15)) << 2));
+        };
+        f32x4 Bq[CV_DB][2];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const f32x4 A = *(const f32x4*)(arow + (((2 * j + h) ^ key) << 2));
-                const f32x4 B0 = *(const f32x4*)(ft + (j * 2 + 0) * 256);
-                const f32x4 B1 = *(const f32x4*)(ft + (j * 2 + 1) * 256);
+        for (int d = 0; d < CV_DB; ++d) { Bq[d][0] = ldB(d, 0); Bq[d][1] = ldB(d, 1); }
+        f32x4 Acur = ldA(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { acc0 = mfma32(A[i], B0[i], acc0); acc1 = mfma32(A[i], B1[i], acc1); }
-            }
+        for (int it = 0; it < NIT; ++it) {
+            f32x4 Anext = Acur;
+            if (it + 1 < NIT) Anext = ldA(it + 1);
+            const f32x4 B0 = Bq[it % CV_DB][0], B1 = Bq[it % CV_DB][1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc0 = mfma32(Acur[i], B0[i], acc0); acc1 = mfma32(Acur[i], B1[i], acc1); }
+            if (it + CV_DB < NIT) { Bq[it % CV_DB][0] = ldB(it + CV_DB, 0); Bq[it % CV_DB][1] = ldB(it + CV_DB, 1); }
+            Acur = Anext;
+            __builtin_amdgcn_sched_barrier(0);           // (the scheduler otherwise sinks the prefetches back to their uses)
         }
     }
     conv_epilogue(acc0, acc1, lds, a.g, a.npix, ep0, g0, b, t, tiles, a.out, a.stats, a.dot);
