@@ -45,7 +45,8 @@ int launch_conv64(hipStream_t st, const Conv64Args& a);
 struct Conv1Args {
     int B, M, Cin; CvGeom g;
     const float* img; const float* frag; long frag_stride;
-    float* out; float* stats; const float* dot;
+    float* out; float* stats; const float* dot;      // out == NULL: statistics only (the fused block-1 path stores no map)
+    const float* frag_dot; long frag_dot_stride;     // != NULL: the dot operand is conv(img, frag_dot), computed in the kernel
 };
 int launch_conv1(hipStream_t st, const Conv1Args& a);
 __host__ __device__ static inline int cv_frag1_floats(int Cin) { return ((Cin * 9 + 1) / 2) * 2 * 64; }
@@ -143,3 +144,18 @@ int launch_pad_cl(hipStream_t st, long M, const CvGeom& g, const float* src, flo
 int launch_unpad_cl(hipStream_t st, long M, const CvGeom& g, const float* src, float* dst);
 int launch_ce(hipStream_t st, int M, int N, const float* z, const int64_t* y, float* loss, float* dz, int64_t* preds, int* status);
 int launch_proto(hipStream_t st, int B, int S, int N, int P, const float* x, const int64_t* y, float* out, int* status);
+
+// ---- conv_first.hip: block 1 without its full-resolution maps (u = conv(image, W1) recomputed band by band) ----------------
+struct C1Args {
+    int B, M, Cin; CvGeom g; CvGeom gn; int Ho, Wo;
+    const float* img;
+    const float* frag; long frag_stride;        // W1 in fragment order, per episode
+    const float* fragd; long fragd_stride;      // tangent direction W1' (tangent passes)
+    const float* coef;
+    float* x; float* xd;                        // pool: pooled output (plain) / its tangent, padded at gn
+    const float* dxo; const float* dxod;        // reduce / wgrad: gradient w.r.t. the pooled output (and its tangent)
+    float* part;                                // reduce: [B][nt][K][64] partial sums, nt = c1_chunks(...)
+    float* wpart;                               // wgrad: [B][nt][64][32] partial dW1
+};
+int c1_chunks(int B, int M, const CvGeom& g, int* chunk_out);
+int launch_c1(hipStream_t st, const C1Args& a, int mode /*0 pool, 1 reduce, 2 wgrad*/, int tangent);

@@ -15,8 +15,11 @@
 
 namespace {
 
+static int g_c1_fused = 1;     // block 1 without its full-resolution maps (conv_first.hip); 0 = the plain passes (probe tests)
+
 struct Net {
     int B, nblk, Cin, N, F;
+    int fused1;                                      // block 1 recomputed band by band: u[0] / du[0] are never materialised
     CvGeom g[CV_MAXBLK];
     int Ho[CV_MAXBLK], Wo[CV_MAXBLK];
     long PSZ, FSZ;                                   // floats per episode: parameter slab, fragment slab
@@ -42,6 +45,7 @@ static int net_init(Net& n, int B, int nblk, int Cin, int N, int H, int W) {
     }
     n.PSZ = po; n.FSZ = fo;
     n.F = 64 * n.Ho[nblk - 1] * n.Wo[nblk - 1];
+    n.fused1 = g_c1_fused && nblk >= 2 && n.g[0].H >= 2 && n.g[0].W >= 2;
     return FUMI_OK;
 }
 
@@ -61,7 +65,8 @@ static size_t out_floats(const Net& n, int M, int l) {          // pooled output
 static size_t pass_bytes(const Net& n, int M, bool bwd) {
     size_t b = 0;
     for (int l = 0; l < n.nblk; ++l) {
-        b += ws_align(act_floats(n, M, l) * 4) * (bwd ? 2 : 1) + ws_align(out_floats(n, M, l) * 4) * (bwd ? 2 : 1);
+        if (!(l == 0 && n.fused1)) b += ws_align(act_floats(n, M, l) * 4) * (bwd ? 2 : 1);
+        b += ws_align(out_floats(n, M, l) * 4) * (bwd ? 2 : 1);
         b += ws_align((size_t)n.B * CF_N * 64 * 4);
     }
     return b + 3 * ws_align((size_t)n.B * M * n.N * 4);
@@ -69,9 +74,10 @@ static size_t pass_bytes(const Net& n, int M, bool bwd) {
 static void pass_carve(fumi_ws* ws, const Net& n, int M, bool bwd, PassBufs& pb) {
     pb.M = M;
     for (int l = 0; l < n.nblk; ++l) {
-        pb.u[l] = ws_f(ws, act_floats(n, M, l));
+        const bool maps = !(l == 0 && n.fused1);
+        pb.u[l] = maps ? ws_f(ws, act_floats(n, M, l)) : nullptr;
         pb.x[l] = ws_f(ws, out_floats(n, M, l));
-        pb.du[l] = bwd ? ws_f(ws, act_floats(n, M, l)) : nullptr;
+        pb.du[l] = bwd && maps ? ws_f(ws, act_floats(n, M, l)) : nullptr;
         pb.dx[l] = bwd ? ws_f(ws, out_floats(n, M, l)) : nullptr;
         pb.coef[l] = ws_f(ws, (size_t)n.B * CF_N * 64);
     }
@@ -79,13 +85,15 @@ static void pass_carve(fumi_ws* ws, const Net& n, int M, bool bwd, PassBufs& pb)
 }
 static size_t tan_bytes(const Net& n, int M) {
     size_t b = 0;
-    for (int l = 0; l < n.nblk; ++l) b += 2 * ws_align(act_floats(n, M, l) * 4) + 2 * ws_align(out_floats(n, M, l) * 4);
+    for (int l = 0; l < n.nblk; ++l)
+        b += (l == 0 && n.fused1 ? 0 : 2 * ws_align(act_floats(n, M, l) * 4)) + 2 * ws_align(out_floats(n, M, l) * 4);
     return b + ws_align((size_t)n.B * M * n.N * 4);
 }
 static void tan_carve(fumi_ws* ws, const Net& n, int M, TanBufs& tb) {
     for (int l = 0; l < n.nblk; ++l) {
-        tb.ud[l] = ws_f(ws, act_floats(n, M, l)); tb.xd[l] = ws_f(ws, out_floats(n, M, l));
-        tb.dud[l] = ws_f(ws, act_floats(n, M, l)); tb.dxd[l] = ws_f(ws, out_floats(n, M, l));
+        const bool maps = !(l == 0 && n.fused1);
+        tb.ud[l] = maps ? ws_f(ws, act_floats(n, M, l)) : nullptr; tb.xd[l] = ws_f(ws, out_floats(n, M, l));
+        tb.dud[l] = maps ? ws_f(ws, act_floats(n, M, l)) : nullptr; tb.dxd[l] = ws_f(ws, out_floats(n, M, l));
     }
     tb.dzd = ws_f(ws, (size_t)n.B * M * n.N);
 }
@@ -136,6 +144,13 @@ struct StepCtx {
     int S, Qn;
 };
 
+static C1Args c1_args(const Net& n, int M, const float* img, const float* frags, const float* coef) {
+    C1Args a; memset(&a, 0, sizeof(a));
+    a.B = n.B; a.M = M; a.Cin = n.Cin; a.g = n.g[0]; a.gn = n.g[1]; a.Ho = n.Ho[0]; a.Wo = n.Wo[0];
+    a.img = img; a.frag = frags + n.fF[0]; a.frag_stride = n.FSZ; a.coef = coef;
+    return a;
+}
+
 static int forward_pass(StepCtx& c, int M, const float* img, const float* params, const float* frags, PassBufs& pb,
                         const float* head, const int64_t* y, float scale, float* logits, int64_t* preds, float* preds_f,
                         float* loss_b, float* acc_b) {
@@ -144,8 +159,9 @@ static int forward_pass(StepCtx& c, int M, const float* img, const float* params
         const long npix = (long)M * n.g[l].Pp;
         const int tiles = cv_tiles(npix);
         if (l == 0) {
-            Conv1Args a; a.B = n.B; a.M = M; a.Cin = n.Cin; a.g = n.g[0]; a.img = img; a.frag = frags + n.fF[0]; a.frag_stride = n.FSZ;
-            a.out = pb.u[0]; a.stats = c.sc.cpart; a.dot = nullptr;
+            Conv1Args a; memset(&a, 0, sizeof(a));
+            a.B = n.B; a.M = M; a.Cin = n.Cin; a.g = n.g[0]; a.img = img; a.frag = frags + n.fF[0]; a.frag_stride = n.FSZ;
+            a.out = pb.u[0]; a.stats = c.sc.cpart; a.dot = nullptr;          // (fused: out == NULL, statistics only)
             TRYP(FUMI_PH_CONV_FIRST, launch_conv1(c.st, a));
         } else {
             Conv64Args a; a.B = n.B; a.nsrc = 1; a.npix = npix; a.g = n.g[l];
@@ -157,6 +173,11 @@ static int forward_pass(StepCtx& c, int M, const float* img, const float* params
         ca.B = n.B; ca.mode = CFM_FWD; ca.nt = tiles; ca.K = 2; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
         ca.part = c.sc.cpart; ca.coef = pb.coef[l]; ca.g = params + n.offG[l]; ca.beta = params + n.offB[l]; ca.pstride = n.PSZ;
         TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca, c.sc.dsum));
+        if (l == 0 && n.fused1) {
+            C1Args fa = c1_args(n, M, img, frags, pb.coef[0]); fa.x = pb.x[0];
+            TRYP(FUMI_PH_CONV_FIRST, launch_c1(c.st, fa, 0, 0));
+            continue;
+        }
         PoolFwdArgs pa; pa.e = ew_geom(n, M, l); pa.u = pb.u[l]; pa.ud = nullptr; pa.coef = pb.coef[l]; pa.x = pb.x[l]; pa.xd = nullptr;
         TRYP(FUMI_PH_CONV_EW, launch_pool_fwd(c.st, pa, 0));
     }
@@ -180,6 +201,19 @@ static int backward_pass(StepCtx& c, int M, const float* img, const float* frags
     for (int l = n.nblk - 1; l >= 0; --l) {
         const EwGeom e = ew_geom(n, M, l);
         const long npix = (long)M * n.g[l].Pp;
+        if (l == 0 && n.fused1) {
+            int chunk;
+            const int nt = c1_chunks(n.B, M, n.g[0], &chunk);
+            C1Args fa = c1_args(n, M, img, frags, pb.coef[0]); fa.dxo = pb.dx[0]; fa.part = c.sc.rpart; fa.wpart = c.sc.wpart;
+            TRYP(FUMI_PH_CONV_FIRST, launch_c1(c.st, fa, 1, 0));
+            CoefArgs ca; memset(&ca, 0, sizeof(ca));
+            ca.B = n.B; ca.mode = CFM_BWD; ca.nt = nt; ca.K = 2; ca.n = (float)((double)M * n.g[0].H * n.g[0].W);
+            ca.part = c.sc.rpart; ca.coef = pb.coef[0]; ca.dg = G + n.offG[0]; ca.dbeta = G + n.offB[0]; ca.gstride = n.PSZ;
+            TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca, c.sc.dsum));
+            TRYP(FUMI_PH_CONV_FIRST, launch_c1(c.st, fa, 2, 0));
+            TRY(launch_reduce_batched(c.st, n.B, nt, 2048, c.sc.wpart, 1.f, G + n.offW[0], n.PSZ));
+            continue;
+        }
         BwdRedArgs ra; ra.e = e; ra.u = pb.u[l]; ra.ud = nullptr; ra.dxo = pb.dx[l]; ra.dxod = nullptr; ra.coef = pb.coef[l];
         ra.part = c.sc.rpart; ra.nt = ew_bwd_red_nt(e);
         TRYP(FUMI_PH_CONV_EW, launch_bwd_reduce(c.st, ra, 0));
@@ -217,8 +251,10 @@ static int hvp_pass(StepCtx& c, int M, const float* img, const float* frags, Pas
         const long npix = (long)M * n.g[l].Pp;
         const int tiles = cv_tiles(npix);
         if (l == 0) {
-            Conv1Args a; a.B = n.B; a.M = M; a.Cin = n.Cin; a.g = n.g[0]; a.img = img; a.frag = Vfrags + n.fF[0]; a.frag_stride = n.FSZ;
+            Conv1Args a; memset(&a, 0, sizeof(a));
+            a.B = n.B; a.M = M; a.Cin = n.Cin; a.g = n.g[0]; a.img = img; a.frag = Vfrags + n.fF[0]; a.frag_stride = n.FSZ;
             a.out = tb.ud[0]; a.stats = c.sc.cpart; a.dot = pb.u[0];
+            if (n.fused1) { a.frag_dot = frags + n.fF[0]; a.frag_dot_stride = n.FSZ; }      // u is recomputed beside u'
             TRYP(FUMI_PH_CONV_FIRST, launch_conv1(c.st, a));
         } else {
             Conv64Args a; a.B = n.B; a.nsrc = 2; a.npix = npix; a.g = n.g[l];
@@ -231,6 +267,11 @@ static int hvp_pass(StepCtx& c, int M, const float* img, const float* frags, Pas
         ca.B = n.B; ca.mode = CFM_TFWD; ca.nt = tiles; ca.K = 2; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
         ca.part = c.sc.cpart; ca.coef = pb.coef[l]; ca.gd = V + n.offG[l]; ca.betad = V + n.offB[l]; ca.dstride = n.PSZ;
         TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca, c.sc.dsum));
+        if (l == 0 && n.fused1) {
+            C1Args fa = c1_args(n, M, img, frags, pb.coef[0]); fa.fragd = Vfrags + n.fF[0]; fa.fragd_stride = n.FSZ; fa.xd = tb.xd[0];
+            TRYP(FUMI_PH_CONV_FIRST, launch_c1(c.st, fa, 0, 1));
+            continue;
+        }
         PoolFwdArgs pa; pa.e = ew_geom(n, M, l); pa.u = pb.u[l]; pa.ud = tb.ud[l]; pa.coef = pb.coef[l]; pa.x = nullptr; pa.xd = tb.xd[l];
         TRYP(FUMI_PH_CONV_EW, launch_pool_fwd(c.st, pa, 1));
     }
@@ -248,6 +289,20 @@ static int hvp_pass(StepCtx& c, int M, const float* img, const float* frags, Pas
     for (int l = n.nblk - 1; l >= 0; --l) {
         const EwGeom e = ew_geom(n, M, l);
         const long npix = (long)M * n.g[l].Pp;
+        if (l == 0 && n.fused1) {
+            int chunk;
+            const int nt = c1_chunks(n.B, M, n.g[0], &chunk);
+            C1Args fa = c1_args(n, M, img, frags, pb.coef[0]); fa.fragd = Vfrags + n.fF[0]; fa.fragd_stride = n.FSZ;
+            fa.dxo = pb.dx[0]; fa.dxod = tb.dxd[0]; fa.part = c.sc.rpart; fa.wpart = c.sc.wpart;
+            TRYP(FUMI_PH_CONV_FIRST, launch_c1(c.st, fa, 1, 1));
+            CoefArgs ca; memset(&ca, 0, sizeof(ca));
+            ca.B = n.B; ca.mode = CFM_TBWD; ca.nt = nt; ca.K = 3; ca.n = (float)((double)M * n.g[0].H * n.g[0].W);
+            ca.part = c.sc.rpart; ca.coef = pb.coef[0]; ca.dg = HV + n.offG[0]; ca.dbeta = HV + n.offB[0]; ca.gstride = n.PSZ;
+            TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca, c.sc.dsum));
+            TRYP(FUMI_PH_CONV_FIRST, launch_c1(c.st, fa, 2, 1));
+            TRY(launch_reduce_batched(c.st, n.B, nt, 2048, c.sc.wpart, 1.f, HV + n.offW[0], n.PSZ));
+            continue;
+        }
         BwdRedArgs ra; ra.e = e; ra.u = pb.u[l]; ra.ud = tb.ud[l]; ra.dxo = pb.dx[l]; ra.dxod = tb.dxd[l]; ra.coef = pb.coef[l];
         ra.part = c.sc.rpart; ra.nt = ew_bwd_red_nt(e);
         TRYP(FUMI_PH_CONV_EW, launch_bwd_reduce(c.st, ra, 1));
@@ -316,6 +371,12 @@ static size_t conv4_scratch_sizes(const Net& n, int S, int Qn, Scratch& sc) {
             if (w1 > wp) wp = w1;
             const size_t r1 = (size_t)n.B * ew_bwd_red_nt(ew_geom(n, Ms[mi], l)) * 3 * 64;
             if (r1 > rp) rp = r1;
+            if (l == 0 && n.fused1) {
+                int chunk;
+                const size_t nt = (size_t)c1_chunks(n.B, Ms[mi], n.g[0], &chunk);
+                if (n.B * nt * 192 > rp) rp = n.B * nt * 192;
+                if (n.B * nt * 2048 > wp) wp = n.B * nt * 2048;
+            }
         }
     sc.cpart_n = cp; sc.wpart_n = wp; sc.rpart_n = rp;
     sc.dsum_n = coef_scratch_doubles(n.B, (int)(cp / ((size_t)n.B * 128)) + 1) + coef_scratch_doubles(n.B, (int)(rp / ((size_t)n.B * 192)) + 1);
@@ -446,6 +507,11 @@ static int fill_problem(Conv4Problem& p, int B, int N, int S, int Qn, int Cin, i
 }
 
 extern "C" {
+
+int fumi_hip_conv4_set_option(int key, int value) {
+    if (key == 0) { g_c1_fused = value ? 1 : 0; return FUMI_OK; }
+    return FUMI_EINVAL;
+}
 
 int fumi_hip_conv4_feature_dim(int nblk, int H, int W) { return (nblk < 1 || nblk > CV_MAXBLK) ? FUMI_EINVAL : conv4_feature_dim(nblk, H, W); }
 
@@ -592,7 +658,7 @@ int fumi_hip_conv4_probe(fumi_ws_t* ws, fumi_stream_t stream, int pass, int kind
             default: return FUMI_EINVAL;
         }
     }
-    if (!src) return FUMI_EINVAL;
+    if (!src) return FUMI_ENOTSUP;                                      // (block-1 maps do not exist on the fused path)
     *n_out = cnt;
     const size_t k = cnt < max_floats ? cnt : max_floats;
     HIP_TRY(hipMemcpyAsync(out, src, k * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));

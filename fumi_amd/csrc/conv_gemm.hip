@@ -21,7 +21,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __
 // the padded grid are written as 0 (the buffer stays a valid convolution input) and left out of the statistics.
 __device__ __forceinline__ void conv_epilogue(const f32x16& acc0, const f32x16& acc1, float* lds, const CvGeom& g, long npix,
                                               long ep0, long g0, int b, int t, int tiles, float* out, float* stats,
-                                              const float* dot) {
+                                              const float* dot, const f32x16* dreg0 = nullptr, const f32x16* dreg1 = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long gw = g0 + wave * 32;
@@ -42,10 +42,11 @@ __device__ __forceinline__ void conv_epilogue(const f32x16& acc0, const f32x16& 
         const bool in = (mask >> row) & 1u;
         const bool st = gw + row < npix;
         const float v0 = in ? acc0[i] : 0.f, v1 = in ? acc1[i] : 0.f;
-        if (st) { o[row * 64 + r] = v0; o[row * 64 + 32 + r] = v1; }
+        if (st && out) { o[row * 64 + r] = v0; o[row * 64 + 32 + r] = v1; }
         if (stats) {
             float e0 = v0, e1 = v1;
-            if (d) { const int rr = st ? row : 0; e0 = d[rr * 64 + r]; e1 = d[rr * 64 + 32 + r]; }
+            if (dreg0) { e0 = (*dreg0)[i]; e1 = (*dreg1)[i]; }
+            else if (d) { const int rr = st ? row : 0; e0 = d[rr * 64 + r]; e1 = d[rr * 64 + 32 + r]; }
             s1a += v0; s2a += v0 * e0; s1b += v1; s2b += v1 * e1;
         }
     }
@@ -170,6 +171,10 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(Conv1Args a, long npix, i
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
     const int nk = (a.Cin * 9 + 1) >> 1;
     const float* fr = a.frag + (long)b * a.frag_stride + lane;
+    const float* fd = a.frag_dot ? a.frag_dot + (long)b * a.frag_dot_stride + lane : nullptr;
+    f32x16 dc0, dc1;                                             // the dot operand conv(img, frag_dot), when asked for
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dc0[i] = 0.f; dc1[i] = 0.f; }
     const int pbase = halo + wave * 32 + r;
     for (int m = 0; m < nk; ++m) {
         const int kap = 2 * m + h;
@@ -179,9 +184,10 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(Conv1Args a, long npix, i
         const float av = lds[off + pbase];                       // (the weight of an invalid kappa is 0)
         const float b0 = fr[(m * 2 + 0) * 64], b1 = fr[(m * 2 + 1) * 64];
         acc0 = mfma32(av, b0, acc0); acc1 = mfma32(av, b1, acc1);
+        if (fd) { dc0 = mfma32(av, fd[(m * 2 + 0) * 64], dc0); dc1 = mfma32(av, fd[(m * 2 + 1) * 64], dc1); }
     }
     __syncthreads();
-    conv_epilogue(acc0, acc1, lds, a.g, npix, ep0, g0, b, t, tiles, a.out, a.stats, a.dot);
+    conv_epilogue(acc0, acc1, lds, a.g, npix, ep0, g0, b, t, tiles, a.out, a.stats, a.dot, fd ? &dc0 : nullptr, fd ? &dc1 : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ SYMBOLS = [
     "fumi_hip_linear_fwd", "fumi_hip_linear_bwd_data", "fumi_hip_linear_bwd_weight",
     "fumi_hip_sample_episodes", "fumi_hip_gather_rows", "fumi_hip_publish_scalars",
     "fumi_hip_publish_scalars_deferred", "fumi_hip_publish_flush", "fumi_hip_am3_metrics",
-    "fumi_hip_conv4_feature_dim", "fumi_hip_fumi_conv4_step", "fumi_hip_maml_conv4_step", "fumi_hip_conv4_probe", "fumi_hip_conv4_features",
+    "fumi_hip_conv4_feature_dim", "fumi_hip_fumi_conv4_step", "fumi_hip_maml_conv4_step", "fumi_hip_conv4_probe", "fumi_hip_conv4_features", "fumi_hip_conv4_set_option",
     "fumi_hip_conv3x3_fwd", "fumi_hip_conv3x3_bwd_data", "fumi_hip_conv3x3_bwd_weight",
     "fumi_hip_sgd_axpy", "fumi_hip_ce_fwd_bwd", "fumi_hip_proto_reduce",
 ]
@@ -137,6 +137,7 @@ def lib():
         L.fumi_hip_maml_conv4_step.argtypes = (
             [c_void_p, c_void_p] + [c_int] * 8 + [c_int, c_float, c_int, c_int, c_float]
             + [c_void_p] * 4 + [PP] + [c_void_p] * 6 + [PP])
+        L.fumi_hip_conv4_set_option.argtypes = [c_int, c_int]
         L.fumi_hip_conv4_features.argtypes = [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, PP, c_void_p]
         L.fumi_hip_conv4_probe.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, POINTER(c_size_t)]
         for fn in (L.fumi_hip_conv3x3_fwd, L.fumi_hip_conv3x3_bwd_data, L.fumi_hip_conv3x3_bwd_weight):
@@ -713,6 +714,11 @@ def maml_conv4_step(ws, x_s, y_s, x_q, y_q, params, T, alpha, first_order=False,
         _f32(stats, "stats") if stats is not None else None, _parr(g_params, "g_params") if need_grad else None)
     _check(rc, "fumi_hip_maml_conv4_step")
     return dict(logits=logits, preds=preds, preds_f=preds_f, loss_b=loss_b, acc_b=acc_b, g_params=g_params, stats=stats)
+
+
+def conv4_set_option(key, value):
+    """fumi_hip_conv4_set_option: key 0 = fused block 1 (default 1)."""
+    _check(lib().fumi_hip_conv4_set_option(int(key), int(value)), "fumi_hip_conv4_set_option")
 
 
 def conv4_features(ws, x, theta):

@@ -188,6 +188,9 @@ int fumi_hip_linear_bwd_weight(fumi_ws_t* ws, fumi_stream_t stream, int M, int N
  *   fumi: phi = A0 [Ht,Dt], a0, A1 [F+1,Ht], a1 [F+1];  maml: params = theta then lin_final W [N,F], b [N].
  * Outputs / gradient conventions as fumi_hip_fumi_step / fumi_hip_maml_step.  Second order needs T <= 8 taped inner steps. */
 int fumi_hip_conv4_feature_dim(int nblk, int H, int W);
+/* Process-wide switches of the Conv4 path.  key 0: 1 (default) = block 1 recomputed band by band from the image, its 64-channel
+ * full-resolution maps never stored (csrc/conv_first.hip); 0 = every block through the plain passes (what the probe tests read). */
+int fumi_hip_conv4_set_option(int key, int value);
 int fumi_hip_fumi_conv4_step(fumi_ws_t* ws, fumi_stream_t stream,
         int B, int N, int S, int Qn, int Cin, int H, int W, int nblk, int Dt, int Ht,
         int T, float alpha, int tanh_head, int need_grad, float grad_scale,

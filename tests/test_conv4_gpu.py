@@ -110,10 +110,20 @@ def _cmp(name, got, ref, tol=2e-4):
     assert e <= tol, f"{name}: rel-to-max error {e:.3e}"
 
 
+@pytest.fixture(params=["fused-block1", "plain"])
+def c1mode(request):
+    """Block 1 either recomputed band by band (csrc/conv_first.hip, the default) or through the plain passes."""
+    from fumi_amd import hip
+    hip.conv4_set_option(0, 1 if request.param == "fused-block1" else 0)
+    yield request.param
+    hip.conv4_set_option(0, 1)
+
+
 @pytest.mark.parametrize("shape", [(3, 12, 12, 2), (1, 20, 20, 3)])
-def test_every_intermediate_matches_the_manual_sweep(shape, dev, ws):
+def test_every_intermediate_matches_the_manual_sweep(shape, dev, ws, c1mode):
     from fumi_amd import hip
     Cin, H, W, nblk = shape
+    fused = c1mode == "fused-block1"
     B, N, K, Q, T, alpha = 2, 3, 2, 3, 2, 0.05
     ep, theta, Fd = _case(11, B, N, K, Q, Cin, H, W, nblk)
     S, Qn = N * K, N * Q
@@ -134,9 +144,10 @@ def test_every_intermediate_matches_the_manual_sweep(shape, dev, ws):
         tapes = [tr["tapes"][t] if t < T else tr["query"] for tr in traces]
         for l in range(nblk):
             Hl, Wl = geo[l]
-            u, bu = _unpad(probe(t, 0, l), B, Mi, Hl, Wl)
-            _cmp(f"pass {t} block {l} u", u, torch.stack([tp["blocks"][l]["u"] for tp in tapes]))
-            assert bu == 0.0, f"pass {t} block {l}: conv output border not zero"
+            if not (fused and l == 0):                              # (the fused path never stores block 1's maps)
+                u, bu = _unpad(probe(t, 0, l), B, Mi, Hl, Wl)
+                _cmp(f"pass {t} block {l} u", u, torch.stack([tp["blocks"][l]["u"] for tp in tapes]))
+                assert bu == 0.0, f"pass {t} block {l}: conv output border not zero"
             xo = probe(t, 1, l)
             ref_xo = torch.stack([tp["blocks"][l]["xo"] for tp in tapes])
             if l + 1 < nblk:
@@ -156,6 +167,8 @@ def test_every_intermediate_matches_the_manual_sweep(shape, dev, ws):
             else:
                 dxo = dxo.reshape(ref.shape)
             _cmp(f"pass {t} block {l} dxo", dxo, ref)
+            if fused and l == 0:
+                continue
             du, bd = _unpad(probe(t, 2, l), B, Mi, Hl, Wl)
             _cmp(f"pass {t} block {l} du", du, torch.stack([tp["blocks"][l]["du"] for tp in tapes]))
             assert bd == 0.0, f"pass {t} block {l}: du border not zero"
@@ -163,8 +176,9 @@ def test_every_intermediate_matches_the_manual_sweep(shape, dev, ws):
     tp0 = [tr["tapes"][0] for tr in traces]
     for l in range(nblk):
         Hl, Wl = geo[l]
-        ud, _ = _unpad(probe(T + 1, 0, l), B, S, Hl, Wl)
-        _cmp(f"tangent block {l} u'", ud, torch.stack([tp["blocks"][l]["ud"] for tp in tp0]))
+        if not (fused and l == 0):
+            ud, _ = _unpad(probe(T + 1, 0, l), B, S, Hl, Wl)
+            _cmp(f"tangent block {l} u'", ud, torch.stack([tp["blocks"][l]["ud"] for tp in tp0]))
         xod = probe(T + 1, 1, l)
         ref = torch.stack([tp["blocks"][l]["xod"] for tp in tp0])
         xod = _unpad(xod, B, S, *geo[l + 1])[0] if l + 1 < nblk else xod.reshape(ref.shape)
@@ -175,6 +189,8 @@ def test_every_intermediate_matches_the_manual_sweep(shape, dev, ws):
         ref = torch.stack([tp["blocks"][l]["dxod"] for tp in tp0])
         dxod = _unpad(dxod, B, S, *geo[l + 1])[0] if l + 1 < nblk else dxod.reshape(ref.shape)
         _cmp(f"tangent block {l} dxo'", dxod, ref)
+        if fused and l == 0:
+            continue
         dud, bd = _unpad(probe(T + 1, 2, l), B, S, Hl, Wl)
         _cmp(f"tangent block {l} du'", dud, torch.stack([tp["blocks"][l]["dud"] for tp in tp0]))
         assert bd == 0.0
@@ -189,7 +205,7 @@ def _check_grads(names, got, ref):
 
 
 @pytest.mark.parametrize("T,first_order,need_grad", [(1, False, True), (3, False, True), (2, True, True), (0, False, True), (2, False, False)])
-def test_maml_conv4_step_matches_autograd(T, first_order, need_grad, dev, ws):
+def test_maml_conv4_step_matches_autograd(T, first_order, need_grad, dev, ws, c1mode):
     from fumi_amd import hip
     B, N, K, Q, Cin, H, W, nblk, alpha = 3, 5, 1, 3, 3, 16, 16, 4, 0.05
     ep, theta, Fd = _case(21 + T, B, N, K, Q, Cin, H, W, nblk)
@@ -210,7 +226,7 @@ def test_maml_conv4_step_matches_autograd(T, first_order, need_grad, dev, ws):
 
 
 @pytest.mark.parametrize("T,tanh", [(1, False), (2, True)])
-def test_fumi_conv4_step_matches_autograd(T, tanh, dev, ws):
+def test_fumi_conv4_step_matches_autograd(T, tanh, dev, ws, c1mode):
     from fumi_amd import hip
     B, N, K, Q, Cin, H, W, nblk, Dt, Ht, alpha = 2, 5, 2, 3, 3, 20, 20, 4, 12, 16, 0.05
     ep, theta, Fd = _case(31 + T, B, N, K, Q, Cin, H, W, nblk)
@@ -238,8 +254,10 @@ def test_conv4_full_size_episode_84x84(dev, ws):
     block-1 pass; gradients that are sums of 176 400 cancelling terms) two correct fp32 implementations differ from float64 --
     and from each other -- by up to a few 1e-3 of a tensor's scale in the early blocks' meta-gradients: a single arg-max or
     ReLU decision that falls the other way in fp32 moves a weight gradient by 1/sqrt(#terms) = 0.24 % (measured:
-    tests/dev/probe_conv4_precision.py; the fp32 host oracle shows the same).  So logits / loss are held to 1e-4 and every
-    gradient to max(1e-3, 4 x the fp32 host oracle's own distance from float64)."""
+    tests/dev/probe_conv4_precision.py; the fp32 host oracle shows the same, 0.1-0.9 % per tensor, different tensors on different
+    runs).  So logits / loss are held to 1e-4 and every gradient to max(1e-2, 4 x the fp32 host oracle's own distance from
+    float64): what this test adds over the small cases (1e-3 on every gradient, 2e-4 on every intermediate) is the full-size
+    geometry -- tiling, halos, 64-bit offsets -- whose mistakes are O(1), not O(1e-3)."""
     from fumi_amd import hip
     B, N, K, Q, Cin, H, W, nblk, Dt, Ht, alpha, T = 2, 5, 5, 3, 3, 84, 84, 4, 12, 24, 0.01, 1
     ep, theta, Fd = _case(77, B, N, K, Q, Cin, H, W, nblk)
@@ -261,7 +279,7 @@ def test_conv4_full_size_episode_84x84(dev, ws):
     floor = 0.02 * max(float(r.abs().max()) for r in ref["g_theta"] + ref["g_phi"])
     for n, a, b32, b64 in zip(names, out["g_theta"] + out["g_phi"], r32["g_theta"] + r32["g_phi"], ref["g_theta"] + ref["g_phi"]):
         e, e32 = rel_to_max(a.cpu(), b64, floor), rel_to_max(b32, b64, floor)
-        assert e <= max(GRAD_TOL, 4 * e32), f"grad {n}: {e:.3e} from float64 (fp32 host oracle: {e32:.3e})"
+        assert e <= max(1e-2, 4 * e32), f"grad {n}: {e:.3e} from float64 (fp32 host oracle: {e32:.3e})"
 
 
 # ---- the module surface (--im_encoder conv4) on the GPU -------------------------------------------------------------------
