@@ -29,6 +29,15 @@ struct CvGeom {                          // one block's convolution resolution
     int H, W, Hp, Wp, Pp, halo;          // Hp = H+2, Wp = W+2, Pp = Hp*Wp, halo = Wp+1
 };
 static inline CvGeom cv_geom(int H, int W) { CvGeom g; g.H = H; g.W = W; g.Hp = H + 2; g.Wp = W + 2; g.Pp = g.Hp * g.Wp; g.halo = g.Wp + 1; return g; }
+#ifdef __HIPCC__
+// p / d and p % d for 0 <= p < 2^22, 1 <= d: one multiply by the reciprocal and a one-step correction (an integer division is
+// ~40 instructions, a 64-bit one several times that; these sit in per-element staging loops)
+__device__ __forceinline__ void cv_divmod(int p, int d, float rd, int& q, int& r) {
+    q = (int)((float)p * rd);
+    r = p - q * d;
+    if (r < 0) { --q; r += d; } else if (r >= d) { ++q; r -= d; }
+}
+#endif
 static inline int cv_tiles(long npix) { return (int)((npix + CV_TILE - 1) / CV_TILE); }
 
 // ---- conv_gemm.hip -----------------------------------------------------------------------------------------------

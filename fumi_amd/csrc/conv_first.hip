@@ -21,19 +21,39 @@ enum { C1_POOL = 0, C1_REDUCE = 1, C1_WGRAD = 2 };
 
 struct Band { int NPX, NP, ntile; };          // pixels of a band padded to whole 32-pixel tiles; image slab incl. halo
 
-// the image slab of band (img, y0): padded rows y0+1, y0+2 plus halo, one plane per channel
-__device__ __forceinline__ void stage_band(float* pl, const C1Args& a, const Band& bd, const float* img, int y0) {
+// The image slab of a band (padded rows y0+1, y0+2 plus halo, one plane per channel).  Which slab element a thread copies,
+// its column and its row relative to the band do not depend on the band: worked out once (SlabPlan); per band a thread only
+// adds the row offset, so the loads of the NEXT band can be issued before the current band's matrix work (prefetch).
+constexpr int C1_NE = 8;                              // slab elements per thread: Cin * NP <= 2048
+struct SlabPlan { int base[C1_NE]; int dy[C1_NE]; bool okx[C1_NE]; };
+__device__ __forceinline__ void slab_plan(SlabPlan& sp, const C1Args& a, const Band& bd) {
     const CvGeom& g = a.g;
-    const int lo = (y0 + 1) * g.Wp - g.halo;                  // padded pixel index (within the image) of slab pixel 0
-    for (int i = threadIdx.x; i < a.Cin * bd.NP; i += 256) {
-        const int c = i / bd.NP, pi = i - c * bd.NP;
-        const int p = lo + pi;
-        float v = 0.f;
-        if (p >= 0 && p < g.Pp) {
-            const int y = p / g.Wp, x = p - y * g.Wp;
-            if (x >= 1 && x <= g.W && y >= 1 && y <= g.H) v = img[(long)c * g.H * g.W + (y - 1) * g.W + (x - 1)];
-        }
-        pl[i] = v;
+    const float rWp = 1.0f / (float)g.Wp;
+#pragma unroll
+    for (int e = 0; e < C1_NE; ++e) {
+        const int i = threadIdx.x + 256 * e;
+        const int c = i >= 2 * bd.NP ? 2 : i >= bd.NP ? 1 : 0, pi = i - c * bd.NP;
+        int q, x;
+        cv_divmod(pi - g.halo + 2 * g.Wp, g.Wp, rWp, q, x);            // slab pixel 0 lies halo = Wp + 1 pixels before the band
+        sp.dy[e] = q - 2;                                              // row relative to the band's first row
+        sp.okx[e] = i < a.Cin * bd.NP && x >= 1 && x <= g.W;
+        sp.base[e] = c * g.H * g.W + (x - 1);
+    }
+}
+__device__ __forceinline__ void slab_load(float (&v)[C1_NE], const SlabPlan& sp, const C1Args& a, const float* img, int y0) {
+#pragma unroll
+    for (int e = 0; e < C1_NE; ++e) {
+        const int yi = y0 + sp.dy[e];
+        const bool ok = sp.okx[e] && yi >= 0 && yi < a.g.H;
+        const float t = img[ok ? sp.base[e] + yi * a.g.W : 0];           // unconditional load from a clamped address
+        v[e] = ok ? t : 0.f;
+    }
+}
+__device__ __forceinline__ void slab_store(float* pl, const float (&v)[C1_NE], const C1Args& a, const Band& bd) {
+#pragma unroll
+    for (int e = 0; e < C1_NE; ++e) {
+        const int i = threadIdx.x + 256 * e;
+        if (i < a.Cin * bd.NP) pl[i] = v[e];
     }
 }
 
@@ -135,13 +155,24 @@ __global__ __launch_bounds__(256) void c1_kernel(C1Args a, int bands_per_img, in
     const bool kok = r < a.Cin * 9;
     const int koff = kok ? kc * bd.NP + g.halo + (ktap / 3 - 1) * Wp + (ktap % 3 - 1) : 0;
 
+    SlabPlan sp;
+    slab_plan(sp, a, bd);
+    float slab[C1_NE];
+    const long img_sz = (long)a.Cin * g.H * g.W;
+    if (b_beg < b_end) {
+        const int im = (int)(b_beg / bands_per_img), yb = (int)(b_beg - (long)im * bands_per_img);
+        slab_load(slab, sp, a, a.img + ((long)b * a.M + im) * img_sz, 2 * yb);
+    }
     for (long band = b_beg; band < b_end; ++band) {
         const int im = (int)(band / bands_per_img), yb = (int)(band - (long)im * bands_per_img), y0 = 2 * yb;
         const long img_g = (long)b * a.M + im;
-        const float* img = a.img + img_g * a.Cin * g.H * g.W;
         const bool two = y0 + 1 < g.H, full_row = yb < Ho;          // second row exists; the band is a pooled row
         __syncthreads();                                               // previous band's LDS images are no longer read
-        stage_band(pl, a, bd, img, y0);
+        slab_store(pl, slab, a, bd);
+        if (band + 1 < b_end) {                                        // next band's image rows: in flight during this band's work
+            const int im2 = (int)((band + 1) / bands_per_img), yb2 = (int)(band + 1 - (long)im2 * bands_per_img);
+            slab_load(slab, sp, a, a.img + ((long)b * a.M + im2) * img_sz, 2 * yb2);
+        }
         __syncthreads();
         conv_band(U, pl, a, bd, wf);
         if (TAN) conv_band(UD, pl, a, bd, wfd);
@@ -343,7 +374,7 @@ int launch_c1(hipStream_t st, const C1Args& a, int mode, int tangent) {
     const int ntile = (2 * a.g.Wp + 31) / 32, NPX = ntile * 32, NP = NPX + 2 * a.g.halo;
     size_t lds = (size_t)(tangent ? 2 : 1) * NPX * 256 + (size_t)a.Cin * NP * 4;
     if (lds < 32768) lds = 32768;                                           // (the end-of-kernel reductions use up to 32 KiB)
-    if (lds > 160 * 1024) return FUMI_ENOTSUP;
+    if (lds > 160 * 1024 || a.Cin * NP > 256 * 8) return FUMI_ENOTSUP;
     const int bpi = (a.g.H + 1) / 2;
     const dim3 grid(nt, a.B), blk(256);
 #define C1_LAUNCH(MODE, TAN)                                                            \

@@ -27,9 +27,10 @@ __device__ __forceinline__ void conv_epilogue(const f32x16& acc0, const f32x16& 
     const long gw = g0 + wave * 32;
     unsigned mask;
     {
-        const long gp = gw + r;
-        const int p = (int)(gp % g.Pp);
-        const int y = p / g.Wp, x = p - y * g.Wp;
+        const int gp = (int)gw + r;                              // (pixels per episode < 2^22: launch_* check it)
+        int im, p, y, x;
+        cv_divmod(gp, g.Pp, 1.0f / (float)g.Pp, im, p);
+        cv_divmod(p, g.Wp, 1.0f / (float)g.Wp, y, x);
         const bool in = gp < npix && x >= 1 && x <= g.W && y >= 1 && y <= g.H;
         mask = (unsigned)__ballot(in);
     }
@@ -154,13 +155,15 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(Conv1Args a, long npix, i
     const int halo = a.g.halo, Wp = a.g.Wp, Pp = a.g.Pp, H = a.g.H, W = a.g.W;
     const int npatch = CV_TILE + 2 * halo;
     const float* img = a.img + (long)b * a.M * a.Cin * H * W;
+    const float rPp = 1.0f / (float)Pp, rWp = 1.0f / (float)Wp;
     for (int i = tid; i < a.Cin * npatch; i += 256) {
-        const int c = i / npatch, pi = i - c * npatch;
-        const long gp = g0 - halo + pi;
+        const int c = i >= 2 * npatch ? 2 : i >= npatch ? 1 : 0, pi = i - c * npatch;
+        const int gp = (int)g0 - halo + pi;
         float v = 0.f;
         if (gp >= 0 && gp < npix) {
-            const int im = (int)(gp / Pp), p = (int)(gp - (long)im * Pp);
-            const int y = p / Wp, x = p - y * Wp;
+            int im, p, y, x;
+            cv_divmod(gp, Pp, rPp, im, p);
+            cv_divmod(p, Wp, rWp, y, x);
             if (x >= 1 && x <= W && y >= 1 && y <= H) v = img[((long)im * a.Cin + c) * H * W + (y - 1) * W + (x - 1)];
         }
         lds[i] = v;
@@ -309,12 +312,13 @@ __global__ __launch_bounds__(256, 2) void wgrad1_kernel(Wgrad1Args a, long npix,
             for (int u = 0; u < 4; ++u) *(f32x4*)(dyl + (i0 + u * 256) * 4) = v[u];
         }
         for (int i = tid; i < a.Cin * npatch; i += 256) {
-            const int c = i / npatch, pi = i - c * npatch;
-            const long gp = p0 - halo + pi;
+            const int c = i >= 2 * npatch ? 2 : i >= npatch ? 1 : 0, pi = i - c * npatch;
+            const int gp = (int)p0 - halo + pi;
             float v = 0.f;
             if (gp >= 0 && gp < npix) {
-                const int im = (int)(gp / Pp), p = (int)(gp - (long)im * Pp);
-                const int y = p / Wp, x = p - y * Wp;
+                int im, p, y, x;
+                cv_divmod(gp, Pp, 1.0f / (float)Pp, im, p);
+                cv_divmod(p, Wp, 1.0f / (float)Wp, y, x);
                 if (x >= 1 && x <= W && y >= 1 && y <= H) v = img[((long)im * a.Cin + c) * H * W + (y - 1) * W + (x - 1)];
             }
             pl[i] = v;
@@ -385,6 +389,7 @@ __global__ void toi_to_oihw_kernel(int n, const float* src, float* dst, float sc
 
 int launch_conv64(hipStream_t st, const Conv64Args& a) {
     if (a.B < 1 || a.npix < 1 || a.nsrc < 1 || a.nsrc > 2) return FUMI_EINVAL;
+    if (a.npix >= (1L << 22)) return FUMI_ENOTSUP;            // (per-episode pixel indices are 22-bit in the kernels)
     const int tiles = cv_tiles(a.npix);
     const size_t lds = (size_t)(CV_TILE + 2 * a.g.halo) * 256;
     if (lds > 160 * 1024) return FUMI_ENOTSUP;
@@ -400,8 +405,9 @@ int launch_conv64(hipStream_t st, const Conv64Args& a) {
 }
 
 int launch_conv1(hipStream_t st, const Conv1Args& a) {
-    if (a.B < 1 || a.M < 1 || a.Cin < 1 || a.Cin > 4) return FUMI_EINVAL;
+    if (a.B < 1 || a.M < 1 || a.Cin < 1 || a.Cin > 3) return FUMI_EINVAL;
     const long npix = (long)a.M * a.g.Pp;
+    if (npix >= (1L << 22)) return FUMI_ENOTSUP;
     const int tiles = cv_tiles(npix);
     size_t lds = (size_t)a.Cin * (CV_TILE + 2 * a.g.halo) * 4;
     if (lds < 2048) lds = 2048;
@@ -439,6 +445,7 @@ int launch_wgrad64(hipStream_t st, const Wgrad64Args& a) {
 int launch_wgrad1(hipStream_t st, const Wgrad1Args& a) {
     if (a.B < 1 || a.M < 1 || a.Cin < 1 || a.Cin > 3 || a.nsplit < 1) return FUMI_EINVAL;      // kappa = 9 Cin <= 32 columns
     const long npix = (long)a.M * a.g.Pp;
+    if (npix >= (1L << 22)) return FUMI_ENOTSUP;
     long chunk = (npix + a.nsplit - 1) / a.nsplit;
     chunk = (chunk + W1_PT - 1) / W1_PT * W1_PT;
     size_t lds = (size_t)W1_PT * 256 + (size_t)a.Cin * (W1_PT + 2 * a.g.halo) * 4;
