@@ -167,4 +167,4 @@ struct C1Args {
     float* wpart;                               // wgrad: [B][nt][64][32] partial dW1
 };
 int c1_chunks(int B, int M, const CvGeom& g, int* chunk_out);
-int launch_c1(hipStream_t st, const C1Args& a, int mode /*0 pool, 1 reduce, 2 wgrad*/, int tangent);
+int launch_c1(hipStream_t st, const C1Args& a, int mode /*0 pool, 1 reduce, 2 wgrad, 3 batch statistics*/, int tangent);

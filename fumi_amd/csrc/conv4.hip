@@ -158,10 +158,16 @@ static int forward_pass(StepCtx& c, int M, const float* img, const float* params
     for (int l = 0; l < n.nblk; ++l) {
         const long npix = (long)M * n.g[l].Pp;
         const int tiles = cv_tiles(npix);
-        if (l == 0) {
+        int nt_stats = tiles;
+        if (l == 0 && n.fused1) {
+            int chunk;
+            nt_stats = c1_chunks(n.B, M, n.g[0], &chunk);
+            C1Args fa = c1_args(n, M, img, frags, nullptr); fa.part = c.sc.cpart;
+            TRYP(FUMI_PH_CONV_FIRST, launch_c1(c.st, fa, 3, 0));
+        } else if (l == 0) {
             Conv1Args a; memset(&a, 0, sizeof(a));
             a.B = n.B; a.M = M; a.Cin = n.Cin; a.g = n.g[0]; a.img = img; a.frag = frags + n.fF[0]; a.frag_stride = n.FSZ;
-            a.out = pb.u[0]; a.stats = c.sc.cpart; a.dot = nullptr;          // (fused: out == NULL, statistics only)
+            a.out = pb.u[0]; a.stats = c.sc.cpart; a.dot = nullptr;
             TRYP(FUMI_PH_CONV_FIRST, launch_conv1(c.st, a));
         } else {
             Conv64Args a; a.B = n.B; a.nsrc = 1; a.npix = npix; a.g = n.g[l];
@@ -170,7 +176,7 @@ static int forward_pass(StepCtx& c, int M, const float* img, const float* params
             TRYP(FUMI_PH_CONV_GEMM, launch_conv64(c.st, a));
         }
         CoefArgs ca; memset(&ca, 0, sizeof(ca));
-        ca.B = n.B; ca.mode = CFM_FWD; ca.nt = tiles; ca.K = 2; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
+        ca.B = n.B; ca.mode = CFM_FWD; ca.nt = nt_stats; ca.K = 2; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
         ca.part = c.sc.cpart; ca.coef = pb.coef[l]; ca.g = params + n.offG[l]; ca.beta = params + n.offB[l]; ca.pstride = n.PSZ;
         TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca, c.sc.dsum));
         if (l == 0 && n.fused1) {
@@ -250,11 +256,16 @@ static int hvp_pass(StepCtx& c, int M, const float* img, const float* frags, Pas
     for (int l = 0; l < n.nblk; ++l) {
         const long npix = (long)M * n.g[l].Pp;
         const int tiles = cv_tiles(npix);
-        if (l == 0) {
+        int nt_stats = tiles;
+        if (l == 0 && n.fused1) {
+            int chunk;
+            nt_stats = c1_chunks(n.B, M, n.g[0], &chunk);
+            C1Args fa = c1_args(n, M, img, frags, nullptr); fa.fragd = Vfrags + n.fF[0]; fa.fragd_stride = n.FSZ; fa.part = c.sc.cpart;
+            TRYP(FUMI_PH_CONV_FIRST, launch_c1(c.st, fa, 3, 1));
+        } else if (l == 0) {
             Conv1Args a; memset(&a, 0, sizeof(a));
             a.B = n.B; a.M = M; a.Cin = n.Cin; a.g = n.g[0]; a.img = img; a.frag = Vfrags + n.fF[0]; a.frag_stride = n.FSZ;
             a.out = tb.ud[0]; a.stats = c.sc.cpart; a.dot = pb.u[0];
-            if (n.fused1) { a.frag_dot = frags + n.fF[0]; a.frag_dot_stride = n.FSZ; }      // u is recomputed beside u'
             TRYP(FUMI_PH_CONV_FIRST, launch_conv1(c.st, a));
         } else {
             Conv64Args a; a.B = n.B; a.nsrc = 2; a.npix = npix; a.g = n.g[l];
@@ -264,7 +275,7 @@ static int hvp_pass(StepCtx& c, int M, const float* img, const float* frags, Pas
             TRYP(FUMI_PH_CONV_GEMM, launch_conv64(c.st, a));
         }
         CoefArgs ca; memset(&ca, 0, sizeof(ca));
-        ca.B = n.B; ca.mode = CFM_TFWD; ca.nt = tiles; ca.K = 2; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
+        ca.B = n.B; ca.mode = CFM_TFWD; ca.nt = nt_stats; ca.K = 2; ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
         ca.part = c.sc.cpart; ca.coef = pb.coef[l]; ca.gd = V + n.offG[l]; ca.betad = V + n.offB[l]; ca.dstride = n.PSZ;
         TRYP(FUMI_PH_CONV_EW, launch_coef(c.st, ca, c.sc.dsum));
         if (l == 0 && n.fused1) {

@@ -17,7 +17,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
 __device__ __forceinline__ f32x4 cf(const float* coef, int b, int field, int c4) { return ld4(coef + ((long)b * CF_N + field) * 64 + 4 * c4); }
 
-enum { C1_POOL = 0, C1_REDUCE = 1, C1_WGRAD = 2 };
+enum { C1_POOL = 0, C1_REDUCE = 1, C1_WGRAD = 2, C1_STATS = 3 };
 
 struct Band { int NPX, NP, ntile; };          // pixels of a band padded to whole 32-pixel tiles; image slab incl. halo
 
@@ -74,25 +74,57 @@ __device__ __forceinline__ void load_w1(W1Frag& f, const float* fr, const C1Args
     }
 }
 
-// u[NPX][64] (LDS) = conv(image band, weights): tiles round-robin over the 4 waves
+// u[2 Wp][64] (LDS) = conv(image band, weights).  Work units = (32-pixel tile, 32-channel half): 12 units at Wp = 86, three per
+// wave (whole tiles would leave two of the four waves idle in the second round).
 __device__ __forceinline__ void conv_band(float* U, const float* pl, const C1Args& a, const Band& bd, const W1Frag& f) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int t = wave; t < bd.ntile; t += 4) {
-        f32x16 acc0, acc1;
+    const int npx = 2 * a.g.Wp;
+    for (int u = wave; u < 2 * bd.ntile; u += 4) {
+        const int t = u >> 1, ct = u & 1;
+        f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const int pbase = a.g.halo + t * 32 + r;
+#pragma unroll
+        for (int m = 0; m < C1_NK; ++m) acc = mfma32(pl[f.off[m] + pbase], ct ? f.w1[m] : f.w0[m], acc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int px = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (px < npx) U[px * 64 + ct * 32 + r] = acc[i];
+        }
+    }
+}
+
+// batch statistics of a band straight from the accumulators (nothing goes to LDS): s1 += out, s2 += out * dot over interior
+// pixels, out = conv(image, f) and dot = out (plain) or conv(image, fdot) (tangent pass: out = u', dot = u).  A wave's units all
+// have the same channel half (unit u = wave mod 4), so a lane keeps two scalars.
+template <bool TAN>
+__device__ __forceinline__ void conv_band_stats(const float* pl, const C1Args& a, const Band& bd, const W1Frag& f, const W1Frag& fdot,
+                                                bool two, float& s1, float& s2) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Wp = a.g.Wp, W = a.g.W;
+    for (int u = wave; u < 2 * bd.ntile; u += 4) {
+        const int t = u >> 1, ct = u & 1;
+        f32x16 acc, dac;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[i] = 0.f; dac[i] = 0.f; }
         const int pbase = a.g.halo + t * 32 + r;
 #pragma unroll
         for (int m = 0; m < C1_NK; ++m) {
             const float av = pl[f.off[m] + pbase];
-            acc0 = mfma32(av, f.w0[m], acc0);
-            acc1 = mfma32(av, f.w1[m], acc1);
+            acc = mfma32(av, ct ? f.w1[m] : f.w0[m], acc);
+            if (TAN) dac = mfma32(av, ct ? fdot.w1[m] : fdot.w0[m], dac);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int px = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            U[px * 64 + r] = acc0[i]; U[px * 64 + 32 + r] = acc1[i];
+            const bool row1 = px >= Wp;
+            const int x = row1 ? px - Wp : px;
+            const bool in = px < 2 * Wp && x >= 1 && x <= W && (!row1 || two);
+            const float v = in ? acc[i] : 0.f;
+            s1 += v; s2 += v * (TAN ? dac[i] : v);
         }
     }
 }
@@ -127,9 +159,10 @@ __global__ __launch_bounds__(256) void c1_kernel(C1Args a, int bands_per_img, in
     const CvGeom& g = a.g;
     Band bd;
     bd.ntile = (2 * g.Wp + 31) / 32; bd.NPX = bd.ntile * 32; bd.NP = bd.NPX + 2 * g.halo;
-    float* U = lds;                                   // [NPX][64]
-    float* UD = lds + bd.NPX * 64;                    // [NPX][64] (TAN)
-    float* pl = lds + (TAN ? 2 : 1) * bd.NPX * 64;    // [Cin][NP]
+    const int npx = 2 * g.Wp;                         // pixels of a band (two padded rows)
+    float* U = lds;                                   // [npx][64]
+    float* UD = lds + npx * 64;                       // [npx][64] (TAN)
+    float* pl = lds + (TAN ? 2 : 1) * npx * 64;       // [Cin][NP]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y, t = blockIdx.x;
@@ -147,6 +180,7 @@ __global__ __launch_bounds__(256) void c1_kernel(C1Args a, int bands_per_img, in
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int k = 0; k < RK; ++k) rs[i][k] = z4;
+    float st1 = 0.f, st2 = 0.f;                       // C1_STATS: this lane's channel (32 (wave & 1) + lane & 31), its pixels
     f32x16 wa0, wa1;                                  // C1_WGRAD: dW1 quadrants [co 0..31 | 32..63] x [kappa 0..31], this wave's pixels
 #pragma unroll
     for (int i = 0; i < 16; ++i) { wa0[i] = 0.f; wa1[i] = 0.f; }
@@ -174,6 +208,11 @@ __global__ __launch_bounds__(256) void c1_kernel(C1Args a, int bands_per_img, in
             slab_load(slab, sp, a, a.img + ((long)b * a.M + im2) * img_sz, 2 * yb2);
         }
         __syncthreads();
+        if (MODE == C1_STATS) {                                        // (tangent: statistics of u' = conv(image, W1') against u)
+            if (TAN) conv_band_stats<true>(pl, a, bd, wfd, wf, two, st1, st2);
+            else conv_band_stats<false>(pl, a, bd, wf, wf, two, st1, st2);
+            continue;
+        }
         conv_band(U, pl, a, bd, wf);
         if (TAN) conv_band(UD, pl, a, bd, wfd);
         __syncthreads();
@@ -303,18 +342,17 @@ __global__ __launch_bounds__(256) void c1_kernel(C1Args a, int bands_per_img, in
                     if (k == 0 || valid[k]) *(f32x4*)(D + offs[k] * 64 + 4 * c4) = valid[k] ? o : z4;
                 }
             }
-            // zero everything that is not an interior pixel of an existing row: x = 0, x = Wp-1, the tile padding, a missing row
-            for (int it = tid; it < bd.NPX * 16; it += 256) {
-                const int px = it >> 4, c4 = it & 15;
-                const int row = px / Wp, x = px - row * Wp;
-                const bool interior = px < 2 * Wp && x >= 1 && x <= g.W && (row == 0 || two);
-                if (!interior) *(f32x4*)(D + px * 64 + 4 * c4) = z4;
+            // zero what is not an interior pixel of an existing row: the four border pixels (x = 0, x = Wp-1), a missing row
+            if (tid < 64) {
+                const int k = tid >> 4, c4 = tid & 15;
+                *(f32x4*)(D + ((k >> 1) * Wp + (k & 1) * (Wp - 1)) * 64 + 4 * c4) = z4;
             }
+            if (!two) for (int it = tid; it < Wp * 16; it += 256) *(f32x4*)(D + (Wp + (it >> 4)) * 64 + 4 * (it & 15)) = z4;
             __syncthreads();
             // dW1[co][kappa] += sum_px du[px][co] * image[kappa][px + off]: pixel pairs round-robin over the waves
             const float* ap = D + h * 64 + r;
             const float* bp = pl + koff + h;
-            for (int m = wave; m < bd.NPX / 2; m += 4) {
+            for (int m = wave; m < Wp; m += 4) {                  // 2 Wp pixels = Wp pairs
                 const float bv = kok ? bp[2 * m] : 0.f;
                 wa0 = mfma32(ap[m * 128], bv, wa0);
                 wa1 = mfma32(ap[m * 128 + 32], bv, wa1);
@@ -322,6 +360,17 @@ __global__ __launch_bounds__(256) void c1_kernel(C1Args a, int bands_per_img, in
         }
     }
 
+    if (MODE == C1_STATS) {
+        st1 += __shfl_xor(st1, 32); st2 += __shfl_xor(st2, 32);
+        __syncthreads();
+        float* red = lds;                                   // [4 waves][2][32]
+        if (h == 0) { red[(wave * 2 + 0) * 32 + r] = st1; red[(wave * 2 + 1) * 32 + r] = st2; }
+        __syncthreads();
+        if (tid < 128) {                                    // k = tid >> 6, channel c = tid & 63: waves (c >> 5) and (c >> 5) + 2
+            const int k = tid >> 6, c = tid & 63, w0 = c >> 5;
+            a.part[(((long)b * gridDim.x + t) * 2 + k) * 64 + c] = red[(w0 * 2 + k) * 32 + (c & 31)] + red[((w0 + 2) * 2 + k) * 32 + (c & 31)];
+        }
+    }
     if (MODE == C1_REDUCE) {
         __syncthreads();
         // fold the (up to 3) window columns of a thread, then the 16 threads that share a channel quad
@@ -372,7 +421,7 @@ int launch_c1(hipStream_t st, const C1Args& a, int mode, int tangent) {
     int chunk;
     const int nt = c1_chunks(a.B, a.M, a.g, &chunk);
     const int ntile = (2 * a.g.Wp + 31) / 32, NPX = ntile * 32, NP = NPX + 2 * a.g.halo;
-    size_t lds = (size_t)(tangent ? 2 : 1) * NPX * 256 + (size_t)a.Cin * NP * 4;
+    size_t lds = (size_t)(tangent ? 2 : 1) * 2 * a.g.Wp * 256 + (size_t)a.Cin * NP * 4;
     if (lds < 32768) lds = 32768;                                           // (the end-of-kernel reductions use up to 32 KiB)
     if (lds > 160 * 1024 || a.Cin * NP > 256 * 8) return FUMI_ENOTSUP;
     const int bpi = (a.g.H + 1) / 2;
@@ -385,6 +434,7 @@ int launch_c1(hipStream_t st, const C1Args& a, int mode, int tangent) {
     if (mode == C1_POOL) { if (tangent) C1_LAUNCH(C1_POOL, true); else C1_LAUNCH(C1_POOL, false); }
     else if (mode == C1_REDUCE) { if (tangent) C1_LAUNCH(C1_REDUCE, true); else C1_LAUNCH(C1_REDUCE, false); }
     else if (mode == C1_WGRAD) { if (tangent) C1_LAUNCH(C1_WGRAD, true); else C1_LAUNCH(C1_WGRAD, false); }
+    else if (mode == C1_STATS) { if (tangent) C1_LAUNCH(C1_STATS, true); else C1_LAUNCH(C1_STATS, false); }
     else return FUMI_EINVAL;
 #undef C1_LAUNCH
     LAUNCH_CHECK();
