@@ -72,7 +72,9 @@ def block_fwd(x, W, g, b):
     first = ((vw == mx[..., None]).to(torch.int8).cumsum(-1) == 1) & (vw == mx[..., None])     # FIRST maximum of the window
     arg = first.to(torch.int8).argmax(-1)
     mask = (mx > 0).to(x.dtype)
-    return torch.relu(mx), dict(x=x, W=W, g=g.view(1, -1, 1, 1), r=r, xh=xh, arg=arg, mask=mask, shape=u.shape, u=u, mu=mu,
+    top2 = vw.topk(2, dim=-1)[0]
+    margin = float(torch.minimum(mx.abs().min(), (top2[..., 0] - top2[..., 1]).min()))      # distance from a ReLU / arg-max tie
+    return torch.relu(mx), dict(margin=margin, x=x, W=W, g=g.view(1, -1, 1, 1), r=r, xh=xh, arg=arg, mask=mask, shape=u.shape, u=u, mu=mu,
                                 xo=torch.relu(mx))
 
 
@@ -202,3 +204,13 @@ def episode_grads(theta, h0, x_s, y_s, x_q, y_q, T, alpha, first_order=False, tr
             bar_th = [b - alpha * v for b, v in zip(bar_th, hv_th)]
             bar_h = bar_h - alpha * hv_h
     return zq, loss, bar_th, bar_h
+
+
+def min_decision_margin(theta, h0, x_s, y_s, x_q, y_q, T, alpha):
+    """Smallest distance of any ReLU / max-pool decision of the episode (all inner steps + the query pass) from a tie.  A
+    decision closer to a tie than the fp32 noise of its input (~1e-6) may fall either way in two correct implementations; the
+    forward value barely moves, but the gradient routed through it switches on or off -- an O(1/sqrt(#terms)) change of a
+    weight gradient.  Parity cases are drawn so that this margin is comfortably above the noise."""
+    tr = {}
+    episode_grads(theta, h0, x_s, y_s, x_q, y_q, T, alpha, first_order=True, trace=tr)
+    return min(tp["margin"] for tape in tr["tapes"] + [tr["query"]] for tp in tape["blocks"])
