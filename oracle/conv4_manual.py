@@ -60,8 +60,11 @@ def _unwindows(w, H, W):
     return out
 
 
-def block_fwd(x, W, g, b):
-    """conv . BN(batch statistics) . ReLU . max-pool 2 -> (pooled output, tape)."""
+def block_fwd(x, W, g, b, flips=None):
+    """conv . BN(batch statistics) . ReLU . max-pool 2 -> (pooled output, tape).
+    flips: [(kind, flat window index)] decisions to take the OTHER way ("relu": the unit's ReLU mask, "arg": the window's
+    second-largest element instead of the largest) -- used by the parity tests to enumerate decisions that lie within fp32
+    noise of a tie (see ambiguous_decisions)."""
     u = conv(x, W)
     mu = u.mean((0, 2, 3), keepdim=True)
     r = (u.var((0, 2, 3), unbiased=False, keepdim=True) + BN_EPS).rsqrt()
@@ -72,9 +75,17 @@ def block_fwd(x, W, g, b):
     first = ((vw == mx[..., None]).to(torch.int8).cumsum(-1) == 1) & (vw == mx[..., None])     # FIRST maximum of the window
     arg = first.to(torch.int8).argmax(-1)
     mask = (mx > 0).to(x.dtype)
-    top2 = vw.topk(2, dim=-1)[0]
-    margin = float(torch.minimum(mx.abs().min(), (top2[..., 0] - top2[..., 1]).min()))      # distance from a ReLU / arg-max tie
-    return torch.relu(mx), dict(margin=margin, x=x, W=W, g=g.view(1, -1, 1, 1), r=r, xh=xh, arg=arg, mask=mask, shape=u.shape, u=u, mu=mu,
+    top2v, top2i = vw.topk(2, dim=-1)
+    relu_margin, arg_margin = mx.abs(), top2v[..., 0] - top2v[..., 1]
+    margin = float(torch.minimum(relu_margin.min(), arg_margin.min()))                       # distance from a ReLU / arg-max tie
+    if flips:
+        arg, mask = arg.clone(), mask.clone()
+        for kind, idx in flips:
+            if kind == "relu":
+                mask.view(-1)[idx] = 1.0 - mask.view(-1)[idx]
+            else:
+                arg.view(-1)[idx] = top2i[..., 1].reshape(-1)[idx]
+    return torch.relu(mx), dict(margin=margin, relu_margin=relu_margin, arg_margin=arg_margin, x=x, W=W, g=g.view(1, -1, 1, 1), r=r, xh=xh, arg=arg, mask=mask, shape=u.shape, u=u, mu=mu,
                                 xo=torch.relu(mx))
 
 
@@ -133,10 +144,10 @@ def block_tan_bwd(dxod, tp, need_dx=True):
     return dxd, dWd, dgd, dbd
 
 
-def net_fwd(x, theta, h):
+def net_fwd(x, theta, h, flips=None):
     tapes = []
     for i in range(0, len(theta), 3):
-        x, tp = block_fwd(x, theta[i], theta[i + 1], theta[i + 2])
+        x, tp = block_fwd(x, theta[i], theta[i + 1], theta[i + 2], None if not flips else flips.get(i // 3))
         tapes.append(tp)
     f = x.reshape(x.shape[0], -1)
     z = f @ h[:, :-1].t() + h[:, -1]
@@ -176,22 +187,23 @@ def net_hvp(tape, vth, vh, scale):
     return out, dhd
 
 
-def episode_grads(theta, h0, x_s, y_s, x_q, y_q, T, alpha, first_order=False, trace=None):
+def episode_grads(theta, h0, x_s, y_s, x_q, y_q, T, alpha, first_order=False, trace=None, flips=None):
     """(query logits, query loss, d loss / d theta, d loss / d h0) of one episode, no autograd anywhere.
-    trace (dict): receives every intermediate (tapes of the inner steps, the query pass, gradients, adjoints, H v)."""
+    trace (dict): receives every intermediate (tapes of the inner steps, the query pass, gradients, adjoints, H v).
+    flips: {pass (inner step t, or T = query): {block: [(kind, index)]}} decisions taken the other way (block_fwd)."""
     th, h, tapes = [t for t in theta], h0, []
     if trace is not None:
         trace.update(tapes=tapes, params=[list(th)], heads=[h], grads=[], dh=[], hv=[])
     S = x_s.shape[0]
-    for _ in range(T):
-        z, tape = net_fwd(x_s, th, h)
+    for t in range(T):
+        z, tape = net_fwd(x_s, th, h, None if not flips else flips.get(t))
         g, dh = net_bwd(z, y_s, tape, 1.0 / S)
         tapes.append(tape)
         th = [p - alpha * gi for p, gi in zip(th, g)]
         h = h - alpha * dh
         if trace is not None:
             trace["grads"].append(g); trace["dh"].append(dh); trace["params"].append(list(th)); trace["heads"].append(h)
-    zq, tq = net_fwd(x_q, th, h)
+    zq, tq = net_fwd(x_q, th, h, None if not flips else flips.get(T))
     loss = F.cross_entropy(zq, y_q)
     bar_th, bar_h = net_bwd(zq, y_q, tq, 1.0 / x_q.shape[0])
     if trace is not None:
@@ -214,3 +226,23 @@ def min_decision_margin(theta, h0, x_s, y_s, x_q, y_q, T, alpha):
     tr = {}
     episode_grads(theta, h0, x_s, y_s, x_q, y_q, T, alpha, first_order=True, trace=tr)
     return min(tp["margin"] for tape in tr["tapes"] + [tr["query"]] for tp in tape["blocks"])
+
+
+def ambiguous_decisions(trace, tol, limit=8):
+    """[(margin, pass, block, kind, flat window index)] of the ReLU / arg-max decisions of an episode (trace of episode_grads)
+    that lie within `tol` of a tie, smallest margins first, at most `limit`."""
+    out = []
+    for p, tape in enumerate(trace["tapes"] + [trace["query"]]):
+        for blk, tp in enumerate(tape["blocks"]):
+            for kind, m in (("relu", tp["relu_margin"]), ("arg", tp["arg_margin"])):
+                idx = (m.reshape(-1) < tol).nonzero(as_tuple=True)[0]
+                out += [(float(m.reshape(-1)[i]), p, blk, kind, int(i)) for i in idx]
+    return sorted(out)[:limit]
+
+
+def flips_of(subset):
+    """{pass: {block: [(kind, index)]}} from a subset of ambiguous_decisions entries."""
+    fl = {}
+    for _, p, blk, kind, idx in subset:
+        fl.setdefault(p, {}).setdefault(blk, []).append((kind, idx))
+    return fl
