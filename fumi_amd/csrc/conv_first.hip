@@ -74,120 +74,57 @@ __device__ __forceinline__ void load_w1(W1Frag& f, const float* fr, const C1Args
     }
 }
 
-// u[2 Wp][64] (LDS) = conv(image band, weights).  Work units = (32-pixel tile, 32-channel half): 12 units at Wp = 86, three per
-// wave (whole tiles would leave two of the four waves idle in the second round).
-__device__ __forceinline__ void conv_band(float* U, const float* pl, const C1Args& a, const Band& bd, const W1Frag& f) {
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int npx = 2 * a.g.Wp;
-    for (int u = wave; u < 2 * bd.ntile; u += 4) {
-        const int t = u >> 1, ct = u & 1;
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        const int pbase = a.g.halo + t * 32 + r;
-#pragma unroll
-        for (int m = 0; m < C1_NK; ++m) acc = mfma32(pl[f.off[m] + pbase], ct ? f.w1[m] : f.w0[m], acc);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int px = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (px < npx) U[px * 64 + ct * 32 + r] = acc[i];
-        }
-    }
-}
-
-// batch statistics of a band straight from the accumulators (nothing goes to LDS): s1 += out, s2 += out * dot over interior
-// pixels, out = conv(image, f) and dot = out (plain) or conv(image, fdot) (tangent pass: out = u', dot = u).  A wave's units all
-// have the same channel half (unit u = wave mod 4), so a lane keeps two scalars.
-template <bool TAN>
-__device__ __forceinline__ void conv_band_stats(const float* pl, const C1Args& a, const Band& bd, const W1Frag& f, const W1Frag& fdot,
-                                                bool two, float& s1, float& s2) {
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int Wp = a.g.Wp, W = a.g.W;
-    for (int u = wave; u < 2 * bd.ntile; u += 4) {
-        const int t = u >> 1, ct = u & 1;
-        f32x16 acc, dac;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { acc[i] = 0.f; dac[i] = 0.f; }
-        const int pbase = a.g.halo + t * 32 + r;
-#pragma unroll
-        for (int m = 0; m < C1_NK; ++m) {
-            const float av = pl[f.off[m] + pbase];
-            acc = mfma32(av, ct ? f.w1[m] : f.w0[m], acc);
-            if (TAN) dac = mfma32(av, ct ? fdot.w1[m] : fdot.w0[m], dac);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int px = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            const bool row1 = px >= Wp;
-            const int x = row1 ? px - Wp : px;
-            const bool in = px < 2 * Wp && x >= 1 && x <= W && (!row1 || two);
-            const float v = in ? acc[i] : 0.f;
-            s1 += v; s2 += v * (TAN ? dac[i] : v);
-        }
-    }
-}
-
-struct Win4 { f32x4 u[4]; };
-__device__ __forceinline__ void lds_window(const float* U, int Wp, int xo, int c4, f32x4 (&w)[4]) {
-    const float* p = U + (2 * xo + 1) * 64 + 4 * c4;
-    w[0] = ld4(p); w[1] = ld4(p + 64); w[2] = ld4(p + Wp * 64); w[3] = ld4(p + Wp * 64 + 64);
-}
-struct ArgMax { int arg[4]; bool pos[4]; };
-__device__ __forceinline__ ArgMax window_argmax(const f32x4 (&u)[4], const f32x4& A, const f32x4& C0, f32x4* vmax = nullptr) {
-    ArgMax m;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float best = A[e] * u[0][e] + C0[e];
-        int arg = 0;
-#pragma unroll
-        for (int k = 1; k < 4; ++k) {
-            const float v = A[e] * u[k][e] + C0[e];
-            if (v > best) { best = v; arg = k; }
-        }
-        m.arg[e] = arg; m.pos[e] = best > 0.f;
-        if (vmax) (*vmax)[e] = best;
-    }
-    return m;
-}
-__device__ __forceinline__ float pick(const f32x4 (&w)[4], int g, int k) { return g == 0 ? w[0][k] : g == 1 ? w[1][k] : g == 2 ? w[2][k] : w[3][k]; }
+// ------------------------------------------------------------------------------------------------------------
+// Everything stays in the accumulators.  The MFMA's 32 output rows are ours to assign: row 4 w + k of a tile is element k
+// (= (dy, dx) in PyTorch's scan order) of 2x2 block w, so after the product a lane (channel = lane & 31, half h = lane >> 5)
+// holds in registers 4j .. 4j+3 the FOUR pixels of block 2j + h -- a whole pooling window per register quad.  Batch
+// statistics, BN + ReLU + max-pool, the backward reductions and du are then per-lane arithmetic on registers, and for the
+// weight gradient the same registers ARE the A operand of the next MFMA (row = channel = lane & 31, k = pixel of lane half
+// h): u and du never exist in memory of any kind.  LDS holds only the 3-channel image slab (4 KiB).
+// Work units = (tile of 8 blocks, 32-channel half); a wave's units all have channel half (wave & 1).
+// ------------------------------------------------------------------------------------------------------------
+struct LaneCoef { float A, C0, MU, R, GR, D1, D2, TA, TB, TC, M1, M2, K0, DD1, E12; };
+__device__ __forceinline__ float cf1(const float* coef, int b, int field, int c) { return coef[((long)b * CF_N + field) * 64 + c]; }
 
 template <int MODE, bool TAN>
 __global__ __launch_bounds__(256) void c1_kernel(C1Args a, int bands_per_img, int chunk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const CvGeom& g = a.g;
     Band bd;
-    bd.ntile = (2 * g.Wp + 31) / 32; bd.NPX = bd.ntile * 32; bd.NP = bd.NPX + 2 * g.halo;
-    const int npx = 2 * g.Wp;                         // pixels of a band (two padded rows)
-    float* U = lds;                                   // [npx][64]
-    float* UD = lds + npx * 64;                       // [npx][64] (TAN)
-    float* pl = lds + (TAN ? 2 : 1) * npx * 64;       // [Cin][NP]
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int Wb = (g.W + 1) / 2;                     // 2x2 blocks per band (the last one is half a block when W is odd)
+    bd.ntile = (Wb + 7) / 8; bd.NPX = 0; bd.NP = 2 * g.Wp + 2 * g.halo + 32;
+    float* pl = lds;                                  // [Cin][NP] image slab of the band
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ct = wave & 1, co = ct * 32 + r;
     const int b = blockIdx.y, t = blockIdx.x;
     const long nbands = (long)a.M * bands_per_img;
     const long b_beg = (long)t * chunk, b_end = min(nbands, b_beg + (long)chunk);
     W1Frag wf, wfd;
     load_w1(wf, a.frag + (long)b * a.frag_stride, a, bd);
     if (TAN) load_w1(wfd, a.fragd + (long)b * a.fragd_stride, a, bd);
-    const int Wo = a.Wo, Ho = a.Ho, Wp = g.Wp;
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    // ---- per-mode persistent state
-    constexpr int RK = TAN ? 3 : 2;
-    f32x4 rs[3][RK];                                  // C1_REDUCE: sums of this thread's (up to 3) window columns
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int k = 0; k < RK; ++k) rs[i][k] = z4;
-    float st1 = 0.f, st2 = 0.f;                       // C1_STATS: this lane's channel (32 (wave & 1) + lane & 31), its pixels
-    f32x16 wa0, wa1;                                  // C1_WGRAD: dW1 quadrants [co 0..31 | 32..63] x [kappa 0..31], this wave's pixels
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { wa0[i] = 0.f; wa1[i] = 0.f; }
-    const int r = lane & 31, h = lane >> 5;
+    const int Wo = a.Wo, Ho = a.Ho, Wp = g.Wp, W = g.W;
+    LaneCoef q;
+    if (MODE != C1_STATS) {
+        q.A = cf1(a.coef, b, CF_A, co); q.C0 = cf1(a.coef, b, CF_C0, co); q.MU = cf1(a.coef, b, CF_MU, co); q.R = cf1(a.coef, b, CF_R, co);
+        q.GR = cf1(a.coef, b, CF_GR, co);
+        if (MODE == C1_WGRAD) { q.D1 = cf1(a.coef, b, CF_D1, co); q.D2 = cf1(a.coef, b, CF_D2, co); }
+        if (TAN) {
+            q.TA = cf1(a.coef, b, CF_TA, co); q.TB = cf1(a.coef, b, CF_TB, co); q.TC = cf1(a.coef, b, CF_TC, co);
+            q.M1 = cf1(a.coef, b, CF_M1, co); q.M2 = cf1(a.coef, b, CF_M2, co);
+            if (MODE == C1_WGRAD) { q.K0 = cf1(a.coef, b, CF_K0, co); q.DD1 = cf1(a.coef, b, CF_DD1, co); q.E12 = cf1(a.coef, b, CF_E12, co); }
+        }
+    }
+    // conv A operand: MFMA row rho = lane & 31 = 4 (block within tile) + element
+    const int a_base = g.halo + 1 + ((r & 3) >> 1) * Wp + 2 * (r >> 2) + (r & 1);
+    // wgrad B operand: column kappa = lane & 31; pixel of register 4j + k of lane half h = block 2j + h, element k
     const int kc = r / 9, ktap = r - kc * 9;
     const bool kok = r < a.Cin * 9;
-    const int koff = kok ? kc * bd.NP + g.halo + (ktap / 3 - 1) * Wp + (ktap % 3 - 1) : 0;
+    const int b_base = (kok ? kc * bd.NP + (ktap / 3 - 1) * Wp + (ktap % 3 - 1) : 0) + g.halo + 1 + 2 * h;
+    float st1 = 0.f, st2 = 0.f, st3 = 0.f;            // per-lane sums (C1_STATS: 2, C1_REDUCE: 2 or 3)
+    f32x16 wacc;                                      // C1_WGRAD: dW1[co half][kappa], this wave's pixels
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wacc[i] = 0.f;
 
     SlabPlan sp;
     slab_plan(sp, a, bd);
@@ -201,206 +138,145 @@ __global__ __launch_bounds__(256) void c1_kernel(C1Args a, int bands_per_img, in
         const int im = (int)(band / bands_per_img), yb = (int)(band - (long)im * bands_per_img), y0 = 2 * yb;
         const long img_g = (long)b * a.M + im;
         const bool two = y0 + 1 < g.H, full_row = yb < Ho;          // second row exists; the band is a pooled row
-        __syncthreads();                                               // previous band's LDS images are no longer read
+        __syncthreads();                                               // the previous band's slab is no longer read
         slab_store(pl, slab, a, bd);
         if (band + 1 < b_end) {                                        // next band's image rows: in flight during this band's work
             const int im2 = (int)((band + 1) / bands_per_img), yb2 = (int)(band + 1 - (long)im2 * bands_per_img);
             slab_load(slab, sp, a, a.img + ((long)b * a.M + im2) * img_sz, 2 * yb2);
         }
         __syncthreads();
-        if (MODE == C1_STATS) {                                        // (tangent: statistics of u' = conv(image, W1') against u)
-            if (TAN) conv_band_stats<true>(pl, a, bd, wfd, wf, two, st1, st2);
-            else conv_band_stats<false>(pl, a, bd, wf, wf, two, st1, st2);
-            continue;
-        }
-        conv_band(U, pl, a, bd, wf);
-        if (TAN) conv_band(UD, pl, a, bd, wfd);
-        __syncthreads();
+        const long orow = (img_g * a.gn.Pp + (long)(yb + 1) * a.gn.Wp + 1) * 64 + co;     // pooled row yb, column 0, channel co
 
-        if (MODE == C1_POOL) {
-            // items: padded output columns 0 .. Wo+1 (x borders = 0), 16 channel quads each; plus the top / bottom border rows
-            if (full_row) {
-                float* xo_row = (TAN ? a.xd : a.x) + (img_g * a.gn.Pp + (long)(yb + 1) * a.gn.Wp) * 64;
-                for (int it = tid; it < a.gn.Wp * 16; it += 256) {
-                    const int xp = it >> 4, c4 = it & 15;
-                    f32x4 out = z4;
-                    if (xp >= 1 && xp <= Wo) {
-                        f32x4 u[4];
-                        lds_window(U, Wp, xp - 1, c4, u);
-                        f32x4 vmax;
-                        const ArgMax m = window_argmax(u, cf(a.coef, b, CF_A, c4), cf(a.coef, b, CF_C0, c4), &vmax);
-                        if (!TAN) {
+        for (int u = wave; u < 2 * bd.ntile; u += 4) {
+            const int tl = u >> 1;
+            f32x16 acc, dac;
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) out[k] = vmax[k] > 0.f ? vmax[k] : 0.f;
-                        } else {
-                            f32x4 ud[4];
-                            lds_window(UD, Wp, xp - 1, c4, ud);
-                            const f32x4 mu = cf(a.coef, b, CF_MU, c4), rr = cf(a.coef, b, CF_R, c4);
-                            const f32x4 TA = cf(a.coef, b, CF_TA, c4), TB = cf(a.coef, b, CF_TB, c4), TC = cf(a.coef, b, CF_TC, c4);
+            for (int i = 0; i < 16; ++i) { acc[i] = 0.f; dac[i] = 0.f; }
+            const int pbase = a_base + 16 * tl;
 #pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                out[k] = m.pos[k] ? TA[k] * pick(ud, m.arg[k], k) + TB[k] * ((pick(u, m.arg[k], k) - mu[k]) * rr[k]) + TC[k] : 0.f;
-                        }
-                    }
-                    *(f32x4*)(xo_row + xp * 64 + 4 * c4) = out;
-                }
-                if (yb == 0 || yb == Ho - 1) {
-                    float* base = (TAN ? a.xd : a.x) + img_g * a.gn.Pp * 64;
-                    for (int it = tid; it < a.gn.Wp * 16; it += 256) {
-                        if (yb == 0) *(f32x4*)(base + it * 4) = z4;
-                        if (yb == Ho - 1) *(f32x4*)(base + ((long)(Ho + 1) * a.gn.Wp) * 64 + it * 4) = z4;
-                    }
-                }
+            for (int m = 0; m < C1_NK; ++m) {
+                const float av = pl[wf.off[m] + pbase];
+                acc = mfma32(av, ct ? wf.w1[m] : wf.w0[m], acc);
+                if (TAN) dac = mfma32(av, ct ? wfd.w1[m] : wfd.w0[m], dac);
             }
-        }
-
-        if (MODE == C1_REDUCE) {
-            if (full_row) {
+            float dreg[16];                                            // C1_WGRAD: du (du') of this lane's 16 pixels
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const int it = tid + 256 * i;
-                    if (it < Wo * 16) {
-                        const int xo = it >> 4, c4 = it & 15;
-                        f32x4 u[4];
-                        lds_window(U, Wp, xo, c4, u);
-                        const ArgMax m = window_argmax(u, cf(a.coef, b, CF_A, c4), cf(a.coef, b, CF_C0, c4));
-                        const f32x4 mu = cf(a.coef, b, CF_MU, c4), rr = cf(a.coef, b, CF_R, c4);
-                        const long dpix = (img_g * a.gn.Pp + (long)(yb + 1) * a.gn.Wp + (xo + 1)) * 64 + 4 * c4;
-                        const f32x4 dxo = ld4(a.dxo + dpix);
-                        f32x4 ud[4], dxod = z4, M1 = z4, M2 = z4;
-                        if (TAN) {
-                            lds_window(UD, Wp, xo, c4, ud);
-                            dxod = ld4(a.dxod + dpix);
-                            M1 = cf(a.coef, b, CF_M1, c4); M2 = cf(a.coef, b, CF_M2, c4);
-                        }
+            for (int j = 0; j < 4; ++j) {
+                const int xo = tl * 8 + 2 * j + h;                     // block column
+                const bool vb = xo < Wb, vx = 2 * xo + 1 < W;
+                const bool val[4] = {vb, vb && vx, vb && two, vb && vx && two};
+                const bool full = full_row && xo < Wo;
+                const float u0 = acc[4 * j], u1 = acc[4 * j + 1], u2 = acc[4 * j + 2], u3 = acc[4 * j + 3];
+                if (MODE == C1_STATS) {
+                    // (tangent pass: acc = u, dac = u' -- sums of u' and u u')
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float xh = (pick(u, m.arg[k], k) - mu[k]) * rr[k];
-                            const float dv = m.pos[k] ? dxo[k] : 0.f;
-                            if (!TAN) { rs[i][0][k] += dv; rs[i][1][k] += dv * xh; }
-                            else {
-                                const float xhd = rr[k] * (pick(ud, m.arg[k], k) - M1[k] - xh * M2[k]);
-                                const float dvd = m.pos[k] ? dxod[k] : 0.f;
-                                rs[i][0][k] += dvd; rs[i][1][k] += dvd * xh; rs[i][2][k] += dv * xhd;
-                            }
-                        }
+                    for (int k = 0; k < 4; ++k) {
+                        const float uu = val[k] ? acc[4 * j + k] : 0.f;
+                        if (!TAN) { st1 += uu; st2 += uu * uu; }
+                        else { const float ud = val[k] ? dac[4 * j + k] : 0.f; st1 += ud; st2 += ud * uu; }
+                    }
+                    continue;
+                }
+                // arg-max of the window (first maximum in scan order), ReLU mask
+                float best = q.A * u0 + q.C0; int arg = 0;
+                { const float v = q.A * u1 + q.C0; if (v > best) { best = v; arg = 1; } }
+                { const float v = q.A * u2 + q.C0; if (v > best) { best = v; arg = 2; } }
+                { const float v = q.A * u3 + q.C0; if (v > best) { best = v; arg = 3; } }
+                const bool pos = best > 0.f;
+                const float ua = arg == 0 ? u0 : arg == 1 ? u1 : arg == 2 ? u2 : u3;
+                const float xha = (ua - q.MU) * q.R;
+                float uda = 0.f;
+                if (TAN) uda = arg == 0 ? dac[4 * j] : arg == 1 ? dac[4 * j + 1] : arg == 2 ? dac[4 * j + 2] : dac[4 * j + 3];
+                if (MODE == C1_POOL) {
+                    if (full) {
+                        if (!TAN) a.x[orow + (long)xo * 64] = pos ? best : 0.f;
+                        else a.xd[orow + (long)xo * 64] = pos ? q.TA * uda + q.TB * xha + q.TC : 0.f;
                     }
                 }
-            }
-        }
-
-        if (MODE == C1_WGRAD) {
-            // du (or du') of every pixel of the band, in place over U (UD); border / padding / missing-row pixels = 0
-            float* D = TAN ? UD : U;
-            const int Wb = (g.W + 1) / 2;
-            for (int it = tid; it < Wb * 16; it += 256) {
-                const int xb = it >> 4, c4 = it & 15;
-                const bool vx = 2 * xb + 1 < g.W, full = full_row && xb < Wo;
-                const int p00 = 2 * xb + 1;
-                const int offs[4] = {p00, p00 + 1, Wp + p00, Wp + p00 + 1};
-                const bool valid[4] = {true, vx, two, vx && two};
-                f32x4 u[4], ud[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) u[k] = ld4(U + offs[k] * 64 + 4 * c4);
-                if (TAN) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) ud[k] = ld4(UD + offs[k] * 64 + 4 * c4);
-                }
-                const f32x4 mu = cf(a.coef, b, CF_MU, c4), rr = cf(a.coef, b, CF_R, c4);
-                const f32x4 D1 = cf(a.coef, b, CF_D1, c4), D2 = cf(a.coef, b, CF_D2, c4), GR = cf(a.coef, b, CF_GR, c4);
-                f32x4 dxo = z4, dxod = z4;
-                ArgMax m;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { m.arg[k] = -1; m.pos[k] = false; }
-                if (full) {
-                    const long dpix = (img_g * a.gn.Pp + (long)(yb + 1) * a.gn.Wp + (xb + 1)) * 64 + 4 * c4;
-                    dxo = ld4(a.dxo + dpix);
-                    if (TAN) dxod = ld4(a.dxod + dpix);
-                    m = window_argmax(u, cf(a.coef, b, CF_A, c4), cf(a.coef, b, CF_C0, c4));
-                }
-                f32x4 M1 = z4, M2 = z4, K0 = z4, DD1 = z4, E12 = z4;
-                if (TAN) {
-                    M1 = cf(a.coef, b, CF_M1, c4); M2 = cf(a.coef, b, CF_M2, c4); K0 = cf(a.coef, b, CF_K0, c4);
-                    DD1 = cf(a.coef, b, CF_DD1, c4); E12 = cf(a.coef, b, CF_E12, c4);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    f32x4 o;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float xh = (u[k][c] - mu[c]) * rr[c];
-                        const bool hit = m.arg[c] == k && m.pos[c];
-                        const float dv = hit ? dxo[c] : 0.f;
-                        const float base = dv - D1[c] - xh * D2[c];
-                        if (!TAN) o[c] = GR[c] * base;
+                if (MODE == C1_REDUCE) {
+                    if (full) {
+                        const float dv = pos ? a.dxo[orow + (long)xo * 64] : 0.f;
+                        if (!TAN) { st1 += dv; st2 += dv * xha; }
                         else {
-                            const float xhd = rr[c] * (ud[k][c] - M1[c] - xh * M2[c]);
-                            const float dvd = hit ? dxod[c] : 0.f;
-                            o[c] = K0[c] * base + GR[c] * (dvd - DD1[c] - xhd * D2[c] - xh * E12[c]);
+                            const float dvd = pos ? a.dxod[orow + (long)xo * 64] : 0.f;
+                            const float xhd = q.R * (uda - q.M1 - xha * q.M2);
+                            st1 += dvd; st2 += dvd * xha; st3 += dv * xhd;
                         }
                     }
-                    if (k == 0 || valid[k]) *(f32x4*)(D + offs[k] * 64 + 4 * c4) = valid[k] ? o : z4;
+                }
+                if (MODE == C1_WGRAD) {
+                    float dxo = 0.f, dxod = 0.f;
+                    if (full) {
+                        dxo = a.dxo[orow + (long)xo * 64];
+                        if (TAN) dxod = a.dxod[orow + (long)xo * 64];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float uu = acc[4 * j + k];
+                        const float xh = (uu - q.MU) * q.R;
+                        const bool hit = full && pos && arg == k;
+                        const float dv = hit ? dxo : 0.f;
+                        const float base = dv - q.D1 - xh * q.D2;
+                        float o;
+                        if (!TAN) o = q.GR * base;
+                        else {
+                            const float xhd = q.R * (dac[4 * j + k] - q.M1 - xh * q.M2);
+                            const float dvd = hit ? dxod : 0.f;
+                            o = q.K0 * base + q.GR * (dvd - q.DD1 - xhd * q.D2 - xh * q.E12);
+                        }
+                        dreg[4 * j + k] = val[k] ? o : 0.f;
+                    }
                 }
             }
-            // zero what is not an interior pixel of an existing row: the four border pixels (x = 0, x = Wp-1), a missing row
-            if (tid < 64) {
-                const int k = tid >> 4, c4 = tid & 15;
-                *(f32x4*)(D + ((k >> 1) * Wp + (k & 1) * (Wp - 1)) * 64 + 4 * c4) = z4;
+            if (MODE == C1_WGRAD) {
+                // dW1[co][kappa] += sum over the unit's 32 pixels: A = du straight from the registers, B = the image slab
+                const float* bp = pl + b_base + 16 * tl;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float bv = kok ? bp[((i & 3) >> 1) * Wp + 4 * (i >> 2) + (i & 1)] : 0.f;
+                    wacc = mfma32(dreg[i], bv, wacc);
+                }
             }
-            if (!two) for (int it = tid; it < Wp * 16; it += 256) *(f32x4*)(D + (Wp + (it >> 4)) * 64 + 4 * (it & 15)) = z4;
-            __syncthreads();
-            // dW1[co][kappa] += sum_px du[px][co] * image[kappa][px + off]: pixel pairs round-robin over the waves
-            const float* ap = D + h * 64 + r;
-            const float* bp = pl + koff + h;
-            for (int m = wave; m < Wp; m += 4) {                  // 2 Wp pixels = Wp pairs
-                const float bv = kok ? bp[2 * m] : 0.f;
-                wa0 = mfma32(ap[m * 128], bv, wa0);
-                wa1 = mfma32(ap[m * 128 + 32], bv, wa1);
-            }
+        }
+
+        if (MODE == C1_POOL && full_row) {
+            // zero border of the pooled map: columns 0 and Wo+1 of this row; the top / bottom rows once per image
+            float* xb = (TAN ? a.xd : a.x) + img_g * a.gn.Pp * 64;
+            if (tid < 128) xb[((long)(yb + 1) * a.gn.Wp + (tid >> 6) * (Wo + 1)) * 64 + (tid & 63)] = 0.f;
+            if (yb == 0 || yb == Ho - 1)
+                for (int it = tid; it < a.gn.Wp * 64; it += 256) {
+                    if (yb == 0) xb[it] = 0.f;
+                    if (yb == Ho - 1) xb[(long)(Ho + 1) * a.gn.Wp * 64 + it] = 0.f;
+                }
         }
     }
 
-    if (MODE == C1_STATS) {
-        st1 += __shfl_xor(st1, 32); st2 += __shfl_xor(st2, 32);
+    if (MODE == C1_STATS || MODE == C1_REDUCE) {
+        constexpr int RK = (MODE == C1_REDUCE && TAN) ? 3 : 2;
+        st1 += __shfl_xor(st1, 32); st2 += __shfl_xor(st2, 32); st3 += __shfl_xor(st3, 32);
         __syncthreads();
-        float* red = lds;                                   // [4 waves][2][32]
-        if (h == 0) { red[(wave * 2 + 0) * 32 + r] = st1; red[(wave * 2 + 1) * 32 + r] = st2; }
+        float* red = lds;                                   // [4 waves][3][32]
+        if (h == 0) { red[(wave * 3 + 0) * 32 + r] = st1; red[(wave * 3 + 1) * 32 + r] = st2; red[(wave * 3 + 2) * 32 + r] = st3; }
         __syncthreads();
-        if (tid < 128) {                                    // k = tid >> 6, channel c = tid & 63: waves (c >> 5) and (c >> 5) + 2
+        if (tid < RK * 64) {                                // k = tid >> 6, channel c = tid & 63: waves (c >> 5) and (c >> 5) + 2
             const int k = tid >> 6, c = tid & 63, w0 = c >> 5;
-            a.part[(((long)b * gridDim.x + t) * 2 + k) * 64 + c] = red[(w0 * 2 + k) * 32 + (c & 31)] + red[((w0 + 2) * 2 + k) * 32 + (c & 31)];
-        }
-    }
-    if (MODE == C1_REDUCE) {
-        __syncthreads();
-        // fold the (up to 3) window columns of a thread, then the 16 threads that share a channel quad
-        float* red = lds;                                   // [RK][16 slots][64]
-        f32x4 s[RK];
-#pragma unroll
-        for (int k = 0; k < RK; ++k) s[k] = rs[0][k] + rs[1][k] + rs[2][k];
-        const int c4 = tid & 15, slot = tid >> 4;
-#pragma unroll
-        for (int k = 0; k < RK; ++k) *(f32x4*)(red + (k * 16 + slot) * 64 + 4 * c4) = s[k];
-        __syncthreads();
-        if (tid < RK * 64) {
-            const int k = tid >> 6, c = tid & 63;
-            float acc = 0.f;
-            for (int sl = 0; sl < 16; ++sl) acc += red[(k * 16 + sl) * 64 + c];
-            a.part[(((long)b * gridDim.x + t) * RK + k) * 64 + c] = acc;
+            a.part[(((long)b * gridDim.x + t) * RK + k) * 64 + c] = red[(w0 * 3 + k) * 32 + (c & 31)] + red[((w0 + 2) * 3 + k) * 32 + (c & 31)];
         }
     }
     if (MODE == C1_WGRAD) {
         __syncthreads();
-        float* red = lds;                                   // [4 waves][64 co][32]
+        float* red = lds;                                   // [4 waves][32 co of the wave's half][32 kappa]
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-            red[(wave * 64 + row) * 32 + r] = wa0[i];
-            red[(wave * 64 + 32 + row) * 32 + r] = wa1[i];
+            red[(wave * 32 + row) * 32 + r] = wacc[i];
         }
         __syncthreads();
         float* o = a.wpart + ((long)b * gridDim.x + t) * 2048;
-        for (int i = tid; i < 2048; i += 256) o[i] = (red[i] + red[2048 + i]) + (red[4096 + i] + red[6144 + i]);
+        for (int i = tid; i < 2048; i += 256) {             // output row co = i >> 5: half (co >> 5) = waves (co >> 5) and (co >> 5) + 2
+            const int cc = i >> 5, kk = i & 31, w0 = cc >> 5;
+            o[i] = red[(w0 * 32 + (cc & 31)) * 32 + kk] + red[((w0 + 2) * 32 + (cc & 31)) * 32 + kk];
+        }
     }
 }
 
@@ -420,9 +296,9 @@ int launch_c1(hipStream_t st, const C1Args& a, int mode, int tangent) {
     if (a.Cin < 1 || a.Cin > 3) return FUMI_EINVAL;
     int chunk;
     const int nt = c1_chunks(a.B, a.M, a.g, &chunk);
-    const int ntile = (2 * a.g.Wp + 31) / 32, NPX = ntile * 32, NP = NPX + 2 * a.g.halo;
-    size_t lds = (size_t)(tangent ? 2 : 1) * 2 * a.g.Wp * 256 + (size_t)a.Cin * NP * 4;
-    if (lds < 32768) lds = 32768;                                           // (the end-of-kernel reductions use up to 32 KiB)
+    const int NP = 2 * a.g.Wp + 2 * a.g.halo + 32;
+    size_t lds = (size_t)a.Cin * NP * 4;
+    if (lds < 16384) lds = 16384;                                           // (the end-of-kernel reductions use up to 16 KiB)
     if (lds > 160 * 1024 || a.Cin * NP > 256 * 8) return FUMI_ENOTSUP;
     const int bpi = (a.g.H + 1) / 2;
     const dim3 grid(nt, a.B), blk(256);
