@@ -153,6 +153,16 @@ __global__ __launch_bounds__(256) void c1_kernel(C1Args a, int bands_per_img, in
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc[i] = 0.f; dac[i] = 0.f; }
             const int pbase = a_base + 16 * tl;
+            // gradients w.r.t. this lane's four pooled outputs: requested before the matrix work (unconditional, clamped column)
+            float gx[4] = {0.f, 0.f, 0.f, 0.f}, gxd[4] = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == C1_REDUCE || MODE == C1_WGRAD) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const long o = orow + (long)min(tl * 8 + 2 * j + h, Wo - 1) * 64;
+                    gx[j] = a.dxo[o];
+                    if (TAN) gxd[j] = a.dxod[o];
+                }
+            }
 #pragma unroll
             for (int m = 0; m < C1_NK; ++m) {
                 const float av = pl[wf.off[m] + pbase];
@@ -195,21 +205,17 @@ __global__ __launch_bounds__(256) void c1_kernel(C1Args a, int bands_per_img, in
                 }
                 if (MODE == C1_REDUCE) {
                     if (full) {
-                        const float dv = pos ? a.dxo[orow + (long)xo * 64] : 0.f;
+                        const float dv = pos ? gx[j] : 0.f;
                         if (!TAN) { st1 += dv; st2 += dv * xha; }
                         else {
-                            const float dvd = pos ? a.dxod[orow + (long)xo * 64] : 0.f;
+                            const float dvd = pos ? gxd[j] : 0.f;
                             const float xhd = q.R * (uda - q.M1 - xha * q.M2);
                             st1 += dvd; st2 += dvd * xha; st3 += dv * xhd;
                         }
                     }
                 }
                 if (MODE == C1_WGRAD) {
-                    float dxo = 0.f, dxod = 0.f;
-                    if (full) {
-                        dxo = a.dxo[orow + (long)xo * 64];
-                        if (TAN) dxod = a.dxod[orow + (long)xo * 64];
-                    }
+                    const float dxo = full ? gx[j] : 0.f, dxod = full ? gxd[j] : 0.f;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float uu = acc[4 * j + k];
