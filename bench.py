@@ -252,8 +252,20 @@ def as_worded(dev, steps, warmup, cpu_budget_s, with_cpu):
         tot, n = prof["conv_gemm"]
         per_step = tot / steps * 1e-3
         ach = gemm_flops / per_step / 1e12
+        # HBM bytes per meta-step of these kernels, from separate rocprofv3 --pmc passes (profiles/<round>/conv4_pmc_traffic.json)
+        traffic, pix = None, [S * c["T"] * B, Qn * B]                # images per step: support (per inner step), query
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "conv4_pmc_traffic.json")))[-1:]:
+            ks = json.load(open(f))["per_step"]
+            traffic = int(sum(v["hbm_bytes"] for k, v in ks.items() if k.startswith("conv64_kernel") or k.startswith("wgrad64_kernel")))
+        # algorithmic bytes: every map (padded channels-last: (H+2)^2 x 64 floats per image) read or written once per product
+        maps = [256.0 * (hh + 2) ** 2 for hh in (42, 21, 10)]
+        alg = sum(m * (pix[0] * (2 + 2 + 3 + 3 + 2 + 4) + pix[1] * (2 + 2 + 2)) for m in maps)
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                           "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of tools/bench_conv4.py, "
+                                             "bytes per meta-step summed over these kernels' launches (not re-measured in this run)",
+                           "algorithmic_bytes": int(alg),
                            "kernel": "conv64_kernel + wgrad64_kernel: the 64 -> 64 channel 3x3 products (forward, input-gradient, "
                                      "weight-gradient and their tangents) as implicit GEMMs on v_mfma_f32_32x32x2_f32",
                            "flops_per_step": gemm_flops, "ms_per_step": round(per_step * 1e3, 3), "launches_per_step": n // steps,
