@@ -221,3 +221,42 @@ def get_inat_anim(args):
         out.append(GpuEpisodeSampler(images, sp.class_of_image, sp.class_text, args.num_ways, args.num_shots, q,
                                      args.batch_size, seed=args.seed + len(split), row_ids=sp.image_ids))
     return out[0], out[1], out[2], ({} if args.text_encoder == "BERT" else train_dictionary)
+
+
+class SupervisedSplit:
+    """``--dataset supervised-inat-anim`` (data.py:54-70,231-291): items (image embedding, mean-pooled BERT embedding of the
+    class description, category id), shuffled mini-batches like DataLoader(shuffle=True)."""
+
+    def __init__(self, images, class_of_image, class_text, category_ids, batch_size, seed):
+        self.images, self.coi, self.text = images, np.asarray(class_of_image), class_text
+        self.cat = np.asarray(category_ids)
+        self.bs, self.rs = batch_size, np.random.RandomState(seed)
+
+    def __len__(self):
+        return len(self.coi)
+
+    def __iter__(self):
+        perm = self.rs.permutation(len(self.coi))
+        for i in range(0, len(perm), self.bs):
+            idx = perm[i:i + self.bs]
+            cls = self.coi[idx]
+            yield [self.images[torch.as_tensor(idx)], self.text[torch.as_tensor(cls)], torch.from_numpy(self.cat[cls])]
+
+
+def get_supervised_inat_anim(args):
+    """(train, val, test, {}) loaders of the CLIP baseline (data.py:54-70): BERT text only, like the reference."""
+    if args.text_encoder != "BERT":
+        raise NotImplementedError()                                                     # data.py:62-63
+    root = args.data_dir + "/iNat-Anim"
+    json_path = root + "/inat_anim.json"
+    if not os.path.exists(json_path):
+        raise FileNotFoundError(f"{json_path} not found: --dataset supervised-inat-anim needs the iNat-Anim files under {root}")
+    ann = load_annotations(json_path)
+    emb = open_embeddings(root, args.image_embedding_model)
+    out = []
+    for split in ("train", "val", "test"):
+        sp = InatAnimSplit(root, json_path, split, "BERT", args.text_type, args.remove_stop_words, ann, args.device)
+        images = torch.from_numpy(read_rows(emb, sp.image_ids))
+        out.append(SupervisedSplit(images, sp.class_of_image, sp.class_text.cpu(), np.arange(sp.class_text.shape[0]), args.batch_size,
+                                   args.seed + len(split)))
+    return out[0], out[1], out[2], {}

@@ -96,3 +96,29 @@ def get_synthetic_resident(args, images_per_class=48):
         return GpuEpisodeSampler(torch.from_numpy(images.astype(np.float32)).to(args.device), coi, torch.from_numpy(base.text),
                                  args.num_ways, args.num_shots, q, args.batch_size, seed=args.seed + len(split))
     return mk("train", args.num_shots_test), mk("val", q_eval), mk("test", q_eval), dictionary
+
+
+class SyntheticSupervised:
+    """Supervised (image embedding, class text embedding, class id) mini-batches with the item contract of the reference's
+    SupervisedInatAnim + DataLoader (fumi/dataset/data.py:54-70,231-291): batch = [images [bs, D], text [bs, Dt], ids [bs]],
+    shuffled every epoch.  Same learnable task family as SyntheticEpisodes."""
+
+    def __init__(self, n_classes, per_class, D, Dt, batch_size, seed, split):
+        base = SyntheticEpisodes(n_classes, D, Dt, 1, 1, 1, 1, seed, split)
+        rs = np.random.RandomState(seed * 17 + len(split))
+        self.ids = np.repeat(np.arange(n_classes), per_class)
+        self.images = torch.from_numpy((base.mu[self.ids] + 2.0 * rs.standard_normal((len(self.ids), D))).astype(np.float32))
+        self.text = torch.from_numpy(base.text)
+        self.bs, self.rs = batch_size, rs
+
+    def __iter__(self):
+        perm = self.rs.permutation(len(self.ids))
+        for i in range(0, len(perm), self.bs):
+            idx = perm[i:i + self.bs]
+            yield [self.images[idx], self.text[self.ids[idx]], torch.from_numpy(self.ids[idx])]
+
+
+def get_synthetic_supervised(args, per_class=6):
+    mk = lambda split: SyntheticSupervised(args.synthetic_classes, per_class, args.im_emb_dim, args.text_emb_dim, args.batch_size,
+                                           args.seed, split)
+    return mk("train"), mk("val"), mk("test"), {}

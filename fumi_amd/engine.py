@@ -55,6 +55,12 @@ class HipEngine:
     def conv4_features(self, x, theta):
         return hip.conv4_features(self._ws(x), x, theta)
 
+    def clip_step(self, text, image, w, need_loss=True, need_grad=True, g_w=None):
+        return hip.clip_step(self._ws(text), text, image, w, need_loss=need_loss, need_grad=need_grad, g_w=g_w)
+
+    def lstm_bidir(self, tokens, table, lstm_w, pad_id, use_cell):
+        return hip.lstm_bidir(self._ws(tokens), tokens, table, lstm_w, pad_id, use_cell)
+
     def am3_metrics(self, n_way, stats):
         return hip.am3_metrics(self._ws(stats), n_way, stats)
 

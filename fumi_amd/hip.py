@@ -27,7 +27,7 @@ SYMBOLS = [
     "fumi_hip_publish_scalars_deferred", "fumi_hip_publish_flush", "fumi_hip_am3_metrics",
     "fumi_hip_conv4_feature_dim", "fumi_hip_fumi_conv4_step", "fumi_hip_maml_conv4_step", "fumi_hip_conv4_probe", "fumi_hip_conv4_features", "fumi_hip_conv4_set_option",
     "fumi_hip_conv3x3_fwd", "fumi_hip_conv3x3_bwd_data", "fumi_hip_conv3x3_bwd_weight",
-    "fumi_hip_sgd_axpy", "fumi_hip_ce_fwd_bwd", "fumi_hip_proto_reduce",
+    "fumi_hip_sgd_axpy", "fumi_hip_ce_fwd_bwd", "fumi_hip_proto_reduce", "fumi_hip_clip_step", "fumi_hip_lstm_bidir",
 ]
 
 ST_LABEL_RANGE, ST_CLASS_MISSING = 1, 2
@@ -144,6 +144,8 @@ def lib():
             fn.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
         L.fumi_hip_sgd_axpy.argtypes = [c_void_p, c_void_p, ctypes.c_long, c_void_p, c_float, c_void_p, c_void_p]
         L.fumi_hip_ce_fwd_bwd.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.fumi_hip_clip_step.argtypes = [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, PP, c_int, c_void_p, c_void_p, PP]
+        L.fumi_hip_lstm_bidir.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_int64, c_void_p, c_int64, PP, c_int, c_void_p]
         L.fumi_hip_proto_reduce.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p] * 3
         _lib = L
     return _lib
@@ -800,4 +802,43 @@ def proto_reduce(ws, x, y, n_way):
     out = torch.empty(B, n_way, P, device=dev, dtype=torch.float32)
     _check(lib().fumi_hip_proto_reduce(ws.handle, _stream(dev), B, S, int(n_way), P, _f32(x, "x"), _i64(y, "y"), _f32(out, "out")),
            "fumi_hip_proto_reduce")
+    return out
+
+
+CLIP_KEYS = ["text_fc.weight", "text_fc.bias", "text_fc2.weight", "text_fc2.bias",
+             "image_fc.weight", "image_fc.bias", "image_fc2.weight", "image_fc2.bias"]
+
+
+def clip_step(ws, text, image, w, *, need_loss=True, need_grad=True, g_w=None):
+    """CLIP baseline (fumi/models/clip.py): sim [nt, ni]; with need_loss the symmetric cross-entropy [1] and, with need_grad, its
+    gradients w.r.t. the eight tensors of CLIP_KEYS order."""
+    dev = _dev(text)
+    nt, Dt = text.shape
+    ni, D = image.shape
+    P = int(w[0].shape[0])
+    for t, shp, k in zip(w, [(P, Dt), (P,), (P, P), (P,), (P, D), (P,), (P, P), (P,)], CLIP_KEYS):
+        _shape(t, shp, k)
+    sim = torch.empty(nt, ni, device=dev, dtype=torch.float32)
+    loss = torch.empty(1, device=dev, dtype=torch.float32) if need_loss else None
+    if need_grad and g_w is None:
+        g_w = [torch.empty_like(t) for t in w]
+    _check(lib().fumi_hip_clip_step(ws.handle, _stream(dev), nt, ni, Dt, D, P, _f32(text, "text"), _f32(image, "image"), _parr(w, "w"),
+                                    int(bool(need_grad)), _f32(sim, "sim"), _f32(loss, "loss") if need_loss else None,
+                                    _parr(g_w, "g_w") if need_grad else None), "fumi_hip_clip_step")
+    return dict(sim=sim, loss=loss, grads=g_w if need_grad else None)
+
+
+def lstm_bidir(ws, tokens, table, lstm_w, pad_id, use_cell):
+    """[..., 2H] final states of a bidirectional LSTM over the non-PAD prefix of token rows [..., L] (common.py:44-161)."""
+    dev = _dev(tokens)
+    L = tokens.shape[-1]
+    R = tokens.numel() // L
+    V, E = table.shape
+    H = int(lstm_w[1].shape[1])
+    for d in range(2):
+        _shape(lstm_w[4 * d], (4 * H, E), "weight_ih"); _shape(lstm_w[4 * d + 1], (4 * H, H), "weight_hh")
+        _shape(lstm_w[4 * d + 2], (4 * H,), "bias_ih"); _shape(lstm_w[4 * d + 3], (4 * H,), "bias_hh")
+    out = torch.empty(*tokens.shape[:-1], 2 * H, device=dev, dtype=torch.float32)
+    _check(lib().fumi_hip_lstm_bidir(ws.handle, _stream(dev), R, L, E, H, _i64(tokens, "tokens"), int(pad_id), _f32(table, "table"), V,
+                                     _parr(lstm_w, "lstm_w"), int(bool(use_cell)), _f32(out, "out")), "fumi_hip_lstm_bidir")
     return out

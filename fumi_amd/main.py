@@ -15,12 +15,18 @@ import numpy as np
 import torch
 
 from . import dist as fdist
-from .models import am3, fumi, maml
+from .models import am3, clip, fumi, maml
 from .utils import utils
 from .utils.wandb_compat import wandb
 
 
 def get_dataset(args):
+    if args.model == "clip" and args.dataset == "synthetic":        # the CLIP baseline consumes supervised mini-batches
+        from .dataset.synthetic import get_synthetic_supervised
+        return get_synthetic_supervised(args)
+    if args.dataset == "supervised-inat-anim":                       # data.py:54-70
+        from .dataset.inat_anim import get_supervised_inat_anim
+        return get_supervised_inat_anim(args)
     if args.dataset == "synthetic":
         from .dataset.synthetic import get_synthetic
         return get_synthetic(args)
@@ -60,8 +66,8 @@ def _restore(args, model, optimizer):
 
 
 def main(args):
-    family = args.model if args.model in ("maml", "fumi") else "am3"      # unknown names are AM3, like utils.init_model
-    mod = {"maml": maml, "fumi": fumi, "am3": am3}[family]
+    family = args.model if args.model in ("maml", "fumi", "clip") else "am3"      # unknown names are AM3, like utils.init_model
+    mod = {"maml": maml, "fumi": fumi, "am3": am3, "clip": clip}[family]
     results_path = f"{args.log_dir}/results"
     os.makedirs(results_path, exist_ok=True)
     os.environ["FUMI_LOG_DIR"] = args.log_dir        # where the local W&B stand-in keeps run directories
@@ -81,6 +87,15 @@ def main(args):
     optimizer = utils.init_optim(args, model)
     if args.checkpoint:
         model = _restore(args, model, optimizer)
+    if family == "clip":                                               # supervised baseline (main.py:86-91,109-111)
+        opt = optimizer[0] if type(optimizer) == tuple else optimizer
+        if not args.evaluate:
+            model = clip.training_run(args, model, opt, train_loader, val_loader, n_epochs=args.epochs)
+        test_acc = clip.evaluate(args, model, test_loader)
+        print(f"\n TEST: \ntest acc: {test_acc}")
+        wandb.log({"test/acc": test_acc})
+        wandb.finish()
+        return dict(test_acc=float(test_acc))
     if not args.evaluate:
         model = mod.training_run(args, model, optimizer, train_loader, val_loader, max_test_batches // 2)
 

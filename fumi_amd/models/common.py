@@ -2,8 +2,10 @@
 
 ``WordEmbedding`` (common.py:8-41) keeps its constructor, attributes (``embed``, ``embedding_dim``, ``padding_token``)
 and ``state_dict`` key (``embed.weight``); its forward is the HIP embedding-bag kernel (csrc/glove.hip).
-The bi-LSTM encoders ``RNN`` / ``RnnHid`` (common.py:44-161) are outside the hot path named by BASELINE.json
- and raise.
+The bi-LSTM encoders ``RNN`` / ``RnnHid`` (common.py:44-161) keep their constructors, attributes and ``state_dict`` keys
+(``embed.weight``, ``rnn.weight_ih_l0`` ...); their forward is the engine's bidirectional-LSTM op (csrc/textenc.hip), forward
+only: like every text encoder they are frozen unless ``--fine_tune`` (fumi.py:65-67), and fine-tuning an LSTM is not
+supported by the engine.
 """
 import numpy as np
 import torch
@@ -74,10 +76,47 @@ class WordEmbedding(nn.Module):
         return _engine.get_engine().glove_bag(x.contiguous(), self.embed.weight, self.padding_token, self.pooling_strat)
 
 
-class RNN(nn.Module):
-    def __init__(self, *a, **k):
+class _BiLstmEncoder(nn.Module):
+    """Shared body of RNN / RnnHid (common.py:44-75,110-138): word embedding + single-layer bidirectional LSTM."""
+    use_cell = False
+
+    def __init__(self, embedding_type, pooling_strat, dictionary, rnn_hid_dim, word_model=None):
         super().__init__()
-        raise NotImplementedError("bi-LSTM text encoders (fumi/models/common.py:44-161) are outside the MI355X hot path")
+        self.pooling_strat = pooling_strat
+        self.dictionary = dictionary
+        self.embedding_type = embedding_type
+        self.rnn_hid_dim = rnn_hid_dim // 2      # assuming bidirectional
+        self.padding_token = self.dictionary["PAD"]
+        if embedding_type == "rand":
+            self.embed = nn.Embedding(len(self.dictionary), rnn_hid_dim)
+            self.text_emb_size = rnn_hid_dim
+        else:
+            weights = get_embedding_weights(dictionary, embedding_type, word_model)
+            self.text_emb_size = weights.shape[-1]
+            self.embed = nn.Embedding.from_pretrained(torch.as_tensor(np.asarray(weights), dtype=torch.float32))
+        self.rnn = nn.LSTM(input_size=self.text_emb_size, hidden_size=self.rnn_hid_dim, num_layers=1, bidirectional=True,
+                           batch_first=True)
+
+    def lstm_weights(self):
+        names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+        return [getattr(self.rnn, n + suffix) for suffix in ("", "_reverse") for n in names]
+
+    def forward(self, x):
+        """x: int64 tokens (b, N*K, L) -> (b, N*K, rnn_hid_dim): the forward direction's state at the last real token and the
+        backward direction's at token 0 (common.py:98-107 / :154-161), i.e. each direction's final state."""
+        if any(p.requires_grad for p in self.parameters()) and torch.is_grad_enabled() and self.training:
+            raise NotImplementedError("fine-tuning the bi-LSTM text encoder (--fine_tune with RNN / RNNhid) is not supported by "
+                                      "the engine: its LSTM op is forward only")
+        return _engine.get_engine().lstm_bidir(x.contiguous(), self.embed.weight.detach(),
+                                               [w.detach().contiguous() for w in self.lstm_weights()], self.padding_token,
+                                               self.use_cell)
 
 
-RnnHid = RNN
+class RNN(_BiLstmEncoder):
+    """common.py:44-107: the LSTM's OUTPUT states (= final hidden state h_n of each direction)."""
+    use_cell = False
+
+
+class RnnHid(_BiLstmEncoder):
+    """common.py:110-161: the LSTM's final CELL states c_n of each direction."""
+    use_cell = True

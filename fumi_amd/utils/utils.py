@@ -90,7 +90,7 @@ def parser():
 
 def init_model(args, dictionary, watch=True):
     """Model factory (utils.py:232-274).  Unknown names fall through to AM3 exactly like the reference."""
-    from ..models import am3, fumi, maml
+    from ..models import am3, clip, fumi, maml
     if args.model == "maml":
         conv = dict(im_encoder="conv4", image_size=args.image_size, image_channels=args.image_channels) if args.im_encoder == "conv4" else {}
         model = maml.PureImageNetwork(im_embed_dim=args.im_emb_dim, n_way=args.num_ways, hidden_dims=args.im_hid_dim, **conv)
@@ -103,7 +103,7 @@ def init_model(args, dictionary, watch=True):
                           **(dict(im_encoder="conv4", image_size=args.image_size, image_channels=args.image_channels)
                              if args.im_encoder == "conv4" else {}))
     elif args.model == "clip":
-        raise NotImplementedError("the supervised CLIP baseline (fumi/models/clip.py) is outside the episodic hot path")
+        model = clip.CLIP(text_input_dim=args.text_emb_dim, image_input_dim=args.im_emb_dim, latent_dim=args.clip_latent_dim)
     else:
         model = am3.AM3(im_encoder=args.im_encoder, im_emb_dim=args.im_emb_dim, text_encoder=args.text_encoder,
                         text_emb_dim=args.text_emb_dim, text_hid_dim=args.text_hid_dim,

@@ -229,6 +229,22 @@ int fumi_hip_ce_fwd_bwd(fumi_ws_t* ws, fumi_stream_t stream, int M, int N, const
 int fumi_hip_proto_reduce(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int N, int P, const float* x, const int64_t* y, float* out);
 
 
+/* ---- beside the episodic path -------------------------------------------------------------------------------
+ * CLIP baseline, fumi/models/clip.py.  w: 8 pointers text_fc W [P,Dt], b [P], text_fc2 W [P,P], b, image_fc W [P,D], b,
+ * image_fc2 W [P,P], b.  sim [nt,ni] = cosine similarity of every (text row, image row) pair (clip.py:27-41).  loss != NULL
+ * (needs nt == ni): the symmetric cross-entropy against the diagonal, (CE(sim) + CE(sim^T)) / 2 (clip.py:101-105); need_grad:
+ * its gradient w.r.t. the 8 tensors (written, not accumulated). */
+int fumi_hip_clip_step(fumi_ws_t* ws, fumi_stream_t stream, int nt, int ni, int Dt, int D, int P,
+        const float* text, const float* image, const float* const* w, int need_grad,
+        float* sim, float* loss, float* const* g_w);
+/* bi-LSTM text encoders RNN / RnnHid (fumi/models/common.py:44-161), forward only: tokens [R,L] int64 -> embedding rows of
+ * table [V,E] -> single-layer bidirectional LSTM over the non-PAD prefix of every row (pack_padded_sequence semantics) ->
+ * out [R,2H] = each direction's final hidden state (use_cell = 0: RNN) or cell state (use_cell = 1: RnnHid).
+ * w: 8 pointers in nn.LSTM's layout (gate order i,f,g,o): weight_ih_l0 [4H,E], weight_hh_l0 [4H,H], bias_ih_l0, bias_hh_l0, then
+ * the four *_reverse tensors. */
+int fumi_hip_lstm_bidir(fumi_ws_t* ws, fumi_stream_t stream, int R, int L, int E, int H,
+        const int64_t* tokens, int64_t pad_id, const float* table, int64_t V, const float* const* w, int use_cell, float* out);
+
 /* FuMI meta-step on ZERO-COPY episodes: identical to fumi_hip_fumi_step except that the image rows are not handed over as
  * x_s [B,S,D] / x_q [B,Qn,D] but addressed in an HBM-resident table [n_rows, D] through idx_s [B,S] / idx_q [B,Qn] (what
  * fumi_hip_sample_episodes produces): the two X-panel kernels read the rows where they lie, the 2*B*(S+Qn)*D*4 bytes of a

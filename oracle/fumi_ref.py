@@ -8,6 +8,8 @@ What it restates (reference = /root/reference, s-a-malik/fumi):
   * MAML meta-step          fumi/models/maml.py:134-193 (PureImageNetwork :15-33)
   * AM3 step                fumi/models/am3.py:90-126,128-212 + fumi/utils/utils.py:302-402
   * WordEmbedding pooling   fumi/models/common.py:23-41
+  * bi-LSTM text encoders   fumi/models/common.py:44-161 (RNN: output states, RnnHid: cell states)
+  * CLIP baseline           fumi/models/clip.py:11-41 (forward), :96-108 (symmetric cross-entropy step)
   * torchmeta 1.7.0 functional-linear / gradient_update_parameters contract (requirements.txt:10; source
     absent from /root/reference -> restated from its published behaviour)
 
@@ -227,6 +229,62 @@ def am3_step(w, text_s, x_s, y_s, x_q, y_q, n_way, lamda_fixed=None, need_grad=T
         names = ["Wi", "bi", "G0", "g0", "G1", "g1", "H0", "h0", "H1", "h1"]
         g = torch.autograd.grad(loss, [w[k] for k in names], allow_unused=True)
         out["grads"] = OrderedDict((k, torch.zeros_like(w[k]) if gi is None else gi) for k, gi in zip(names, g))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# bi-LSTM text encoders (common.py:44-161): frozen unless --fine_tune
+# ----------------------------------------------------------------------------------------------
+def lstm_encode(tokens, table, lstm_w, pad_id, use_cell):
+    """RNN.forward (use_cell=False, common.py:76-107) / RnnHid.forward (use_cell=True, :139-161) on tokens [B, S, L]:
+    embedding gather, packed bidirectional single-layer LSTM, then the forward direction's state at the last real token and
+    the backward direction's state at token 0 -- i.e. each direction's FINAL hidden state h_n (RNN) or cell state c_n (RnnHid).
+    lstm_w = [W_ih, W_hh, b_ih, b_hh, W_ih_reverse, W_hh_reverse, b_ih_reverse, b_hh_reverse] (nn.LSTM's own layout: gate order
+    i, f, g, o).  Rows with no real token get zeros (pack_padded_sequence would raise; the loader never produces them)."""
+    B, S, L = tokens.shape
+    flat = tokens.reshape(-1, L)
+    lens = (flat != pad_id).sum(-1)
+    x = table[flat]                                                  # [R, L, E]
+    H = lstm_w[1].shape[1]
+    outs = []
+    for d in range(2):
+        W_ih, W_hh, b_ih, b_hh = lstm_w[4 * d:4 * d + 4]
+        h = x.new_zeros(flat.shape[0], H)
+        c = x.new_zeros(flat.shape[0], H)
+        steps = range(L) if d == 0 else range(L - 1, -1, -1)
+        for t in steps:
+            g = F.linear(x[:, t], W_ih, b_ih) + F.linear(h, W_hh, b_hh)
+            i, f, gg, o = g.chunk(4, -1)
+            c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+            h2 = torch.sigmoid(o) * torch.tanh(c2)
+            live = (t < lens).unsqueeze(-1)
+            c, h = torch.where(live, c2, c), torch.where(live, h2, h)
+        outs.append(c if use_cell else h)
+    return torch.cat(outs, -1).view(B, S, 2 * H)
+
+
+# ----------------------------------------------------------------------------------------------
+# CLIP baseline (clip.py)
+# ----------------------------------------------------------------------------------------------
+CLIP_KEYS = ["text_fc.weight", "text_fc.bias", "text_fc2.weight", "text_fc2.bias",
+             "image_fc.weight", "image_fc.bias", "image_fc2.weight", "image_fc2.bias"]
+
+
+def clip_forward(w, text, image):
+    """clip.py:27-41 -- two Linear.ReLU.Linear towers, cosine similarity of every (text row, image row) pair: [nt, ni]."""
+    tl = F.linear(torch.relu(F.linear(text, w[0], w[1])), w[2], w[3])
+    il = F.linear(torch.relu(F.linear(image, w[4], w[5])), w[6], w[7])
+    return (tl @ il.t()) / tl.norm(dim=1)[:, None] / il.norm(dim=1)[None, :]
+
+
+def clip_step(w, text, image, need_grad=True):
+    """clip.py:96-108 -- symmetric cross-entropy of the similarity matrix against the diagonal (no temperature)."""
+    sim = clip_forward(w, text, image)
+    labels = torch.arange(sim.shape[0])
+    loss = (F.cross_entropy(sim, labels) + F.cross_entropy(sim.t(), labels)) / 2.
+    out = dict(sim=sim.detach(), loss=loss.detach())
+    if need_grad:
+        out["grads"] = list(torch.autograd.grad(loss, list(w)))
     return out
 
 

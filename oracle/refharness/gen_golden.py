@@ -176,6 +176,49 @@ def gen_wordemb(ref_common):
     print("wordemb: table", out["table"].shape)
 
 
+def gen_clip():
+    """CLIP baseline (clip.py): similarity matrix, symmetric-CE loss, all eight gradients, and the zero-shot call shape."""
+    ref_clip = stubs.import_reference_clip()
+    torch.manual_seed(0)
+    n, Dt, D, P = 6, 20, 48, 16
+    m = ref_clip.CLIP(text_input_dim=Dt, image_input_dim=D, latent_dim=P)
+    rs = np.random.RandomState(17)
+    text, image = torch.from_numpy(rs.standard_normal((n, Dt)).astype(np.float32)), torch.from_numpy(rs.standard_normal((n, D)).astype(np.float32))
+    out = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    sim = m(text, image)
+    labels = torch.arange(n)
+    loss = (torch.nn.CrossEntropyLoss()(sim, labels) + torch.nn.CrossEntropyLoss()(sim.T, labels)) / 2.
+    loss.backward()
+    out.update(text=text.numpy(), image=image.numpy(), sim=sim.detach().numpy(), loss=np.float32(loss.item()))
+    for k, p in m.named_parameters():
+        out["grad." + k] = p.grad.numpy().copy()
+    out["zero_shot"] = m(text[:1], image[:5]).detach().numpy()            # evaluate(): one text row against n_ways images
+    np.savez(os.path.join(OUT, "clip.npz"), **out)
+    print("clip: loss", float(loss))
+
+
+def gen_rnn(ref_common):
+    """bi-LSTM text encoders (common.py:44-161) with embedding_type='rand' (no gensim): RNN (output states) and RnnHid (cell
+    states) on ragged token rows, same weights."""
+    torch.manual_seed(3)
+    V, L, hid = 30, 9, 16
+    dictionary = {"PAD": 0, **{f"w{i}": i for i in range(1, V)}}
+    rs = np.random.RandomState(5)
+    tokens = np.zeros((2, 5, L), dtype=np.int64)
+    for b in range(2):
+        for s_ in range(5):
+            ln = 1 if s_ == 0 else (L if s_ == 1 else rs.randint(1, L + 1))
+            tokens[b, s_, :ln] = rs.randint(1, V, size=ln)
+    r = ref_common.RNN("rand", "mean", dictionary, hid)
+    rh = ref_common.RnnHid("rand", "mean", dictionary, hid)
+    rh.load_state_dict(r.state_dict())
+    out = {k: v.detach().numpy().copy() for k, v in r.state_dict().items()}
+    with torch.no_grad():
+        out.update(tokens=tokens, rnn=r(torch.from_numpy(tokens)).numpy(), rnnhid=rh(torch.from_numpy(tokens)).numpy())
+    np.savez(os.path.join(OUT, "rnn.npz"), **out)
+    print("rnn:", out["rnn"].shape)
+
+
 def gen_surface(ref_fumi, ref_maml, ref_am3, ref_utils):
     """The drop-in surface: every CLI flag's default/type (utils.py:19-229) and the state_dict keys/shapes of the three
     models at the CLI defaults -> tests/golden/surface.json."""
@@ -218,6 +261,10 @@ def main():
             gen_am3(ref_am3, name, c)
     if not only or "wordemb" in only:
         gen_wordemb(ref_common)
+    if not only or "clip" in only:
+        gen_clip()
+    if not only or "rnn" in only:
+        gen_rnn(ref_common)
     if not only or "surface" in only:
         gen_surface(ref_fumi, ref_maml, ref_am3, ref_utils)
 

@@ -182,3 +182,10 @@ def import_reference():
     import models.common as ref_common
     import utils.utils as ref_utils
     return ref_fumi, ref_maml, ref_am3, ref_utils, ref_common
+
+
+def import_reference_clip():
+    """models.clip of the reference, unmodified (after import_reference)."""
+    import_reference()
+    import models.clip as ref_clip
+    return ref_clip

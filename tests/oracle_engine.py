@@ -93,6 +93,18 @@ class OracleEngine:
         from oracle import conv4_ref as C
         return torch.stack([C.conv4_features(x[g], theta) for g in range(x.shape[0])])
 
+    def clip_step(self, text, image, w, need_loss=True, need_grad=True, g_w=None):
+        ww = [t.detach().clone().requires_grad_(True) for t in w]
+        if not need_loss:
+            return dict(sim=R.clip_forward([t.detach() for t in ww], text, image), loss=None, grads=None)
+        out = R.clip_step(ww, text, image, need_grad=need_grad)
+        return dict(sim=out["sim"], loss=out["loss"].reshape(1), grads=out.get("grads"))
+
+    def lstm_bidir(self, tokens, table, lstm_w, pad_id, use_cell):
+        lead = tokens.shape[:-1]
+        out = R.lstm_encode(tokens.reshape(1, -1, tokens.shape[-1]), table, lstm_w, pad_id, use_cell)
+        return out.reshape(*lead, -1)
+
     def glove_bag(self, tokens, table, pad_id, mode):
         return R.word_embedding_pool(tokens, table, pad_id, mode)
 

@@ -781,3 +781,57 @@ def test_maml_step_odd_shapes_match_oracle(c, dev, ws):
     assert rel_to_max(out["loss_b"].cpu(), ref["loss_b"]) <= LOGIT_TOL
     names = [f"net.lin_{i}.{k}" for i in range(len(c["hid"] or [])) for k in ("weight", "bias")] + ["net.lin_final.weight", "net.lin_final.bias"]
     _check_grads(names, out["g_params"], None, ref["g_params"])
+
+
+# ---- beside the episodic path: CLIP baseline and the bi-LSTM text encoders --------------------------------
+def test_clip_step_matches_reference(dev, ws):
+    """fumi_hip_clip_step against the reference's own CLIP outputs (golden) and the oracle at the CLI's default sizes."""
+    from fumi_amd import hip
+    gold = load_golden("clip")
+    w = [torch.from_numpy(gold[k]) for k in R.CLIP_KEYS]
+    out = hip.clip_step(ws, _g(torch.from_numpy(gold["text"]), dev), _g(torch.from_numpy(gold["image"]), dev), [_g(t, dev) for t in w])
+    assert rel_to_max(out["sim"].cpu(), gold["sim"]) <= 1e-5
+    assert abs(float(out["loss"]) - float(gold["loss"])) <= 1e-5
+    for k, g in zip(R.CLIP_KEYS, out["grads"]):
+        assert rel_to_max(g.cpu(), gold["grad." + k], 1e-6) <= 1e-4, k
+    zs = hip.clip_step(ws, _g(torch.from_numpy(gold["text"][:1]), dev), _g(torch.from_numpy(gold["image"][:5]), dev), [_g(t, dev) for t in w],
+                       need_loss=False, need_grad=False)
+    assert rel_to_max(zs["sim"].cpu(), gold["zero_shot"]) <= 1e-5
+    g = torch.Generator().manual_seed(4)
+    n, Dt, D, P = 61, 768, 2048, 512                                    # --text_emb_dim / --im_emb_dim / --clip_latent_dim defaults
+    w = []
+    for o, i in ((P, Dt), (P, P), (P, D), (P, P)):
+        w += [torch.randn(o, i, generator=g) / i ** 0.5, torch.randn(o, generator=g) * 0.1]
+    text, image = torch.randn(n, Dt, generator=g), torch.randn(n, D, generator=g)
+    out = hip.clip_step(ws, _g(text, dev), _g(image, dev), [_g(t, dev) for t in w])
+    ref = R.clip_step([t.clone().requires_grad_(True) for t in w], text, image)
+    assert rel_to_max(out["sim"].cpu(), ref["sim"]) <= 1e-5 and abs(float(out["loss"]) - float(ref["loss"])) <= 1e-5
+    for k, a, b in zip(R.CLIP_KEYS, out["grads"], ref["grads"]):
+        assert rel_to_max(a.cpu(), b, 1e-7) <= 1e-3, k
+
+
+def test_lstm_bidir_matches_reference(dev, ws):
+    """fumi_hip_lstm_bidir against the reference's RNN / RnnHid outputs (golden) and the oracle at GloVe-sized rows."""
+    from fumi_amd import hip
+    gold = load_golden("rnn")
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    w = [torch.from_numpy(gold["rnn." + n + sfx]) for sfx in ("", "_reverse") for n in names]
+    tokens, table = torch.from_numpy(gold["tokens"]), torch.from_numpy(gold["embed.weight"])
+    for use_cell, key in ((False, "rnn"), (True, "rnnhid")):
+        out = hip.lstm_bidir(ws, _g(tokens, dev), _g(table, dev), [_g(t, dev) for t in w], 0, use_cell).cpu()
+        assert rel_to_max(out, gold[key]) <= 1e-5, key
+    g = torch.Generator().manual_seed(6)
+    V, E, H, L = 500, 300, 150, 40
+    table = torch.rand(V, E, generator=g) * 2 - 1
+    table[0] = 0
+    w = []
+    for _ in range(2):
+        w += [torch.randn(4 * H, E, generator=g) / E ** 0.5, torch.randn(4 * H, H, generator=g) / H ** 0.5,
+              torch.randn(4 * H, generator=g) * 0.1, torch.randn(4 * H, generator=g) * 0.1]
+    tok = torch.randint(1, V, (3, 7, L), generator=g)
+    for r in range(7):
+        tok[:, r, 1 + 5 * r:] = 0
+    for use_cell in (False, True):
+        out = hip.lstm_bidir(ws, _g(tok, dev), _g(table, dev), [_g(t, dev) for t in w], 0, use_cell).cpu()
+        assert rel_to_max(out, R.lstm_encode(tok, table, w, 0, use_cell)) <= 2e-5
+    assert ws.read_status() == 0

@@ -323,3 +323,49 @@ def test_fumi_conv4_module_trains_through_evaluate(oracle_engine):
     feats = m.im_net(ep["x_q"])                                         # [B, Qn, F]: batch statistics per query set
     assert feats.shape == (2, 6, 64)
     assert torch.allclose(feats[1], C.conv4_features(ep["x_q"][1], [t.detach() for t in m.im_net.theta()]), atol=1e-6)
+
+
+def test_rnn_text_encoders_keep_the_reference_surface(oracle_engine):
+    """RNN / RnnHid (common.py:44-161): same state_dict keys as the reference's modules (the golden fixture stores the
+    reference's own state_dict) and the same outputs on ragged token rows."""
+    from fumi_amd.models.common import RNN, RnnHid
+    gold = load_golden("rnn")
+    dictionary = {"PAD": 0, **{f"w{i}": i for i in range(1, 30)}}
+    keys = {k for k in gold if k.startswith(("embed.", "rnn."))}
+    for cls, name in ((RNN, "rnn"), (RnnHid, "rnnhid")):
+        m = cls("rand", "mean", dictionary, 16)
+        assert set(m.state_dict()) == keys
+        m.load_state_dict({k: torch.from_numpy(gold[k]) for k in keys})
+        m.eval()
+        out = m(torch.from_numpy(gold["tokens"]))
+        assert out.shape == (2, 5, 16)
+        np.testing.assert_allclose(out.numpy(), gold[name], atol=1e-6)
+    m.train()
+    with pytest.raises(NotImplementedError):                           # fine-tuning the LSTM is not supported by the engine
+        m(torch.from_numpy(gold["tokens"]))
+
+
+def test_clip_baseline_surface_and_cli_on_cpu(oracle_engine, tmp_path, monkeypatch):
+    """CLIP (clip.py): state_dict keys / similarity / loss / gradients against the reference's own outputs, then `--model clip`
+    through main.py on a synthetic supervised loader (training_run + zero-shot evaluate + checkpoint)."""
+    from fumi_amd import main as cli
+    from fumi_amd.models.clip import CLIP
+    gold = load_golden("clip")
+    keys = [k for k in gold if k.split(".")[0] in ("text_fc", "text_fc2", "image_fc", "image_fc2")]
+    m = CLIP(text_input_dim=20, image_input_dim=48, latent_dim=16)
+    assert set(m.state_dict()) == set(keys)
+    m.load_state_dict({k: torch.from_numpy(gold[k]) for k in keys})
+    text, image = torch.from_numpy(gold["text"]), torch.from_numpy(gold["image"])
+    np.testing.assert_allclose(m(text, image).numpy(), gold["sim"], atol=1e-6)
+    loss = m.loss_and_grads(text, image)
+    assert abs(float(loss) - float(gold["loss"])) < 1e-6
+    for k, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.numpy(), gold["grad." + k], atol=1e-6)
+    monkeypatch.chdir(tmp_path)
+    argv = ["--model", "clip", "--dataset", "synthetic", "--disable_cuda", "--text_encoder", "BERT", "--text_emb_dim", "24",
+            "--im_emb_dim", "512", "--image_embedding_model", "resnet-34", "--clip_latent_dim", "16", "--batch_size", "16",
+            "--num_ways", "5", "--epochs", "3", "--lr", "1e-2", "--log_dir", str(tmp_path / "res"), "--synthetic_classes", "12"]
+    res = cli.main(cli.parse_args(argv))
+    assert 0.0 <= res["test_acc"] <= 1.0
+    runs = os.listdir(tmp_path / "res" / "runs")
+    assert os.path.exists(tmp_path / "res" / "runs" / runs[0] / "ckpt.pth.tar")

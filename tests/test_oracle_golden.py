@@ -87,3 +87,26 @@ def test_word_embedding_oracle_matches_reference():
     for mode in ("mean", "max"):
         out = R.word_embedding_pool(tokens, table, int(gold["pad"]), mode)
         assert_close_max(out, gold[mode], 1e-6, mode)
+
+
+def test_clip_restatement_matches_reference():
+    """oracle/fumi_ref.py clip_forward / clip_step against the reference's own CLIP (clip.py:11-41,96-108) outputs."""
+    gold = load_golden("clip")
+    w = [torch.from_numpy(gold[k]).requires_grad_(True) for k in R.CLIP_KEYS]
+    out = R.clip_step(w, torch.from_numpy(gold["text"]), torch.from_numpy(gold["image"]))
+    assert_close_max(out["sim"], gold["sim"], 1e-6, "sim")
+    assert abs(float(out["loss"]) - float(gold["loss"])) < 1e-6
+    for k, g in zip(R.CLIP_KEYS, out["grads"]):
+        assert_close_max(g, gold["grad." + k], 1e-5, k)
+    zs = R.clip_forward([t.detach() for t in w], torch.from_numpy(gold["text"][:1]), torch.from_numpy(gold["image"][:5]))
+    assert_close_max(zs, gold["zero_shot"], 1e-6, "zero-shot call")
+
+
+def test_lstm_encoder_restatement_matches_reference():
+    """oracle/fumi_ref.py lstm_encode against the reference's RNN (output states) and RnnHid (cell states), common.py:44-161."""
+    gold = load_golden("rnn")
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    w = [torch.from_numpy(gold["rnn." + n + suffix]) for suffix in ("", "_reverse") for n in names]
+    tokens, table = torch.from_numpy(gold["tokens"]), torch.from_numpy(gold["embed.weight"])
+    assert_close_max(R.lstm_encode(tokens, table, w, 0, False), gold["rnn"], 1e-6, "RNN")
+    assert_close_max(R.lstm_encode(tokens, table, w, 0, True), gold["rnnhid"], 1e-6, "RnnHid")

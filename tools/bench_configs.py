@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--only", type=str, default=None, help="run one configuration")
+    ap.add_argument("--roofline", action="store_true",
+                    help="time every phase of the library with HIP events and add a roofline object for the configuration's "
+                         "dominant kernel (AM3: the image encoder pass over the 2048-wide rows, HBM-bound)")
     o = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -76,16 +79,34 @@ def main():
             return model.evaluate(b, opt_, sched, a.num_ways, dev, "train")
         for i in range(o.warmup):
             step(bs[i % len(bs)])
-        hip.raise_on_status(hip.Workspace.get(dev).read_status())
+        ws = hip.Workspace.get(dev)
+        hip.raise_on_status(ws.read_status())
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(o.steps):
             last = step(bs[i % len(bs)])
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        print(json.dumps({"config": name, "argv": " ".join(argv), "episodes_per_meta_batch": a.batch_size,
-                          "ms_per_step": round(el / o.steps * 1e3, 4), "episodes_per_s": round(a.batch_size * o.steps / el, 1),
-                          "final_loss": float(last[0])}), flush=True)
+        rec = {"config": name, "argv": " ".join(argv), "episodes_per_meta_batch": a.batch_size,
+               "ms_per_step": round(el / o.steps * 1e3, 4), "episodes_per_s": round(a.batch_size * o.steps / el, 1),
+               "final_loss": float(last[0])}
+        if o.roofline:
+            ws.set_profiling(True, None, every=1)                 # every phase bracketed (adds event bubbles: separate loop)
+            for i in range(o.steps):
+                step(bs[i % len(bs)])
+            prof = ws.profile()
+            ws.set_profiling(False)
+            rec["phase_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items()}
+            if a.model == "am3" and "xpanel_fwd" in prof:
+                B, R, D, P = a.batch_size, a.num_ways * (a.num_shots + a.num_shots_test), a.im_emb_dim, a.prototype_dim
+                byt = 4.0 * (B * R * D + P * D + B * R * P)         # rows read once, encoder weight once, embeddings written once
+                dur = prof["xpanel_fwd"][0] / prof["xpanel_fwd"][1] * 1e-3
+                rec["roofline"] = {"bound": "hbm", "achieved": round(byt / dur / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                   "frac": round(byt / dur / 8e12, 4), "traffic": None, "algorithmic_bytes": int(byt),
+                                   "kernel": "xpanel_fwd (AM3 image encoder: [B*(S+Qn), 2048] x [2048, 64] in one pass over the "
+                                             "episode panels; 4 FLOP/B: HBM-bound)", "avg_us": round(dur * 1e6, 2),
+                                   "launches": prof["xpanel_fwd"][1], "timed": "HIP events around every launch"}
+        print(json.dumps(rec), flush=True)
 
 
 if __name__ == "__main__":
