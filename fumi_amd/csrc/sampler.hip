@@ -65,6 +65,49 @@ __global__ __launch_bounds__(64) void sample_episodes_kernel(unsigned key, int B
     }
 }
 
+// torchmeta's task semantics on top of the same hash stream:
+//   * Categorical(N): the N class slots of a task get a random permutation of the labels 0..N-1 (labels_out [B,N]);
+//   * ClassSplitter(shuffle=True) seeds its per-class permutation with hash(task) + seed, so the support / query split of a
+//     given class tuple is the same every time the tuple is drawn: with fixed_split the item key is derived from
+//     (seed, the tuple's class ids in slot order) instead of (seed, step, episode).
+__global__ __launch_bounds__(64) void sample_episodes_tm_kernel(unsigned key, unsigned seed_key, int fixed_split, int B, int N, int K,
+                                                                int Q, int C, const int64_t* __restrict__ class_ptr,
+                                                                const int64_t* __restrict__ class_items,
+                                                                int64_t* __restrict__ cls_out, int64_t* __restrict__ lab_out,
+                                                                int64_t* __restrict__ img_s, int64_t* __restrict__ img_q, int* status) {
+    __shared__ int s_cls[SMAXN];
+    __shared__ int s_lab[SMAXN];
+    __shared__ unsigned s_tkey;
+    extern __shared__ int s_rows[];                       // [N][K+Q]
+    const int b = blockIdx.x, tid = threadIdx.x, m = K + Q;
+    if (tid == 0) {
+        sample_distinct(key, (unsigned)b, 0xFFFFu, C, N, s_cls);
+        sample_distinct(key, (unsigned)b, 0xFFFEu, N, N, s_lab);            // a uniformly random permutation of 0..N-1
+        unsigned tk = seed_key;
+        for (int n = 0; n < N; ++n) tk = smix(tk ^ ((unsigned)s_cls[n] * 0x9E3779B9U + (unsigned)n));
+        s_tkey = tk;
+    }
+    __syncthreads();
+    if (tid < N) {
+        const int c = s_cls[tid];
+        const long p0 = class_ptr[c];
+        const int n_c = (int)(class_ptr[c + 1] - p0);
+        int* sel = s_rows + tid * m;
+        if (n_c < m) {
+            atomicOr(status, FUMI_ST_CLASS_MISSING);
+            for (int i = 0; i < m; ++i) sel[i] = n_c > 0 ? i % n_c : 0;
+        } else if (fixed_split) {
+            sample_distinct(s_tkey, 0u, (unsigned)tid, n_c, m, sel);
+        } else {
+            sample_distinct(key, (unsigned)b, (unsigned)tid, n_c, m, sel);
+        }
+        cls_out[(long)b * N + tid] = c;
+        lab_out[(long)b * N + tid] = s_lab[tid];
+        for (int k = 0; k < K; ++k) img_s[((long)b * N + tid) * K + k] = n_c > 0 ? class_items[p0 + sel[k]] : 0;
+        for (int q = 0; q < Q; ++q) img_q[((long)b * N + tid) * Q + q] = n_c > 0 ? class_items[p0 + sel[K + q]] : 0;
+    }
+}
+
 // out[i, :] = table[idx[i], :]; rows of `row_f4` float4 (VEC) or `row_f` floats.  One wave per row, all of a row's loads in
 // flight before the first store (8 KB rows: 8 x 16 bytes per lane).
 template <bool VEC>
@@ -123,6 +166,25 @@ extern "C" int fumi_hip_sample_episodes(fumi_ws_t* ws, fumi_stream_t stream, uin
     key = mix(key ^ (unsigned)(step >> 32));
     hipLaunchKernelGGL(sample_episodes_kernel, dim3(B), dim3(64), (size_t)N * (K + Q) * sizeof(int), (hipStream_t)stream, key, B, N,
                        K, Q, C, class_ptr, class_items, classes, items_s, items_q, ws->status);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+extern "C" int fumi_hip_sample_episodes_tm(fumi_ws_t* ws, fumi_stream_t stream, uint64_t seed, uint64_t step, int B, int N, int K,
+        int Q, int C, const int64_t* class_ptr, const int64_t* class_items, int fixed_split, int64_t* classes, int64_t* labels,
+        int64_t* items_s, int64_t* items_q) {
+    if (!ws || !class_ptr || !class_items || !classes || !labels || !items_s || !items_q) return FUMI_EINVAL;
+    if (B < 1 || N < 1 || K < 1 || Q < 0 || C < N) return FUMI_EINVAL;
+    if (N > SMAXN || K + Q > SMAXM) return FUMI_ENOTSUP;
+    HIP_TRY(hipSetDevice(ws->device));
+    auto mix = [](unsigned x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; };
+    unsigned skey = mix((unsigned)(seed & 0xffffffffULL));
+    skey = mix(skey ^ (unsigned)(seed >> 32));
+    unsigned key = mix(skey ^ (unsigned)(step & 0xffffffffULL));
+    key = mix(key ^ (unsigned)(step >> 32));
+    hipLaunchKernelGGL(sample_episodes_tm_kernel, dim3(B), dim3(64), (size_t)N * (K + Q) * sizeof(int), (hipStream_t)stream, key,
+                       mix(skey ^ 0x5bd1e995U), fixed_split ? 1 : 0, B, N, K, Q, C, class_ptr, class_items, classes, labels, items_s,
+                       items_q, ws->status);
     LAUNCH_CHECK();
     return FUMI_OK;
 }

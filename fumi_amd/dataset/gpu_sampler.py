@@ -21,14 +21,17 @@ from .. import hip
 
 class GpuEpisodeSampler:
     def __init__(self, images, class_of_image, class_text, num_ways, num_shots, num_shots_test, batch_size, seed=123,
-                 length=None, zero_copy=False, row_ids=None, skip_small_classes=False):
+                 length=None, zero_copy=False, row_ids=None, skip_small_classes=False, torchmeta_tasks=False):
         """images [n_images, D] fp32 (moved to the device once), class_of_image [n_images] ints (category of every row, as
         inat_anim.json's annotations give it), class_text [C, Dt] fp32 or [C, L] int64 tokens (one row per class: the text of
         a sample is its class description, data.py:543-549).  row_ids [n_images] ints: the id reported for every table row in
         the batch's index field (the dataset's image ids, data.py:568-571); default: the row number.
         A class with fewer than num_shots + num_shots_test images cannot fill an episode: torchmeta's ClassSplitter raises
         ValueError when such a class is drawn, so the constructor raises it up front; ``skip_small_classes=True`` samples
-        among the classes that are large enough instead (the kernel never sees an under-populated class)."""
+        among the classes that are large enough instead (the kernel never sees an under-populated class).
+        torchmeta_tasks=True reproduces torchmeta's task semantics: the class slots of a task get a
+        random permutation of the labels 0..N-1 (Categorical) and a class tuple drawn again has the same support / query
+        members (ClassSplitter seeds its shuffle with hash(task) + seed); False keeps label n for slot n."""
         coi = np.asarray(class_of_image, dtype=np.int64)
         C = int(class_text.shape[0])
         if coi.min() < 0 or coi.max() >= C or len(coi) != images.shape[0]:
@@ -64,6 +67,7 @@ class GpuEpisodeSampler:
         if self.class_ids is not None:
             self.class_ids = self.class_ids.to(self.dev)
         self.seed, self.length = int(seed), length
+        self.torchmeta_tasks = bool(torchmeta_tasks)
         self.zero_copy = bool(zero_copy)       # hand out RowRefs into the table instead of gathered image rows (FuMI engine only)
         S, Qn = self.N * self.K, self.N * self.Q
         lab = torch.arange(self.N, device=self.dev, dtype=torch.int64)
@@ -76,7 +80,12 @@ class GpuEpisodeSampler:
 
     def batch(self, step):
         B, N, K, Q = self.B, self.N, self.K, self.Q
-        cls, it_s, it_q = hip.sample_episodes(self.ws, self.seed, step, B, N, K, Q, self.class_ptr, self.class_items)
+        y_s, y_q = self.y_s, self.y_q
+        if self.torchmeta_tasks:
+            cls, lab, it_s, it_q = hip.sample_episodes_tm(self.ws, self.seed, step, B, N, K, Q, self.class_ptr, self.class_items, True)
+            y_s, y_q = lab.repeat_interleave(K, dim=1), lab.repeat_interleave(Q, dim=1)
+        else:
+            cls, it_s, it_q = hip.sample_episodes(self.ws, self.seed, step, B, N, K, Q, self.class_ptr, self.class_items)
         if self.zero_copy:
             x_s, x_q = hip.RowRef(self.images, it_s.view(B, N * K)), hip.RowRef(self.images, it_q.view(B, N * Q))
         else:
@@ -90,7 +99,7 @@ class GpuEpisodeSampler:
         id_s, id_q = it_s.view(B, N * K), it_q.view(B, N * Q)
         if self.row_ids is not None:
             id_s, id_q = self.row_ids[id_s], self.row_ids[id_q]
-        return {'train': ([id_s, text_s, x_s], self.y_s), 'test': ([id_q, text_q, x_q], self.y_q)}
+        return {'train': ([id_s, text_s, x_s], y_s), 'test': ([id_q, text_q, x_q], y_q)}
 
     def __iter__(self):
         i = 0

@@ -219,7 +219,7 @@ def get_inat_anim(args):
             train_dictionary = sp.dictionary
         images = torch.from_numpy(read_rows(emb, sp.image_ids)).to(args.device)
         out.append(GpuEpisodeSampler(images, sp.class_of_image, sp.class_text, args.num_ways, args.num_shots, q,
-                                     args.batch_size, seed=args.seed + len(split), row_ids=sp.image_ids))
+                                     args.batch_size, seed=args.seed + len(split), row_ids=sp.image_ids, torchmeta_tasks=True))
     return out[0], out[1], out[2], ({} if args.text_encoder == "BERT" else train_dictionary)
 
 

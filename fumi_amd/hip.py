@@ -23,7 +23,7 @@ SYMBOLS = [
     "fumi_hip_glove_bag", "fumi_hip_glove_bag_select", "fumi_hip_class_text_select", "fumi_hip_xpanel_fwd", "fumi_hip_xpanel_bwd",
     "fumi_hip_adam_step",
     "fumi_hip_linear_fwd", "fumi_hip_linear_bwd_data", "fumi_hip_linear_bwd_weight",
-    "fumi_hip_sample_episodes", "fumi_hip_gather_rows", "fumi_hip_publish_scalars",
+    "fumi_hip_sample_episodes", "fumi_hip_sample_episodes_tm", "fumi_hip_gather_rows", "fumi_hip_publish_scalars",
     "fumi_hip_publish_scalars_deferred", "fumi_hip_publish_flush", "fumi_hip_am3_metrics",
     "fumi_hip_conv4_feature_dim", "fumi_hip_fumi_conv4_step", "fumi_hip_maml_conv4_step", "fumi_hip_conv4_probe", "fumi_hip_conv4_features", "fumi_hip_conv4_set_option",
     "fumi_hip_conv3x3_fwd", "fumi_hip_conv3x3_bwd_data", "fumi_hip_conv3x3_bwd_weight",
@@ -126,6 +126,8 @@ def lib():
         L.fumi_hip_linear_bwd_data.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 3
         L.fumi_hip_linear_bwd_weight.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 4
         L.fumi_hip_sample_episodes.argtypes = [c_void_p, c_void_p, ctypes.c_uint64, ctypes.c_uint64] + [c_int] * 5 + [c_void_p] * 5
+        L.fumi_hip_sample_episodes_tm.argtypes = ([c_void_p, c_void_p, ctypes.c_uint64, ctypes.c_uint64] + [c_int] * 5 + [c_void_p] * 2
+                                                  + [c_int] + [c_void_p] * 4)
         L.fumi_hip_gather_rows.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]
         L.fumi_hip_publish_scalars.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_uint64]
         L.fumi_hip_publish_scalars_deferred.argtypes = [c_void_p, c_void_p, c_int, c_void_p, ctypes.c_uint64]
@@ -601,6 +603,22 @@ def sample_episodes(ws, seed, step, B, N, K, Q, class_ptr, class_items):
                                           _i64(cls, "classes"), _i64(it_s, "items_s"), _i64(it_q, "items_q")),
            "fumi_hip_sample_episodes")
     return cls, it_s, it_q
+
+
+def sample_episodes_tm(ws, seed, step, B, N, K, Q, class_ptr, class_items, fixed_split=True):
+    """Episode indices with torchmeta's task semantics: classes [B,N], labels [B,N] (a permutation of 0..N-1 per task), items_s
+    [B,N,K], items_q [B,N,Q]; fixed_split: a class tuple always yields the same support / query members."""
+    dev = _dev(class_ptr)
+    C = int(class_ptr.numel()) - 1
+    cls = torch.empty(B, N, device=dev, dtype=torch.int64)
+    lab = torch.empty(B, N, device=dev, dtype=torch.int64)
+    it_s = torch.empty(B, N, K, device=dev, dtype=torch.int64)
+    it_q = torch.empty(B, N, Q, device=dev, dtype=torch.int64)
+    _check(lib().fumi_hip_sample_episodes_tm(ws.handle, _stream(dev), int(seed) & 0xFFFFFFFFFFFFFFFF, int(step) & 0xFFFFFFFFFFFFFFFF,
+                                             B, N, K, Q, C, _i64(class_ptr, "class_ptr"), _i64(class_items, "class_items"),
+                                             int(bool(fixed_split)), _i64(cls, "classes"), _i64(lab, "labels"), _i64(it_s, "items_s"),
+                                             _i64(it_q, "items_q")), "fumi_hip_sample_episodes_tm")
+    return cls, lab, it_s, it_q
 
 
 def gather_rows(ws, table, idx):

@@ -270,6 +270,13 @@ int fumi_hip_fumi_step_indexed(fumi_ws_t* ws, fumi_stream_t stream,
  *   or the per-class text rows / token rows.  An index outside [0, n_rows) sets FUMI_ST_LABEL_RANGE and reads row 0. */
 int fumi_hip_sample_episodes(fumi_ws_t* ws, fumi_stream_t stream, uint64_t seed, uint64_t step, int B, int N, int K, int Q,
         int C, const int64_t* class_ptr, const int64_t* class_items, int64_t* classes, int64_t* items_s, int64_t* items_q);
+/* The same with torchmeta's task semantics: labels [B,N] = a random permutation of 0..N-1 per task
+ * (torchmeta.transforms.Categorical relabels the class slots); fixed_split != 0: the K + Q members of every class are a
+ * function of (seed, the task's class tuple) only -- ClassSplitter(shuffle=True) seeds its permutation with hash(task) + seed, so
+ * a class tuple drawn again has the same support / query split.  Same (seed, step) stream for the class draw as above. */
+int fumi_hip_sample_episodes_tm(fumi_ws_t* ws, fumi_stream_t stream, uint64_t seed, uint64_t step, int B, int N, int K, int Q,
+        int C, const int64_t* class_ptr, const int64_t* class_items, int fixed_split, int64_t* classes, int64_t* labels,
+        int64_t* items_s, int64_t* items_q);
 int fumi_hip_gather_rows(fumi_ws_t* ws, fumi_stream_t stream, const void* table, int64_t n_rows, int64_t row_bytes,
         const int64_t* idx, int64_t n_idx, void* out);
 

@@ -58,3 +58,33 @@ def sample_episodes(seed, step, B, N, K, Q, class_ptr, class_items):
             it_s[b, n] = [class_items[p0 + s] for s in sel[:K]]
             it_q[b, n] = [class_items[p0 + s] for s in sel[K:]]
     return cls, it_s, it_q
+
+
+def sample_episodes_tm(seed, step, B, N, K, Q, class_ptr, class_items, fixed_split=True):
+    """torchmeta's task semantics on the same stream (sampler.hip: sample_episodes_tm_kernel): -> classes, labels (a random
+    permutation of 0..N-1 per task: Categorical), items_s, items_q; fixed_split: the members drawn for a class depend only on
+    (seed, the task's class tuple) -- ClassSplitter's hash(task) + seed seeding."""
+    C = len(class_ptr) - 1
+    seed, step = int(seed), int(step)
+    skey = mix(mix(seed & M32) ^ ((seed >> 32) & M32))
+    key = mix(mix(skey ^ (step & M32)) ^ ((step >> 32) & M32))
+    seed_key = mix(skey ^ 0x5bd1e995)
+    m = K + Q
+    cls = np.zeros((B, N), np.int64); lab = np.zeros((B, N), np.int64)
+    it_s = np.zeros((B, N, K), np.int64); it_q = np.zeros((B, N, Q), np.int64)
+    for b in range(B):
+        cs = sample_distinct(key, b, 0xFFFF, C, N)
+        lab[b] = sample_distinct(key, b, 0xFFFE, N, N)
+        tk = seed_key
+        for n, c in enumerate(cs):
+            tk = mix(tk ^ ((c * 0x9E3779B9 + n) & M32))
+        for n, c in enumerate(cs):
+            p0, n_c = int(class_ptr[c]), int(class_ptr[c + 1] - class_ptr[c])
+            if n_c < m:
+                sel = [i % max(n_c, 1) for i in range(m)]
+            else:
+                sel = sample_distinct(tk, 0, n, n_c, m) if fixed_split else sample_distinct(key, b, n, n_c, m)
+            cls[b, n] = c
+            it_s[b, n] = [class_items[p0 + s_] for s_ in sel[:K]]
+            it_q[b, n] = [class_items[p0 + s_] for s_ in sel[K:]]
+    return cls, lab, it_s, it_q

@@ -238,3 +238,54 @@ def test_gpu_sampler_skips_small_classes_on_request():
         seen |= set(cls_s.unique().tolist())
     assert seen <= {0, 1, 2, 3, 4, 5, 8} and 8 in seen
     assert hip.Workspace.get(torch.device("cuda:0")).read_status() == 0
+
+
+@pytest.mark.gpu
+def test_torchmeta_task_semantics_match_oracle_and_hold_their_properties():
+    """fumi_hip_sample_episodes_tm: bit-exact against oracle/sampler_ref.py; labels are a permutation of 0..N-1 per task
+    (torchmeta's Categorical); with fixed_split a class tuple drawn again has the same support / query members (ClassSplitter's
+    hash(task) + seed seeding), without it the members change from step to step."""
+    from fumi_amd import hip
+    dev = torch.device("cuda:0"); ws = hip.Workspace.get(dev)
+    rs = np.random.RandomState(4)
+    coi, ptr, items = _classes(rs, 6, 12, 30)                       # 6 classes, 5-way: tuples repeat quickly
+    tp, ti = torch.from_numpy(ptr).to(dev), torch.from_numpy(items).to(dev)
+    seen, seen_free = {}, {}
+    for step in range(12):
+        for fixed in (True, False):
+            cls, lab, it_s, it_q = hip.sample_episodes_tm(ws, 7, step, 8, 5, 2, 3, tp, ti, fixed)
+            r = SR.sample_episodes_tm(7, step, 8, 5, 2, 3, ptr, items, fixed)
+            for a, b in zip((cls, lab, it_s, it_q), r):
+                assert np.array_equal(a.cpu().numpy(), b)
+            assert all(sorted(row) == list(range(5)) for row in lab.cpu().tolist())
+            store = seen if fixed else seen_free
+            for b in range(8):
+                key = tuple(cls[b].tolist())
+                val = (it_s[b].cpu().numpy().tobytes(), it_q[b].cpu().numpy().tobytes())
+                store.setdefault(key, set()).add(val)
+    assert ws.read_status() == 0
+    assert any(len(v) > 0 for v in seen.values()) and all(len(v) == 1 for v in seen.values())       # one split per class tuple
+    assert any(len(v) > 1 for v in seen_free.values())
+
+
+@pytest.mark.gpu
+def test_gpu_sampler_torchmeta_tasks_feed_the_engine():
+    from fumi_amd.dataset.gpu_sampler import GpuEpisodeSampler
+    rs = np.random.RandomState(2)
+    C, D, Dt, per = 12, 64, 16, 30
+    coi = np.repeat(np.arange(C), per); rs.shuffle(coi)
+    images = torch.from_numpy(rs.standard_normal((C * per, D)).astype(np.float32))
+    text = torch.arange(C, dtype=torch.float32)[:, None].repeat(1, Dt)
+    smp = GpuEpisodeSampler(images, coi, text, num_ways=5, num_shots=2, num_shots_test=3, batch_size=4, seed=3, torchmeta_tasks=True)
+    b = smp.batch(0)
+    (idx_s, text_s, x_s), y_s = b['train']
+    (idx_q, text_q, x_q), y_q = b['test']
+    cls_s = torch.from_numpy(coi)[idx_s.cpu()]
+    for e in range(4):
+        assert sorted(y_s[e].cpu().tolist()) == sorted(list(range(5)) * 2) and sorted(y_q[e].cpu().tolist()) == sorted(list(range(5)) * 3)
+        # one label per class, the same in support and query, text row = the class's
+        m = {int(c): int(y) for c, y in zip(cls_s[e], y_s[e].cpu())}
+        assert len(m) == 5 and len(set(m.values())) == 5
+        cls_q = torch.from_numpy(coi)[idx_q[e].cpu()]
+        assert all(m[int(c)] == int(y) for c, y in zip(cls_q, y_q[e].cpu()))
+    assert torch.equal(text_s[..., 0].cpu(), cls_s.float())
