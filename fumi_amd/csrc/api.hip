@@ -1,5 +1,6 @@
 // C-ABI entry points (include/fumi_hip.h): workspace management and the orchestration of one meta-step.
 #include "common.h"
+#include "hyper_fwd.h"
 #include <stdio.h>
 #include <string.h>
 
@@ -258,13 +259,22 @@ static int fumi_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
         return FUMI_OK;
     };
     using HF = decltype(hyper_forward);
+    HyperFwdArgs rider;
     if (fork) {
         // enqueued from inside run_episodes, right after xpanel_fwd: the matrix pass is not held up by this host work
         p.inputs_ready = ws->ev[0];
         p.after_xpanel_fwd = [](void* c) -> int { return (*(HF*)c)(); };
         p.hook_ctx = &hyper_forward;
         p.head_ready = ws->ev[1];
-    } else if ((rc = hyper_forward())) return rc;
+    } else {
+        // default: the hypernetwork forward rides at the front of the forward X-panel launch (hyper_fwd.h) -- one dependent
+        // launch less, no events; shapes the rider does not cover get their own launch right after that pass
+        if (hyper_lds && hyper_fwd_split_args(R, Dt, Ht, H1, tanh_head, ctext, phi[0], phi[1], phi[2], phi[3], u, h, hfp, ws->hcnt, &rider)) {
+            p.fwd_rider = &rider;
+            p.fwd_rider_fallback = [](void* c) -> int { return (*(HF*)c)(); };
+            p.hook_ctx = &hyper_forward;
+        } else if ((rc = hyper_forward())) return rc;
+    }
     if (fork_bwd) p.after_reverse = ws->ev[2];
 
     p.head = h; p.head_bar = hbar;

@@ -145,8 +145,10 @@ int launch_colsum_multi(hipStream_t st, const ColsumJobs& jobs, float* part /* j
 // ------------------------------------------------------------------------------------------------------------
 // zero-copy episodes: rows of the meta-batch addressed through indices into an HBM-resident table (x_s / x_q unused)
 struct XRows { const float* table; const int64_t* idx_s; const int64_t* idx_q; long n_rows; };
+struct HyperFwdArgs;         // hyper_fwd.h: a split hypernetwork forward that can ride at the front of the forward X-panel launch
 int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
-                      const float* W0, float* A0 /*[B,S+Qn,h0]*/, float* G /*[B,S+Qn,S]*/, const XRows* rows = nullptr);
+                      const float* W0, float* A0 /*[B,S+Qn,h0]*/, float* G /*[B,S+Qn,S]*/, const XRows* rows = nullptr,
+                      const HyperFwdArgs* rider = nullptr, int* rider_done = nullptr /* set to 1 when the rider was launched */);
 int xpanel_bwd_nsplit(int B, int S, int Qn, int D, int h0, int* kchunk_out);
 int launch_xpanel_bwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
                       const float* Abar /*[B,S+Qn,h0]*/, float* slabs /*[nsplit,h0,D]*/, int kchunk, int nsplit,
@@ -180,6 +182,8 @@ struct EpisodeProblem {
     struct ReduceSegs* defer_reduce;            // not NULL: the final sums over episodes / slabs are appended here and the
                                                 // caller launches them (one launch for the whole step) instead of run_episodes
     hipEvent_t inputs_ready;                    // recorded on the caller's stream BEFORE the first launch (fork point)
+    const HyperFwdArgs* fwd_rider;              // not NULL: the producer of `head` as rider workgroups of xpanel_fwd (hyper_fwd.h);
+    int (*fwd_rider_fallback)(void*);           // called (with hook_ctx) right after xpanel_fwd when that launch could not carry it
     int (*after_xpanel_fwd)(void*); void* hook_ctx;   // host callback right after xpanel_fwd is enqueued: the producer of `head`
                                                 // is launched there, so its host-side preparation does not delay the matrix pass
 };

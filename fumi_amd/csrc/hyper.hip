@@ -9,10 +9,11 @@
 //   bwd0:  gA0 = scale * ubar^T c            grid (Dt/64, Ht/64)  block: 64 x 64 outputs, K = R
 // The per-row-block partial slabs of bwd1 are summed by launch_reduce_multi.
 #include "common.h"
+#include "hyper_fwd.h"
 
 namespace {
 
-constexpr int HB = 16;                 // rows per block
+constexpr int HB = HF_HB;                 // rows per block
 constexpr int HCAP = 38000;            // floats of dynamic LDS
 
 __host__ __device__ inline int h_r4(int x) { return (x + 3) & ~3; }
@@ -56,9 +57,7 @@ __global__ __launch_bounds__(512) void hyper_lin_kernel(StageTab stg, LinDims d,
 // global load, so a wave that owns NT 16-column tiles of the hidden layer just keeps two FCH*16-deep chunks of those loads
 // in flight (a CU fetching a 300 KB weight matrix alone is latency-bound: everything is requested up front).  The block's input rows (zero-padded to a chunk multiple) and the hidden activations -- layer 1's contraction
 // operand -- are the only LDS images; layer 1's weight fragments are fetched while layer 0's epilogue runs.
-constexpr int FCH = 12;                // 16-deep steps per chunk of weight-fragment loads
-struct FwdDims { int R, Dt, Ht, H1, ldx, tanh_head; };
-__host__ __device__ inline int fwd_ldx(int Dt) { return (Dt + FCH * 16 - 1) / (FCH * 16) * (FCH * 16) + 4; }
+constexpr int FCH = HF_FCH;            // 16-deep steps per chunk of weight-fragment loads (FwdDims, fwd_ldx: hyper_fwd.h)
 
 template <int NT, int NCH>              // NT tiles per wave (Ht <= 128 NT), NCH chunks of FCH*16 contraction columns
 __global__ __launch_bounds__(512) void hyper_fwd_fused_kernel(FwdDims d, const float* __restrict__ c, const float* __restrict__ A0,
@@ -205,118 +204,13 @@ __global__ __launch_bounds__(512) void hyper_fwd_fused_kernel(FwdDims d, const f
     }
 }
 
-// ---- forward, both layers in one launch, layer 0's columns split over workgroups ------------------------------------------
-// A CU that fetches the whole 300 KB weight matrix alone is bound by its own load path (the fused kernel above: 10 CUs busy,
-// ~15 us).  Here a row block is handled by Ht/64 workgroups of 4 waves: each takes 64 hidden columns (one 16-column tile per
-// wave, the wave's weight fragments requested up front as above), writes its slice of the hidden activations and its
-// PARTIAL product with the matching 64 columns of layer 1's weights; the workgroup that arrives last at the row block's
-// counter adds the partials in chunk order (deterministic), the bias and the optional tanh.  Partials travel with
-// agent-scope stores / loads like the reverse sweep's exchange; nobody waits for anybody.  Ids are XCD-grouped: the chunks of
-// a row block share an XCD (ids equal mod 8), so the partials meet in that L2.
-template <int KS>                       // 16-deep contraction steps held in registers (Dt <= 16 KS)
-__global__ __launch_bounds__(256) void hyper_fwd_split_kernel(FwdDims d, const float* __restrict__ c, const float* __restrict__ A0,
-                                                              const float* __restrict__ b0, const float* __restrict__ A1,
-                                                              const float* __restrict__ b1, float* __restrict__ u,
-                                                              float* __restrict__ h, float* hpart, int* cnt, int nrb) {
+// ---- forward, both layers in one launch, layer 0's columns split over workgroups: hyper_fwd.h (the same body also rides at
+// the front of the forward X-panel launch, xpanel.hip) ------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void hyper_fwd_split_kernel(HyperFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ int s_last;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, q = lane >> 4;
-    const int Dt = d.Dt, Ht = d.Ht, H1 = d.H1, ldx = d.ldx;
-    const int nch = Ht >> 6;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int rb = xcd + 8 * (slot / nch), cb = slot % nch;
-    if (rb >= nrb) return;
-    const int m0 = rb * HB, nr = min(HB, d.R - m0);
-    constexpr int ldu = 64 + 4;
-    float* xs = sm; float* us = sm + HB * ldx;
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-
-    const int n0 = cb * 64 + wave * 16;
-    const float* wrow = A0 + (long)(n0 + r) * Dt;
-    f32x4 wf[KS];
-#pragma unroll
-    for (int s_ = 0; s_ < KS; ++s_) wf[s_] = *(const f32x4*)(wrow + min(s_ * 16 + 4 * q, Dt - 4));
-    {
-        const int l4 = ldx >> 2, tot4 = HB * l4;
-        for (int i0 = tid; i0 < tot4; i0 += 4 * 256) {
-            f32x4 v[4]; bool ok[4];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int i = min(i0 + x * 256, tot4 - 1);
-                const int m = i / l4, k4 = i - m * l4;
-                ok[x] = m < nr && 4 * k4 < Dt;
-                v[x] = *(const f32x4*)(c + (long)(m0 + min(m, nr - 1)) * Dt + min(4 * k4, Dt - 4));
-            }
-#pragma unroll
-            for (int x = 0; x < 4; ++x) if (i0 + x * 256 < tot4) *(f32x4*)(xs + 4 * (i0 + x * 256)) = ok[x] ? v[x] : z4;
-        }
-    }
-    const f32x4 bias0 = *(const f32x4*)(b0 + n0 + 4 * q);
-    // layer 1 fragments of this chunk: tiles wave and wave + 4 (H1 <= 128), contraction over the chunk's 64 columns
-    const int ntile1 = (H1 + 15) >> 4;
-    f32x4 w1[2][4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const float* a1r = A1 + (long)min((wave + 4 * t) * 16 + r, H1 - 1) * Ht + cb * 64 + 4 * q;
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) w1[t][s_] = *(const f32x4*)(a1r + s_ * 16);
-    }
-    __syncthreads();
-
-    f32x4 acc = z4;
-    const float* xr = xs + r * ldx + 4 * q;
-    const int nstep = (Dt + 15) >> 4;
-#pragma unroll
-    for (int s_ = 0; s_ < KS; ++s_) {
-        if (s_ < nstep) {
-            const f32x4 xf = *(const f32x4*)(xr + s_ * 16);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s_][e], xf[e], acc, 0, 0, 0);
-        }
-    }
-    {
-        f32x4 v = acc + bias0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-        *(f32x4*)(us + r * ldu + wave * 16 + 4 * q) = v;
-        if (r < nr) *(f32x4*)(u + (long)(m0 + r) * Ht + n0 + 4 * q) = v;
-    }
-    wg_lds_barrier();
-    float* mine = hpart + ((long)rb * nch + cb) * HB * H1;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int t1 = wave + 4 * t;
-        if (t1 < ntile1) {
-            f32x4 a = z4;
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) {
-                const f32x4 uf = *(const f32x4*)(us + r * ldu + s_ * 16 + 4 * q);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) a = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[t][s_][e], uf[e], a, 0, 0, 0);
-            }
-            const int n = t1 * 16 + 4 * q;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (n + e < H1) __hip_atomic_store(mine + r * H1 + n + e, a[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();                                      // every wave's partial stores have left (vmcnt(0)) before the signal
-    if (tid == 0) {
-        const int old = __hip_atomic_fetch_add(cnt + rb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = old == nch - 1;
-        if (old == nch - 1) __hip_atomic_store(cnt + rb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const float* all = hpart + (long)rb * nch * HB * H1;
-    for (int i = tid; i < nr * H1; i += 256) {
-        const int m = i / H1, n = i - m * H1;
-        float v = b1[n];
-        for (int cc = 0; cc < nch; ++cc) v += __hip_atomic_load(all + (long)cc * HB * H1 + m * H1 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        h[(long)(m0 + m) * H1 + n] = d.tanh_head ? tanhf(v) : v;
-    }
+    hyper_fwd_split_body<KS>(a, (int)blockIdx.x, sm, &s_last);
 }
 
 // ---- bwd1 -------------------------------------------------------------------------------------------------------------
@@ -427,6 +321,18 @@ size_t hyper_fwd_workspace_floats(int R, int Ht, int H1) {
     return (size_t)((R + HB - 1) / HB) * (Ht / 64 + 1) * HB * H1 + 64;
 }
 
+int hyper_fwd_split_args(int R, int Dt, int Ht, int H1, int tanh_head, const float* c, const float* A0, const float* b0,
+                         const float* A1, const float* b1, float* u, float* h, float* hpart, int* cnt, HyperFwdArgs* a) {
+    if (!hyper_lds_fits(R, Dt, Ht, H1)) return 0;
+    const bool al16_ = (((uintptr_t)c | (uintptr_t)A0 | (uintptr_t)A1 | (uintptr_t)b0 | (uintptr_t)u) & 15) == 0;
+    const int nrb = (R + HB - 1) / HB, nch = Ht / 64;
+    if (!(hpart && cnt && al16_ && Dt <= 768 && H1 <= 128 && nrb <= FUMI_HCNT)) return 0;
+    a->d = FwdDims{R, Dt, Ht, H1, fwd_ldx(Dt), tanh_head};
+    a->c = c; a->A0 = A0; a->b0 = b0; a->A1 = A1; a->b1 = b1; a->u = u; a->h = h; a->hpart = hpart; a->cnt = cnt;
+    a->nrb = nrb; a->nblk = 8 * nch * ((nrb + 7) / 8);
+    return 1;
+}
+
 int launch_hyper_fwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_head, const float* c, const float* A0,
                      const float* b0, const float* A1, const float* b1, float* u, float* h, float* hpart, int* cnt) {
     if (!hyper_lds_fits(R, Dt, Ht, H1)) return FUMI_ENOTSUP;
@@ -434,18 +340,15 @@ int launch_hyper_fwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_hea
     // 0 one launch per layer
     static const int hsplit = getenv("FUMI_HYPER_FWD") ? atoi(getenv("FUMI_HYPER_FWD")) : 2;
     {
-        const bool al16_ = (((uintptr_t)c | (uintptr_t)A0 | (uintptr_t)A1 | (uintptr_t)b0 | (uintptr_t)u) & 15) == 0;
-        const int nrb = (R + HB - 1) / HB, nch = Ht / 64;
-        if (hsplit == 2 && hpart && cnt && al16_ && Dt <= 768 && H1 <= 128 && nrb <= FUMI_HCNT) {
-            FwdDims d{R, Dt, Ht, H1, fwd_ldx(Dt), tanh_head};
-            const size_t lds = (size_t)HB * (d.ldx + 64 + 4) * sizeof(float);
-            const dim3 grid(8 * nch * ((nrb + 7) / 8));
+        HyperFwdArgs a;
+        if (hsplit == 2 && hyper_fwd_split_args(R, Dt, Ht, H1, tanh_head, c, A0, b0, A1, b1, u, h, hpart, cnt, &a)) {
+            const size_t lds = hyper_fwd_split_lds_bytes(a.d.ldx);
             if (Dt <= 320) {
                 FUMI_SET_DYN_LDS(hyper_fwd_split_kernel<20>, lds);
-                hipLaunchKernelGGL(hyper_fwd_split_kernel<20>, grid, dim3(256), lds, st, d, c, A0, b0, A1, b1, u, h, hpart, cnt, nrb);
+                hipLaunchKernelGGL(hyper_fwd_split_kernel<20>, dim3(a.nblk), dim3(256), lds, st, a);
             } else {
                 FUMI_SET_DYN_LDS(hyper_fwd_split_kernel<48>, lds);
-                hipLaunchKernelGGL(hyper_fwd_split_kernel<48>, grid, dim3(256), lds, st, d, c, A0, b0, A1, b1, u, h, hpart, cnt, nrb);
+                hipLaunchKernelGGL(hyper_fwd_split_kernel<48>, dim3(a.nblk), dim3(256), lds, st, a);
             }
             LAUNCH_CHECK();
             return FUMI_OK;

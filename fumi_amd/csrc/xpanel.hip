@@ -16,7 +16,9 @@
 // b is given only ids with id % 8 == b % 8: all column tiles of an episode's row panel, and the W0 slab they all stream,
 // hit one 4 MiB L2.  Placement only affects speed.
 #include "common.h"
+#include "hyper_fwd.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -329,15 +331,23 @@ __device__ __forceinline__ void xp_static_for(F&& f) {
     if constexpr (I < N) { f(WgInt<I>{}); xp_static_for<I + 1, N>(f); }
 }
 
-template <int NST>
+// RIDER: the first rider.nblk workgroups (a multiple of 8, so the XCD grouping of the rest is unchanged) run the split
+// hypernetwork forward (hyper_fwd.h) in this kernel's LDS and leave; they are dispatched first and are done in ~10 us.
+template <int NST, bool RIDER>
 __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* __restrict__ A0, float* __restrict__ G,
-                                                                int tiles_m, int tiles_n) {
+                                                                int tiles_m, int tiles_n, HyperFwdArgs rider) {
     __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][3][SPLANE];      // [buffer][operand][piece]
+    int bid = blockIdx.x;
+    if constexpr (RIDER) {
+        __shared__ int s_last;
+        if (bid < rider.nblk) { hyper_fwd_split_body<HF_RIDER_KS>(rider, bid, (float*)&lds[0][0][0][0], &s_last); return; }
+        bid -= rider.nblk;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int R = p.S + p.Qn, C = p.h0 + p.gcols, K = p.D;
     const int tiles = tiles_m * tiles_n;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xcd = bid & 7, j = bid >> 3;
     const int b = xcd + 8 * (j / tiles), t = j % tiles;
     if (b >= p.B) return;
     const int m0 = (t / tiles_n) * 64, n0 = (t % tiles_n) * 64;
@@ -656,7 +666,8 @@ unsigned long long* g_trace = nullptr;      // dev tracing only (tools/trace_xpa
 extern "C" void fumi_dbg_set_trace(void* p) { g_trace = (unsigned long long*)p; }
 
 int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
-                      const float* W0, float* A0, float* G, const XRows* rows) {
+                      const float* W0, float* A0, float* G, const XRows* rows, const HyperFwdArgs* rider, int* rider_done) {
+    if (rider_done) *rider_done = 0;
     XPanel p{x_s, x_q, W0, B, S, Qn, D, h0, nullptr, nullptr, nullptr, 0, G ? S : 0};
     if (rows && rows->table) { p.table = rows->table; p.idx_s = rows->idx_s; p.idx_q = rows->idx_q; p.n_rows = rows->n_rows; p.x_s = p.x_q = rows->table; }
     const int tiles_m = (S + Qn + 63) / 64, tiles_n = (h0 + p.gcols + 63) / 64;
@@ -669,8 +680,15 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
     static const int use_sb = getenv("FUMI_XP_SB") ? atoi(getenv("FUMI_XP_SB")) : 1;
     if (aligned && D % SBK == 0 && use_sb) {
         static const int sbn = getenv("FUMI_XP_SBN") ? atoi(getenv("FUMI_XP_SBN")) : 2;          // ring depth (tuning knob)
-        if (sbn <= 2) hipLaunchKernelGGL(xpanel_fwd_sb_kernel<2>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n);
-        else hipLaunchKernelGGL(xpanel_fwd_sb_kernel<4>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n);
+        static const int ride = getenv("FUMI_XP_RIDER") ? atoi(getenv("FUMI_XP_RIDER")) : 1;     // 0: never carry the hypernetwork forward
+        HyperFwdArgs none; memset(&none, 0, sizeof(none));
+        if (ride && rider && rider_done && rider->nblk > 0 && rider->nblk % 8 == 0 && rider->d.Dt <= 16 * HF_RIDER_KS &&
+            hyper_fwd_split_lds_bytes(rider->d.ldx) <= sizeof(unsigned short) * 2 * 2 * 3 * SPLANE && sbn <= 2) {
+            hipLaunchKernelGGL((xpanel_fwd_sb_kernel<2, true>), dim3(grid.x + rider->nblk), dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, *rider);
+            *rider_done = 1;
+        }
+        else if (sbn <= 2) hipLaunchKernelGGL((xpanel_fwd_sb_kernel<2, false>), grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, none);
+        else hipLaunchKernelGGL((xpanel_fwd_sb_kernel<4, false>), grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, none);
     } else if (aligned && D % FBK == 0) {
         if (nst == 1) hipLaunchKernelGGL(xpanel_fwd_kernel<1>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, g_trace);
         else if (nst == 2) hipLaunchKernelGGL(xpanel_fwd_kernel<2>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, g_trace);
