@@ -80,14 +80,19 @@ def flops_dominant(B):
     """xpanel_bwd: gW0 = sum_b Abar0_b^T [Xs_b;Xq_b] -> 2 (S+Qn) h0 D flops per episode."""
     c = CFG
     S, Qn = c["N"] * c["K"], c["N"] * c["Q"]
-    return 2.0 * B * (S + Qn) * c["hid"][0] * c["D"]
+    # + the hypernetwork backward that rides in the same launch (hyper_bwd.h): ubar, hp^T u, ubar^T c over the B N class rows
+    H1 = c["hid"][-1] + 1
+    rider = 2.0 * B * c["N"] * (2 * H1 * c["Ht"] + c["Ht"] * c["E"])
+    return 2.0 * B * (S + Qn) * c["hid"][0] * c["D"] + rider
 
 
 def bytes_dominant(B):
     """xpanel_bwd algorithmic HBM bytes: X and Abar0 read once, gW0 written once."""
     c = CFG
     S, Qn, h0 = c["N"] * c["K"], c["N"] * c["Q"], c["hid"][0]
-    return 4.0 * (B * (S + Qn) * c["D"] + B * (S + Qn) * h0 + h0 * c["D"])
+    H1, R = c["hid"][-1] + 1, B * c["N"]
+    rider = R * (c["E"] + c["Ht"] + 2 * H1) + H1 * c["Ht"] + (R + 15) // 16 * (c["Ht"] * c["E"] + H1 * c["Ht"])   # rows in, slabs out
+    return 4.0 * (B * (S + Qn) * c["D"] + B * (S + Qn) * h0 + h0 * c["D"] + rider)
 
 
 def flops_step_algorithmic(B):
@@ -435,7 +440,8 @@ def main():
                                "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this command, "
                                                  "committed as profiles/<round>/pmc_traffic.json (not re-measured in this run)",
                                "algorithmic_bytes": int(bytes_dominant(c["B_per_gpu"])),
-                               "kernel": "xpanel_bwd256_kernel (gW0 = sum_b Abar0_b^T [Xs_b;Xq_b]: 256 x 2048 outputs in 256 x 64 tiles, contraction over 32 x 185 rows in 16 slabs, fp32 MFMA 32x32x2)",
+                               "kernel": "xpanel_bwd256_kernel (gW0 = sum_b Abar0_b^T [Xs_b;Xq_b]: 256 x 2048 outputs in 256 x 64 tiles, contraction over 32 x 185 rows in 16 slabs, fp32 MFMA 32x32x2; "
+                                         "the launch also carries the hypernetwork backward as 40 rider workgroups, hyper_bwd.h: its 0.09 GFLOP are counted, its ~5 us stretch the launch)",
                                "avg_us": round(dur * 1e6, 2), "launches": n,
                                "timed": f"HIP events around every {prof_every}th launch of the timed region"}
             out["phase_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items()}

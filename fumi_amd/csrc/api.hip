@@ -1,6 +1,7 @@
 // C-ABI entry points (include/fumi_hip.h): workspace management and the orchestration of one meta-step.
 #include "common.h"
 #include "hyper_fwd.h"
+#include "hyper_bwd.h"
 #include <stdio.h>
 #include <string.h>
 
@@ -210,7 +211,8 @@ static int fumi_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     const bool hyper_lds = hyper_lds_fits(R, Dt, Ht, H1) != 0;         // LDS-resident hypernetwork kernels (hyper.hip)
     const size_t hpart_n = hyper_lds ? hyper_bwd_workspace_floats(R, Ht, H1) : 0;
     const size_t hfp_n = hyper_lds ? hyper_fwd_workspace_floats(R, Ht, H1) : 0;     // partial layer-1 products of the split forward
-    bytes += ws_align(hpart_n * 4) + ws_align(hfp_n * 4);
+    const size_t hbf_n = need_grad ? hyper_bwd_fused_workspace_floats(R, Dt, Ht, H1) : 0;   // row-block slabs of the fused backward
+    bytes += ws_align(hpart_n * 4) + ws_align(hfp_n * 4) + ws_align(hbf_n * 4);
     int rc = ws_reserve(ws, bytes);
     if (rc) return rc;
     float* c = ws_f(ws, (size_t)R * Dt);
@@ -221,6 +223,7 @@ static int fumi_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     float* hpb = ws_f(ws, (size_t)R * H1);
     float* hpart = hyper_lds ? ws_f(ws, hpart_n) : nullptr;
     float* hfp = hyper_lds ? ws_f(ws, hfp_n) : nullptr;
+    float* hbf = hbf_n ? ws_f(ws, hbf_n) : nullptr;
 
     // class text rows (fumi.py:207-210), then the hypernetwork (fumi.py:70-86,104-113)
     const float* ctext = cls_text;
@@ -280,6 +283,19 @@ static int fumi_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     p.head = h; p.head_bar = hbar;
     ReduceSegs fin; fin.n = 0; fin.scale = grad_scale;          // every final sum of the step (episodes, gW0 slabs, hypernet
     if (need_grad) p.defer_reduce = &fin;                       // row-block slabs) goes into ONE launch at the very end
+    // hypernetwork backward as one grid of independent workgroups (hyper_bwd.h) riding at the front of the backward X-panel
+    // launch: its slabs join the step's final reduction
+    HyperBwdArgs brider;
+    struct BwdCtx { hipStream_t st; const HyperBwdArgs* a; } bctx{st, &brider};
+    bool fused_bwd = false;
+    if (need_grad && !fork_bwd && hbf &&
+        hyper_bwd_fused_args(R, Dt, Ht, H1, tanh_head, 1.f, ctext, u, h, hbar, phi[2], hbf, g_phi[0], g_phi[1], g_phi[2], g_phi[3],
+                             &fin, &brider)) {
+        fused_bwd = true;
+        p.bwd_rider = &brider;
+        p.bwd_rider_fallback = [](void* c) -> int { BwdCtx* x = (BwdCtx*)c; return launch_hyper_bwd_fused(x->st, *x->a); };
+        p.hook_ctx2 = &bctx;
+    }
     if ((rc = run_episodes(ws, st, p))) return rc;
     if (!need_grad) return FUMI_OK;
 
@@ -287,6 +303,7 @@ static int fumi_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     sh = fork_bwd ? ws->side : st;
     if (fork_bwd) HIP_TRY(hipStreamWaitEvent(sh, ws->ev[2], 0));   // head_bar is complete (recorded after the reverse sweep)
     rc = [&]() -> int {
+    if (fused_bwd) return FUMI_OK;
     ProfScope ps(ws, sh, FUMI_PH_HYPER_BWD);
     if (hyper_lds) {
         int rc2 = launch_hyper_bwd(sh, R, Dt, Ht, H1, tanh_head, grad_scale, ctext, u, h, hbar, phi[2], ub, hpart,

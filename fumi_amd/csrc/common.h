@@ -150,9 +150,10 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
                       const float* W0, float* A0 /*[B,S+Qn,h0]*/, float* G /*[B,S+Qn,S]*/, const XRows* rows = nullptr,
                       const HyperFwdArgs* rider = nullptr, int* rider_done = nullptr /* set to 1 when the rider was launched */);
 int xpanel_bwd_nsplit(int B, int S, int Qn, int D, int h0, int* kchunk_out);
+struct HyperBwdArgs;         // hyper_bwd.h: the hypernetwork backward, able to ride at the front of the backward X-panel launch
 int launch_xpanel_bwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
                       const float* Abar /*[B,S+Qn,h0]*/, float* slabs /*[nsplit,h0,D]*/, int kchunk, int nsplit,
-                      const XRows* rows = nullptr);
+                      const XRows* rows = nullptr, const HyperBwdArgs* rider = nullptr, int* rider_done = nullptr);
 // sets FUMI_ST_LABEL_RANGE when an index is outside [0, n_rows) (the X-panel kernels clamp such an index to row 0)
 int launch_index_range_check(hipStream_t st, const int64_t* idx, long n, long n_rows, int* status);
 
@@ -184,6 +185,9 @@ struct EpisodeProblem {
     hipEvent_t inputs_ready;                    // recorded on the caller's stream BEFORE the first launch (fork point)
     const HyperFwdArgs* fwd_rider;              // not NULL: the producer of `head` as rider workgroups of xpanel_fwd (hyper_fwd.h);
     int (*fwd_rider_fallback)(void*);           // called (with hook_ctx) right after xpanel_fwd when that launch could not carry it
+    const HyperBwdArgs* bwd_rider;              // not NULL: the consumer of `head_bar` as rider workgroups of xpanel_bwd (hyper_bwd.h);
+    int (*bwd_rider_fallback)(void*);           // called (with hook_ctx2) right after xpanel_bwd when that launch could not carry it
+    void* hook_ctx2;
     int (*after_xpanel_fwd)(void*); void* hook_ctx;   // host callback right after xpanel_fwd is enqueued: the producer of `head`
                                                 // is launched there, so its host-side preparation does not delay the matrix pass
 };

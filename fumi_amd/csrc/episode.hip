@@ -1596,7 +1596,10 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
         const int ns = xpanel_bwd_nsplit(p.B, p.S, p.Qn, p.D, h0, &kc);
         const long slab = (long)h0 * p.D;
         float* slabs = ws_f(ws, (size_t)ns * slab);
-        if ((rc = launch_xpanel_bwd(st, p.B, p.S, p.Qn, p.D, h0, p.x_s, p.x_q, w.A0bar, slabs, kc, ns, p.rows.table ? &p.rows : nullptr))) return rc;
+        int rider_done = 0;
+        if ((rc = launch_xpanel_bwd(st, p.B, p.S, p.Qn, p.D, h0, p.x_s, p.x_q, w.A0bar, slabs, kc, ns, p.rows.table ? &p.rows : nullptr,
+                                    p.bwd_rider, &rider_done))) return rc;
+        if (p.bwd_rider && !rider_done && p.bwd_rider_fallback && (rc = p.bwd_rider_fallback(p.hook_ctx2))) return rc;
         if (p.defer_reduce && p.defer_reduce->n < 24 && p.defer_reduce->scale == p.grad_scale) p.defer_reduce->add(slabs, ns, slab, slab, p.gW[0]);
         else if ((rc = launch_reduce_slabs(st, slabs, ns, slab, slab, p.grad_scale, p.gW[0]))) return rc;
     }

@@ -9,7 +9,9 @@
 //   bwd0:  gA0 = scale * ubar^T c            grid (Dt/64, Ht/64)  block: 64 x 64 outputs, K = R
 // The per-row-block partial slabs of bwd1 are summed by launch_reduce_multi.
 #include "common.h"
+#include <stdlib.h>
 #include "hyper_fwd.h"
+#include "hyper_bwd.h"
 
 namespace {
 
@@ -278,6 +280,12 @@ __global__ __launch_bounds__(512) void hyper_bwd0_kernel(StageTab stg, HyperDims
     });
 }
 
+// ---- backward, one grid of independent (row block, column chunk) workgroups: hyper_bwd.h -------------------------------------
+__global__ __launch_bounds__(512) void hyper_bwd_fused_kernel(HyperBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    hyper_bwd_body(a, (int)blockIdx.x, sm);
+}
+
 }  // namespace
 
 // column chunk of a forward layer with contraction depth K: largest of 64/32/16 whose block stays under LIN_CAP floats
@@ -423,4 +431,39 @@ int launch_hyper_bwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_hea
     sg.add(pb1, nrb, H1, H1, gb1);
     sg.add(pb0, nrb, Ht, Ht, gb0);
     return &sg == &own ? launch_reduce_multi(st, own) : FUMI_OK;
+}
+
+// ---- fused backward (hyper_bwd.h) ------------------------------------------------------------------------------------------
+size_t hyper_bwd_fused_workspace_floats(int R, int Dt, int Ht, int H1) {
+    const size_t nrb = (R + HB - 1) / HB;
+    return nrb * ((size_t)H1 * Ht + H1 + Ht + (size_t)Ht * Dt) + 256;
+}
+
+int hyper_bwd_fused_args(int R, int Dt, int Ht, int H1, int tanh_head, float mscale, const float* c, const float* u, const float* h,
+                         const float* hbar, const float* A1, float* part, float* gA0, float* gb0, float* gA1, float* gb1,
+                         ReduceSegs* segs, HyperBwdArgs* a) {
+    static const int on = getenv("FUMI_HYPER_BWD") ? atoi(getenv("FUMI_HYPER_BWD")) : 1;     // 0: the two-launch form (bwd1 + bwd0)
+    if (!on || R < 1 || (Dt & 3) || (Ht & 63) || H1 < 1 || !part || !segs || segs->n + 4 > 24) return 0;
+    if ((((uintptr_t)c | (uintptr_t)u | (uintptr_t)A1 | (uintptr_t)part) & 15) != 0) return 0;
+    if ((size_t)hyper_bwd_lds_floats(Dt, H1) * 4 > 150 * 1024) return 0;
+    const int nrb = (R + HB - 1) / HB, nch = Ht / 64;
+    a->R = R; a->Dt = Dt; a->Ht = Ht; a->H1 = H1; a->tanh_head = tanh_head; a->mscale = mscale;
+    a->c = c; a->u = u; a->h = h; a->hbar = hbar; a->A1 = A1;
+    auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
+    a->pA1 = part; a->pb1 = a->pA1 + up4((size_t)nrb * H1 * Ht); a->pb0 = a->pb1 + up4((size_t)nrb * H1);
+    a->pA0 = a->pb0 + up4((size_t)nrb * Ht);
+    a->nrb = nrb; a->nblk = 8 * nch * ((nrb + 7) / 8);
+    segs->add(a->pA1, nrb, (long)H1 * Ht, (long)H1 * Ht, gA1);
+    segs->add(a->pb1, nrb, H1, H1, gb1);
+    segs->add(a->pb0, nrb, Ht, Ht, gb0);
+    segs->add(a->pA0, nrb, (long)Ht * Dt, (long)Ht * Dt, gA0);
+    return 1;
+}
+
+int launch_hyper_bwd_fused(hipStream_t st, const HyperBwdArgs& a) {
+    const size_t lds = (size_t)hyper_bwd_lds_floats(a.Dt, a.H1) * 4;
+    FUMI_SET_DYN_LDS(hyper_bwd_fused_kernel, lds);
+    hipLaunchKernelGGL(hyper_bwd_fused_kernel, dim3(a.nblk), dim3(512), lds, st, a);
+    LAUNCH_CHECK();
+    return FUMI_OK;
 }

@@ -17,6 +17,7 @@
 // hit one 4 MiB L2.  Placement only affects speed.
 #include "common.h"
 #include "hyper_fwd.h"
+#include "hyper_bwd.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -576,10 +577,17 @@ __global__ __launch_bounds__(256) void xpanel_bwd_kernel(XPanel p, const float* 
 // launch for 54.6 MB of operands.  Here a workgroup owns all 256 rows of a 64-column block, so X is streamed once and only
 // the small Abar0 panel (L2 / Infinity-Cache resident) is re-read.  8 waves as 4 (M) x 2 (N), two 32x32 accumulators each;
 // 32-deep slabs double-buffered in 80 KB of LDS (two workgroups per CU), next slab prefetched to registers.
+// RIDER: the first rider.nblk workgroups (a multiple of 8) run the hypernetwork backward (hyper_bwd.h) in this kernel's LDS.
+template <bool RIDER>
 __global__ __launch_bounds__(512) void xpanel_bwd256_kernel(XPanel p, const float* __restrict__ Abar, float* __restrict__ slabs,
-                                                            int kchunk, int nsplit, int tiles_n, int tiles_m) {
+                                                            int kchunk, int nsplit, int tiles_n, int tiles_m, HyperBwdArgs rider) {
     extern __shared__ __attribute__((aligned(16))) float lds256[];       // [2][ A: 32 x 256 | B: 32 x 64 ]
     constexpr int ASZ = 32 * 256, BSZ = 32 * 64, STG = ASZ + BSZ;
+    int bid = blockIdx.x;
+    if constexpr (RIDER) {
+        if (bid < rider.nblk) { hyper_bwd_body(rider, bid, lds256); return; }
+        bid -= rider.nblk;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int R = p.S + p.Qn, M = p.h0, Nn = p.D;
@@ -587,7 +595,7 @@ __global__ __launch_bounds__(512) void xpanel_bwd256_kernel(XPanel p, const floa
     // XCD-aware ids (workgroup ids equal mod 8 share an XCD): all tiles of contraction slab z run on XCD z % 8, so the slab's
     // rows of Abar0 (0.4-0.8 MB) stay in that XCD's L2 while its 32 column tiles stream their X pieces
     const int tiles = tiles_n * tiles_m;
-    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    const int xcd = bid & 7, jq = bid >> 3;
     const int z = xcd + 8 * (jq / tiles), tl = jq % tiles;
     if (z >= nsplit) return;
     const int m0 = (tl / tiles_n) * 256, n0 = (tl % tiles_n) * 64;
@@ -721,16 +729,29 @@ int xpanel_bwd_nsplit(int B, int S, int Qn, int D, int h0, int* kchunk_out) {
 }
 
 int launch_xpanel_bwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
-                      const float* Abar, float* slabs, int kchunk, int nsplit, const XRows* rows) {
+                      const float* Abar, float* slabs, int kchunk, int nsplit, const XRows* rows, const HyperBwdArgs* rider,
+                      int* rider_done) {
+    if (rider_done) *rider_done = 0;
     XPanel p{x_s, x_q, nullptr, B, S, Qn, D, h0, nullptr, nullptr, nullptr, 0, S};
     if (rows && rows->table) { p.table = rows->table; p.idx_s = rows->idx_s; p.idx_q = rows->idx_q; p.n_rows = rows->n_rows; p.x_s = p.x_q = rows->table; }
     const bool fast = (D % 64 == 0) && (h0 % 64 == 0) && al16(p.x_s) && al16(p.x_q) && al16(Abar);
     if (fast && xpanel_bwd_wide(D, h0)) {
         const size_t lds_bytes = 2 * (32 * 256 + 32 * 64) * sizeof(float);
-        FUMI_SET_DYN_LDS(xpanel_bwd256_kernel, lds_bytes);
         const int tn = D / 64, tm = h0 / 256;
-        hipLaunchKernelGGL(xpanel_bwd256_kernel, dim3(8 * ((nsplit + 7) / 8) * tn * tm), dim3(512), lds_bytes, st, p, Abar, slabs,
-                           kchunk, nsplit, tn, tm);
+        const unsigned nwg = 8 * ((nsplit + 7) / 8) * tn * tm;
+        static const int ride = getenv("FUMI_XP_RIDER") ? atoi(getenv("FUMI_XP_RIDER")) : 1;     // 0: never carry the hypernetwork backward
+        if (ride && rider && rider_done && rider->nblk > 0 && rider->nblk % 8 == 0 &&
+            (size_t)hyper_bwd_lds_floats(rider->Dt, rider->H1) * 4 <= lds_bytes) {
+            FUMI_SET_DYN_LDS(xpanel_bwd256_kernel<true>, lds_bytes);
+            hipLaunchKernelGGL(xpanel_bwd256_kernel<true>, dim3(nwg + rider->nblk), dim3(512), lds_bytes, st, p, Abar, slabs,
+                               kchunk, nsplit, tn, tm, *rider);
+            *rider_done = 1;
+        } else {
+            HyperBwdArgs none; memset(&none, 0, sizeof(none));
+            FUMI_SET_DYN_LDS(xpanel_bwd256_kernel<false>, lds_bytes);
+            hipLaunchKernelGGL(xpanel_bwd256_kernel<false>, dim3(nwg), dim3(512), lds_bytes, st, p, Abar, slabs,
+                               kchunk, nsplit, tn, tm, none);
+        }
         LAUNCH_CHECK();
         return FUMI_OK;
     }
