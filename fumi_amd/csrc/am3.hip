@@ -13,6 +13,9 @@
 //     the N classes, first arg-min, and the backward to every embedding in the same pass (per-wave slabs in LDS for the
 //     prototype adjoints: deterministic, no float atomics)
 #include "common.h"
+#include <stdlib.h>
+#include "hyper_fwd.h"
+#include "hyper_bwd.h"
 
 namespace {
 
@@ -401,6 +404,12 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     const size_t cpart_n = (size_t)((Rs + 127) / 128) * (size_t)(2 * ((Ht + 3) & ~3) + ((P + 3) & ~3) + 4)
                          + (size_t)((Rs + Rq + 127) / 128) * (size_t)((P + 3) & ~3) + 64;       // ColsumJobs partial sums
     if (need_grad) { A((Rs + Rq) * P); A(Rs * P); A(Rs); A(Rs * Ht); A(Rs * Ht); A((size_t)xns * P * D); A(cpart_n); A(wslab_n); }
+    // the text MLPs g (text -> Ht -> P) and h (P -> Ht -> 1) on the hypernetwork kernels (hyper_fwd.h / hyper_bwd.h): both layers of
+    // a forward in one launch, a whole backward in one launch of independent (row block, column chunk) workgroups
+    static const int mlp_fused = getenv("FUMI_AM3_MLP") ? atoi(getenv("FUMI_AM3_MLP")) : 1;      // 0: one GEMM launch per product
+    const size_t hfg_n = hyper_fwd_workspace_floats((int)Rs, Ht, P), hfh_n = hyper_fwd_workspace_floats((int)Rs, Ht, 1);
+    const size_t hbh_n = hyper_bwd_fused_workspace_floats((int)Rs, P, Ht, 1), hbg_n = hyper_bwd_fused_workspace_floats((int)Rs, 0, Ht, P);
+    if (mlp_fused) { A(hfg_n); A(hfh_n); if (need_grad) { A(hbh_n); A(hbg_n); } }
     int rc = ws_reserve(ws, bytes);
     if (rc) return rc;
     float* im = ws_f(ws, (Rs + Rq) * P);          // image embeddings, [B, S+Qn, P]: an episode's support rows, then its query rows
@@ -424,17 +433,32 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     }
     {
         ProfScope ps(ws, st, FUMI_PH_HYPER_FWD);
-        g = gemm_args((int)Rs, Ht, Dt, text_s, Dt, G0, Dt, t1, Ht); g.bias = g0; g.act = 1;
-        g.drop_thr = thr; g.drop_key = dkey(1); g.drop_scale = dsc;
-        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
-        g = gemm_args((int)Rs, P, Ht, t1, Ht, G1, Ht, tx, P); g.bias = g1;
-        if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+        HyperFwdArgs fa;
+        float* hfg = mlp_fused ? ws_f(ws, hfg_n) : nullptr;
+        float* hfh = mlp_fused ? ws_f(ws, hfh_n) : nullptr;
+        if (mlp_fused && Rs < (1 << 30) / Ht &&
+            hyper_fwd_split_args((int)Rs, Dt, Ht, P, 0, text_s, G0, g0, G1, g1, t1, tx, hfg, ws->hcnt, &fa)) {
+            fa.d.drop_thr = thr; fa.d.drop_key = dkey(1); fa.d.drop_scale = dsc;
+            if ((rc = launch_hyper_fwd_split(st, fa))) return rc;
+        } else {
+            g = gemm_args((int)Rs, Ht, Dt, text_s, Dt, G0, Dt, t1, Ht); g.bias = g0; g.act = 1;
+            g.drop_thr = thr; g.drop_key = dkey(1); g.drop_scale = dsc;
+            if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+            g = gemm_args((int)Rs, P, Ht, t1, Ht, G1, Ht, tx, P); g.bias = g1;
+            if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+        }
         if (lamda_fixed < 0) {
-            g = gemm_args((int)Rs, Ht, P, tx, P, H0, P, l1, Ht); g.bias = h0; g.act = 1;
-            g.drop_thr = thr; g.drop_key = dkey(2); g.drop_scale = dsc;
-            if ((rc = launch_gemm(st, g, 0, 0))) return rc;
-            g = gemm_args((int)Rs, 1, Ht, l1, Ht, H1, Ht, lamda_s, 1); g.bias = h1; g.act = 3;
-            if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+            if (mlp_fused && Rs < (1 << 30) / Ht &&
+                hyper_fwd_split_args((int)Rs, P, Ht, 1, 2 /* sigmoid */, tx, H0, h0, H1, h1, l1, lamda_s, hfh, ws->hcnt, &fa)) {
+                fa.d.drop_thr = thr; fa.d.drop_key = dkey(2); fa.d.drop_scale = dsc;
+                if ((rc = launch_hyper_fwd_split(st, fa))) return rc;
+            } else {
+                g = gemm_args((int)Rs, Ht, P, tx, P, H0, P, l1, Ht); g.bias = h0; g.act = 1;
+                g.drop_thr = thr; g.drop_key = dkey(2); g.drop_scale = dsc;
+                if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+                g = gemm_args((int)Rs, 1, Ht, l1, Ht, H1, Ht, lamda_s, 1); g.bias = h1; g.act = 3;
+                if ((rc = launch_gemm(st, g, 0, 0))) return rc;
+            }
         }
     }
     float *imb = nullptr, *txb = nullptr, *zlb = nullptr, *l1b = nullptr, *t1b = nullptr, *slabs = nullptr, *cpart = nullptr, *wslabs = nullptr;
@@ -490,15 +514,23 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
         wslab_next += (size_t)wns * M_ * N_;
         return FUMI_OK;
     };
+    HyperBwdArgs ba;
+    float* hbh = (mlp_fused && need_grad) ? ws_f(ws, hbh_n) : nullptr;
+    float* hbg = (mlp_fused && need_grad) ? ws_f(ws, hbg_n) : nullptr;
     if (lamda_fixed < 0) {
         // h network: lam = sigmoid(l1 H1^T + h1), l1 = relu(tx H0^T + h0)
-        if ((rc = wgrad(1, Ht, zlb, 1, l1, Ht, g_w[8]))) return rc;                    // gH1 = zlbar^T l1
-        cj.add(zlb, (int)Rs, 1, 1, g_w[9]);
-        g = gemm_args((int)Rs, Ht, 1, zlb, 1, H1, Ht, l1b, Ht);                        // l1bar = (zlbar H1) * relu'(l1) * dropout scale
-        g.mask = l1; g.alpha = dsc;
-        if ((rc = launch_gemm(st, g, 0, 1))) return rc;
-        if ((rc = wgrad(Ht, P, l1b, Ht, tx, P, g_w[6]))) return rc;                    // gH0 = l1bar^T tx
-        cj.add(l1b, (int)Rs, Ht, Ht, g_w[7]);
+        if (mlp_fused && hyper_bwd_fused_args((int)Rs, P, Ht, 1, 0, dsc, tx, l1, nullptr, zlb, H1, hbh, g_w[6], g_w[7], g_w[8], g_w[9],
+                                              &tail_, &ba, l1b)) {
+            if ((rc = launch_hyper_bwd_fused(st, ba))) return rc;                      // gH1, gh1, l1bar, gh0, gH0 (row-block slabs)
+        } else {
+            if ((rc = wgrad(1, Ht, zlb, 1, l1, Ht, g_w[8]))) return rc;                // gH1 = zlbar^T l1
+            cj.add(zlb, (int)Rs, 1, 1, g_w[9]);
+            g = gemm_args((int)Rs, Ht, 1, zlb, 1, H1, Ht, l1b, Ht);                    // l1bar = (zlbar H1) * relu'(l1) * dropout scale
+            g.mask = l1; g.alpha = dsc;
+            if ((rc = launch_gemm(st, g, 0, 1))) return rc;
+            if ((rc = wgrad(Ht, P, l1b, Ht, tx, P, g_w[6]))) return rc;                // gH0 = l1bar^T tx
+            cj.add(l1b, (int)Rs, Ht, Ht, g_w[7]);
+        }
         g = gemm_args((int)Rs, P, Ht, l1b, Ht, H0, P, txb, P); g.accumulate = 1;       // txbar += l1bar H0
         if ((rc = launch_gemm(st, g, 0, 1))) return rc;
     } else {
@@ -506,13 +538,18 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
         HIP_TRY(hipMemsetAsync(g_w[8], 0, (size_t)Ht * 4, st)); HIP_TRY(hipMemsetAsync(g_w[9], 0, 4, st));
     }
     // g network: tx = t1 G1^T + g1, t1 = relu(text G0^T + g0)
-    if ((rc = wgrad(P, Ht, txb, P, t1, Ht, g_w[4]))) return rc;                        // gG1 = txbar^T t1
-    cj.add(txb, (int)Rs, P, P, g_w[5]);
-    g = gemm_args((int)Rs, Ht, P, txb, P, G1, Ht, t1b, Ht);                            // t1bar = (txbar G1) * relu'(t1) * dropout scale
-    g.mask = t1; g.alpha = dsc;
-    if ((rc = launch_gemm(st, g, 0, 1))) return rc;
-    if ((rc = wgrad(Ht, Dt, t1b, Ht, text_s, Dt, g_w[2]))) return rc;                  // gG0 = t1bar^T text
-    cj.add(t1b, (int)Rs, Ht, Ht, g_w[3]);
+    if (mlp_fused && hyper_bwd_fused_args((int)Rs, Dt, Ht, P, 0, dsc, text_s, t1, nullptr, txb, G1, hbg, nullptr, g_w[3], g_w[4], g_w[5],
+                                          &tail_, &ba, t1b)) {
+        if ((rc = launch_hyper_bwd_fused(st, ba))) return rc;                          // gG1, gg1, t1bar, gg0 (row-block slabs)
+    } else {
+        if ((rc = wgrad(P, Ht, txb, P, t1, Ht, g_w[4]))) return rc;                    // gG1 = txbar^T t1
+        cj.add(txb, (int)Rs, P, P, g_w[5]);
+        g = gemm_args((int)Rs, Ht, P, txb, P, G1, Ht, t1b, Ht);                        // t1bar = (txbar G1) * relu'(t1) * dropout scale
+        g.mask = t1; g.alpha = dsc;
+        if ((rc = launch_gemm(st, g, 0, 1))) return rc;
+        cj.add(t1b, (int)Rs, Ht, Ht, g_w[3]);
+    }
+    if ((rc = wgrad(Ht, Dt, t1b, Ht, text_s, Dt, g_w[2]))) return rc;                  // gG0 = t1bar^T text (800 x 768: 128-row slabs)
     // image encoder: gWi = imbar_s^T Xs + imbar_q^T Xq (split over the contraction), gbi = colsum(imbar)
     {
         ProfScope pg(ws, st, FUMI_PH_XPANEL_BWD);

@@ -331,14 +331,27 @@ size_t hyper_fwd_workspace_floats(int R, int Ht, int H1) {
 
 int hyper_fwd_split_args(int R, int Dt, int Ht, int H1, int tanh_head, const float* c, const float* A0, const float* b0,
                          const float* A1, const float* b1, float* u, float* h, float* hpart, int* cnt, HyperFwdArgs* a) {
-    if (!hyper_lds_fits(R, Dt, Ht, H1)) return 0;
+    if ((Dt & 3) || (Ht & 63) || R < 1 || H1 < 1) return 0;
     const bool al16_ = (((uintptr_t)c | (uintptr_t)A0 | (uintptr_t)A1 | (uintptr_t)b0 | (uintptr_t)u) & 15) == 0;
     const int nrb = (R + HB - 1) / HB, nch = Ht / 64;
     if (!(hpart && cnt && al16_ && Dt <= 768 && H1 <= 128 && nrb <= FUMI_HCNT)) return 0;
-    a->d = FwdDims{R, Dt, Ht, H1, fwd_ldx(Dt), tanh_head};
+    a->d = FwdDims{R, Dt, Ht, H1, fwd_ldx(Dt), tanh_head, 0u, 0u, 1.f};
     a->c = c; a->A0 = A0; a->b0 = b0; a->A1 = A1; a->b1 = b1; a->u = u; a->h = h; a->hpart = hpart; a->cnt = cnt;
     a->nrb = nrb; a->nblk = 8 * nch * ((nrb + 7) / 8);
     return 1;
+}
+
+int launch_hyper_fwd_split(hipStream_t st, const HyperFwdArgs& a) {
+    const size_t lds = hyper_fwd_split_lds_bytes(a.d.ldx);
+    if (a.d.Dt <= 320) {
+        FUMI_SET_DYN_LDS(hyper_fwd_split_kernel<20>, lds);
+        hipLaunchKernelGGL(hyper_fwd_split_kernel<20>, dim3(a.nblk), dim3(256), lds, st, a);
+    } else {
+        FUMI_SET_DYN_LDS(hyper_fwd_split_kernel<48>, lds);
+        hipLaunchKernelGGL(hyper_fwd_split_kernel<48>, dim3(a.nblk), dim3(256), lds, st, a);
+    }
+    LAUNCH_CHECK();
+    return FUMI_OK;
 }
 
 int launch_hyper_fwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_head, const float* c, const float* A0,
@@ -349,18 +362,8 @@ int launch_hyper_fwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_hea
     static const int hsplit = getenv("FUMI_HYPER_FWD") ? atoi(getenv("FUMI_HYPER_FWD")) : 2;
     {
         HyperFwdArgs a;
-        if (hsplit == 2 && hyper_fwd_split_args(R, Dt, Ht, H1, tanh_head, c, A0, b0, A1, b1, u, h, hpart, cnt, &a)) {
-            const size_t lds = hyper_fwd_split_lds_bytes(a.d.ldx);
-            if (Dt <= 320) {
-                FUMI_SET_DYN_LDS(hyper_fwd_split_kernel<20>, lds);
-                hipLaunchKernelGGL(hyper_fwd_split_kernel<20>, dim3(a.nblk), dim3(256), lds, st, a);
-            } else {
-                FUMI_SET_DYN_LDS(hyper_fwd_split_kernel<48>, lds);
-                hipLaunchKernelGGL(hyper_fwd_split_kernel<48>, dim3(a.nblk), dim3(256), lds, st, a);
-            }
-            LAUNCH_CHECK();
-            return FUMI_OK;
-        }
+        if (hsplit == 2 && hyper_fwd_split_args(R, Dt, Ht, H1, tanh_head, c, A0, b0, A1, b1, u, h, hpart, cnt, &a))
+            return launch_hyper_fwd_split(st, a);
     }
     const int no_fuse = hsplit == 0;
     const bool al = (((uintptr_t)c | (uintptr_t)A0 | (uintptr_t)A1 | (uintptr_t)b0 | (uintptr_t)u) & 15) == 0;
@@ -436,27 +439,28 @@ int launch_hyper_bwd(hipStream_t st, int R, int Dt, int Ht, int H1, int tanh_hea
 // ---- fused backward (hyper_bwd.h) ------------------------------------------------------------------------------------------
 size_t hyper_bwd_fused_workspace_floats(int R, int Dt, int Ht, int H1) {
     const size_t nrb = (R + HB - 1) / HB;
-    return nrb * ((size_t)H1 * Ht + H1 + Ht + (size_t)Ht * Dt) + 256;
+    return nrb * ((size_t)H1 * Ht + H1 + Ht + (size_t)Ht * Dt) + 256;        // (Dt = 0: without the layer-0 weight slabs)
 }
 
 int hyper_bwd_fused_args(int R, int Dt, int Ht, int H1, int tanh_head, float mscale, const float* c, const float* u, const float* h,
                          const float* hbar, const float* A1, float* part, float* gA0, float* gb0, float* gA1, float* gb1,
-                         ReduceSegs* segs, HyperBwdArgs* a) {
+                         ReduceSegs* segs, HyperBwdArgs* a, float* ub_out) {
     static const int on = getenv("FUMI_HYPER_BWD") ? atoi(getenv("FUMI_HYPER_BWD")) : 1;     // 0: the two-launch form (bwd1 + bwd0)
     if (!on || R < 1 || (Dt & 3) || (Ht & 63) || H1 < 1 || !part || !segs || segs->n + 4 > 24) return 0;
-    if ((((uintptr_t)c | (uintptr_t)u | (uintptr_t)A1 | (uintptr_t)part) & 15) != 0) return 0;
+    if ((((uintptr_t)c | (uintptr_t)u | (uintptr_t)A1 | (uintptr_t)part | (uintptr_t)ub_out) & 15) != 0) return 0;
     if ((size_t)hyper_bwd_lds_floats(Dt, H1) * 4 > 150 * 1024) return 0;
     const int nrb = (R + HB - 1) / HB, nch = Ht / 64;
     a->R = R; a->Dt = Dt; a->Ht = Ht; a->H1 = H1; a->tanh_head = tanh_head; a->mscale = mscale;
     a->c = c; a->u = u; a->h = h; a->hbar = hbar; a->A1 = A1;
     auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
     a->pA1 = part; a->pb1 = a->pA1 + up4((size_t)nrb * H1 * Ht); a->pb0 = a->pb1 + up4((size_t)nrb * H1);
-    a->pA0 = a->pb0 + up4((size_t)nrb * Ht);
+    a->pA0 = gA0 ? a->pb0 + up4((size_t)nrb * Ht) : nullptr;
+    a->ub_out = ub_out;
     a->nrb = nrb; a->nblk = 8 * nch * ((nrb + 7) / 8);
     segs->add(a->pA1, nrb, (long)H1 * Ht, (long)H1 * Ht, gA1);
     segs->add(a->pb1, nrb, H1, H1, gb1);
     segs->add(a->pb0, nrb, Ht, Ht, gb0);
-    segs->add(a->pA0, nrb, (long)Ht * Dt, (long)Ht * Dt, gA0);
+    if (gA0) segs->add(a->pA0, nrb, (long)Ht * Dt, (long)Ht * Dt, gA0);
     return 1;
 }
 

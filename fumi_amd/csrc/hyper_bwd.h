@@ -20,7 +20,8 @@ struct HyperBwdArgs {
     int R, Dt, Ht, H1, tanh_head;
     float mscale;                          // factor of the ReLU derivative (1, or 1/(1-p) with dropout after the ReLU)
     const float *c, *u, *h, *hbar, *A1;    // rows [R,Dt]; hidden activations [R,Ht]; output [R,H1]; its adjoint; layer 1 [H1,Ht]
-    float *pA1, *pb1, *pb0, *pA0;          // slabs: [nrb,H1,Ht] [nrb,H1] [nrb,Ht] [nrb,Ht,Dt]
+    float *pA1, *pb1, *pb0, *pA0;          // slabs: [nrb,H1,Ht] [nrb,H1] [nrb,Ht] [nrb,Ht,Dt] (pA0 NULL: layer-0 weight gradient not formed)
+    float* ub_out;                         // optional [R,Ht]: ubar to memory (callers that need ubar A0 or form ubar^T c themselves)
     int nrb, nblk;                         // row blocks; workgroups = 8 * (Ht/64) * ceil(nrb/8)
 };
 __host__ __device__ inline int hyper_bwd_lds_floats(int Dt, int H1) {
@@ -69,7 +70,7 @@ __device__ __forceinline__ void hyper_bwd_body(const HyperBwdArgs& a, int bid, f
     }
     {
         const int d4 = Dt >> 2, n4 = nr * d4;
-        for (int i0 = tid; i0 < n4; i0 += 4 * nt) {
+        for (int i0 = tid; a.pA0 && i0 < n4; i0 += 4 * nt) {
             f32x4 v[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
@@ -92,6 +93,7 @@ __device__ __forceinline__ void hyper_bwd_body(const HyperBwdArgs& a, int bid, f
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = uv[e] > 0.f ? acc[e] * a.mscale : 0.f;
         *(f32x4*)(ubc + m * ldc + n) = v;
+        if (a.ub_out) *(f32x4*)(a.ub_out + (long)(m0 + m) * Ht + cb * 64 + n) = v;
     });
     // ---- layer-1 weight slab of this chunk, bias slabs
     float* pA = a.pA1 + (long)rb * H1 * Ht + cb * 64;
@@ -102,6 +104,7 @@ __device__ __forceinline__ void hyper_bwd_body(const HyperBwdArgs& a, int bid, f
     wg_lds_barrier();
     wg_lcolsum(nr, 64, ubc, ldc, [&](int n, float s_) { a.pb0[(long)rb * Ht + cb * 64 + n] = s_; });
     // ---- layer-0 weight slab: rows of this chunk, every input column
+    if (!a.pA0) return;
     float* p0 = a.pA0 + ((long)rb * Ht + cb * 64) * Dt;
     wg_lmm_wide<false>(64, Dt, HBW_HB, ubc, ldc, cr, ldd, [&](int m, int n, const f32x4& acc, int cnt, auto) {
         wg_st4(p0 + (long)m * Dt + n, acc, cnt);
@@ -111,7 +114,8 @@ __device__ __forceinline__ void hyper_bwd_body(const HyperBwdArgs& a, int bid, f
 size_t hyper_bwd_fused_workspace_floats(int R, int Dt, int Ht, int H1);
 // fills `a` (slabs carved from `part`, >= hyper_bwd_fused_workspace_floats floats) and appends the final sums to `segs`
 // (which must have room for 4 more and carry the gradient scale); 0 when the shapes do not fit this form
+// gA0 == NULL: no layer-0 weight slabs (ub_out is then the caller's input for that product)
 int hyper_bwd_fused_args(int R, int Dt, int Ht, int H1, int tanh_head, float mscale, const float* c, const float* u, const float* h,
                          const float* hbar, const float* A1, float* part, float* gA0, float* gb0, float* gA1, float* gb1,
-                         struct ReduceSegs* segs, HyperBwdArgs* a);
+                         struct ReduceSegs* segs, HyperBwdArgs* a, float* ub_out = nullptr);
 int launch_hyper_bwd_fused(hipStream_t st, const HyperBwdArgs& a);

@@ -10,7 +10,12 @@
 
 constexpr int HF_HB = 16;                  // rows per block
 constexpr int HF_FCH = 12;                 // 16-deep steps per chunk of weight-fragment loads (LDS row padding unit)
-struct FwdDims { int R, Dt, Ht, H1, ldx, tanh_head; };
+struct FwdDims {
+    int R, Dt, Ht, H1, ldx;
+    int tanh_head;                         // output activation: 0 none, 1 tanh (FuMI's --tanh_head), 2 sigmoid (AM3's lamda network)
+    unsigned drop_thr, drop_key;           // dropout after the ReLU (AM3 g / h, am3.py:80-88): keep iff mix(key ^ element index) >= thr
+    float drop_scale;
+};
 __host__ __device__ inline int fwd_ldx(int Dt) { return (Dt + HF_FCH * 16 - 1) / (HF_FCH * 16) * (HF_FCH * 16) + 4; }
 
 struct HyperFwdArgs {
@@ -93,6 +98,14 @@ __device__ __forceinline__ void hyper_fwd_split_body(const HyperFwdArgs& a, int 
         f32x4 v = acc + bias0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        if (d.drop_thr) {                  // the same counter-based mask as gemm.hip's epilogue: element index = row * Ht + column
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned x = d.drop_key ^ (unsigned)((long)(m0 + r) * Ht + n0 + 4 * q + e);
+                x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+                v[e] = x >= d.drop_thr ? v[e] * d.drop_scale : 0.f;
+            }
+        }
         *(f32x4*)(us + r * ldu + wave * 16 + 4 * q) = v;
         if (r < nr) *(f32x4*)(a.u + (long)(m0 + r) * Ht + n0 + 4 * q) = v;
     }
@@ -128,10 +141,11 @@ __device__ __forceinline__ void hyper_fwd_split_body(const HyperFwdArgs& a, int 
         const int m = i / H1, n = i - m * H1;
         float v = a.b1[n];
         for (int cc = 0; cc < nch; ++cc) v += __hip_atomic_load(all + (long)cc * HF_HB * H1 + m * H1 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.h[(long)(m0 + m) * H1 + n] = d.tanh_head ? tanhf(v) : v;
+        a.h[(long)(m0 + m) * H1 + n] = d.tanh_head == 1 ? tanhf(v) : d.tanh_head == 2 ? 1.f / (1.f + expf(-v)) : v;
     }
 }
 
 // fills `a` when the split forward applies to these shapes / pointers (hyper.hip); 0 otherwise
 int hyper_fwd_split_args(int R, int Dt, int Ht, int H1, int tanh_head, const float* c, const float* A0, const float* b0,
                          const float* A1, const float* b1, float* u, float* h, float* hpart, int* cnt, HyperFwdArgs* a);
+int launch_hyper_fwd_split(hipStream_t st, const HyperFwdArgs& a);     // the same forward as its own launch
