@@ -410,6 +410,8 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
     const size_t hfg_n = hyper_fwd_workspace_floats((int)Rs, Ht, P), hfh_n = hyper_fwd_workspace_floats((int)Rs, Ht, 1);
     const size_t hbh_n = hyper_bwd_fused_workspace_floats((int)Rs, P, Ht, 1), hbg_n = hyper_bwd_fused_workspace_floats((int)Rs, 0, Ht, P);
     if (mlp_fused) { A(hfg_n); A(hfh_n); if (need_grad) { A(hbh_n); A(hbg_n); } }
+    const int xks = xpanel_fwd_ksplit(B, S, Qn, D, P, 0);              // contraction parts of the image-encoder pass (narrow output)
+    if (xks > 1) A((size_t)xks * (Rs + Rq) * P);
     int rc = ws_reserve(ws, bytes);
     if (rc) return rc;
     float* im = ws_f(ws, (Rs + Rq) * P);          // image embeddings, [B, S+Qn, P]: an episode's support rows, then its query rows
@@ -429,7 +431,8 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
         // image encoder on every support and query row in ONE pass of the X-panel kernel (xpanel.hip: the panel [Xs_b;Xq_b]
         // times Wi^T per episode, rows never copied; G = NULL: no Gram block).  The bias is added where the head reads.
         ProfScope ps(ws, st, FUMI_PH_XPANEL_FWD);
-        if ((rc = launch_xpanel_fwd(st, B, S, Qn, D, P, x_s, x_q, Wi, im, nullptr))) return rc;
+        float* xparts = xks > 1 ? ws_f(ws, (size_t)xks * (Rs + Rq) * P) : nullptr;
+        if ((rc = launch_xpanel_fwd(st, B, S, Qn, D, P, x_s, x_q, Wi, im, nullptr, nullptr, nullptr, nullptr, xparts))) return rc;
     }
     {
         ProfScope ps(ws, st, FUMI_PH_HYPER_FWD);

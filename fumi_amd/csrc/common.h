@@ -148,7 +148,9 @@ struct XRows { const float* table; const int64_t* idx_s; const int64_t* idx_q; l
 struct HyperFwdArgs;         // hyper_fwd.h: a split hypernetwork forward that can ride at the front of the forward X-panel launch
 int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
                       const float* W0, float* A0 /*[B,S+Qn,h0]*/, float* G /*[B,S+Qn,S]*/, const XRows* rows = nullptr,
-                      const HyperFwdArgs* rider = nullptr, int* rider_done = nullptr /* set to 1 when the rider was launched */);
+                      const HyperFwdArgs* rider = nullptr, int* rider_done = nullptr /* set to 1 when the rider was launched */,
+                      float* parts = nullptr /* [xpanel_fwd_ksplit(), B, S+Qn, h0] partial products of a split contraction */);
+int xpanel_fwd_ksplit(int B, int S, int Qn, int D, int h0, int with_gram);
 int xpanel_bwd_nsplit(int B, int S, int Qn, int D, int h0, int* kchunk_out);
 struct HyperBwdArgs;         // hyper_bwd.h: the hypernetwork backward, able to ride at the front of the backward X-panel launch
 int launch_xpanel_bwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,

@@ -34,6 +34,8 @@ struct XPanel {
     // instead of x_s[b,r] / x_q[b,r-S] -- the meta-batch is never materialised
     const float* table; const int64_t* idx_s; const int64_t* idx_q; long n_rows;
     int gcols;              // Gram columns computed: S (FuMI / MAML), or 0 when the caller passed G = NULL (AM3's image encoder)
+    int ksplit;             // split-bf16 forward only: the contraction is cut into ksplit parts (one workgroup each); part z writes its
+    long part_stride;       // partial product to A0 + z * part_stride (narrow outputs: too few tiles to fill the chip otherwise)
 };
 
 __device__ __forceinline__ const float* xrow(const XPanel& p, int b, int r) {
@@ -349,13 +351,15 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* 
     const int R = p.S + p.Qn, C = p.h0 + p.gcols, K = p.D;
     const int tiles = tiles_m * tiles_n;
     const int xcd = bid & 7, j = bid >> 3;
-    const int b = xcd + 8 * (j / tiles), t = j % tiles;
+    const int ks = p.ksplit, per = tiles * ks;
+    const int b = xcd + 8 * (j / per), tz = j % per, kz = tz / tiles, t = tz - kz * tiles;
     if (b >= p.B) return;
     const int m0 = (t / tiles_n) * 64, n0 = (t % tiles_n) * 64;
+    const int kbeg = kz * (K / ks);             // this part's first contraction column
 
     // staging map: float4 f = tid + 256 i  ->  tile row (f >> 3), k offset (f & 7) * 4
     const float* arow[2]; const float* brow[2]; bool aok[2], bok[2];
-    const int k4 = (tid & 7) << 2;
+    const int k4 = ((tid & 7) << 2) + kbeg;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int rr = (tid >> 3) + 32 * i;
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int nslab = K / SBK;
+    const int nslab = K / ks / SBK;
 
     auto gload = [&](auto sc, int k0) {
         constexpr int ST = decltype(sc)::value;
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* 
         constexpr int ST = decltype(sc)::value;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int off = ((tid >> 3) + 32 * i) * SROW + k4;
+            const int off = ((tid >> 3) + 32 * i) * SROW + ((tid & 7) << 2);
             // no masking: a row past the panel (read from a clamped, valid address) only feeds outputs that are never stored
             u32x2 h, m, l;
             split3(ga[ST][i], h, m, l);
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                      // float4 q of the staged slab: A0, A1, B0, B1
             const f32x4 v = q < 2 ? ga[ST][q] : gb[ST][q - 2];
-            const int off = ((tid >> 3) + 32 * (q & 1)) * SROW + k4;
+            const int off = ((tid >> 3) + 32 * (q & 1)) * SROW + ((tid & 7) << 2);
             unsigned hp[2], mp[2], lp[2];
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* 
     const int n = n0 + wn * 32 + li;
     if (n < C) {
         float* base; long ld; int col;
-        if (n < p.h0) { base = A0 + (long)b * R * p.h0; ld = p.h0; col = n; }
+        if (n < p.h0) { base = A0 + kz * p.part_stride + (long)b * R * p.h0; ld = p.h0; col = n; }
         else          { base = G + (long)b * R * p.S;  ld = p.S;  col = n - p.h0; }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -673,19 +677,37 @@ unsigned long long* g_trace = nullptr;      // dev tracing only (tools/trace_xpa
 
 extern "C" void fumi_dbg_set_trace(void* p) { g_trace = (unsigned long long*)p; }
 
+// contraction parts of the split-bf16 forward: 1 unless the output is narrow (no Gram block, few column tiles) and the tile count
+// would leave most of the chip idle -- AM3's image encoder (P = 64 columns: 96 workgroups for 256 CUs, 46 us for a pass that
+// is HBM-bound at 8 us).  The caller then passes `parts` ([ks, B, S+Qn, h0] floats) and the launch ends with their sum.
+int xpanel_fwd_ksplit(int B, int S, int Qn, int D, int h0, int with_gram) {
+    static const int off = getenv("FUMI_XP_KSPLIT") ? atoi(getenv("FUMI_XP_KSPLIT")) : -1;    // 1: never split, n: force n parts
+    if (with_gram || D % SBK) return 1;
+    const long wgs = 8L * ((B + 7) / 8) * ((S + Qn + 63) / 64) * ((h0 + 63) / 64);
+    int ks = 1;
+    if (off > 0) ks = off;
+    else while (ks < 8 && wgs * ks < 384 && D % (2 * ks * SBK) == 0 && D / (2 * ks) >= 8 * SBK) ks *= 2;
+    while (ks > 1 && (D % (ks * SBK) != 0)) ks >>= 1;
+    return ks;
+}
+
 int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
-                      const float* W0, float* A0, float* G, const XRows* rows, const HyperFwdArgs* rider, int* rider_done) {
+                      const float* W0, float* A0, float* G, const XRows* rows, const HyperFwdArgs* rider, int* rider_done,
+                      float* parts) {
     if (rider_done) *rider_done = 0;
-    XPanel p{x_s, x_q, W0, B, S, Qn, D, h0, nullptr, nullptr, nullptr, 0, G ? S : 0};
+    float* const A0_final = A0;
+    XPanel p{x_s, x_q, W0, B, S, Qn, D, h0, nullptr, nullptr, nullptr, 0, G ? S : 0, 1, 0};
     if (rows && rows->table) { p.table = rows->table; p.idx_s = rows->idx_s; p.idx_q = rows->idx_q; p.n_rows = rows->n_rows; p.x_s = p.x_q = rows->table; }
     const int tiles_m = (S + Qn + 63) / 64, tiles_n = (h0 + p.gcols + 63) / 64;
     const int nper = (B + 7) / 8;
     const bool aligned = al16(p.x_s) && al16(p.x_q) && al16(W0);
-    const dim3 grid(8 * nper * tiles_m * tiles_n);
+    static const int use_sb = getenv("FUMI_XP_SB") ? atoi(getenv("FUMI_XP_SB")) : 1;
+    const int ks = xpanel_fwd_ksplit(B, S, Qn, D, h0, G != nullptr);
+    if (ks > 1 && parts && aligned && D % SBK == 0 && use_sb) { p.ksplit = ks; p.part_stride = (long)B * (S + Qn) * h0; A0 = parts; }
+    const dim3 grid(8 * nper * tiles_m * tiles_n * p.ksplit);
     static const int nst = getenv("FUMI_XP_NST") ? atoi(getenv("FUMI_XP_NST")) : 2;      // staging ring depth (tuning knob)
     // Default: the split-bf16 kernel (65 us at the bench shapes, error against fp64 below the fp32 MFMA kernel's: DESIGN.md).
     // FUMI_XP_SB=0 selects the fp32 MFMA kernel (78 us).
-    static const int use_sb = getenv("FUMI_XP_SB") ? atoi(getenv("FUMI_XP_SB")) : 1;
     if (aligned && D % SBK == 0 && use_sb) {
         static const int sbn = getenv("FUMI_XP_SBN") ? atoi(getenv("FUMI_XP_SBN")) : 2;          // ring depth (tuning knob)
         static const int ride = getenv("FUMI_XP_RIDER") ? atoi(getenv("FUMI_XP_RIDER")) : 1;     // 0: never carry the hypernetwork forward
@@ -705,6 +727,7 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
     else if (aligned && D % BK == 0) hipLaunchKernelGGL(xpanel_fwd_generic_kernel<true>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, 0);
     else hipLaunchKernelGGL(xpanel_fwd_generic_kernel<false>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, 0);
     LAUNCH_CHECK();
+    if (p.ksplit > 1) return launch_reduce_slabs(st, parts, p.ksplit, p.part_stride, p.part_stride, 1.f, A0_final);
     return FUMI_OK;
 }
 
