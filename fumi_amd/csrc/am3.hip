@@ -361,12 +361,14 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
 
 }  // namespace
 
-extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
+// dx_s [B,S,D] / dx_q [B,Qn,D] (optional, need_grad): adjoints of the image rows, imbar Wi -- what an image encoder in front of
+// this step (the Conv4 backbone, fumi_hip_conv4_encode_bwd) continues from
+static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
         int B, int N, int S, int Qn, int D, int Dt, int Ht, int P, int lamda_fixed, int need_grad, float grad_scale,
         float dropout_p, uint64_t seed,
         const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q, const float* text_s,
         const float* const* w, float* loss, int64_t* preds_q, float* lamda_s, float* correct, float* const* g_w,
-        float* stats) {
+        float* stats, float* dx_s, float* dx_q) {
     if (!ws || !x_s || !y_s || !x_q || !y_q || !text_s || !w || !loss || !preds_q || !lamda_s || !correct) return FUMI_EINVAL;
     if (B < 1 || N < 1 || S < 1 || Qn < 1 || D < 1 || Dt < 1 || Ht < 1 || P < 1 || lamda_fixed < -1 || lamda_fixed > 1) return FUMI_EINVAL;
     for (int i = 0; i < 10; ++i) if (!w[i] || (need_grad && (!g_w || !g_w[i]))) return FUMI_EINVAL;
@@ -500,6 +502,12 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
         if ((rc = launch_reduce_multi(st, fin))) return rc;
     }
     if (!need_grad) return FUMI_OK;
+    if (dx_s && dx_q) {                     // one batched product per side: rows of episode b sit at imbar + b (S+Qn) P
+        g = gemm_args(S, D, P, imb, P, Wi, D, dx_s, D); g.nbatch = B; g.sA = imst; g.sC = (long)S * D;
+        if ((rc = launch_gemm(st, g, 0, 1))) return rc;
+        g = gemm_args(Qn, D, P, imb + (long)S * P, P, Wi, D, dx_q, D); g.nbatch = B; g.sA = imst; g.sC = (long)Qn * D;
+        if ((rc = launch_gemm(st, g, 0, 1))) return rc;
+    }
 
     ProfScope pb(ws, st, FUMI_PH_HYPER_BWD);
     ColsumJobs cj; cj.n = 0; cj.part_total = 0;
@@ -564,6 +572,27 @@ extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
         if ((rc = launch_colsum_multi(st, cj, cpart, &tail_))) return rc;
     }
     return FUMI_OK;
+}
+
+extern "C" int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int D, int Dt, int Ht, int P, int lamda_fixed, int need_grad, float grad_scale,
+        float dropout_p, uint64_t seed,
+        const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q, const float* text_s,
+        const float* const* w, float* loss, int64_t* preds_q, float* lamda_s, float* correct, float* const* g_w,
+        float* stats) {
+    return am3_step_impl(ws, stream, B, N, S, Qn, D, Dt, Ht, P, lamda_fixed, need_grad, grad_scale, dropout_p, seed, x_s, y_s, x_q, y_q,
+                         text_s, w, loss, preds_q, lamda_s, correct, g_w, stats, nullptr, nullptr);
+}
+
+extern "C" int fumi_hip_am3_step_dx(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int D, int Dt, int Ht, int P, int lamda_fixed, int need_grad, float grad_scale,
+        float dropout_p, uint64_t seed,
+        const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q, const float* text_s,
+        const float* const* w, float* loss, int64_t* preds_q, float* lamda_s, float* correct, float* const* g_w,
+        float* stats, float* dx_s, float* dx_q) {
+    if (need_grad && (!dx_s || !dx_q)) return FUMI_EINVAL;
+    return am3_step_impl(ws, stream, B, N, S, Qn, D, Dt, Ht, P, lamda_fixed, need_grad, grad_scale, dropout_p, seed, x_s, y_s, x_q, y_q,
+                         text_s, w, loss, preds_q, lamda_s, correct, g_w, stats, dx_s, dx_q);
 }
 
 // ---- accuracy and macro precision / recall / F1 from the confusion matrix (what the reference asks sklearn for on the host

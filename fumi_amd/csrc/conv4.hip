@@ -200,10 +200,12 @@ static int forward_pass(StepCtx& c, int M, const float* img, const float* params
 static int backward_pass(StepCtx& c, int M, const float* img, const float* frags, PassBufs& pb, const float* head,
                          float* G, float* dh) {
     const Net& n = c.n;
-    HeadGradArgs hg; memset(&hg, 0, sizeof(hg));
-    hg.B = n.B; hg.M = M; hg.N = n.N; hg.F = n.F; hg.nsrc = 1; hg.dz[0] = pb.dz; hg.f[0] = pb.x[n.nblk - 1]; hg.head[0] = head;
-    hg.dh = dh; hg.df = pb.dx[n.nblk - 1];
-    TRYP(FUMI_PH_CONV_EW, launch_head_grad(c.st, hg));
+    if (head) {                             // (head == NULL: the caller put the feature adjoints into pb.dx[last] itself)
+        HeadGradArgs hg; memset(&hg, 0, sizeof(hg));
+        hg.B = n.B; hg.M = M; hg.N = n.N; hg.F = n.F; hg.nsrc = 1; hg.dz[0] = pb.dz; hg.f[0] = pb.x[n.nblk - 1]; hg.head[0] = head;
+        hg.dh = dh; hg.df = pb.dx[n.nblk - 1];
+        TRYP(FUMI_PH_CONV_EW, launch_head_grad(c.st, hg));
+    }
     for (int l = n.nblk - 1; l >= 0; --l) {
         const EwGeom e = ew_geom(n, M, l);
         const long npix = (long)M * n.g[l].Pp;
@@ -702,6 +704,90 @@ int fumi_hip_conv4_features(fumi_ws_t* ws, fumi_stream_t stream, int G, int M, i
     TRY(frags_of_slot(st, n, params, frags, tmp1));
     TRY(forward_pass(c, M, x, params, frags, pb, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr));
     HIP_TRY(hipMemcpyAsync(feats, pb.x[n.nblk - 1], (size_t)G * M * n.F * 4, hipMemcpyDeviceToDevice, st));
+    return FUMI_OK;
+}
+
+// ---- Conv4 as the image encoder in front of a step that owns its own workspace (AM3): forward with the tape kept, backward from
+// the feature adjoints.  Every episode's support set and query set is one batch-statistics group, as in the meta-steps above.
+// The two calls share the tape through `ws`: encode(keep_tape = 1) lays the activations out in the workspace, encode_bwd carves
+// the identical layout again (same arguments) and walks it backwards -- so `ws` must not serve any other call in between (give the
+// encoder a workspace of its own: fumi_hip_workspace_create).  A token records what was laid out; a mismatch is FUMI_EINVAL.
+namespace {
+struct EncodeToken { bool valid; fumi_ws* ws; char* base; int B, S, Qn, Cin, H, W, nblk; };
+EncodeToken g_enc = {false, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
+struct EncodeBufs { PassBufs ps, pq; float *params, *frags, *tmp1, *toi_tmp, *Gs, *Gq, *gsum; };
+
+size_t encode_bytes(const Net& n, int S, int Qn, Scratch& sc) {
+    size_t b = conv4_scratch_sizes(n, S, Qn, sc) + pass_bytes(n, S, true) + pass_bytes(n, Qn, true);
+    b += 3 * ws_align((size_t)n.B * n.PSZ * 4) + ws_align((size_t)n.B * n.FSZ * 4) + ws_align((size_t)n.B * (2048 + 4096) * 4) +
+         ws_align((size_t)n.nblk * 36864 * 4) + ws_align((size_t)n.PSZ * 4);
+    return b;
+}
+void encode_carve(fumi_ws* ws, StepCtx& c, int S, int Qn, EncodeBufs& e) {
+    const Net& n = c.n;
+    c.sc.cpart = ws_f(ws, c.sc.cpart_n); c.sc.wpart = ws_f(ws, c.sc.wpart_n); c.sc.rpart = ws_f(ws, c.sc.rpart_n);
+    c.sc.dsum = (double*)ws_f(ws, c.sc.dsum_n * 2); c.sc.rowl = ws_f(ws, c.sc.rowl_n);
+    pass_carve(ws, n, S, true, e.ps); pass_carve(ws, n, Qn, true, e.pq);
+    e.params = ws_f(ws, (size_t)n.B * n.PSZ);
+    e.Gs = ws_f(ws, 2 * (size_t)n.B * n.PSZ); e.Gq = e.Gs + (size_t)n.B * n.PSZ;     // adjacent: summed as 2 B slabs
+    e.frags = ws_f(ws, (size_t)n.B * n.FSZ);
+    e.tmp1 = ws_f(ws, (size_t)n.B * (2048 + 4096)); e.toi_tmp = ws_f(ws, (size_t)n.nblk * 36864); e.gsum = ws_f(ws, (size_t)n.PSZ);
+}
+}  // namespace
+
+int fumi_hip_conv4_encode(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int Qn, int Cin, int H, int W, int nblk,
+        const float* x_s, const float* x_q, const float* const* theta, float* feats_s, float* feats_q, int keep_tape) {
+    if (!ws || !x_s || !x_q || !theta || !feats_s || !feats_q || B < 1 || S < 1 || Qn < 1) return FUMI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ws->device));
+    StepCtx c; c.ws = ws; c.st = st;
+    int rc = net_init(c.n, B, nblk, Cin, 1, H, W);
+    if (rc) return rc;
+    const Net& n = c.n;
+    for (int i = 0; i < 3 * nblk; ++i) if (!theta[i]) return FUMI_EINVAL;
+    g_enc.valid = false; g_probe.valid = false;
+    if ((rc = ws_reserve(ws, encode_bytes(n, S, Qn, c.sc)))) return rc;
+    EncodeBufs e; encode_carve(ws, c, S, Qn, e);
+    TRY(slot0_from_theta(st, n, theta, e.params, e.toi_tmp));
+    TRY(frags_of_slot(st, n, e.params, e.frags, e.tmp1));
+    TRY(forward_pass(c, S, x_s, e.params, e.frags, e.ps, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr));
+    TRY(forward_pass(c, Qn, x_q, e.params, e.frags, e.pq, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr));
+    HIP_TRY(hipMemcpyAsync(feats_s, e.ps.x[n.nblk - 1], (size_t)B * S * n.F * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(feats_q, e.pq.x[n.nblk - 1], (size_t)B * Qn * n.F * 4, hipMemcpyDeviceToDevice, st));
+    if (keep_tape) g_enc = EncodeToken{true, ws, ws->base, B, S, Qn, Cin, H, W, nblk};
+    return FUMI_OK;
+}
+
+// g_theta (3 nblk pointers, torch layouts) = scale * d/dtheta of sum over images <dfeats, feats>, summed over the episodes
+int fumi_hip_conv4_encode_bwd(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int Qn, int Cin, int H, int W, int nblk,
+        const float* x_s, const float* x_q, const float* dfeats_s, const float* dfeats_q, float scale, float* const* g_theta) {
+    if (!ws || !x_s || !x_q || !dfeats_s || !dfeats_q || !g_theta) return FUMI_EINVAL;
+    const EncodeToken& t = g_enc;
+    if (!t.valid || t.ws != ws || t.base != ws->base || t.B != B || t.S != S || t.Qn != Qn || t.Cin != Cin || t.H != H || t.W != W ||
+        t.nblk != nblk) return FUMI_EINVAL;                       // no tape of this shape in this workspace
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ws->device));
+    StepCtx c; c.ws = ws; c.st = st;
+    int rc = net_init(c.n, B, nblk, Cin, 1, H, W);
+    if (rc) return rc;
+    const Net& n = c.n;
+    for (int i = 0; i < 3 * nblk; ++i) if (!g_theta[i]) return FUMI_EINVAL;
+    g_enc.valid = false;                                           // the backward pass overwrites parts of the tape
+    if ((rc = ws_reserve(ws, encode_bytes(n, S, Qn, c.sc)))) return rc;
+    if (ws->base != t.base) return FUMI_EINVAL;
+    EncodeBufs e; encode_carve(ws, c, S, Qn, e);
+    HIP_TRY(hipMemcpyAsync(e.ps.dx[n.nblk - 1], dfeats_s, (size_t)B * S * n.F * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(e.pq.dx[n.nblk - 1], dfeats_q, (size_t)B * Qn * n.F * 4, hipMemcpyDeviceToDevice, st));
+    TRY(backward_pass(c, S, x_s, e.frags, e.ps, nullptr, e.Gs, nullptr));
+    TRY(backward_pass(c, Qn, x_q, e.frags, e.pq, nullptr, e.Gq, nullptr));
+    // Gs and Gq are adjacent [B][PSZ] slabs: one sum over 2 B parameter slabs
+    TRY(launch_reduce_batched(st, 1, 2 * n.B, n.PSZ, e.Gs, scale, e.gsum, 0));
+    TRY(launch_w1_from_canon(st, n.Cin, e.gsum + n.offW[0], g_theta[0], 1.f));
+    for (int l = 0; l < n.nblk; ++l) {
+        if (l) TRY(launch_toi_to_oihw(st, 1, e.gsum + n.offW[l], g_theta[3 * l], 1.f));
+        HIP_TRY(hipMemcpyAsync(g_theta[3 * l + 1], e.gsum + n.offG[l], 64 * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(g_theta[3 * l + 2], e.gsum + n.offB[l], 64 * 4, hipMemcpyDeviceToDevice, st));
+    }
     return FUMI_OK;
 }
 

@@ -36,9 +36,17 @@ class HipEngine:
                              grad_scale=grad_scale, g_params=g_params, stats=stats)
 
     def am3_step(self, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad, grad_scale, g_w=None,
-                 dropout_p=0.0, seed=0, stats=None):
+                 dropout_p=0.0, seed=0, stats=None, want_dx=False):
         return hip.am3_step(self._ws(x_s), x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad=need_grad,
-                            grad_scale=grad_scale, g_w=g_w, dropout_p=dropout_p, seed=seed, stats=stats)
+                            grad_scale=grad_scale, g_w=g_w, dropout_p=dropout_p, seed=seed, stats=stats, want_dx=want_dx)
+
+    def conv4_encode(self, x_s, x_q, theta, keep_tape=False):
+        """Conv4 in front of a step with its own workspace (AM3): the tape lives in the device's "encoder" workspace."""
+        return hip.conv4_encode(hip.Workspace.get(x_s.device, "encoder"), x_s, x_q, theta, keep_tape=keep_tape)
+
+    def conv4_encode_bwd(self, x_s, x_q, dfeats_s, dfeats_q, theta_like, scale=1.0, g_theta=None):
+        return hip.conv4_encode_bwd(hip.Workspace.get(x_s.device, "encoder"), x_s, x_q, dfeats_s, dfeats_q, theta_like,
+                                    scale=scale, g_theta=g_theta)
 
     def fumi_conv4_step(self, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head, need_grad, grad_scale,
                         g_theta=None, g_phi=None, cls_text=None, stats=None):

@@ -26,6 +26,7 @@ SYMBOLS = [
     "fumi_hip_sample_episodes", "fumi_hip_sample_episodes_tm", "fumi_hip_gather_rows", "fumi_hip_publish_scalars",
     "fumi_hip_publish_scalars_deferred", "fumi_hip_publish_flush", "fumi_hip_am3_metrics",
     "fumi_hip_conv4_feature_dim", "fumi_hip_fumi_conv4_step", "fumi_hip_maml_conv4_step", "fumi_hip_conv4_probe", "fumi_hip_conv4_features", "fumi_hip_conv4_set_option",
+    "fumi_hip_conv4_encode", "fumi_hip_conv4_encode_bwd", "fumi_hip_am3_step_dx",
     "fumi_hip_conv3x3_fwd", "fumi_hip_conv3x3_bwd_data", "fumi_hip_conv3x3_bwd_weight",
     "fumi_hip_sgd_axpy", "fumi_hip_ce_fwd_bwd", "fumi_hip_proto_reduce", "fumi_hip_clip_step", "fumi_hip_lstm_bidir",
 ]
@@ -113,6 +114,7 @@ def lib():
             + [c_void_p] * 4 + [PP] + [c_void_p] * 6 + [PP])
         L.fumi_hip_am3_step.argtypes = (
             [c_void_p, c_void_p] + [c_int] * 10 + [c_float, c_float, ctypes.c_uint64] + [c_void_p] * 5 + [PP] + [c_void_p] * 4 + [PP, c_void_p])
+        L.fumi_hip_am3_step_dx.argtypes = L.fumi_hip_am3_step.argtypes + [c_void_p, c_void_p]
         L.fumi_hip_am3_metrics.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p]
         L.fumi_hip_glove_bag.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int, c_int,
                                          c_int, c_void_p]
@@ -141,6 +143,8 @@ def lib():
             + [c_void_p] * 4 + [PP] + [c_void_p] * 6 + [PP])
         L.fumi_hip_conv4_set_option.argtypes = [c_int, c_int]
         L.fumi_hip_conv4_features.argtypes = [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, PP, c_void_p]
+        L.fumi_hip_conv4_encode.argtypes = [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p, PP, c_void_p, c_void_p, c_int]
+        L.fumi_hip_conv4_encode_bwd.argtypes = [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p] * 4 + [c_float, PP]
         L.fumi_hip_conv4_probe.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, POINTER(c_size_t)]
         for fn in (L.fumi_hip_conv3x3_fwd, L.fumi_hip_conv3x3_bwd_data, L.fumi_hip_conv3x3_bwd_weight):
             fn.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
@@ -246,12 +250,15 @@ class Workspace:
         self._h = h
 
     @classmethod
-    def get(cls, device):
+    def get(cls, device, role=None):
+        """The device's workspace; ``role`` names a further one (the Conv4 encoder's tape lives in its own slab, so that the
+        step it feeds can lay out the main one)."""
         device = torch.device(device)
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        ws = cls._per_device.get(idx)
+        key = idx if role is None else (idx, role)
+        ws = cls._per_device.get(key)
         if ws is None:
-            ws = cls._per_device[idx] = Workspace(torch.device("cuda", idx))
+            ws = cls._per_device[key] = Workspace(torch.device("cuda", idx))
         return ws
 
     @property
@@ -434,7 +441,7 @@ AM3_KEYS = ["Wi", "bi", "G0", "g0", "G1", "g1", "H0", "h0", "H1", "h1"]
 
 
 def am3_step(ws, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed=None, *, need_grad=True, grad_scale=None, g_w=None,
-             dropout_p=0.0, seed=0, stats=None):
+             dropout_p=0.0, seed=0, stats=None, want_dx=False):
     """One AM3 step (fumi/models/am3.py:160-200).  w: list of the 10 tensors in AM3_KEYS order.  ``stats``: optional fp32
     [3 + n_way**2] device tensor receiving [loss, correct count, grad_scale * sum of the episodes' mean lamda, confusion
     counts] (the input of ``am3_metrics``)."""
@@ -460,14 +467,18 @@ def am3_step(ws, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed=None, *, need
     lf = -1 if lamda_fixed is None else int(lamda_fixed)
     if grad_scale is None:
         grad_scale = 1.0 / B
-    rc = L.fumi_hip_am3_step(
-        ws.handle, _stream(dev), B, n_way, S, Qn, D, Dt, Ht, P, lf, int(bool(need_grad)), float(grad_scale),
-        float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
-        _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"), _f32(text_s, "text_s"),
-        _parr(w, "w"), _f32(loss, "loss"), _i64(preds, "preds"), _f32(lam, "lamda_s"), _f32(correct, "correct"),
-        _parr(g_w, "g_w") if need_grad else None, _f32(stats, "stats") if stats is not None else None)
-    _check(rc, "fumi_hip_am3_step")
-    return dict(loss=loss, preds=preds, lamda_s=lam, correct=correct, grads=g_w, stats=stats)
+    args = [ws.handle, _stream(dev), B, n_way, S, Qn, D, Dt, Ht, P, lf, int(bool(need_grad)), float(grad_scale),
+            float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+            _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"), _f32(text_s, "text_s"),
+            _parr(w, "w"), _f32(loss, "loss"), _i64(preds, "preds"), _f32(lam, "lamda_s"), _f32(correct, "correct"),
+            _parr(g_w, "g_w") if need_grad else None, _f32(stats, "stats") if stats is not None else None]
+    dx_s = dx_q = None
+    if want_dx and need_grad:               # adjoints of the image rows (an encoder in front of the step continues from them)
+        dx_s, dx_q = torch.empty_like(x_s), torch.empty_like(x_q)
+        _check(L.fumi_hip_am3_step_dx(*args, _f32(dx_s, "dx_s"), _f32(dx_q, "dx_q")), "fumi_hip_am3_step_dx")
+    else:
+        _check(L.fumi_hip_am3_step(*args), "fumi_hip_am3_step")
+    return dict(loss=loss, preds=preds, lamda_s=lam, correct=correct, grads=g_w, stats=stats, dx_s=dx_s, dx_q=dx_q)
 
 
 def am3_metrics(ws, n_way, stats):
@@ -753,6 +764,41 @@ def conv4_features(ws, x, theta):
     _check(lib().fumi_hip_conv4_features(ws.handle, _stream(dev), G, M, Cin, H, W, nblk, _f32(x, "x"), _parr(theta, "theta"),
                                          _f32(out, "feats")), "fumi_hip_conv4_features")
     return out
+
+
+def conv4_encode(ws, x_s, x_q, theta, keep_tape=False):
+    """(feats_s [B,S,F], feats_q [B,Qn,F]) = Conv4 of every episode's support / query images (one batch-statistics group each).
+    keep_tape: the activations stay laid out in ``ws`` for ``conv4_encode_bwd`` -- no other call may use ``ws`` in between."""
+    dev = _dev(x_s)
+    if x_s.dim() != 5 or x_q.dim() != 5 or x_s.shape[0] != x_q.shape[0] or x_s.shape[2:] != x_q.shape[2:]:
+        raise FumiHipError("conv4_encode: x_s [B,S,C,H,W] and x_q [B,Qn,C,H,W] expected")
+    B, S, Cin, H, W = x_s.shape
+    Qn = x_q.shape[1]
+    nblk = len(theta) // 3
+    F = conv4_feature_dim(nblk, H, W)
+    fs = torch.empty(B, S, F, device=dev, dtype=torch.float32)
+    fq = torch.empty(B, Qn, F, device=dev, dtype=torch.float32)
+    _check(lib().fumi_hip_conv4_encode(ws.handle, _stream(dev), B, S, Qn, Cin, H, W, nblk, _f32(x_s, "x_s"), _f32(x_q, "x_q"),
+                                       _parr(theta, "theta"), _f32(fs, "feats_s"), _f32(fq, "feats_q"), int(bool(keep_tape))),
+           "fumi_hip_conv4_encode")
+    return fs, fq
+
+
+def conv4_encode_bwd(ws, x_s, x_q, dfeats_s, dfeats_q, theta_like, scale=1.0, g_theta=None):
+    """Gradient of sum <dfeats, Conv4(x)> w.r.t. the encoder's parameters (summed over episodes, times ``scale``) from the tape the
+    last ``conv4_encode(..., keep_tape=True)`` left in ``ws``."""
+    dev = _dev(x_s)
+    B, S, Cin, H, W = x_s.shape
+    Qn = x_q.shape[1]
+    nblk = len(theta_like) // 3
+    F = conv4_feature_dim(nblk, H, W)
+    _shape(dfeats_s, (B, S, F), "dfeats_s"); _shape(dfeats_q, (B, Qn, F), "dfeats_q")
+    if g_theta is None:
+        g_theta = [torch.empty_like(t) for t in theta_like]
+    _check(lib().fumi_hip_conv4_encode_bwd(ws.handle, _stream(dev), B, S, Qn, Cin, H, W, nblk, _f32(x_s, "x_s"), _f32(x_q, "x_q"),
+                                           _f32(dfeats_s, "dfeats_s"), _f32(dfeats_q, "dfeats_q"), float(scale),
+                                           _parr(g_theta, "g_theta")), "fumi_hip_conv4_encode_bwd")
+    return g_theta
 
 
 def conv4_probe(ws, device, pass_, kind, block=0):

@@ -23,7 +23,8 @@ from .common import RNN, RnnHid, WordEmbedding
 
 class AM3(nn.Module):
     def __init__(self, im_encoder, im_emb_dim, text_encoder, text_emb_dim=300, text_hid_dim=300, prototype_dim=512,
-                 dropout=0.7, fine_tune=False, dictionary=None, pooling_strat="mean", lamda_fixed=None):
+                 dropout=0.7, fine_tune=False, dictionary=None, pooling_strat="mean", lamda_fixed=None, image_size=84,
+                 image_channels=3):
         super().__init__()
         self.im_emb_dim = im_emb_dim
         self.text_encoder_type = text_encoder
@@ -36,8 +37,17 @@ class AM3(nn.Module):
         self.pooling_strat = pooling_strat
         self.lamda_fixed = lamda_fixed
 
+        self.conv = None
         if im_encoder in ("precomputed", "resnet"):            # "resnet" is the same Linear in the reference (am3.py:44-46)
             self.image_encoder = nn.Linear(im_emb_dim, prototype_dim)
+        elif im_encoder == "conv4":
+            # this engine's extension at the image_encoder seam (am3.py:41-46; BASELINE configs[3] as worded): the Conv4 backbone
+            # on raw images, then the reference's Linear into the prototype space.  Every episode's support set and query set
+            # is one batch-statistics group (like the MAML / FuMI Conv4 path); "parity unpinned" (oracle/conv4_ref.py).
+            from .conv4 import Conv4
+            self.conv = Conv4(image_channels, 64, 4, image_size)
+            self.im_emb_dim = self.conv.feature_dim
+            self.image_encoder = nn.Linear(self.conv.feature_dim, prototype_dim)
         else:
             raise NameError(f"{im_encoder} not allowed as image encoder")
         if text_encoder in ("BERT", "precomputed"):
@@ -68,7 +78,7 @@ class AM3(nn.Module):
                 self.g[3].bias, self.h[0].weight, self.h[0].bias, self.h[3].weight, self.h[3].bias]
 
     def _flat_grads(self, num_ways=0):
-        params = self._w()
+        params = self._w() + (self.conv.theta() if self.conv is not None else [])
         extra = 3 + num_ways * num_ways                 # [loss, correct, lamda | confusion counts] ride in the all-reduce
         if self._flat is None or not self._flat.matches(params) or self._flat.tail.numel() != extra:
             self._flat = FlatGrads(params, extra=extra)
@@ -87,6 +97,8 @@ class AM3(nn.Module):
         eng = _engine.get_engine()
         idx, text, im = inputs
         w = [p.detach() for p in self._w()]
+        if self.conv is not None:
+            im = self.conv(im)              # [..., M, C, H, W] -> [..., M, F], batch statistics per image set
         lead = im.shape[:-1]
         im_emb = eng.linear(im.reshape(-1, im.shape[-1]).contiguous(), w[0], w[1]).reshape(*lead, -1)
         if im_only:
@@ -120,10 +132,18 @@ class AM3(nn.Module):
         # moves the predictions to the host and calls sklearn every meta-batch (utils.py:319-326): a blocking copy per step
         on_device = task != "test" and x_s.is_cuda and num_ways <= 64 and hasattr(eng, "am3_metrics")
         tail = fg.tail if need_grad else torch.empty(3 + num_ways * num_ways, device=x_s.device, dtype=torch.float32)
+        img_s = img_q = theta = None
+        if self.conv is not None:           # raw images -> Conv4 features; the tape stays in the encoder's own workspace
+            img_s, img_q = x_s, x_q
+            theta = [p.detach() for p in self.conv.theta()]
+            x_s, x_q = eng.conv4_encode(img_s, img_q, theta, keep_tape=need_grad)
         out = eng.am3_step(x_s, y_s, x_q, y_q, text, [p.detach() for p in self._w()], num_ways,
                            self.lamda_fixed, need_grad=need_grad, grad_scale=1.0 / B,
-                           g_w=fg.views if need_grad else None, dropout_p=drop_p, seed=drop_seed,
-                           **({"stats": tail} if on_device else {}))
+                           g_w=fg.views[:10] if need_grad else None, dropout_p=drop_p, seed=drop_seed,
+                           **({"stats": tail} if on_device else {}),
+                           **({"want_dx": True} if (self.conv is not None and need_grad) else {}))
+        if self.conv is not None and need_grad:     # ... and backwards from the adjoints of the features (already scaled by 1/B)
+            eng.conv4_encode_bwd(img_s, img_q, out["dx_s"], out["dx_q"], theta, scale=1.0, g_theta=fg.views[10:])
         if not on_device:
             torch.stack([out["loss"].reshape(()), out["correct"].reshape(()) / (B * Qn),
                          out["lamda_s"].sum() / (B * out["lamda_s"].shape[1])], out=tail[:3])

@@ -108,7 +108,8 @@ def init_model(args, dictionary, watch=True):
         model = am3.AM3(im_encoder=args.im_encoder, im_emb_dim=args.im_emb_dim, text_encoder=args.text_encoder,
                         text_emb_dim=args.text_emb_dim, text_hid_dim=args.text_hid_dim,
                         prototype_dim=args.prototype_dim, dropout=args.dropout, fine_tune=args.fine_tune,
-                        dictionary=dictionary, pooling_strat=args.pooling_strat, lamda_fixed=args.lamda_fixed)
+                        dictionary=dictionary, pooling_strat=args.pooling_strat, lamda_fixed=args.lamda_fixed,
+                        **(dict(image_size=args.image_size, image_channels=args.image_channels) if args.im_encoder == "conv4" else {}))
     if watch:
         wandb.watch(model, log="all")
     model.to(args.device)

@@ -137,6 +137,15 @@ int fumi_hip_am3_step(fumi_ws_t* ws, fumi_stream_t stream,
         const float* const* w,
         float* loss, int64_t* preds_q, float* lamda_s, float* correct,
         float* const* g_w, float* stats);
+/* The same step with the adjoints of the image rows as extra outputs (need_grad): dx_s [B,S,D], dx_q [B,Qn,D] = imbar Wi.  An
+ * image encoder in front of the step (the Conv4 backbone at the image_encoder seam, am3.py:41-46) continues from them. */
+int fumi_hip_am3_step_dx(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int D, int Dt, int Ht, int P, int lamda_fixed, int need_grad, float grad_scale,
+        float dropout_p, uint64_t seed,
+        const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q, const float* text_s,
+        const float* const* w,
+        float* loss, int64_t* preds_q, float* lamda_s, float* correct,
+        float* const* g_w, float* stats, float* dx_s, float* dx_q);
 /* out6 = [loss, accuracy, macro F1, macro precision, macro recall, mean lamda] from `stats` (fumi_hip_am3_step): what
  * AM3.evaluate returns per meta-batch (am3.py:203-212 via sklearn on the host, utils.py:319-326), without leaving the device.
  * N <= 64. */
@@ -209,6 +218,15 @@ int fumi_hip_maml_conv4_step(fumi_ws_t* ws, fumi_stream_t stream,
 /* Forward only: feats [G*M, F] = Conv4(x [G,M,Cin,H,W]); batch statistics per group of M images (one support or query set). */
 int fumi_hip_conv4_features(fumi_ws_t* ws, fumi_stream_t stream, int G, int M, int Cin, int H, int W, int nblk,
         const float* x, const float* const* theta, float* feats);
+/* Conv4 as the image encoder in front of a step that lays out its own workspace (AM3 at the seam am3.py:41-46; "parity
+ * unpinned" like the rest of the Conv4 rows).  encode: feats_s [B,S,F], feats_q [B,Qn,F]; every episode's support set and query
+ * set is one batch-statistics group.  keep_tape = 1 leaves the activations laid out in `ws`; encode_bwd (same shapes, same `ws`,
+ * no other call on `ws` in between -- give the encoder its own workspace) walks them backwards from the feature adjoints:
+ * g_theta (3 nblk pointers, torch layouts) = scale * sum over episodes of d<dfeats, feats>/dtheta.  FUMI_EINVAL without a tape. */
+int fumi_hip_conv4_encode(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int Qn, int Cin, int H, int W, int nblk,
+        const float* x_s, const float* x_q, const float* const* theta, float* feats_s, float* feats_q, int keep_tape);
+int fumi_hip_conv4_encode_bwd(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int Qn, int Cin, int H, int W, int nblk,
+        const float* x_s, const float* x_q, const float* dfeats_s, const float* dfeats_q, float scale, float* const* g_theta);
 /* Test hook: copies one intermediate tensor of the LAST conv4 step of this process out of the workspace (layouts:
  * fumi_amd/csrc/conv4.hip, fumi_hip_conv4_probe).  *n_out = its size in floats; at most max_floats are copied. */
 int fumi_hip_conv4_probe(fumi_ws_t* ws, fumi_stream_t stream, int pass, int kind, int block, float* out, size_t max_floats,

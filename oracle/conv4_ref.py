@@ -100,6 +100,40 @@ def maml_conv4_meta_step(params, x_s, y_s, x_q, y_q, T, alpha, first_order=False
     return out
 
 
+def am3_conv4_step(theta, w, text_s, x_s, y_s, x_q, y_q, n_way, lamda_fixed=None, need_grad=True, masks=None):
+    """AM3 (am3.py:128-212 through oracle/fumi_ref.am3_step) with the Conv4 backbone in front of ``image_encoder`` (the seam at
+    am3.py:41-46): x_s [B,S,C,H,W], x_q [B,Qn,C,H,W]; every episode's support set and query set is one batch-statistics group.
+    Returns fumi_ref.am3_step's dict with ``grads_theta`` (list like theta) added."""
+    B = x_s.shape[0]
+    th = [t.detach().clone().requires_grad_(need_grad) for t in theta]
+    f_s = torch.stack([conv4_features(x_s[b], th) for b in range(B)])
+    f_q = torch.stack([conv4_features(x_q[b], th) for b in range(B)])
+    wl = {k: v.detach().clone().requires_grad_(need_grad) for k, v in w.items()}
+    out = R.am3_step(wl, text_s, f_s, y_s, f_q, y_q, n_way, lamda_fixed=lamda_fixed, need_grad=False, masks=masks)
+    out["feats_s"], out["feats_q"] = f_s.detach(), f_q.detach()
+    if need_grad:
+        # am3_step detaches its loss: restate the loss on the graph that includes the backbone
+        im_s = F.linear(f_s, wl["Wi"], wl["bi"]); im_q = F.linear(f_q, wl["Wi"], wl["bi"])
+        t1 = torch.relu(F.linear(text_s, wl["G0"], wl["g0"]))
+        if masks is not None:
+            t1 = t1 * masks[0].view_as(t1)
+        tx = F.linear(t1, wl["G1"], wl["g1"])
+        l1 = torch.relu(F.linear(tx, wl["H0"], wl["h0"]))
+        if masks is not None:
+            l1 = l1 * masks[1].view_as(l1)
+        lam = torch.sigmoid(F.linear(l1, wl["H1"], wl["h1"]))
+        if lamda_fixed == 0:
+            lam = torch.zeros_like(lam)
+        elif lamda_fixed == 1:
+            lam = torch.ones_like(lam)
+        loss = R.prototypical_loss(R.get_prototypes(im_s, tx, lam, y_s, n_way), im_q, y_q)
+        names = ["Wi", "bi", "G0", "g0", "G1", "g1", "H0", "h0", "H1", "h1"]
+        g = torch.autograd.grad(loss, [wl[k] for k in names] + th, allow_unused=True)
+        out["grads"] = {k: (torch.zeros_like(wl[k]) if gi is None else gi) for k, gi in zip(names, g[:10])}
+        out["grads_theta"] = [torch.zeros_like(t) if gi is None else gi for t, gi in zip(th, g[10:])]
+    return out
+
+
 def make_conv4_params(seed, Cin=3, C=64, n_blocks=4, dtype=torch.float32):
     """Deterministic parameters for the parity cases (uniform +-1/sqrt(fan_in) conv weights like nn.Conv2d's default scale,
     BN weight around 1, BN bias around 0 -- not exactly 1 / 0 so their gradients' paths are exercised)."""

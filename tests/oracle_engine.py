@@ -44,10 +44,35 @@ class OracleEngine:
             stats.copy_(torch.stack([out["loss_b"].sum(), out["acc_b"].sum()]) * grad_scale)
         return dict(logits=out["logits"], preds=out["preds"], preds_f=out["preds"].float(), loss_b=out["loss_b"], acc_b=out["acc_b"])
 
-    def am3_step(self, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad, grad_scale, g_w=None, dropout_p=0.0, seed=0):
+    def am3_step(self, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed, need_grad, grad_scale, g_w=None, dropout_p=0.0, seed=0,
+                 want_dx=False):
         from fumi_amd.hip import AM3_KEYS
         B, Qn = x_q.shape[0], x_q.shape[1]
         wd = {k: t.detach().clone().requires_grad_(True) for k, t in zip(AM3_KEYS, w)}
+        if want_dx and need_grad:           # adjoints of the image rows: one more autograd pass over the same loss
+            xs, xq = x_s.detach().clone().requires_grad_(True), x_q.detach().clone().requires_grad_(True)
+            masks_ = None
+            if dropout_p > 0:
+                from helpers import dropout_mask_flat
+                Rs_, Ht_ = x_s.shape[0] * x_s.shape[1], w[2].shape[0]
+                masks_ = (dropout_mask_flat(seed, dropout_p, 1, Rs_, Ht_), dropout_mask_flat(seed, dropout_p, 2, Rs_, Ht_))
+            wl = {k: t.detach() for k, t in zip(AM3_KEYS, w)}
+            im_s = torch.nn.functional.linear(xs, wl["Wi"], wl["bi"]); im_q = torch.nn.functional.linear(xq, wl["Wi"], wl["bi"])
+            t1 = torch.relu(torch.nn.functional.linear(text_s, wl["G0"], wl["g0"]))
+            if masks_ is not None:
+                t1 = t1 * masks_[0].view_as(t1)
+            tx = torch.nn.functional.linear(t1, wl["G1"], wl["g1"])
+            l1 = torch.relu(torch.nn.functional.linear(tx, wl["H0"], wl["h0"]))
+            if masks_ is not None:
+                l1 = l1 * masks_[1].view_as(l1)
+            lam = torch.sigmoid(torch.nn.functional.linear(l1, wl["H1"], wl["h1"]))
+            if lamda_fixed == 0:
+                lam = torch.zeros_like(lam)
+            elif lamda_fixed == 1:
+                lam = torch.ones_like(lam)
+            loss_x = R.prototypical_loss(R.get_prototypes(im_s, tx, lam, y_s, n_way), im_q, y_q)
+            dxs, dxq = torch.autograd.grad(loss_x, [xs, xq])
+            self._dx = (dxs * (B * grad_scale), dxq * (B * grad_scale))
         masks = None
         if dropout_p > 0:
             from helpers import dropout_mask_flat
@@ -58,8 +83,32 @@ class OracleEngine:
             for dst, k in zip(g_w, AM3_KEYS):
                 dst.copy_(out["grads"][k] * (B * grad_scale))
         correct = out["preds"].eq(y_q).float().sum().reshape(1)
+        dx = getattr(self, "_dx", (None, None)) if (want_dx and need_grad) else (None, None)
         return dict(loss=(out["loss"] * (B * grad_scale)).reshape(1), preds=out["preds"], lamda_s=out["lamda_s"],
-                    correct=correct)
+                    correct=correct, dx_s=dx[0], dx_q=dx[1])
+
+    def conv4_encode(self, x_s, x_q, theta, keep_tape=False):
+        from oracle import conv4_ref as C
+        with torch.no_grad():
+            f_s = torch.stack([C.conv4_features(x_s[b], theta) for b in range(x_s.shape[0])])
+            f_q = torch.stack([C.conv4_features(x_q[b], theta) for b in range(x_q.shape[0])])
+        self._tape = keep_tape
+        return f_s, f_q
+
+    def conv4_encode_bwd(self, x_s, x_q, dfeats_s, dfeats_q, theta_like, scale=1.0, g_theta=None):
+        from oracle import conv4_ref as C
+        assert getattr(self, "_tape", False), "conv4_encode_bwd without a kept tape"
+        self._tape = False
+        th = [t.detach().clone().requires_grad_(True) for t in theta_like]
+        tot = 0.0
+        for b in range(x_s.shape[0]):
+            tot = tot + (C.conv4_features(x_s[b], th) * dfeats_s[b]).sum() + (C.conv4_features(x_q[b], th) * dfeats_q[b]).sum()
+        gs = torch.autograd.grad(tot, th)
+        if g_theta is None:
+            g_theta = [torch.empty_like(t) for t in theta_like]
+        for dst, g in zip(g_theta, gs):
+            dst.copy_(g * scale)
+        return g_theta
 
     def fumi_conv4_step(self, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head, need_grad, grad_scale,
                         g_theta=None, g_phi=None, cls_text=None, stats=None):

@@ -410,3 +410,59 @@ def test_cli_fumi_conv4_end_to_end_on_gpu(dev, tmp_path, monkeypatch):
     res = cli.main(args)
     assert np.isfinite(res["test_loss"]) and 0.0 <= res["test_acc"] <= 1.0
     assert res["test_acc"] > 0.3                                        # chance = 0.2: the engine's gradients train the encoder
+
+
+# ---- AM3 with the Conv4 backbone at the image_encoder seam (BASELINE.json configs[3] as worded) ------------------------------
+@pytest.mark.parametrize("lamda_fixed,Ht", [(None, 64), (1, 24)])
+def test_am3_conv4_step_matches_autograd(lamda_fixed, Ht, dev):
+    """encode (tape kept in the encoder's own workspace) -> fumi_hip_am3_step_dx -> encode_bwd against float64 autograd through
+    oracle/conv4_ref.am3_conv4_step: features, loss, predictions, the ten AM3 gradients and the twelve backbone gradients."""
+    from fumi_amd import hip
+    B, N, K, Q, Cin, H, W, Dt, P = 3, 4, 2, 3, 3, 20, 20, 12, 32
+    ep, theta, Fd = _case(21, B, N, K, Q, Cin, H, W, 4)
+    w = cg.make_am3_params(21, Fd, Dt, Ht, P)
+    wl = [w[k] for k in hip.AM3_KEYS]
+    ws_main, ws_enc = hip.Workspace.get(dev), hip.Workspace.get(dev, "encoder")
+    th_d = [_g(t, dev) for t in theta]
+    xs, xq = _g(ep["x_s"], dev), _g(ep["x_q"], dev)
+    f_s, f_q = hip.conv4_encode(ws_enc, xs, xq, th_d, keep_tape=True)
+    out = hip.am3_step(ws_main, f_s, _g(ep["y_s"], dev), f_q, _g(ep["y_q"], dev), _g(ep["text_s"], dev), [_g(t, dev) for t in wl],
+                       N, lamda_fixed, want_dx=True)
+    g_th = hip.conv4_encode_bwd(ws_enc, xs, xq, out["dx_s"], out["dx_q"], th_d)
+    assert ws_main.read_status() == 0
+    d64 = lambda t: t.double()
+    ref = C.am3_conv4_step([d64(t) for t in theta], {k: d64(v) for k, v in w.items()}, d64(ep["text_s"]), d64(ep["x_s"]), ep["y_s"],
+                           d64(ep["x_q"]), ep["y_q"], N, lamda_fixed)
+    assert rel_to_max(f_s.cpu().double(), ref["feats_s"]) <= 1e-5 and rel_to_max(f_q.cpu().double(), ref["feats_q"]) <= 1e-5
+    assert abs(float(out["loss"]) - float(ref["loss"])) <= LOGIT_TOL * max(1.0, abs(float(ref["loss"])))
+    d2 = ref["dist"].transpose(1, 2).topk(2, dim=-1, largest=False)[0]
+    mask = (d2[..., 1] - d2[..., 0]) > 1e-4 * d2[..., 1].abs().clamp_min(1.0)
+    assert torch.equal(out["preds"].cpu()[mask], ref["preds"][mask])
+    for k, g in zip(hip.AM3_KEYS, out["grads"]):
+        if float(ref["grads"][k].abs().max()) < 1e-9:      # identically zero (the image bias cancels in every distance when lamda = 1)
+            assert float(g.abs().max()) < 1e-6, k
+        else:
+            assert rel_to_max(g.cpu().double(), ref["grads"][k]) <= GRAD_TOL, k
+    names = [f"block{i}.{p}" for i in range(4) for p in ("W", "g", "b")]
+    for nme, g, r in zip(names, g_th, ref["grads_theta"]):
+        # a ReLU / arg-max decision within round-off of a tie moves an early block's gradient by a percent (the header of
+        # test_conv4_full_size_episode_84x84): 1e-2 of the tensor's scale
+        assert rel_to_max(g.cpu().double(), r) <= 1e-2, (nme, rel_to_max(g.cpu().double(), r))
+    # the tape is consumed: a second backward without a new encode is refused
+    with pytest.raises(hip.FumiHipError):
+        hip.conv4_encode_bwd(ws_enc, xs, xq, out["dx_s"], out["dx_q"], th_d)
+
+
+def test_cli_am3_conv4_end_to_end_on_gpu(dev, tmp_path, monkeypatch):
+    """`python -m fumi_amd.main --model am3 --im_encoder conv4 --dataset synthetic` (BASELINE.json configs[3] as worded, shortened)."""
+    from fumi_amd import main as cli
+    monkeypatch.chdir(tmp_path)
+    argv = ["--model", "am3", "--dataset", "synthetic", "--im_encoder", "conv4", "--image_size", "28", "--text_encoder", "BERT",
+            "--text_emb_dim", "32", "--batch_size", "8", "--num_shots", "5", "--num_ways", "5", "--num_shots_test", "5",
+            "--epochs", "30", "--eval_freq", "15", "--num_ep_test", "16", "--lr", "1e-3", "--dropout", "0.25",
+            "--log_dir", str(tmp_path / "res"), "--synthetic_classes", "16", "--wandb_offline"]
+    args = cli.parse_args(argv)
+    assert args.device.type == "cuda"
+    res = cli.main(args)
+    assert np.isfinite(res["test_loss"]) and 0.0 <= res["test_acc"] <= 1.0
+    assert res["test_acc"] > 0.3                                        # chance = 0.2

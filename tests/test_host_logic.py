@@ -325,6 +325,29 @@ def test_fumi_conv4_module_trains_through_evaluate(oracle_engine):
     assert torch.allclose(feats[1], C.conv4_features(ep["x_q"][1], [t.detach() for t in m.im_net.theta()]), atol=1e-6)
 
 
+def test_am3_conv4_module_trains_through_evaluate(oracle_engine):
+    """AM3(im_encoder='conv4'): Conv4 features feed the reference's Linear into the prototype space; evaluate() fills .grad of the
+    10 AM3 tensors and the 12 backbone tensors (through the step's image-row adjoints) and steps the optimizer."""
+    from fumi_amd.models.am3 import AM3
+    from oracle import conv4_ref as C
+    torch.manual_seed(0)
+    m = AM3(im_encoder="conv4", im_emb_dim=0, text_encoder="BERT", text_emb_dim=12, text_hid_dim=8, prototype_dim=6, dropout=0.0,
+            image_size=16, image_channels=3)
+    assert m.conv.feature_dim == 64 and m.image_encoder.weight.shape == (6, 64)
+    assert {"conv.block0.conv.weight", "conv.block3.norm.bias", "image_encoder.weight", "g.0.weight", "h.3.bias"} <= set(m.state_dict())
+    ep = C.make_image_episodes(4, 2, 3, 2, 2, 3, 16, 16, 12)
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    before = [p.detach().clone() for p in m.parameters()]
+    out = m.evaluate(cg.to_batch(ep), opt, None, 3, torch.device("cpu"), "train")
+    assert len(out) == 6 and np.isfinite(float(out[0]))
+    changed = [not torch.equal(a, b.detach()) for a, b in zip(before, m.parameters())]
+    assert all(changed), "every parameter receives a gradient (image encoder, g, h and the Conv4 backbone)"
+    r = m.evaluate(cg.to_batch(ep), None, None, 3, torch.device("cpu"), "test")
+    assert len(r) == 11 and r[6].shape == (2, 6)
+    im_emb = m([ep["idx_q"], None, ep["x_q"]], im_only=True)            # forward(): raw images -> prototype space
+    assert im_emb.shape == (2, 6, 6)
+
+
 def test_rnn_text_encoders_keep_the_reference_surface(oracle_engine):
     """RNN / RnnHid (common.py:44-161): same state_dict keys as the reference's modules (the golden fixture stores the
     reference's own state_dict) and the same outputs on ragged token rows."""
