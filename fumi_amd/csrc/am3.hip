@@ -187,11 +187,20 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
                                                        float* __restrict__ lam_b, float lscale,
                                                        float* __restrict__ im_s_bar, float* __restrict__ tx_bar,
                                                        float* __restrict__ zl_bar, float* __restrict__ im_q_bar,
-                                                       long im_stride, const float* __restrict__ im_bias, int* status) {
+                                                       long im_stride, const float* __restrict__ im_bias, int* status,
+                                                       int B, int GQ, float* part, int* arrive) {
+    // GQ workgroups per episode (ids equal mod 8: one XCD): each forms the prototypes and takes a contiguous share of the query
+    // rows; loss / correct counts / prototype adjoints of the shares meet in `part` ([B][GQ][N*P + 2], agent-scope stores) and
+    // the workgroup that arrives last at the episode's counter adds them in share order (deterministic) and runs the support-
+    // side epilogue.  One workgroup per episode walked 10 query rows per wave, each a chain of ~25 dependent cross-lane steps.
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nt = blockDim.x, nw = blockDim.x >> 6;
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, nt = blockDim.x, nw = blockDim.x >> 6;
+    const int b = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) / GQ), gq = (int)((blockIdx.x >> 3) % GQ);
+    if (b >= B) return;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NP = N * P, SP = S * P;
+    const int qper = (Qn + GQ - 1) / GQ, q0 = gq * qper, q1 = min(Qn, q0 + qper);
     float* ip = sm; float* tp = ip + NP; float* pr = tp + NP; float* pb = pr + NP;
     float* ims = pb + nw * NP; float* txs = ims + SP;
     float* lamc = txs + SP; float* cnt = lamc + N; float* lbar = cnt + N; float* wl = lbar + N; float* wc = wl + nw;
@@ -206,8 +215,8 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
 #pragma unroll
     for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; bq[k] = (k < npj && j < P) ? im_bias[j] : 0.f; }
 #pragma unroll
-    for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; xn[k] = (k < npj && j < P && wave < Qn) ? im_q[(long)wave * P + j] : 0.f; }
-    long yn = wave < Qn ? y_q[wave] : 0;
+    for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; xn[k] = (k < npj && j < P && q0 + wave < q1) ? im_q[(long)(q0 + wave) * P + j] : 0.f; }
+    long yn = q0 + wave < q1 ? y_q[q0 + wave] : 0;
     for (int i0 = tid; i0 < SP; i0 += 4 * nt) {
         float a[4], t[4];
 #pragma unroll
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
         if (y < 0 || y >= N) { atomicOr(status, FUMI_ST_LABEL_RANGE); y = -1; }
         ys[s_] = (int)y;
         float l = lamda_fixed >= 0 ? (float)lamda_fixed : lam_s[s_];
-        if (lamda_fixed >= 0) lam_s[s_] = l;                                   // am3.py:174-177
+        if (lamda_fixed >= 0 && gq == 0) lam_s[s_] = l;                        // am3.py:174-177
         lam[s_] = l;
     }
     for (int i = tid; i < nw * NP; i += nt) pb[i] = 0.f;
@@ -246,15 +255,15 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
     // ---- queries: wave per row
     float lsum = 0.f, csum = 0.f;
     float* mypb = pb + wave * NP;
-    for (int q = wave; q < Qn; q += nw) {
+    for (int q = q0 + wave; q < q1; q += nw) {
         float x[HPJ];
 #pragma unroll
         for (int k = 0; k < HPJ; ++k) x[k] = xn[k] + bq[k];
         long yq = yn;
         const int qn = q + nw;                                                  // prefetch the wave's next row
 #pragma unroll
-        for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; xn[k] = (k < npj && j < P && qn < Qn) ? im_q[(long)qn * P + j] : 0.f; }
-        yn = qn < Qn ? y_q[qn] : 0;
+        for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; xn[k] = (k < npj && j < P && qn < q1) ? im_q[(long)qn * P + j] : 0.f; }
+        yn = qn < q1 ? y_q[qn] : 0;
         if (yq < 0 || yq >= N) { if (lane == 0) atomicOr(status, FUMI_ST_LABEL_RANGE); yq = 0; }
         // lane c keeps d_c = |proto_c - x|^2; eight classes are reduced together (their butterflies interleave: one
         // dependent shuffle chain per class would cost ~600 cycles each)
@@ -320,21 +329,59 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
     }
     if (lane == 0) { wl[wave] = lsum; wc[wave] = csum; }
     __syncthreads();
+    // ---- this share's totals (waves in order), then the meeting of the shares
+    float* mine = part + ((long)b * GQ + gq) * (NP + 2);
     if (tid == 0) {
         float l = 0.f, c = 0.f;
         for (int w_ = 0; w_ < nw; ++w_) { l += wl[w_]; c += wc[w_]; }
-        loss_b[b] = l * dscale;
-        corr_b[b] = c;
-        if (lam_b) { float ls_ = 0.f; for (int s2 = 0; s2 < S; ++s2) ls_ += lam_s[s2]; lam_b[b] = ls_ * lscale; }
+        if (GQ == 1) { wl[0] = l; wc[0] = c; }
+        else {
+            __hip_atomic_store(mine + NP, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + NP + 1, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (need_grad) {
+        for (int i = tid; i < NP; i += nt) {
+            float s_ = 0.f;
+            for (int w_ = 0; w_ < nw; ++w_) s_ += pb[w_ * NP + i];
+            if (GQ == 1) pb[i] = s_;                        // slab 0 now holds pbar (only element i of slab 0 is touched by thread i)
+            else __hip_atomic_store(mine + i, s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();                                        // (every partial store has left: vmcnt(0) before the signal)
+    if (GQ > 1) {
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(arrive + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == GQ - 1;
+            if (old == GQ - 1) __hip_atomic_store(arrive + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        __syncthreads();
+        if (!s_last) return;
+        const float* all = part + (long)b * GQ * (NP + 2);
+        if (tid == 0) {
+            float l = 0.f, c = 0.f;
+            for (int g_ = 0; g_ < GQ; ++g_) {
+                l += __hip_atomic_load(all + (long)g_ * (NP + 2) + NP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                c += __hip_atomic_load(all + (long)g_ * (NP + 2) + NP + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            wl[0] = l; wc[0] = c;
+        }
+        if (need_grad) {
+            for (int i = tid; i < NP; i += nt) {
+                float s_ = 0.f;
+                for (int g_ = 0; g_ < GQ; ++g_) s_ += __hip_atomic_load(all + (long)g_ * (NP + 2) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pb[i] = s_;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        loss_b[b] = wl[0] * dscale;
+        corr_b[b] = wc[0];
+        if (lam_b) { float ls_ = 0.f; for (int s2 = 0; s2 < S; ++s2) ls_ += lam[s2]; lam_b[b] = ls_ * lscale; }
     }
     if (!need_grad) return;
     // ---- prototype adjoints -> per-sample gradients (utils.py:358-375 reversed)
-    for (int i = tid; i < NP; i += nt) {
-        float s_ = 0.f;
-        for (int w_ = 0; w_ < nw; ++w_) s_ += pb[w_ * NP + i];
-        pb[i] = s_;                                         // slab 0 now holds pbar (only element i of slab 0 is touched by thread i)
-    }
-    __syncthreads();
     for (int c = wave; c < N; c += nw) {
         float v = 0.f;
         for (int j = lane; j < P; j += 64) v += pb[c * P + j] * (ip[c * P + j] - tp[c * P + j]);
@@ -412,6 +459,14 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     const size_t hfg_n = hyper_fwd_workspace_floats((int)Rs, Ht, P), hfh_n = hyper_fwd_workspace_floats((int)Rs, Ht, 1);
     const size_t hbh_n = hyper_bwd_fused_workspace_floats((int)Rs, P, Ht, 1), hbg_n = hyper_bwd_fused_workspace_floats((int)Rs, 0, Ht, P);
     if (mlp_fused) { A(hfg_n); A(hfh_n); if (need_grad) { A(hbh_n); A(hbg_n); } }
+    // query shares per episode of the head kernel: enough workgroups for the chip, >= 2 rows per wave, counters available
+    static const int hgq_env = getenv("FUMI_AM3_GQ") ? atoi(getenv("FUMI_AM3_GQ")) : 0;
+    int hgq = 1;
+    if (fast_head && B <= FUMI_HCNT) {
+        if (hgq_env > 0) hgq = hgq_env > 16 ? 16 : hgq_env;
+        else while (hgq < 8 && B * hgq * 2 <= 256 && Qn / (hgq * 2) >= 2 * nwaves) hgq *= 2;
+    }
+    if (hgq > 1) A((size_t)B * hgq * ((size_t)N * P + 2));
     const int xks = xpanel_fwd_ksplit(B, S, Qn, D, P, 0);              // contraction parts of the image-encoder pass (narrow output)
     if (xks > 1) A((size_t)xks * (Rs + Rq) * P);
     int rc = ws_reserve(ws, bytes);
@@ -474,14 +529,16 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
         cpart = ws_f(ws, cpart_n);
         wslabs = ws_f(ws, wslab_n);
     }
+    float* hpart = hgq > 1 ? ws_f(ws, (size_t)B * hgq * ((size_t)N * P + 2)) : nullptr;
     {
         ProfScope ps(ws, st, FUMI_PH_AM3);
         const float dscale = grad_scale / (float)Qn;
         if (fast_head) {
             FUMI_SET_DYN_LDS(am3_head_kernel, lds);
-            hipLaunchKernelGGL(am3_head_kernel, dim3(B), dim3(64 * nwaves), lds, st, N, S, Qn, P, lamda_fixed, need_grad ? 1 : 0,
-                               dscale, im, tx, lamda_s, y_s, imq, y_q, preds_q, lc, lc + B, confb, lamb, grad_scale / (float)S,
-                               imb, txb, zlb, imb ? imb + (long)S * P : nullptr, imst, bi, ws->status);
+            hipLaunchKernelGGL(am3_head_kernel, dim3(8 * ((B + 7) / 8) * hgq), dim3(64 * nwaves), lds, st, N, S, Qn, P, lamda_fixed,
+                               need_grad ? 1 : 0, dscale, im, tx, lamda_s, y_s, imq, y_q, preds_q, lc, lc + B, confb, lamb,
+                               grad_scale / (float)S, imb, txb, zlb, imb ? imb + (long)S * P : nullptr, imst, bi, ws->status,
+                               B, hgq, hpart, ws->hcnt);
         } else {
             hipLaunchKernelGGL(am3_bias_rows_kernel, dim3(256), dim3(256), 0, st, im, bi, (long)(Rs + Rq) * P, P);
             FUMI_SET_DYN_LDS(am3_head_generic_kernel, lds);
