@@ -24,8 +24,9 @@ struct HyperBwdArgs {
     float* ub_out;                         // optional [R,Ht]: ubar to memory (callers that need ubar A0 or form ubar^T c themselves)
     int nrb, nblk;                         // row blocks; workgroups = 8 * (Ht/64) * ceil(nrb/8)
 };
+constexpr int HBW_DC = 384;                // input columns of the layer-0 weight slab formed per pass (the rows' LDS image is that wide)
 __host__ __device__ inline int hyper_bwd_lds_floats(int Dt, int H1) {
-    return HBW_HB * wg_ld(H1) + 2 * HBW_HB * wg_ld(64) + ((H1 + 3) & ~3) * wg_ld(64) + HBW_HB * wg_ld(Dt) + 64;
+    return HBW_HB * wg_ld(H1) + 2 * HBW_HB * wg_ld(64) + ((H1 + 3) & ~3) * wg_ld(64) + HBW_HB * wg_ld(Dt < HBW_DC ? Dt : HBW_DC) + 64;
 }
 
 // bid in [0, nblk); sm >= hyper_bwd_lds_floats() floats; any workgroup size that is a multiple of 64
@@ -37,7 +38,8 @@ __device__ __forceinline__ void hyper_bwd_body(const HyperBwdArgs& a, int bid, f
     const int rb = xcd + 8 * (slot / nch), cb = slot % nch;
     if (rb >= a.nrb) return;
     const int m0 = rb * HBW_HB, nr = min(HBW_HB, a.R - m0);
-    const int ld1 = wg_ld(H1), ldc = wg_ld(64), ldd = wg_ld(Dt), H1r = (H1 + 3) & ~3;
+    const int dcw = min(Dt, HBW_DC);                                      // (a multiple of 4: Dt is)
+    const int ld1 = wg_ld(H1), ldc = wg_ld(64), ldd = wg_ld(dcw), H1r = (H1 + 3) & ~3;
     float* hp = sm; float* uc = hp + HBW_HB * ld1; float* ubc = uc + HBW_HB * ldc; float* A1c = ubc + HBW_HB * ldc;
     float* cr = A1c + H1r * ldc;
     const int tot = HBW_HB * ld1 + 2 * HBW_HB * ldc + H1r * ldc + HBW_HB * ldd;
@@ -68,23 +70,26 @@ __device__ __forceinline__ void hyper_bwd_body(const HyperBwdArgs& a, int bid, f
             if (i < H1 * 16) *(f32x4*)(A1c + (i >> 4) * ldc + ((i & 15) << 2)) = v[x];
         }
     }
-    {
-        const int d4 = Dt >> 2, n4 = nr * d4;
-        for (int i0 = tid; a.pA0 && i0 < n4; i0 += 4 * nt) {
-            f32x4 v[4];
+    // the block's rows, columns [dc0, dc0 + w): zero beyond w (the product walks whole 64-column blocks)
+    auto stage_rows = [&](int dc0, int w) {
+        const int d4 = ldd >> 2, n4 = HBW_HB * d4;
+        for (int i0 = tid; i0 < n4; i0 += 4 * nt) {
+            f32x4 v[4]; bool ok[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 const int i = min(i0 + x * nt, n4 - 1);
                 const int m = i / d4, k4 = i - m * d4;
-                v[x] = *(const f32x4*)(a.c + (long)(m0 + m) * Dt + 4 * k4);
+                ok[x] = m < nr && 4 * k4 < w;
+                v[x] = *(const f32x4*)(a.c + (long)(m0 + min(m, nr - 1)) * Dt + dc0 + min(4 * k4, w - 4));
             }
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 const int i = i0 + x * nt;
-                if (i < n4) { const int m = i / d4, k4 = i - m * d4; *(f32x4*)(cr + m * ldd + 4 * k4) = v[x]; }
+                if (i < n4) { const int m = i / d4, k4 = i - m * d4; *(f32x4*)(cr + m * ldd + 4 * k4) = ok[x] ? v[x] : z4; }
             }
         }
-    }
+    };
+    if (a.pA0) stage_rows(0, dcw);
     __syncthreads();
     // ---- ubar chunk
     wg_lmm_wide<true>(nr, 64, H1, hp, ld1, A1c, ldc, [&](int m, int n, const f32x4& acc, int, auto) {
@@ -106,9 +111,13 @@ __device__ __forceinline__ void hyper_bwd_body(const HyperBwdArgs& a, int bid, f
     // ---- layer-0 weight slab: rows of this chunk, every input column
     if (!a.pA0) return;
     float* p0 = a.pA0 + ((long)rb * Ht + cb * 64) * Dt;
-    wg_lmm_wide<false>(64, Dt, HBW_HB, ubc, ldc, cr, ldd, [&](int m, int n, const f32x4& acc, int cnt, auto) {
-        wg_st4(p0 + (long)m * Dt + n, acc, cnt);
-    });
+    for (int dc0 = 0; dc0 < Dt; dc0 += HBW_DC) {
+        const int w = min(HBW_DC, Dt - dc0);
+        if (dc0) { __syncthreads(); stage_rows(dc0, w); __syncthreads(); }      // (the previous pass has read its image)
+        wg_lmm_wide<false>(64, w, HBW_HB, ubc, ldc, cr, ldd, [&](int m, int n, const f32x4& acc, int cnt, auto) {
+            wg_st4(p0 + (long)m * Dt + dc0 + n, acc, cnt);
+        });
+    }
 }
 
 size_t hyper_bwd_fused_workspace_floats(int R, int Dt, int Ht, int H1);

@@ -26,7 +26,9 @@ struct HyperFwdArgs {
     int nrb;                               // row blocks
     int nblk;                              // workgroups of the grid this forward occupies: 8 * (Ht/64) * ceil(nrb/8); 0 = none
 };
-constexpr int HF_RIDER_KS = 20;            // the rider form is instantiated for Dt <= 320 only (register budget beside the X-panel code)
+constexpr int HF_RIDER_KS = 24;            // the rider form keeps 24 steps (384 columns) of weight fragments in registers at a time (register
+                                           // budget beside the X-panel code) and walks wider inputs in several chunks (HF_RIDER_MAXDT)
+constexpr int HF_RIDER_MAXDT = 768;
 __host__ __device__ inline size_t hyper_fwd_split_lds_bytes(int ldx) { return (size_t)HF_HB * (ldx + 64 + 4) * sizeof(float); }
 
 // A row block is handled by Ht/64 workgroups of 4 waves: each takes 64 hidden columns (one 16-column tile per wave, the
@@ -35,7 +37,8 @@ __host__ __device__ inline size_t hyper_fwd_split_lds_bytes(int ldx) { return (s
 // chunk order (deterministic), the bias and the optional tanh.  Partials travel with agent-scope stores / loads; nobody
 // waits for anybody.  Ids are XCD-grouped: the chunks of a row block share an XCD (ids equal mod 8).
 // bid = workgroup id within this forward's own id space [0, nblk); sm = >= hyper_fwd_split_lds_bytes() of LDS; 256 threads.
-template <int KS>                          // 16-deep contraction steps held in registers (Dt <= 16 KS)
+template <int KS, bool CHUNKED = false>    // KS 16-deep contraction steps of weight fragments in registers: Dt <= 16 KS, or CHUNKED: any Dt,
+                                           // 16 KS columns at a time (each chunk's fragments are requested when the previous chunk is done)
 __device__ __forceinline__ void hyper_fwd_split_body(const HyperFwdArgs& a, int bid, float* sm, int* s_last) {
     const FwdDims& d = a.d;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -92,6 +95,20 @@ __device__ __forceinline__ void hyper_fwd_split_body(const HyperFwdArgs& a, int 
             const f32x4 xf = *(const f32x4*)(xr + s_ * 16);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s_][e], xf[e], acc, 0, 0, 0);
+        }
+    }
+    if constexpr (CHUNKED) {
+        for (int s0 = KS; s0 < nstep; s0 += KS) {
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) wf[s_] = *(const f32x4*)(wrow + min((s0 + s_) * 16 + 4 * q, Dt - 4));
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {
+                if (s0 + s_ < nstep) {
+                    const f32x4 xf = *(const f32x4*)(xr + (s0 + s_) * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s_][e], xf[e], acc, 0, 0, 0);
+                }
+            }
         }
     }
     {

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* 
     int bid = blockIdx.x;
     if constexpr (RIDER) {
         __shared__ int s_last;
-        if (bid < rider.nblk) { hyper_fwd_split_body<HF_RIDER_KS>(rider, bid, (float*)&lds[0][0][0][0], &s_last); return; }
+        if (bid < rider.nblk) { hyper_fwd_split_body<HF_RIDER_KS, true>(rider, bid, (float*)&lds[0][0][0][0], &s_last); return; }
         bid -= rider.nblk;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -712,7 +712,7 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
         static const int sbn = getenv("FUMI_XP_SBN") ? atoi(getenv("FUMI_XP_SBN")) : 2;          // ring depth (tuning knob)
         static const int ride = getenv("FUMI_XP_RIDER") ? atoi(getenv("FUMI_XP_RIDER")) : 1;     // 0: never carry the hypernetwork forward
         HyperFwdArgs none; memset(&none, 0, sizeof(none));
-        if (ride && rider && rider_done && rider->nblk > 0 && rider->nblk % 8 == 0 && rider->d.Dt <= 16 * HF_RIDER_KS &&
+        if (ride && rider && rider_done && rider->nblk > 0 && rider->nblk % 8 == 0 && rider->d.Dt <= HF_RIDER_MAXDT &&
             hyper_fwd_split_lds_bytes(rider->d.ldx) <= sizeof(unsigned short) * 2 * 2 * 3 * SPLANE && sbn <= 2) {
             hipLaunchKernelGGL((xpanel_fwd_sb_kernel<2, true>), dim3(grid.x + rider->nblk), dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, *rider);
             *rider_done = 1;
