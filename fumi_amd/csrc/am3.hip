@@ -484,22 +484,25 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     float* imq = im + (long)S * P;
 
     GemmArgs g;
+    HyperFwdArgs fa;
+    float* hfg = nullptr; bool g_split = false; int g_rode = 0;
     {
         // image encoder on every support and query row in ONE pass of the X-panel kernel (xpanel.hip: the panel [Xs_b;Xq_b]
         // times Wi^T per episode, rows never copied; G = NULL: no Gram block).  The bias is added where the head reads.
         ProfScope ps(ws, st, FUMI_PH_XPANEL_FWD);
         float* xparts = xks > 1 ? ws_f(ws, (size_t)xks * (Rs + Rq) * P) : nullptr;
-        if ((rc = launch_xpanel_fwd(st, B, S, Qn, D, P, x_s, x_q, Wi, im, nullptr, nullptr, nullptr, nullptr, xparts))) return rc;
+        // the text MLP g (independent of the images) rides at the front of this launch when it can (hyper_fwd.h)
+        hfg = mlp_fused ? ws_f(ws, hfg_n) : nullptr;
+        g_split = mlp_fused && Rs < (1 << 30) / Ht &&
+                  hyper_fwd_split_args((int)Rs, Dt, Ht, P, 0, text_s, G0, g0, G1, g1, t1, tx, hfg, ws->hcnt, &fa);
+        if (g_split) { fa.d.drop_thr = thr; fa.d.drop_key = dkey(1); fa.d.drop_scale = dsc; }
+        if ((rc = launch_xpanel_fwd(st, B, S, Qn, D, P, x_s, x_q, Wi, im, nullptr, nullptr, g_split ? &fa : nullptr, &g_rode, xparts))) return rc;
     }
     {
         ProfScope ps(ws, st, FUMI_PH_HYPER_FWD);
-        HyperFwdArgs fa;
-        float* hfg = mlp_fused ? ws_f(ws, hfg_n) : nullptr;
         float* hfh = mlp_fused ? ws_f(ws, hfh_n) : nullptr;
-        if (mlp_fused && Rs < (1 << 30) / Ht &&
-            hyper_fwd_split_args((int)Rs, Dt, Ht, P, 0, text_s, G0, g0, G1, g1, t1, tx, hfg, ws->hcnt, &fa)) {
-            fa.d.drop_thr = thr; fa.d.drop_key = dkey(1); fa.d.drop_scale = dsc;
-            if ((rc = launch_hyper_fwd_split(st, fa))) return rc;
+        if (g_split) {
+            if (!g_rode && (rc = launch_hyper_fwd_split(st, fa))) return rc;
         } else {
             g = gemm_args((int)Rs, Ht, Dt, text_s, Dt, G0, Dt, t1, Ht); g.bias = g0; g.act = 1;
             g.drop_thr = thr; g.drop_key = dkey(1); g.drop_scale = dsc;
