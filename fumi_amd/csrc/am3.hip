@@ -458,7 +458,8 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     static const int mlp_fused = getenv("FUMI_AM3_MLP") ? atoi(getenv("FUMI_AM3_MLP")) : 1;      // 0: one GEMM launch per product
     const size_t hfg_n = hyper_fwd_workspace_floats((int)Rs, Ht, P), hfh_n = hyper_fwd_workspace_floats((int)Rs, Ht, 1);
     const size_t hbh_n = hyper_bwd_fused_workspace_floats((int)Rs, P, Ht, 1), hbg_n = hyper_bwd_fused_workspace_floats((int)Rs, 0, Ht, P);
-    if (mlp_fused) { A(hfg_n); A(hfh_n); if (need_grad) { A(hbh_n); A(hbg_n); } }
+    const size_t txp_n = (need_grad && (Ht & 63) == 0) ? (size_t)((Rs + 15) / 16) * (Ht / 64) * 16 * P : 0;   // partials of txbar += l1bar H0
+    if (mlp_fused) { A(hfg_n); A(hfh_n); if (need_grad) { A(hbh_n); A(hbg_n); A(txp_n); } }
     // query shares per episode of the head kernel: enough workgroups for the chip, >= 2 rows per wave, counters available
     static const int hgq_env = getenv("FUMI_AM3_GQ") ? atoi(getenv("FUMI_AM3_GQ")) : 0;
     int hgq = 1;
@@ -586,12 +587,23 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
         return FUMI_OK;
     };
     HyperBwdArgs ba;
+    int tx_nparts = 0;
+    // (the partials are only used when BOTH backward passes take the fused form: g's is checked first)
+    HyperBwdArgs probe; ReduceSegs dummy; dummy.n = 0; dummy.scale = 1.f;
+    float* txparts = nullptr;
+    if (mlp_fused && lamda_fixed < 0 && txp_n) {
+        float* cand = ws_f(ws, txp_n);
+        if (hyper_bwd_fused_args((int)Rs, Dt, Ht, P, 0, dsc, text_s, t1, nullptr, txb, G1, cand /* any aligned pointer */, nullptr,
+                                 g_w[3], g_w[4], g_w[5], &dummy, &probe, t1b)) txparts = cand;
+    }
     float* hbh = (mlp_fused && need_grad) ? ws_f(ws, hbh_n) : nullptr;
     float* hbg = (mlp_fused && need_grad) ? ws_f(ws, hbg_n) : nullptr;
     if (lamda_fixed < 0) {
         // h network: lam = sigmoid(l1 H1^T + h1), l1 = relu(tx H0^T + h0)
         if (mlp_fused && hyper_bwd_fused_args((int)Rs, P, Ht, 1, 0, dsc, tx, l1, nullptr, zlb, H1, hbh, g_w[6], g_w[7], g_w[8], g_w[9],
                                               &tail_, &ba, l1b)) {
+            // txbar += l1bar H0 leaves this launch as per-(row block, chunk) partials that g's backward adds while it stages txbar
+            if (txparts && P <= HBW_XDT && (P & 3) == 0) { ba.A0 = H0; ba.xpart = txparts; tx_nparts = Ht / 64; }
             if ((rc = launch_hyper_bwd_fused(st, ba))) return rc;                      // gH1, gh1, l1bar, gh0, gH0 (row-block slabs)
         } else {
             if ((rc = wgrad(1, Ht, zlb, 1, l1, Ht, g_w[8]))) return rc;                // gH1 = zlbar^T l1
@@ -602,8 +614,10 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
             if ((rc = wgrad(Ht, P, l1b, Ht, tx, P, g_w[6]))) return rc;                // gH0 = l1bar^T tx
             cj.add(l1b, (int)Rs, Ht, Ht, g_w[7]);
         }
-        g = gemm_args((int)Rs, P, Ht, l1b, Ht, H0, P, txb, P); g.accumulate = 1;       // txbar += l1bar H0
-        if ((rc = launch_gemm(st, g, 0, 1))) return rc;
+        if (!tx_nparts) {
+            g = gemm_args((int)Rs, P, Ht, l1b, Ht, H0, P, txb, P); g.accumulate = 1;   // txbar += l1bar H0
+            if ((rc = launch_gemm(st, g, 0, 1))) return rc;
+        }
     } else {
         HIP_TRY(hipMemsetAsync(g_w[6], 0, (size_t)Ht * P * 4, st)); HIP_TRY(hipMemsetAsync(g_w[7], 0, (size_t)Ht * 4, st));
         HIP_TRY(hipMemsetAsync(g_w[8], 0, (size_t)Ht * 4, st)); HIP_TRY(hipMemsetAsync(g_w[9], 0, 4, st));
@@ -611,8 +625,10 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     // g network: tx = t1 G1^T + g1, t1 = relu(text G0^T + g0)
     if (mlp_fused && hyper_bwd_fused_args((int)Rs, Dt, Ht, P, 0, dsc, text_s, t1, nullptr, txb, G1, hbg, nullptr, g_w[3], g_w[4], g_w[5],
                                           &tail_, &ba, t1b)) {
+        if (tx_nparts) { ba.hbar_parts = txparts; ba.hbar_nparts = tx_nparts; }
         if ((rc = launch_hyper_bwd_fused(st, ba))) return rc;                          // gG1, gg1, t1bar, gg0 (row-block slabs)
     } else {
+        if (tx_nparts) return FUMI_EINVAL;                                             // (cannot happen: probed above)
         if ((rc = wgrad(P, Ht, txb, P, t1, Ht, g_w[4]))) return rc;                    // gG1 = txbar^T t1
         cj.add(txb, (int)Rs, P, P, g_w[5]);
         g = gemm_args((int)Rs, Ht, P, txb, P, G1, Ht, t1b, Ht);                        // t1bar = (txbar G1) * relu'(t1) * dropout scale

@@ -456,6 +456,7 @@ int hyper_bwd_fused_args(int R, int Dt, int Ht, int H1, int tanh_head, float msc
     a->pA1 = part; a->pb1 = a->pA1 + up4((size_t)nrb * H1 * Ht); a->pb0 = a->pb1 + up4((size_t)nrb * H1);
     a->pA0 = gA0 ? a->pb0 + up4((size_t)nrb * Ht) : nullptr;
     a->ub_out = ub_out;
+    a->A0 = nullptr; a->xpart = nullptr; a->hbar_parts = nullptr; a->hbar_nparts = 0;
     a->nrb = nrb; a->nblk = 8 * nch * ((nrb + 7) / 8);
     segs->add(a->pA1, nrb, (long)H1 * Ht, (long)H1 * Ht, gA1);
     segs->add(a->pb1, nrb, H1, H1, gb1);
@@ -465,7 +466,8 @@ int hyper_bwd_fused_args(int R, int Dt, int Ht, int H1, int tanh_head, float msc
 }
 
 int launch_hyper_bwd_fused(hipStream_t st, const HyperBwdArgs& a) {
-    const size_t lds = (size_t)hyper_bwd_lds_floats(a.Dt, a.H1) * 4;
+    const size_t lds = (size_t)hyper_bwd_lds_floats(a.Dt, a.H1, a.xpart != nullptr) * 4;
+    if (lds > 160 * 1024 || (a.xpart && (a.Dt > HBW_XDT || !a.A0))) return FUMI_EINVAL;
     FUMI_SET_DYN_LDS(hyper_bwd_fused_kernel, lds);
     hipLaunchKernelGGL(hyper_bwd_fused_kernel, dim3(a.nblk), dim3(512), lds, st, a);
     LAUNCH_CHECK();

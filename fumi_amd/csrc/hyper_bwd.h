@@ -21,12 +21,20 @@ struct HyperBwdArgs {
     float mscale;                          // factor of the ReLU derivative (1, or 1/(1-p) with dropout after the ReLU)
     const float *c, *u, *h, *hbar, *A1;    // rows [R,Dt]; hidden activations [R,Ht]; output [R,H1]; its adjoint; layer 1 [H1,Ht]
     float *pA1, *pb1, *pb0, *pA0;          // slabs: [nrb,H1,Ht] [nrb,H1] [nrb,Ht] [nrb,Ht,Dt] (pA0 NULL: layer-0 weight gradient not formed)
-    float* ub_out;                         // optional [R,Ht]: ubar to memory (callers that need ubar A0 or form ubar^T c themselves)
+    float* ub_out;                         // optional [R,Ht]: ubar to memory (callers that form ubar^T c themselves)
+    // optional adjoint of the INPUT rows, for a network whose input is another network's output (AM3: h reads g's output):
+    //   xpart [nrb][Ht/64][16][Dt] receives this workgroup's partial ubar_chunk A0[chunk, :]   (needs A0 and Dt <= HBW_XDT)
+    //   hbar_parts / hbar_nparts: the adjoint this backward starts from is hbar + the sum of that many such partials
+    //   (the consumer side: same row blocking, parts [nrb][hbar_nparts][16][H1])
+    const float* A0; float* xpart;
+    const float* hbar_parts; int hbar_nparts;
     int nrb, nblk;                         // row blocks; workgroups = 8 * (Ht/64) * ceil(nrb/8)
 };
+constexpr int HBW_XDT = 128;               // widest input whose adjoint partials are formed here (its layer-0 chunk [64, Dt] sits in LDS)
 constexpr int HBW_DC = 384;                // input columns of the layer-0 weight slab formed per pass (the rows' LDS image is that wide)
-__host__ __device__ inline int hyper_bwd_lds_floats(int Dt, int H1) {
-    return HBW_HB * wg_ld(H1) + 2 * HBW_HB * wg_ld(64) + ((H1 + 3) & ~3) * wg_ld(64) + HBW_HB * wg_ld(Dt < HBW_DC ? Dt : HBW_DC) + 64;
+__host__ __device__ inline int hyper_bwd_lds_floats(int Dt, int H1, int with_xpart = 0) {
+    return HBW_HB * wg_ld(H1) + 2 * HBW_HB * wg_ld(64) + ((H1 + 3) & ~3) * wg_ld(64) + HBW_HB * wg_ld(Dt < HBW_DC ? Dt : HBW_DC) + 64 +
+           (with_xpart ? 64 * wg_ld(Dt) : 0);
 }
 
 // bid in [0, nblk); sm >= hyper_bwd_lds_floats() floats; any workgroup size that is a multiple of 64
@@ -42,7 +50,9 @@ __device__ __forceinline__ void hyper_bwd_body(const HyperBwdArgs& a, int bid, f
     const int ld1 = wg_ld(H1), ldc = wg_ld(64), ldd = wg_ld(dcw), H1r = (H1 + 3) & ~3;
     float* hp = sm; float* uc = hp + HBW_HB * ld1; float* ubc = uc + HBW_HB * ldc; float* A1c = ubc + HBW_HB * ldc;
     float* cr = A1c + H1r * ldc;
-    const int tot = HBW_HB * ld1 + 2 * HBW_HB * ldc + H1r * ldc + HBW_HB * ldd;
+    float* A0c = cr + HBW_HB * ldd;                                       // [64][wg_ld(Dt)] rows cb*64.. of layer 0 (xpart only)
+    const int ldx = wg_ld(Dt);
+    const int tot = HBW_HB * ld1 + 2 * HBW_HB * ldc + H1r * ldc + HBW_HB * ldd + (a.xpart ? 64 * ldx : 0);
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     for (int i = tid * 4; i < tot; i += nt * 4) *(f32x4*)(sm + i) = z4;
     __syncthreads();
@@ -50,6 +60,10 @@ __device__ __forceinline__ void hyper_bwd_body(const HyperBwdArgs& a, int bid, f
     for (int i = tid; i < nr * H1; i += nt) {
         const int m = i / H1, n = i - m * H1;
         float v = a.hbar[(long)(m0 + m) * H1 + n];
+        if (a.hbar_parts) {                                                // + the producer's partials, in chunk order
+            const float* pp = a.hbar_parts + ((long)rb * a.hbar_nparts * HBW_HB + m) * H1 + n;
+            for (int c = 0; c < a.hbar_nparts; ++c) v += pp[(long)c * HBW_HB * H1];
+        }
         if (a.tanh_head) { const float hv = a.h[(long)(m0 + m) * H1 + n]; v *= 1.f - hv * hv; }
         hp[m * ld1 + n] = v;
     }
@@ -90,6 +104,13 @@ __device__ __forceinline__ void hyper_bwd_body(const HyperBwdArgs& a, int bid, f
         }
     };
     if (a.pA0) stage_rows(0, dcw);
+    if (a.xpart) {
+        const int d4 = Dt >> 2;
+        for (int i = tid; i < 64 * d4; i += nt) {
+            const int k = i / d4, c4 = (i - k * d4) << 2;
+            *(f32x4*)(A0c + k * ldx + c4) = *(const f32x4*)(a.A0 + (long)(cb * 64 + k) * Dt + c4);
+        }
+    }
     __syncthreads();
     // ---- ubar chunk
     wg_lmm_wide<true>(nr, 64, H1, hp, ld1, A1c, ldc, [&](int m, int n, const f32x4& acc, int, auto) {
@@ -109,6 +130,12 @@ __device__ __forceinline__ void hyper_bwd_body(const HyperBwdArgs& a, int bid, f
     wg_lds_barrier();
     wg_lcolsum(nr, 64, ubc, ldc, [&](int n, float s_) { a.pb0[(long)rb * Ht + cb * 64 + n] = s_; });
     // ---- layer-0 weight slab: rows of this chunk, every input column
+    if (a.xpart) {                                                         // partial input adjoint: ubar_chunk [16,64] A0[chunk] [64,Dt]
+        float* xp = a.xpart + ((long)rb * nch + cb) * HBW_HB * Dt;
+        wg_lmm_wide<true>(HBW_HB, Dt, 64, ubc, ldc, A0c, ldx, [&](int m, int n, const f32x4& acc, int cnt, auto) {
+            wg_st4(xp + (long)m * Dt + n, acc, cnt);
+        });
+    }
     if (!a.pA0) return;
     float* p0 = a.pA0 + ((long)rb * Ht + cb * 64) * Dt;
     for (int dc0 = 0; dc0 < Dt; dc0 += HBW_DC) {
