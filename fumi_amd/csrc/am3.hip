@@ -188,7 +188,9 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
                                                        float* __restrict__ im_s_bar, float* __restrict__ tx_bar,
                                                        float* __restrict__ zl_bar, float* __restrict__ im_q_bar,
                                                        long im_stride, const float* __restrict__ im_bias, int* status,
-                                                       int B, int GQ, float* part, int* arrive) {
+                                                       int B, int GQ, float* part, int* arrive, int imparts, long impart_stride) {
+    // imparts > 1: the image embeddings arrive as that many partial products (split contraction of the encoder pass, xpanel.hip),
+    // im_s / im_q point at part 0 and the parts are added where a row is read.
     // GQ workgroups per episode (ids equal mod 8: one XCD): each forms the prototypes and takes a contiguous share of the query
     // rows; loss / correct counts / prototype adjoints of the shares meet in `part` ([B][GQ][N*P + 2], agent-scope stores) and
     // the workgroup that arrives last at the episode's counter adds them in share order (deterministic) and runs the support-
@@ -214,13 +216,22 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
     float xn[HPJ], bq[HPJ];
 #pragma unroll
     for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; bq[k] = (k < npj && j < P) ? im_bias[j] : 0.f; }
+    auto qrow = [&](int q, int j) {                          // one element of query row q (all parts)
+        float v = im_q[(long)q * P + j];
+        for (int z = 1; z < imparts; ++z) v += im_q[z * impart_stride + (long)q * P + j];
+        return v;
+    };
 #pragma unroll
-    for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; xn[k] = (k < npj && j < P && q0 + wave < q1) ? im_q[(long)(q0 + wave) * P + j] : 0.f; }
+    for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; xn[k] = (k < npj && j < P && q0 + wave < q1) ? qrow(q0 + wave, j) : 0.f; }
     long yn = q0 + wave < q1 ? y_q[q0 + wave] : 0;
     for (int i0 = tid; i0 < SP; i0 += 4 * nt) {
         float a[4], t[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * nt, SP - 1); a[u] = im_s[i] + im_bias[i % P]; t[u] = tx[i]; }
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * nt, SP - 1);
+            a[u] = im_s[i] + im_bias[i % P]; t[u] = tx[i];
+            for (int z = 1; z < imparts; ++z) a[u] += im_s[z * impart_stride + i];
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const int i = i0 + u * nt; if (i < SP) { ims[i] = a[u]; txs[i] = t[u]; } }
     }
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
         long yq = yn;
         const int qn = q + nw;                                                  // prefetch the wave's next row
 #pragma unroll
-        for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; xn[k] = (k < npj && j < P && qn < q1) ? im_q[(long)qn * P + j] : 0.f; }
+        for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; xn[k] = (k < npj && j < P && qn < q1) ? qrow(qn, j) : 0.f; }
         yn = qn < q1 ? y_q[qn] : 0;
         if (yq < 0 || yq >= N) { if (lane == 0) atomicOr(status, FUMI_ST_LABEL_RANGE); yq = 0; }
         // lane c keeps d_c = |proto_c - x|^2; eight classes are reduced together (their butterflies interleave: one
@@ -485,6 +496,8 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     float* imq = im + (long)S * P;
 
     GemmArgs g;
+    ReduceSegs fin;
+    int im_nparts = 0; const float* im_src = im; long im_pstride = 0;
     HyperFwdArgs fa;
     float* hfg = nullptr; bool g_split = false; int g_rode = 0;
     {
@@ -497,7 +510,9 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
         g_split = mlp_fused && Rs < (1 << 30) / Ht &&
                   hyper_fwd_split_args((int)Rs, Dt, Ht, P, 0, text_s, G0, g0, G1, g1, t1, tx, hfg, ws->hcnt, &fa);
         if (g_split) { fa.d.drop_thr = thr; fa.d.drop_key = dkey(1); fa.d.drop_scale = dsc; }
-        if ((rc = launch_xpanel_fwd(st, B, S, Qn, D, P, x_s, x_q, Wi, im, nullptr, nullptr, g_split ? &fa : nullptr, &g_rode, xparts))) return rc;
+        if ((rc = launch_xpanel_fwd(st, B, S, Qn, D, P, x_s, x_q, Wi, im, nullptr, nullptr, g_split ? &fa : nullptr, &g_rode, xparts,
+                                    fast_head ? &im_nparts : nullptr))) return rc;
+        if (im_nparts > 1) { im_src = xparts; im_pstride = (long)(Rs + Rq) * P; }        // the head adds the parts where it reads rows
     }
     {
         ProfScope ps(ws, st, FUMI_PH_HYPER_FWD);
@@ -540,9 +555,9 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
         if (fast_head) {
             FUMI_SET_DYN_LDS(am3_head_kernel, lds);
             hipLaunchKernelGGL(am3_head_kernel, dim3(8 * ((B + 7) / 8) * hgq), dim3(64 * nwaves), lds, st, N, S, Qn, P, lamda_fixed,
-                               need_grad ? 1 : 0, dscale, im, tx, lamda_s, y_s, imq, y_q, preds_q, lc, lc + B, confb, lamb,
+                               need_grad ? 1 : 0, dscale, im_src, tx, lamda_s, y_s, im_src + (long)S * P, y_q, preds_q, lc, lc + B, confb, lamb,
                                grad_scale / (float)S, imb, txb, zlb, imb ? imb + (long)S * P : nullptr, imst, bi, ws->status,
-                               B, hgq, hpart, ws->hcnt);
+                               B, hgq, hpart, ws->hcnt, im_nparts > 1 ? im_nparts : 1, im_pstride);
         } else {
             hipLaunchKernelGGL(am3_bias_rows_kernel, dim3(256), dim3(256), 0, st, im, bi, (long)(Rs + Rq) * P, P);
             FUMI_SET_DYN_LDS(am3_head_generic_kernel, lds);
@@ -551,8 +566,8 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
                                grad_scale / (float)S, imb, txb, zlb, imb ? imb + (long)S * P : nullptr, imst, bi, ws->status);
         }
         LAUNCH_CHECK();
-        ReduceSegs fin; fin.n = 0; fin.scale = 1.f;              // per-episode loss / correct counts -> scalars, one launch
-        fin.add(lc, B, 1, 1, loss);
+        fin.n = 0; fin.scale = 1.f;                              // per-episode loss / correct counts -> scalars: with gradients they
+        fin.add(lc, B, 1, 1, loss);                              // join the step's final reduction, else one small launch here
         fin.add(lc + B, B, 1, 1, correct);
         if (stats) {        // [loss | correct count | this rank's share of the mean lamda | confusion counts]
             fin.add(lc, B, 1, 1, stats);
@@ -560,7 +575,7 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
             fin.add(lamb, B, 1, 1, stats + 2);
             fin.add(confb, B, (long)N * N, (long)N * N, stats + 3);
         }
-        if ((rc = launch_reduce_multi(st, fin))) return rc;
+        if (!need_grad && (rc = launch_reduce_multi(st, fin))) return rc;
     }
     if (!need_grad) return FUMI_OK;
     if (dx_s && dx_q) {                     // one batched product per side: rows of episode b sit at imbar + b (S+Qn) P
@@ -645,6 +660,7 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
         cj.add(imb, (int)(Rs + Rq), P, P, g_w[1]);
         // every bias gradient (column sums over all rows) and the image-encoder weight slabs: two launches in all
         tail_.add(slabs, xns, slab, slab, g_w[0]);
+        if (!tail_.append(fin) && (rc = launch_reduce_multi(st, fin))) return rc;      // loss / correct / statistics: same final launch
         if ((rc = launch_colsum_multi(st, cj, cpart, &tail_))) return rc;
     }
     return FUMI_OK;

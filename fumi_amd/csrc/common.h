@@ -121,6 +121,15 @@ struct ReduceSegs {
         src[n] = s; nslab[n] = ns; stride[n] = st; dst[n] = d; vec[n] = v4 ? 1 : 0;
         end[n] = (n ? end[n - 1] : 0) + (v4 ? cnt / 4 : cnt); ++n;
     }
+    // the segments of `o` (same scale) after this one's; false when they do not fit
+    bool append(const ReduceSegs& o) {
+        if (n + o.n > 24 || o.scale != scale) return false;
+        for (int i = 0; i < o.n; ++i) {
+            src[n] = o.src[i]; nslab[n] = o.nslab[i]; stride[n] = o.stride[i]; dst[n] = o.dst[i]; vec[n] = o.vec[i];
+            end[n] = (n ? end[n - 1] : 0) + (o.end[i] - (i ? o.end[i - 1] : 0)); ++n;
+        }
+        return true;
+    }
 };
 int launch_reduce_multi(hipStream_t st, ReduceSegs& sg);
 // out[n] = scale * sum_m X[m*ld + n]
@@ -149,7 +158,8 @@ struct HyperFwdArgs;         // hyper_fwd.h: a split hypernetwork forward that c
 int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
                       const float* W0, float* A0 /*[B,S+Qn,h0]*/, float* G /*[B,S+Qn,S]*/, const XRows* rows = nullptr,
                       const HyperFwdArgs* rider = nullptr, int* rider_done = nullptr /* set to 1 when the rider was launched */,
-                      float* parts = nullptr /* [xpanel_fwd_ksplit(), B, S+Qn, h0] partial products of a split contraction */);
+                      float* parts = nullptr /* [xpanel_fwd_ksplit(), B, S+Qn, h0] partial products of a split contraction */,
+                      int* parts_unreduced = nullptr /* not NULL: the parts are NOT summed into A0; receives their number (0: A0 is final) */);
 int xpanel_fwd_ksplit(int B, int S, int Qn, int D, int h0, int with_gram);
 int xpanel_bwd_nsplit(int B, int S, int Qn, int D, int h0, int* kchunk_out);
 struct HyperBwdArgs;         // hyper_bwd.h: the hypernetwork backward, able to ride at the front of the backward X-panel launch

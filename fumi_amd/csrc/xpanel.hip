@@ -693,7 +693,8 @@ int xpanel_fwd_ksplit(int B, int S, int Qn, int D, int h0, int with_gram) {
 
 int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
                       const float* W0, float* A0, float* G, const XRows* rows, const HyperFwdArgs* rider, int* rider_done,
-                      float* parts) {
+                      float* parts, int* parts_unreduced) {
+    if (parts_unreduced) *parts_unreduced = 0;
     if (rider_done) *rider_done = 0;
     float* const A0_final = A0;
     XPanel p{x_s, x_q, W0, B, S, Qn, D, h0, nullptr, nullptr, nullptr, 0, G ? S : 0, 1, 0};
@@ -727,7 +728,10 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
     else if (aligned && D % BK == 0) hipLaunchKernelGGL(xpanel_fwd_generic_kernel<true>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, 0);
     else hipLaunchKernelGGL(xpanel_fwd_generic_kernel<false>, grid, dim3(256), 0, st, p, A0, G, tiles_m, tiles_n, 0);
     LAUNCH_CHECK();
-    if (p.ksplit > 1) return launch_reduce_slabs(st, parts, p.ksplit, p.part_stride, p.part_stride, 1.f, A0_final);
+    if (p.ksplit > 1) {
+        if (parts_unreduced) { *parts_unreduced = p.ksplit; return FUMI_OK; }      // the consumer adds the parts where it reads them
+        return launch_reduce_slabs(st, parts, p.ksplit, p.part_stride, p.part_stride, 1.f, A0_final);
+    }
     return FUMI_OK;
 }
 

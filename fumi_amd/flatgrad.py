@@ -14,6 +14,14 @@ class FlatGrads:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.tail = self.flat[off:]
+        self._splits = {}
+
+    def split(self, n):
+        """(views[:n], views[n:]) as list objects that stay the same from call to call (hip.py validates a list once)."""
+        sp = self._splits.get(n)
+        if sp is None:
+            sp = self._splits[n] = (self.views[:n], self.views[n:])
+        return sp
 
     def matches(self, params):
         params = list(params)

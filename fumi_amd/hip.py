@@ -67,6 +67,11 @@ class RowRef:
     def float(self):
         return self
 
+    dtype = torch.float32
+
+    def is_contiguous(self):
+        return self.idx.is_contiguous()
+
     def materialize(self):
         return self.table[self.idx]
 
@@ -230,7 +235,15 @@ def _parr(tensors, name):
     return arr
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device):
+    """The caller's current stream on `device` (torch.cuda.current_stream builds a Stream object: ~1.4 us a call, and a step
+    asks several times)."""
+    if _RAW_STREAM is not None:
+        idx = device.index
+        return c_void_p(_RAW_STREAM(idx if idx is not None else torch.cuda.current_device()))
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
@@ -349,21 +362,51 @@ def fumi_step_select(ws, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha
                       None, text_s, need_grad, grad_scale, g_theta, g_phi, stats, dropout_p, seed)
 
 
+# Parameter / gradient LISTS that a model hands over unchanged step after step (the same list objects: fumi_amd/models cache
+# them) are validated once: shapes, dtypes, contiguity and the pointer tables are remembered per tuple of list identities
+# (the lists are held here, so an id cannot be recycled) and re-checked only through the first tensor's address.  Callers that
+# build fresh lists every call take the full checks every call.
+_PARAMSETS = {}
+
+
+def _paramset(key_lists, dims, build):
+    key = tuple(id(x) for x in key_lists) + dims
+    ent = _PARAMSETS.get(key)
+    if ent is not None and all(a is b for a, b in zip(ent[0], key_lists)) and ent[1] == key_lists[0][0].data_ptr():
+        return ent[2]
+    val = build()
+    if len(_PARAMSETS) > 64:
+        _PARAMSETS.clear()
+    _PARAMSETS[key] = (tuple(key_lists), key_lists[0][0].data_ptr(), val)
+    return val
+
+
 def _fumi_step(ws, dev, B, N, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head,
                cls_text, text_s, need_grad, grad_scale, g_theta, g_phi, stats=None, dropout_p=0.0, seed=0):
     L = lib()
-    if len(theta) != 2 * len(hid) or len(phi) != 4 or not hid:
-        raise FumiHipError("fumi_step: theta must hold (weight, bias) per hidden layer and phi the 4 hypernetwork tensors")
-    H = _mlp_shapes(theta, D, "theta", len(hid))
-    _shape(phi[1], (Ht,), "phi[1]"); _shape(phi[2], (H + 1, Ht), "phi[2]"); _shape(phi[3], (H + 1,), "phi[3]")
+
+    def check_params():
+        if len(theta) != 2 * len(hid) or len(phi) != 4 or not hid:
+            raise FumiHipError("fumi_step: theta must hold (weight, bias) per hidden layer and phi the 4 hypernetwork tensors")
+        H = _mlp_shapes(theta, D, "theta", len(hid))
+        _shape(phi[0], (Ht, Dt), "phi[0]"); _shape(phi[1], (Ht,), "phi[1]"); _shape(phi[2], (H + 1, Ht), "phi[2]")
+        _shape(phi[3], (H + 1,), "phi[3]")
+        if need_grad and g_theta is not None:
+            for i, (g, t) in enumerate(zip(list(g_theta) + list(g_phi or []), list(theta) + list(phi))):
+                _shape(g, t.shape, f"gradient buffer {i}")
+        return (_parr(theta, "theta"), _parr(phi, "phi"),
+                _parr(g_theta, "g_theta") if (need_grad and g_theta is not None) else None,
+                _parr(g_phi, "g_phi") if (need_grad and g_phi is not None) else None)
+
+    if need_grad and g_theta is not None and g_phi is not None:
+        arrs = _paramset((theta, phi, g_theta, g_phi), (D, Dt, Ht, tuple(hid)), check_params)
+    else:
+        arrs = check_params()
     _shape(x_q, (B, Qn, D), "x_q"); _shape(y_s, (B, S), "y_s"); _shape(y_q, (B, Qn), "y_q")
     if cls_text is not None:
         _shape(cls_text, (B, N, Dt), "cls_text")
     else:
         _shape(text_s, (B, S, Dt), "text_s")
-    if need_grad and g_theta is not None:
-        for i, (g, t) in enumerate(zip(list(g_theta) + list(g_phi or []), list(theta) + list(phi))):
-            _shape(g, t.shape, f"gradient buffer {i}")
     logits = torch.empty(B, Qn, N, device=dev, dtype=torch.float32)
     preds = torch.empty(B, Qn, device=dev, dtype=torch.int64)
     preds_f = torch.empty(B, Qn, device=dev, dtype=torch.float32)      # the reference's float test_preds, same launch
@@ -390,10 +433,12 @@ def _fumi_step(ws, dev, B, N, S, Qn, D, hid, Dt, Ht, x_s, y_s, x_q, y_q, theta, 
         *head, *rows,
         _f32(cls_text, "cls_text") if cls_text is not None else None,
         _f32(text_s, "text_s") if text_s is not None else None,
-        _parr(theta, "theta"), _parr(phi, "phi"),
-        _f32(logits, "logits"), _i64(preds, "preds"), _f32(preds_f, "preds_f"), _f32(loss_b, "loss_b"), _f32(acc_b, "acc_b"),
+        arrs[0], arrs[1],
+        c_void_p(logits.data_ptr()), c_void_p(preds.data_ptr()), c_void_p(preds_f.data_ptr()), c_void_p(loss_b.data_ptr()),
+        c_void_p(acc_b.data_ptr()),
         _f32(stats, "stats") if stats is not None else None,
-        _parr(g_theta, "g_theta") if need_grad else None, _parr(g_phi, "g_phi") if need_grad else None)
+        (arrs[2] if arrs[2] is not None else _parr(g_theta, "g_theta")) if need_grad else None,
+        (arrs[3] if arrs[3] is not None else _parr(g_phi, "g_phi")) if need_grad else None)
     _check(rc, "fumi_hip_fumi_step")
     return dict(logits=logits, preds=preds, preds_f=preds_f, loss_b=loss_b, acc_b=acc_b, g_theta=g_theta, g_phi=g_phi, stats=stats)
 
@@ -452,12 +497,17 @@ def am3_step(ws, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed=None, *, need
     if len(w) != 10:
         raise FumiHipError("am3_step: w must hold the 10 tensors of AM3_KEYS")
     P, Ht, Dt = int(w[0].shape[0]), int(w[2].shape[0]), int(w[2].shape[1])
-    for t, shp, k in zip(w, [(P, D), (P,), (Ht, Dt), (Ht,), (P, Ht), (P,), (Ht, P), (Ht,), (1, Ht), (1,)], AM3_KEYS):
-        _shape(t, shp, f"w[{k}]")
+
+    def check_params():
+        for t, shp, k in zip(w, [(P, D), (P,), (Ht, Dt), (Ht,), (P, Ht), (P,), (Ht, P), (Ht,), (1, Ht), (1,)], AM3_KEYS):
+            _shape(t, shp, f"w[{k}]")
+        if need_grad and g_w is not None:
+            for g, t, k in zip(g_w, w, AM3_KEYS):
+                _shape(g, t.shape, f"g_w[{k}]")
+        return (_parr(w, "w"), _parr(g_w, "g_w") if (need_grad and g_w is not None) else None)
+
+    arrs = _paramset((w, g_w), (D,), check_params) if (need_grad and g_w is not None) else check_params()
     _shape(x_q, (B, Qn, D), "x_q"); _shape(y_s, (B, S), "y_s"); _shape(y_q, (B, Qn), "y_q"); _shape(text_s, (B, S, Dt), "text_s")
-    if need_grad and g_w is not None:
-        for g, t, k in zip(g_w, w, AM3_KEYS):
-            _shape(g, t.shape, f"g_w[{k}]")
     loss = torch.empty(1, device=dev, dtype=torch.float32)
     correct = torch.empty(1, device=dev, dtype=torch.float32)
     preds = torch.empty(B, Qn, device=dev, dtype=torch.int64)
@@ -470,8 +520,9 @@ def am3_step(ws, x_s, y_s, x_q, y_q, text_s, w, n_way, lamda_fixed=None, *, need
     args = [ws.handle, _stream(dev), B, n_way, S, Qn, D, Dt, Ht, P, lf, int(bool(need_grad)), float(grad_scale),
             float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
             _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"), _f32(text_s, "text_s"),
-            _parr(w, "w"), _f32(loss, "loss"), _i64(preds, "preds"), _f32(lam, "lamda_s"), _f32(correct, "correct"),
-            _parr(g_w, "g_w") if need_grad else None, _f32(stats, "stats") if stats is not None else None]
+            arrs[0], c_void_p(loss.data_ptr()), c_void_p(preds.data_ptr()), c_void_p(lam.data_ptr()), c_void_p(correct.data_ptr()),
+            (arrs[1] if arrs[1] is not None else _parr(g_w, "g_w")) if need_grad else None,
+            _f32(stats, "stats") if stats is not None else None]
     dx_s = dx_q = None
     if want_dx and need_grad:               # adjoints of the image rows (an encoder in front of the step continues from them)
         dx_s, dx_q = torch.empty_like(x_s), torch.empty_like(x_q)

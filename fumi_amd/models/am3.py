@@ -72,6 +72,7 @@ class AM3(nn.Module):
         self.h = nn.Sequential(nn.Linear(prototype_dim, text_hid_dim), nn.ReLU(), nn.Dropout(p=dropout),
                                nn.Linear(text_hid_dim, 1))
         self._flat = None
+        self._pcache = None
 
     def _w(self):
         return [self.image_encoder.weight, self.image_encoder.bias, self.g[0].weight, self.g[0].bias, self.g[3].weight,
@@ -83,6 +84,26 @@ class AM3(nn.Module):
         if self._flat is None or not self._flat.matches(params) or self._flat.tail.numel() != extra:
             self._flat = FlatGrads(params, extra=extra)
         return self._flat
+
+    def _step_params(self, need_grad, num_ways):
+        """(detached weights, detached backbone tensors | None, flat gradient buffer | None) as objects that stay the SAME from
+        step to step (hip.py validates a list once); rebuilt when a parameter object was replaced or moved (``_apply``)."""
+        c = self._pcache
+        first = self.image_encoder.weight
+        if c is None or c[0] is not first or c[1] != first.data_ptr():
+            c = self._pcache = (first, first.data_ptr(), [p.detach() for p in self._w()],
+                                [p.detach() for p in self.conv.theta()] if self.conv is not None else None)
+            self._flat = None
+        fg = None
+        if need_grad:
+            fg = self._flat
+            if fg is None or fg.tail.numel() != 3 + num_ways * num_ways:
+                fg = self._flat_grads(num_ways)
+        return c[2], c[3], fg
+
+    def _apply(self, fn, recurse=True):
+        self._pcache = None
+        return super()._apply(fn, recurse)
 
     def _encode_text(self, text):
         if self.text_encoder_type in ("BERT", "precomputed"):
@@ -112,8 +133,9 @@ class AM3(nn.Module):
         """One meta-batch (am3.py:128-212): 6-tuple for train/val, 11-tuple for test."""
         train = task == "train"
         if train:
-            self.train()
-        else:
+            if not self.training:                # (nn.Module.train() walks every submodule: skip it when nothing changes)
+                self.train()
+        elif self.training:
             self.eval()
         drop_p = float(self.dropout) if (train and self.dropout > 0) else 0.0       # nn.Dropout of g / h, train mode only
         drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) + 7919 * fdist.world()[0] if drop_p > 0 else 0
@@ -121,11 +143,19 @@ class AM3(nn.Module):
         (q_idx, _, q_im), q_y = batch['test']
         B, Qn = q_im.shape[0], q_im.shape[1]
         lo, hi = fdist.shard(B)
-        to = lambda t: t[lo:hi].to(device).contiguous()
-        x_s, x_q, y_s, y_q = to(s_im).float(), to(q_im).float(), to(s_y), to(q_y)
+        whole = lo == 0 and hi == B
+        device = torch.device(device) if not isinstance(device, torch.device) else device
+
+        def to(t):                               # this rank's episodes on the device (a tensor that is already there is used as it is)
+            if whole and t.device == device and t.is_contiguous():
+                return t
+            return t[lo:hi].to(device).contiguous()
+        x_s, x_q, y_s, y_q = to(s_im), to(q_im), to(s_y), to(q_y)
+        if x_s.dtype != torch.float32 or x_q.dtype != torch.float32:
+            x_s, x_q = x_s.float(), x_q.float()
         text = self._encode_text(to(s_text))
         need_grad = train and torch.is_grad_enabled()
-        fg = self._flat_grads(num_ways) if need_grad else None
+        w_det, th_det, fg = self._step_params(need_grad, num_ways)
         eng = _engine.get_engine()
         # train / val on the GPU: the step also leaves [loss, correct, mean lamda, confusion counts] in the buffer's tail, one
         # all-reduce covers gradients and statistics, and accuracy / macro P / R / F1 come from one small kernel -- the reference
@@ -135,15 +165,15 @@ class AM3(nn.Module):
         img_s = img_q = theta = None
         if self.conv is not None:           # raw images -> Conv4 features; the tape stays in the encoder's own workspace
             img_s, img_q = x_s, x_q
-            theta = [p.detach() for p in self.conv.theta()]
+            theta = th_det
             x_s, x_q = eng.conv4_encode(img_s, img_q, theta, keep_tape=need_grad)
-        out = eng.am3_step(x_s, y_s, x_q, y_q, text, [p.detach() for p in self._w()], num_ways,
+        out = eng.am3_step(x_s, y_s, x_q, y_q, text, w_det, num_ways,
                            self.lamda_fixed, need_grad=need_grad, grad_scale=1.0 / B,
-                           g_w=fg.views[:10] if need_grad else None, dropout_p=drop_p, seed=drop_seed,
+                           g_w=fg.split(10)[0] if need_grad else None, dropout_p=drop_p, seed=drop_seed,
                            **({"stats": tail} if on_device else {}),
                            **({"want_dx": True} if (self.conv is not None and need_grad) else {}))
         if self.conv is not None and need_grad:     # ... and backwards from the adjoints of the features (already scaled by 1/B)
-            eng.conv4_encode_bwd(img_s, img_q, out["dx_s"], out["dx_q"], theta, scale=1.0, g_theta=fg.views[10:])
+            eng.conv4_encode_bwd(img_s, img_q, out["dx_s"], out["dx_q"], theta, scale=1.0, g_theta=fg.split(10)[1])
         if not on_device:
             torch.stack([out["loss"].reshape(()), out["correct"].reshape(()) / (B * Qn),
                          out["lamda_s"].sum() / (B * out["lamda_s"].shape[1])], out=tail[:3])
@@ -157,7 +187,7 @@ class AM3(nn.Module):
                 # None, so the optimizer (and its weight decay) skips those tensors
                 for p in self.h.parameters():
                     p.grad = None
-            optimizer.step()
+            getattr(optimizer, "step_fused", optimizer.step)()
             if scheduler:
                 scheduler.step()
             lazy.flush(x_s.device)

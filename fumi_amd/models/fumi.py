@@ -104,6 +104,7 @@ class FUMI(nn.Module):
             d = h
         self.im_net = conv if conv is not None else MetaSequential(im)
         self._flat = None
+        self._pcache = None
 
     # ---- parameter views handed to the engine --------------------------------------------------------------------
     def _theta(self):
@@ -123,6 +124,27 @@ class FUMI(nn.Module):
         if self._flat is None or not self._flat.matches(params):
             self._flat = FlatGrads(params, extra=2)
         return self._flat
+
+    def _step_params(self, train):
+        """(theta, phi, flat gradient buffer) as objects that stay the SAME from step to step: detached views of the parameters
+        (they share storage, so optimizer updates show through) and the FlatGrads.  Rebuilt when a parameter object was
+        replaced or moved (``_apply``: .to() / .cuda() / .float())."""
+        c = self._pcache
+        first = self.im_net.theta()[0] if self.im_encoder == "conv4" else self.im_net.linear0.weight
+        if c is None or c[0] is not first or c[1] is not self.hyper_net[0].weight or c[2] != first.data_ptr():
+            theta, phi = self._theta(), self._phi()
+            c = self._pcache = (first, phi[0], first.data_ptr(), [p.detach() for p in theta], [p.detach() for p in phi])
+            self._flat = None
+        fg = None
+        if train:
+            fg = self._flat
+            if fg is None:
+                fg = self._flat_grads()
+        return c[3], c[4], fg
+
+    def _apply(self, fn, recurse=True):
+        self._pcache = None
+        return super()._apply(fn, recurse)
 
     # ---- reference surface ----------------------------------------------------------------------------------------
     def forward(self, text_embed):
@@ -185,8 +207,15 @@ class FUMI(nn.Module):
         (_, q_text, q_im), q_y = batch['test']
         B = s_im.shape[0]
         lo, hi = fdist.shard(B)
-        to = lambda t: t[lo:hi].to(dev).contiguous()
-        x_s, x_q, y_s, y_q = to(s_im).float(), to(q_im).float(), to(s_y), to(q_y)
+        whole = lo == 0 and hi == B
+
+        def to(t):                               # this rank's episodes on the device (a tensor that is already there is used as it is)
+            if whole and t.device == dev and t.is_contiguous():
+                return t
+            return t[lo:hi].to(dev).contiguous()
+        x_s, x_q, y_s, y_q = to(s_im), to(q_im), to(s_y), to(q_y)
+        if x_s.dtype != torch.float32 or x_q.dtype != torch.float32:
+            x_s, x_q = x_s.float(), x_q.float()
         T = args.num_train_adapt_steps if train else args.num_test_adapt_steps
         eng = _engine.get_engine()
         text_s = cls_text = None
@@ -200,28 +229,25 @@ class FUMI(nn.Module):
         else:
             text_s = self._encode_text(to(s_text), dev)
 
-        theta = [p.detach() for p in self._theta()]
-        phi = [p.detach() for p in self._phi()]
-        fg = self._flat_grads() if train else None
+        theta, phi, fg = self._step_params(train)
         nth = len(theta)
+        g_th, g_ph = fg.split(nth) if train else (None, None)
         # [.. grads .. | sum loss / B | sum acc / B], written by the engine -> one all-reduce(sum) -> global means everywhere
         tail = fg.tail if train else torch.empty(2, device=x_s.device, dtype=torch.float32)
         if self.im_encoder == "conv4":
             out = eng.fumi_conv4_step(self.n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, args.step_size, self.norm_hypernet,
                                       need_grad=train, grad_scale=1.0 / B,
-                                      g_theta=fg.views[:nth] if train else None, g_phi=fg.views[nth:] if train else None,
-                                      cls_text=cls_text, stats=tail)
+                                      g_theta=g_th, g_phi=g_ph, cls_text=cls_text, stats=tail)
         else:
             out = eng.fumi_step(self.n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, args.step_size, self.norm_hypernet,
                                 need_grad=train, grad_scale=1.0 / B,
-                                g_theta=fg.views[:nth] if train else None, g_phi=fg.views[nth:] if train else None,
-                                cls_text=cls_text, stats=tail, dropout_p=drop_p, seed=drop_seed)
+                                g_theta=g_th, g_phi=g_ph, cls_text=cls_text, stats=tail, dropout_p=drop_p, seed=drop_seed)
         fdist.all_reduce_sum_(fg.flat if train else tail)
         # read back asynchronously (fumi.py:195 blocks here); in training the two stores ride on the optimizer's launch
         loss, acc = lazy.scalars(tail, 2, defer=train)
         if train:
             fg.attach()                          # .grad of every parameter IS a view of the buffer the engine just filled
-            optimizer.step()                     # (so there is nothing left for zero_grad() to clear, fumi.py:190-193)
+            getattr(optimizer, "step_fused", optimizer.step)()     # (nothing is left for zero_grad() to clear, fumi.py:190-193)
             lazy.flush(x_s.device)
         preds = out["preds_f"]                                   # float, like the reference's test_preds (fumi.py:180-183)
         if fdist.world()[1] > 1 and not train:

@@ -835,3 +835,23 @@ def test_lstm_bidir_matches_reference(dev, ws):
         out = hip.lstm_bidir(ws, _g(tok, dev), _g(table, dev), [_g(t, dev) for t in w], 0, use_cell).cpu()
         assert rel_to_max(out, R.lstm_encode(tok, table, w, 0, use_cell)) <= 2e-5
     assert ws.read_status() == 0
+
+
+def test_fumi_20way_episode_shape_matches_oracle(dev, ws):
+    """BASELINE.json configs[4]'s EPISODE shape on embeddings (20-way 5-shot, 15 query / class, T = 5; its ResNet-12 / bf16 encoder
+    is not built): S = 100 support rows do not fit the LDS-resident phase kernels, so this is the parity test of the
+    global-memory forms at the shape that takes them by itself (tests/dev/probe_20way.py also times it)."""
+    from fumi_amd import hip
+    B, N, K, Q, D, hid, Dt, Ht, T = 3, 20, 5, 15, 2048, [256, 64], 768, 256, 5
+    ep = cg.make_episodes(7, B, N, K, Q, D, Dt)
+    theta, phi = cg.make_fumi_params(7, D, hid, Dt, Ht)
+    out = hip.fumi_step_select(ws, N, _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev),
+                               _g(ep["text_s"], dev), [_g(t, dev) for t in theta], [_g(t, dev) for t in phi], T, 0.01, False)
+    assert ws.read_status() == 0
+    th = [t.clone().requires_grad_(True) for t in theta]
+    ph = [t.clone().requires_grad_(True) for t in phi]
+    ref = R.fumi_meta_step(th, ph, ep["text_s"], ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], N, T, 0.01, False)
+    assert rel_to_max(out["logits"].cpu(), ref["logits"]) <= LOGIT_TOL
+    per = [(float((a.cpu() - b).abs().max()), float(b.abs().max())) for a, b in zip(out["g_theta"] + out["g_phi"], ref["g_theta"] + ref["g_phi"])]
+    floor = 1e-3 * max(m for _, m in per)                 # (a gradient that is analytically zero has no relative error)
+    assert max(e / max(m, floor) for e, m in per) <= 1e-3, per

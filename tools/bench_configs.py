@@ -85,11 +85,12 @@ def main():
         t0 = time.perf_counter()
         for i in range(o.steps):
             last = step(bs[i % len(bs)])
+        t_enq = time.perf_counter() - t0                          # host time to enqueue the steps (>= the total: host-bound)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         rec = {"config": name, "argv": " ".join(argv), "episodes_per_meta_batch": a.batch_size,
                "ms_per_step": round(el / o.steps * 1e3, 4), "episodes_per_s": round(a.batch_size * o.steps / el, 1),
-               "final_loss": float(last[0])}
+               "host_enqueue_ms_per_step": round(t_enq / o.steps * 1e3, 4), "final_loss": float(last[0])}
         if o.roofline:
             ws.set_profiling(True, None, every=1)                 # every phase bracketed (adds event bubbles: separate loop)
             for i in range(o.steps):
