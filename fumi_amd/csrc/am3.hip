@@ -188,7 +188,10 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
                                                        float* __restrict__ im_s_bar, float* __restrict__ tx_bar,
                                                        float* __restrict__ zl_bar, float* __restrict__ im_q_bar,
                                                        long im_stride, const float* __restrict__ im_bias, int* status,
-                                                       int B, int GQ, float* part, int* arrive, int imparts, long impart_stride) {
+                                                       int B, int GQ, float* part, int* arrive, int imparts, long impart_stride,
+                                                       float* __restrict__ bias_bar) {
+    // bias_bar [B][P] (optional, need_grad): the episode's column sums of all embedding adjoints (the image encoder's bias gradient),
+    // so that no separate column-sum pass over imbar is needed.
     // imparts > 1: the image embeddings arrive as that many partial products (split contraction of the encoder pass, xpanel.hip),
     // im_s / im_q point at part 0 and the parts are added where a row is read.
     // GQ workgroups per episode (ids equal mod 8: one XCD): each forms the prototypes and takes a contiguous share of the query
@@ -207,6 +210,9 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
     float* ims = pb + nw * NP; float* txs = ims + SP;
     float* lamc = txs + SP; float* cnt = lamc + N; float* lbar = cnt + N; float* wl = lbar + N; float* wc = wl + nw;
     int* ys = (int*)(wc + nw); float* lam = (float*)(ys + S);
+    float* cf = lam + S;                                     // [N*N] this share's confusion counts (LDS adds: no global atomics, no memset)
+    float* bw = cf + N * N;                                  // [nw][P] per-wave column sums of the query adjoints
+    const int PS = NP + 2 + N * N + P;                       // floats of one share's record in `part`
     im_s += (long)b * im_stride; tx += (long)b * SP; lam_s += (long)b * S; y_s += (long)b * S;
     im_q += (long)b * im_stride; y_q += (long)b * Qn; preds += (long)b * Qn;
 
@@ -244,6 +250,7 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
         lam[s_] = l;
     }
     for (int i = tid; i < nw * NP; i += nt) pb[i] = 0.f;
+    for (int i = tid; i < N * N; i += nt) cf[i] = 0.f;
     __syncthreads();
     // ---- prototypes: wave per class, lanes over P; count clamped to >= 1 (utils.py:353-355).  Membership is a weight, not a
     // branch: the LDS reads of all S rows are independent of each other
@@ -266,6 +273,9 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
     // ---- queries: wave per row
     float lsum = 0.f, csum = 0.f;
     float* mypb = pb + wave * NP;
+    float xbs[HPJ];
+#pragma unroll
+    for (int k = 0; k < HPJ; ++k) xbs[k] = 0.f;
     for (int q = q0 + wave; q < q1; q += nw) {
         float x[HPJ];
 #pragma unroll
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
         lsum += lse + dy;                                                       // -log softmax(-d)[y] = lse - (-d_y)
         csum += (amin == (int)yq) ? 1.f : 0.f;
         if (lane == 0) preds[q] = amin;
-        if (lane == 0 && conf_b) atomicAdd(conf_b + ((long)b * N + yq) * N + amin, 1.f);   // integer-valued: exact in any order
+        if (lane == 0 && conf_b) atomicAdd(cf + yq * N + amin, 1.f);                       // integer-valued: exact in any order
         if (need_grad) {
             // dbar[c] = dL/dd[c] = -(p_c - onehot_c) * dscale ;  xbar = sum_c dbar[c] * (-2)(proto_c - x) ;  pbar_c += dbar[c]*2(proto_c - x)
             const float mydb = lane < N ? -(expf(-myd - lse) - (lane == (int)yq ? 1.f : 0.f)) * dscale : 0.f;
@@ -335,13 +345,17 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
                 }
             }
 #pragma unroll
-            for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; if (k < npj && j < P) im_q_bar[(long)b * im_stride + (long)q * P + j] = xb[k]; }
+            for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; if (k < npj && j < P) { im_q_bar[(long)b * im_stride + (long)q * P + j] = xb[k]; xbs[k] += xb[k]; } }
         }
     }
     if (lane == 0) { wl[wave] = lsum; wc[wave] = csum; }
+    if (need_grad && bias_bar) {
+#pragma unroll
+        for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; if (k < npj && j < P) bw[wave * P + j] = xbs[k]; }
+    }
     __syncthreads();
     // ---- this share's totals (waves in order), then the meeting of the shares
-    float* mine = part + ((long)b * GQ + gq) * (NP + 2);
+    float* mine = part + ((long)b * GQ + gq) * PS;
     if (tid == 0) {
         float l = 0.f, c = 0.f;
         for (int w_ = 0; w_ < nw; ++w_) { l += wl[w_]; c += wc[w_]; }
@@ -359,6 +373,20 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
             else __hip_atomic_store(mine + i, s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (conf_b) {
+        for (int i = tid; i < N * N; i += nt) {
+            if (GQ == 1) conf_b[(long)b * N * N + i] = cf[i];
+            else __hip_atomic_store(mine + NP + 2 + i, cf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (need_grad && bias_bar) {                             // query part of the bias gradient: waves in order
+        for (int j = tid; j < P; j += nt) {
+            float s_ = 0.f;
+            for (int w_ = 0; w_ < nw; ++w_) s_ += bw[w_ * P + j];
+            if (GQ == 1) bw[j] = s_;                         // (thread j only touches column j of wave 0's row)
+            else __hip_atomic_store(mine + NP + 2 + N * N + j, s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     __syncthreads();                                        // (every partial store has left: vmcnt(0) before the signal)
     if (GQ > 1) {
         if (tid == 0) {
@@ -368,20 +396,34 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
         }
         __syncthreads();
         if (!s_last) return;
-        const float* all = part + (long)b * GQ * (NP + 2);
+        const float* all = part + (long)b * GQ * PS;
         if (tid == 0) {
             float l = 0.f, c = 0.f;
             for (int g_ = 0; g_ < GQ; ++g_) {
-                l += __hip_atomic_load(all + (long)g_ * (NP + 2) + NP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                c += __hip_atomic_load(all + (long)g_ * (NP + 2) + NP + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                l += __hip_atomic_load(all + (long)g_ * PS + NP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                c += __hip_atomic_load(all + (long)g_ * PS + NP + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             wl[0] = l; wc[0] = c;
         }
         if (need_grad) {
             for (int i = tid; i < NP; i += nt) {
                 float s_ = 0.f;
-                for (int g_ = 0; g_ < GQ; ++g_) s_ += __hip_atomic_load(all + (long)g_ * (NP + 2) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int g_ = 0; g_ < GQ; ++g_) s_ += __hip_atomic_load(all + (long)g_ * PS + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 pb[i] = s_;
+            }
+        }
+        if (conf_b) {
+            for (int i = tid; i < N * N; i += nt) {
+                float s_ = 0.f;
+                for (int g_ = 0; g_ < GQ; ++g_) s_ += __hip_atomic_load(all + (long)g_ * PS + NP + 2 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                conf_b[(long)b * N * N + i] = s_;
+            }
+        }
+        if (need_grad && bias_bar) {
+            for (int j = tid; j < P; j += nt) {
+                float s_ = 0.f;
+                for (int g_ = 0; g_ < GQ; ++g_) s_ += __hip_atomic_load(all + (long)g_ * PS + NP + 2 + N * N + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bw[j] = s_;
             }
         }
         __syncthreads();
@@ -415,6 +457,13 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
         if (lamda_fixed < 0 && c >= 0) { const float l = lam[s_]; z = lbar[c] / cnt[c] * l * (1.f - l); }
         zl_bar[s_] = z;
     }
+    if (bias_bar) {                                          // + the support rows' adjoints: row s adds lamc[c] pbar_c / cnt[c], c = y_s
+        for (int j = tid; j < P; j += nt) {
+            float s_ = bw[j];
+            for (int r = 0; r < S; ++r) { const int c = ys[r]; if (c >= 0) s_ += lamc[c] * (pb[c * P + j] / cnt[c]); }
+            bias_bar[(long)b * P + j] = s_;
+        }
+    }
 }
 
 }  // namespace
@@ -444,7 +493,7 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     const long Rs = (long)B * S, Rq = (long)B * Qn;
     // fast head: N <= 64 classes, P <= 512, and the episode's support side fits LDS next to the per-wave adjoint slabs
     int nwaves = 16;
-    auto fast_lds = [&](int nw_) { return ((size_t)(3 + nw_) * N * P + 2 * (size_t)S * P + 3 * N + 2 * nw_ + 2 * S + 16) * sizeof(float); };
+    auto fast_lds = [&](int nw_) { return ((size_t)(3 + nw_) * N * P + 2 * (size_t)S * P + 3 * N + 2 * nw_ + 2 * S + (size_t)N * N + (size_t)nw_ * P + 16) * sizeof(float); };
     bool fast_head = N <= 64 && P <= 64 * HPJ;
     if (fast_head && fast_lds(16) > 150 * 1024) nwaves = 8;
     if (fast_head && fast_lds(nwaves) > 150 * 1024) nwaves = 4;
@@ -478,7 +527,8 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
         if (hgq_env > 0) hgq = hgq_env > 16 ? 16 : hgq_env;
         else while (hgq < 8 && B * hgq * 2 <= 256 && Qn / (hgq * 2) >= 2 * nwaves) hgq *= 2;
     }
-    if (hgq > 1) A((size_t)B * hgq * ((size_t)N * P + 2));
+    if (hgq > 1) A((size_t)B * hgq * ((size_t)N * P + 2 + (size_t)N * N + P));
+    if (need_grad) A((size_t)B * P);
     const int xks = xpanel_fwd_ksplit(B, S, Qn, D, P, 0);              // contraction parts of the image-encoder pass (narrow output)
     if (xks > 1) A((size_t)xks * (Rs + Rq) * P);
     int rc = ws_reserve(ws, bytes);
@@ -491,7 +541,7 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     float* confb = ws_f(ws, (size_t)B * N * N + B);       // per-episode confusion counts | lamda sums
     float* lamb = confb + (size_t)B * N * N;
     if (!stats) { confb = nullptr; lamb = nullptr; }
-    else HIP_TRY(hipMemsetAsync(confb, 0, (size_t)B * N * N * sizeof(float), st));
+    else if (!fast_head) HIP_TRY(hipMemsetAsync(confb, 0, (size_t)B * N * N * sizeof(float), st));   // (the fast head stores its counts)
     const long imst = (long)(S + Qn) * P;         // episode stride of the panel
     float* imq = im + (long)S * P;
 
@@ -548,7 +598,8 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
         cpart = ws_f(ws, cpart_n);
         wslabs = ws_f(ws, wslab_n);
     }
-    float* hpart = hgq > 1 ? ws_f(ws, (size_t)B * hgq * ((size_t)N * P + 2)) : nullptr;
+    float* hpart = hgq > 1 ? ws_f(ws, (size_t)B * hgq * ((size_t)N * P + 2 + (size_t)N * N + P)) : nullptr;
+    float* bias_bar = (need_grad && fast_head) ? ws_f(ws, (size_t)B * P) : nullptr;
     {
         ProfScope ps(ws, st, FUMI_PH_AM3);
         const float dscale = grad_scale / (float)Qn;
@@ -557,7 +608,7 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
             hipLaunchKernelGGL(am3_head_kernel, dim3(8 * ((B + 7) / 8) * hgq), dim3(64 * nwaves), lds, st, N, S, Qn, P, lamda_fixed,
                                need_grad ? 1 : 0, dscale, im_src, tx, lamda_s, y_s, im_src + (long)S * P, y_q, preds_q, lc, lc + B, confb, lamb,
                                grad_scale / (float)S, imb, txb, zlb, imb ? imb + (long)S * P : nullptr, imst, bi, ws->status,
-                               B, hgq, hpart, ws->hcnt, im_nparts > 1 ? im_nparts : 1, im_pstride);
+                               B, hgq, hpart, ws->hcnt, im_nparts > 1 ? im_nparts : 1, im_pstride, bias_bar);
         } else {
             hipLaunchKernelGGL(am3_bias_rows_kernel, dim3(256), dim3(256), 0, st, im, bi, (long)(Rs + Rq) * P, P);
             FUMI_SET_DYN_LDS(am3_head_generic_kernel, lds);
@@ -657,7 +708,8 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
         ProfScope pg(ws, st, FUMI_PH_XPANEL_BWD);
         const long slab = (long)P * D;
         if ((rc = launch_xpanel_bwd(st, B, S, Qn, D, P, x_s, x_q, imb, slabs, xkc, xns))) return rc;
-        cj.add(imb, (int)(Rs + Rq), P, P, g_w[1]);
+        if (bias_bar) tail_.add(bias_bar, B, P, P, g_w[1]);        // the head kernel left the episodes' column sums of imbar
+        else cj.add(imb, (int)(Rs + Rq), P, P, g_w[1]);
         // every bias gradient (column sums over all rows) and the image-encoder weight slabs: two launches in all
         tail_.add(slabs, xns, slab, slab, g_w[0]);
         if (!tail_.append(fin) && (rc = launch_reduce_multi(st, fin))) return rc;      // loss / correct / statistics: same final launch
