@@ -670,6 +670,152 @@ __global__ __launch_bounds__(512) void xpanel_bwd256_kernel(XPanel p, const floa
     }
 }
 
+// ---- backward on the bf16 matrix pipe with fp32-equivalent accuracy (the forward kernel's split) -----------------
+// Same 256 x 64 tiles, slabs of the contraction and XCD-aware ids as xpanel_bwd256_kernel, but every fp32 operand is split exactly
+// into three bf16 pieces when its slab goes to LDS and the six piece products of weight >= 2^-16 run on v_mfma_f32_32x32x16_bf16
+// (a quarter of the cycles of the eight fp32 MFMAs they replace).  The operands are k-major here (a row of Abar0 / of X is one
+// contraction index), while a bf16 MFMA lane needs eight CONSECUTIVE k of one output row: the LDS images stay [k][m] (coalesced
+// 8-byte writes of four split values) and the fragments are read with gfx950's transposing ds_read_b64_tr_b16 -- per 16-lane
+// group a 4 (k) x 16 (m) block, lane i receiving column i's four k values.  Row strides 576 B (A: 256 m) / 192 B (B: 64 n) put
+// the four rows a 32-lane half reads into four different quarters of the 64 banks: conflict-free.
+//   16-deep slabs (one MFMA k-step), double-buffered: 2 x (3 x 16 x 576 + 3 x 16 x 192) B = 72 KB -> two workgroups per CU.
+//   8 waves as 4 (M) x 2 (N), two 32x32 accumulators each; register ring of 2 slabs of global loads.
+constexpr int BSK = 16;
+constexpr int BRSA = 288, BRSB = 96;                  // ushorts per LDS row (576 B / 192 B)
+constexpr int BPA = BSK * BRSA, BPB = BSK * BRSB;     // ushorts per plane
+constexpr int BBUF = 3 * BPA + 3 * BPB;               // ushorts per buffer
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned short* a, int row4_ushorts) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + row4_ushorts));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool RIDER>
+__global__ __launch_bounds__(512, 2) void xpanel_bwd256_sb_kernel(XPanel p, const float* __restrict__ Abar, float* __restrict__ slabs,
+                                                                   int kchunk, int nsplit, int tiles_n, int tiles_m, HyperBwdArgs rider) {
+    extern __shared__ __attribute__((aligned(16))) float lds256[];
+    unsigned short* const L = (unsigned short*)lds256;            // [2][ A h|m|l : 16 x 288 | B h|m|l : 16 x 96 ]
+    int bid = blockIdx.x;
+    if constexpr (RIDER) {
+        if (bid < rider.nblk) { hyper_bwd_body(rider, bid, lds256); return; }
+        bid -= rider.nblk;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int R = p.S + p.Qn, M = p.h0, Nn = p.D;
+    const long Ktot = (long)p.B * R;
+    const int tiles = tiles_n * tiles_m;
+    const int xcd = bid & 7, jq = bid >> 3;
+    const int z = xcd + 8 * (jq / tiles), tl = jq % tiles;
+    if (z >= nsplit) return;
+    const int m0 = (tl / tiles_n) * 256, n0 = (tl % tiles_n) * 64;
+    const long kbeg = (long)z * kchunk;
+    const long kend = min(Ktot, kbeg + kchunk);
+    float* C = slabs + (long)z * M * Nn;
+
+    // staging map: A float4 f = tid + 512 i (i < 2) -> contraction row f >> 6, columns (f & 63) * 4; B float4 tid (< 256) -> row
+    // tid >> 4, columns (tid & 15) * 4 (waves 4..7 carry no B element)
+    const int ac4 = (tid & 63) << 2, bc4 = (tid & 15) << 2;
+    const bool hasb = tid < 256;
+    int gb, gr;
+    {
+        const long g = kbeg + (tid >> 4);
+        gb = (int)(g / R); gr = (int)(g - (long)gb * R);
+    }
+    const float* xp = xrow(p, (hasb && kbeg + (tid >> 4) < kend) ? gb : 0, (hasb && kbeg + (tid >> 4) < kend) ? gr : 0);
+    constexpr int NST = 2;
+    f32x4 ra[NST][2], rb[NST]; bool oka[NST][2], okb[NST];
+    auto gload = [&](auto sc, long k0) {
+        constexpr int ST = decltype(sc)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long g = k0 + (tid >> 6) + 8 * i;
+            oka[ST][i] = g < kend;
+            ra[ST][i] = *(const f32x4*)(Abar + (oka[ST][i] ? g : 0) * M + m0 + ac4);        // raw; masked when written to LDS
+        }
+        const long g = k0 + (tid >> 4);
+        okb[ST] = hasb && g < kend;
+        rb[ST] = *(const f32x4*)(xp + n0 + bc4);
+        gr += BSK;
+        while (gr >= R) { gr -= R; ++gb; }
+        const bool okn = hasb && g + BSK < kend;
+        xp = xrow(p, okn ? gb : 0, okn ? gr : 0);
+    };
+    auto lstore = [&](auto sc, int buf) {
+        constexpr int ST = decltype(sc)::value;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        unsigned short* Ab = L + buf * BBUF; unsigned short* Bb = Ab + 3 * BPA;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u32x2 h, m, l;
+            split3(oka[ST][i] ? ra[ST][i] : zero4, h, m, l);
+            const int off = ((tid >> 6) + 8 * i) * BRSA + ac4;
+            *(u32x2*)(Ab + off) = h; *(u32x2*)(Ab + BPA + off) = m; *(u32x2*)(Ab + 2 * BPA + off) = l;
+        }
+        if (hasb) {
+            u32x2 h, m, l;
+            split3(okb[ST] ? rb[ST] : zero4, h, m, l);
+            const int off = (tid >> 4) * BRSB + bc4;
+            *(u32x2*)(Bb + off) = h; *(u32x2*)(Bb + BPB + off) = m; *(u32x2*)(Bb + 2 * BPB + off) = l;
+        }
+    };
+    // fragment addresses: 16-lane group g = lane >> 4 reads the 4 x 16 block rows 8 (g >> 1) + {0..3} (second read: + 4), columns
+    // 16 (g & 1) ..; lane 4q + p of the group supplies the address of row q, columns 4p .. 4p + 3
+    const int grp = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
+    const int arow = 8 * (grp >> 1) + fq;
+    const int aoff = arow * BRSA + wm * 64 + 16 * (grp & 1) + 4 * fp;       // + 32 for the wave's second 32-row block
+    const int boff = arow * BRSB + wn * 32 + 16 * (grp & 1) + 4 * fp;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    const int nslab = (int)((kend - kbeg + BSK - 1) / BSK);
+    auto mma_slab = [&](int buf) {
+        const unsigned short* Ab = L + buf * BBUF; const unsigned short* Bb = Ab + 3 * BPA;
+        bf16x8 a0[3], a1[3], b[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            a0[pl] = tr_frag(Ab + pl * BPA + aoff, 4 * BRSA);
+            a1[pl] = tr_frag(Ab + pl * BPA + aoff + 32, 4 * BRSA);
+            b[pl] = tr_frag(Bb + pl * BPB + boff, 4 * BRSB);
+        }
+        // piece pairs in accumulation order (smallest first): (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[PA[u]], b[PB[u]], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[PA[u]], b[PB[u]], acc1, 0, 0, 0);
+        }
+    };
+    // prologue: slab 0 straight to LDS, slabs 1..NST into the ring (slot of slab q is (q - 1) % NST)
+    if (nslab > 0) { gload(WgInt<0>{}, kbeg); lstore(WgInt<0>{}, 0); }
+    if (1 < nslab) gload(WgInt<0>{}, kbeg + BSK);
+    if (2 < nslab) gload(WgInt<1>{}, kbeg + 2 * BSK);
+    __syncthreads();
+    auto slab = [&](auto sc, int s_) {
+        const int cur = s_ & 1;
+        if (s_ + 1 < nslab) lstore(sc, cur ^ 1);
+        if (s_ + 1 + NST < nslab) gload(sc, kbeg + (long)(s_ + 1 + NST) * BSK);
+        mma_slab(cur);
+        __syncthreads();
+    };
+    for (int s_ = 0; s_ < nslab; s_ += NST) {
+        slab(WgInt<0>{}, s_);
+        if (s_ + 1 < nslab) slab(WgInt<1>{}, s_ + 1);
+    }
+    const int li = lane & 31, kh = lane >> 5;
+    const int n = n0 + wn * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        C[(long)m * Nn + n] = acc0[r];
+        C[(long)(m + 32) * Nn + n] = acc1[r];
+    }
+}
+
 inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 unsigned long long* g_trace = nullptr;      // dev tracing only (tools/trace_xpanel.py)
 
@@ -767,6 +913,24 @@ int launch_xpanel_bwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
         const int tn = D / 64, tm = h0 / 256;
         const unsigned nwg = 8 * ((nsplit + 7) / 8) * tn * tm;
         static const int ride = getenv("FUMI_XP_RIDER") ? atoi(getenv("FUMI_XP_RIDER")) : 1;     // 0: never carry the hypernetwork backward
+        static const int bsb = getenv("FUMI_XPB_SB") ? atoi(getenv("FUMI_XPB_SB")) : 1;          // 0: the fp32-MFMA kernel
+        if (bsb && kchunk % BSK == 0) {
+            const size_t lds_sb = 2 * (size_t)BBUF * sizeof(unsigned short);
+            if (ride && rider && rider_done && rider->nblk > 0 && rider->nblk % 8 == 0 &&
+                (size_t)hyper_bwd_lds_floats(rider->Dt, rider->H1) * 4 <= lds_sb) {
+                FUMI_SET_DYN_LDS(xpanel_bwd256_sb_kernel<true>, lds_sb);
+                hipLaunchKernelGGL(xpanel_bwd256_sb_kernel<true>, dim3(nwg + rider->nblk), dim3(512), lds_sb, st, p, Abar, slabs,
+                                   kchunk, nsplit, tn, tm, *rider);
+                *rider_done = 1;
+            } else {
+                HyperBwdArgs none; memset(&none, 0, sizeof(none));
+                FUMI_SET_DYN_LDS(xpanel_bwd256_sb_kernel<false>, lds_sb);
+                hipLaunchKernelGGL(xpanel_bwd256_sb_kernel<false>, dim3(nwg), dim3(512), lds_sb, st, p, Abar, slabs,
+                                   kchunk, nsplit, tn, tm, none);
+            }
+            LAUNCH_CHECK();
+            return FUMI_OK;
+        }
         if (ride && rider && rider_done && rider->nblk > 0 && rider->nblk % 8 == 0 &&
             (size_t)hyper_bwd_lds_floats(rider->Dt, rider->H1) * 4 <= lds_bytes) {
             FUMI_SET_DYN_LDS(xpanel_bwd256_kernel<true>, lds_bytes);
