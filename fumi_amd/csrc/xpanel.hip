@@ -694,7 +694,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short* a, int row4_usho
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool RIDER>
+template <bool RIDER, int NST>
 __global__ __launch_bounds__(512, 2) void xpanel_bwd256_sb_kernel(XPanel p, const float* __restrict__ Abar, float* __restrict__ slabs,
                                                                    int kchunk, int nsplit, int tiles_n, int tiles_m, HyperBwdArgs rider) {
     extern __shared__ __attribute__((aligned(16))) float lds256[];
@@ -727,7 +727,6 @@ __global__ __launch_bounds__(512, 2) void xpanel_bwd256_sb_kernel(XPanel p, cons
         gb = (int)(g / R); gr = (int)(g - (long)gb * R);
     }
     const float* xp = xrow(p, (hasb && kbeg + (tid >> 4) < kend) ? gb : 0, (hasb && kbeg + (tid >> 4) < kend) ? gr : 0);
-    constexpr int NST = 2;
     f32x4 ra[NST][2], rb[NST]; bool oka[NST][2], okb[NST];
     auto gload = [&](auto sc, long k0) {
         constexpr int ST = decltype(sc)::value;
@@ -792,8 +791,7 @@ __global__ __launch_bounds__(512, 2) void xpanel_bwd256_sb_kernel(XPanel p, cons
     };
     // prologue: slab 0 straight to LDS, slabs 1..NST into the ring (slot of slab q is (q - 1) % NST)
     if (nslab > 0) { gload(WgInt<0>{}, kbeg); lstore(WgInt<0>{}, 0); }
-    if (1 < nslab) gload(WgInt<0>{}, kbeg + BSK);
-    if (2 < nslab) gload(WgInt<1>{}, kbeg + 2 * BSK);
+    xp_static_for<0, NST>([&](auto ic) { if (decltype(ic)::value + 1 < nslab) gload(ic, kbeg + (long)(decltype(ic)::value + 1) * BSK); });
     __syncthreads();
     auto slab = [&](auto sc, int s_) {
         const int cur = s_ & 1;
@@ -802,10 +800,59 @@ __global__ __launch_bounds__(512, 2) void xpanel_bwd256_sb_kernel(XPanel p, cons
         mma_slab(cur);
         __syncthreads();
     };
-    for (int s_ = 0; s_ < nslab; s_ += NST) {
-        slab(WgInt<0>{}, s_);
-        if (s_ + 1 < nslab) slab(WgInt<1>{}, s_ + 1);
-    }
+    // steady state (s_ + 1 + NST < nslab), issue order spelled out like the forward kernel's: the slab's 18 fragment reads, then six
+    // segments of two MFMAs plus a sixth of the work that splits the NEXT slab (one pair of values; every second segment ends
+    // with the three LDS writes of a finished float4).  sched_barrier(0) pins the segments.
+    auto slab_main = [&](auto sc, int s_) {
+        constexpr int ST = decltype(sc)::value;
+        const int cur = s_ & 1;
+        const unsigned short* Ab = L + cur * BBUF; const unsigned short* Bb = Ab + 3 * BPA;
+        unsigned short* An = L + (cur ^ 1) * BBUF; unsigned short* Bn = An + 3 * BPA;
+        bf16x8 a0[3], a1[3], b[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            a0[pl] = tr_frag(Ab + pl * BPA + aoff, 4 * BRSA);
+            a1[pl] = tr_frag(Ab + pl * BPA + aoff + 32, 4 * BRSA);
+            b[pl] = tr_frag(Bb + pl * BPB + boff, 4 * BRSB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {                          // float4 q of the staged slab: A row i = 0, 1, then B
+            const f32x4 v = q < 2 ? (oka[ST][q] ? ra[ST][q] : zero4) : (okb[ST] ? rb[ST] : zero4);
+            unsigned hp[2], mp[2], lp[2];
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const int u = 2 * q + part;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[PA[u]], b[PB[u]], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[PA[u]], b[PB[u]], acc1, 0, 0, 0);
+                split_pair(v[2 * part], v[2 * part + 1], hp[part], mp[part], lp[part]);
+                if (part == 1) {
+                    if (q < 2) {
+                        const int off = ((tid >> 6) + 8 * q) * BRSA + ac4;
+                        *(u32x2*)(An + off) = (u32x2){hp[0], hp[1]};
+                        *(u32x2*)(An + BPA + off) = (u32x2){mp[0], mp[1]};
+                        *(u32x2*)(An + 2 * BPA + off) = (u32x2){lp[0], lp[1]};
+                    } else if (hasb) {
+                        const int off = (tid >> 4) * BRSB + bc4;
+                        *(u32x2*)(Bn + off) = (u32x2){hp[0], hp[1]};
+                        *(u32x2*)(Bn + BPB + off) = (u32x2){mp[0], mp[1]};
+                        *(u32x2*)(Bn + 2 * BPB + off) = (u32x2){lp[0], lp[1]};
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        gload(sc, kbeg + (long)(s_ + 1 + NST) * BSK);
+        __syncthreads();
+    };
+    int s_ = 0;
+    static_assert(NST == 2 || NST == 3, "ring depth");
+    for (; s_ + 2 * NST < nslab; s_ += NST)                      // every slab of this round has s' + 1 + NST < nslab
+        xp_static_for<0, NST>([&](auto ic) { slab_main(ic, s_ + decltype(ic)::value); });
+    for (; s_ < nslab; s_ += NST)
+        xp_static_for<0, NST>([&](auto ic) { if (s_ + decltype(ic)::value < nslab) slab(ic, s_ + decltype(ic)::value); });
     const int li = lane & 31, kh = lane >> 5;
     const int n = n0 + wn * 32 + li;
 #pragma unroll
@@ -916,16 +963,23 @@ int launch_xpanel_bwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
         static const int bsb = getenv("FUMI_XPB_SB") ? atoi(getenv("FUMI_XPB_SB")) : 1;          // 0: the fp32-MFMA kernel
         if (bsb && kchunk % BSK == 0) {
             const size_t lds_sb = 2 * (size_t)BBUF * sizeof(unsigned short);
+            static const int bnst = getenv("FUMI_XPB_NST") ? atoi(getenv("FUMI_XPB_NST")) : 2;    // ring depth (tuning knob)
             if (ride && rider && rider_done && rider->nblk > 0 && rider->nblk % 8 == 0 &&
                 (size_t)hyper_bwd_lds_floats(rider->Dt, rider->H1) * 4 <= lds_sb) {
-                FUMI_SET_DYN_LDS(xpanel_bwd256_sb_kernel<true>, lds_sb);
-                hipLaunchKernelGGL(xpanel_bwd256_sb_kernel<true>, dim3(nwg + rider->nblk), dim3(512), lds_sb, st, p, Abar, slabs,
-                                   kchunk, nsplit, tn, tm, *rider);
+                if (bnst >= 3) {
+                    FUMI_SET_DYN_LDS((xpanel_bwd256_sb_kernel<true, 3>), lds_sb);
+                    hipLaunchKernelGGL((xpanel_bwd256_sb_kernel<true, 3>), dim3(nwg + rider->nblk), dim3(512), lds_sb, st, p, Abar, slabs,
+                                       kchunk, nsplit, tn, tm, *rider);
+                } else {
+                    FUMI_SET_DYN_LDS((xpanel_bwd256_sb_kernel<true, 2>), lds_sb);
+                    hipLaunchKernelGGL((xpanel_bwd256_sb_kernel<true, 2>), dim3(nwg + rider->nblk), dim3(512), lds_sb, st, p, Abar, slabs,
+                                       kchunk, nsplit, tn, tm, *rider);
+                }
                 *rider_done = 1;
             } else {
                 HyperBwdArgs none; memset(&none, 0, sizeof(none));
-                FUMI_SET_DYN_LDS(xpanel_bwd256_sb_kernel<false>, lds_sb);
-                hipLaunchKernelGGL(xpanel_bwd256_sb_kernel<false>, dim3(nwg), dim3(512), lds_sb, st, p, Abar, slabs,
+                FUMI_SET_DYN_LDS((xpanel_bwd256_sb_kernel<false, 2>), lds_sb);
+                hipLaunchKernelGGL((xpanel_bwd256_sb_kernel<false, 2>), dim3(nwg), dim3(512), lds_sb, st, p, Abar, slabs,
                                    kchunk, nsplit, tn, tm, none);
             }
             LAUNCH_CHECK();

@@ -855,3 +855,38 @@ def test_fumi_20way_episode_shape_matches_oracle(dev, ws):
     per = [(float((a.cpu() - b).abs().max()), float(b.abs().max())) for a, b in zip(out["g_theta"] + out["g_phi"], ref["g_theta"] + ref["g_phi"])]
     floor = 1e-3 * max(m for _, m in per)                 # (a gradient that is analytically zero has no relative error)
     assert max(e / max(m, floor) for e, m in per) <= 1e-3, per
+
+
+_SBB_SCRIPT = r"""
+import sys, json, torch
+sys.path.insert(0, %r)
+from fumi_amd import hip
+dev = torch.device("cuda:0"); ws = hip.Workspace.get(dev)
+g = torch.Generator().manual_seed(9)
+B, S, Qn, D, h0 = 5, 25, 43, 256, 256                     # 340 contraction rows: a ragged last slab
+x_s = torch.randn(B, S, D, generator=g).abs(); x_q = torch.randn(B, Qn, D, generator=g) * 3.0
+Ab = torch.randn(B, S + Qn, h0, generator=g) * torch.rand(B, S + Qn, 1, generator=g)      # rows of very different scale
+gW = hip.xpanel_bwd(ws, x_s.to(dev), x_q.to(dev), Ab.to(dev))
+X = torch.cat([x_s, x_q], 1).double().reshape(-1, D)
+ref = Ab.double().reshape(-1, h0).T @ X
+print(json.dumps({"e": float((gW.cpu().double() - ref).abs().max() / ref.abs().max())}))
+"""
+
+
+def test_xpanel_bwd_split_bf16_has_fp32_accuracy(dev):
+    """gW0 = sum_b Abar0_b^T [Xs_b;Xq_b] runs on the bf16 matrix pipe from exact three-way bf16 splits read back with the transposing
+    LDS loads (default; FUMI_XPB_SB=0 selects the fp32 MFMA kernel, xpanel.hip).  Its error against fp64 must not exceed the fp32
+    MFMA kernel's.  The knob is read once per process, hence the child processes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    errs = {}
+    for sb in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", _SBB_SCRIPT % root], env=dict(os.environ, FUMI_XPB_SB=sb), cwd=root,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        errs[sb] = json.loads(r.stdout.strip().splitlines()[-1])["e"]
+    assert errs["0"] < 2e-6 and errs["1"] < 2e-6, errs
+    assert errs["1"] < 1.5 * errs["0"] + 5e-8, errs
