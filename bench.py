@@ -11,8 +11,8 @@ Workload (configs[1]): 5-way 5-shot, 32 query/class, D=2048 ResNet-152-style emb
 GloVe-300 token text (L=128, V=20000, mean pooling), text_hid 256, 1 inner step, 32 episodes per GPU (weak scaling:
 the global meta-batch is 32*N episodes sharded as contiguous blocks, one RCCL all-reduce of the flat gradient).
 
-Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (xpanel_bwd: gW0 = sum_b Abar0_b^T [Xs_b;Xq_b] on the fp32 MFMA,
-the longest kernel of a step: profiles/r01), timed with
+Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (xpanel_bwd: gW0 = sum_b Abar0_b^T [Xs_b;Xq_b], split-bf16 on the
+bf16 matrix pipe since round 2; with the forward X-panel pass the longest kernel of a step), timed with
 HIP events on the launch stream inside the timed region; ``cpu_baseline`` is the oracle restatement of the reference
 path timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -31,6 +31,8 @@ if ROOT not in sys.path:
 
 CFG = dict(N=5, K=5, Q=32, D=2048, hid=[256, 64], E=300, L=128, V=20000, Ht=256, T=1, B_per_gpu=32, alpha=0.01)
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA peak (same guide)
+SPLIT_PRODUCTS = 6                    # bf16 piece products per fp32 product of the split-bf16 kernels (xpanel.hip)
 PROF_EVERY = 8                        # HIP-event timing of the roofline kernel: every 8th step (every steps//16-th of a short run)
 NBATCH = 4                            # distinct pre-generated meta-batches cycled through the steps
 
@@ -420,6 +422,7 @@ def main():
                        "episodes_per_gpu": c["B_per_gpu"], "global_meta_batch": Bg,
                        "layer0_fwd": "split-bf16x3 operands on the bf16 MFMA with fp32 accumulation (fp32-equivalent: error vs "
                                      "fp64 below the fp32-MFMA kernel's, tests/test_hip_parity.py::test_xpanel_fwd_split_bf16_has_fp32_accuracy)",
+                       "layer0_bwd": "the same split for gW0 (test_xpanel_bwd_split_bf16_has_fp32_accuracy)",
                        "parallelism": f"episode-sharded x{world}, 1 all-reduce of the flat gradient"},
             "final_loss": float(last[0]), "final_acc": float(last[1]),
             "step_tflops_algorithmic": round(flops_step_algorithmic(c["B_per_gpu"]) / (ms * 1e-3) / 1e12, 3),
@@ -432,15 +435,22 @@ def main():
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))[-1:]:
                 k = json.load(open(f))["kernels"]
-                key = [x for x in k if x.startswith("xpanel_bwd256_kernel")] or [x for x in k if x.startswith("xpanel_bwd")]
+                key = [x for x in k if x.startswith("xpanel_bwd256")] or [x for x in k if x.startswith("xpanel_bwd")]
                 if key and "hbm_bytes_per_launch" in k[key[0]]:
                     traffic = int(k[key[0]]["hbm_bytes_per_launch"])
-            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            # the kernel computes the fp32 product from six bf16 piece products on the bf16 matrix pipe: its roofline is that pipe's
+            # dense peak divided by six (fp32-equivalent); against the fp32-MFMA peak (157.3) the same rate is `vs_fp32_mfma_peak`
+            peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS if os.environ.get("FUMI_XPB_SB", "1") != "0" else PEAK_F32_MFMA_TFLOPS
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": traffic,
                                "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this command, "
                                                  "committed as profiles/<round>/pmc_traffic.json (not re-measured in this run)",
                                "algorithmic_bytes": int(bytes_dominant(c["B_per_gpu"])),
-                               "kernel": "xpanel_bwd256_kernel (gW0 = sum_b Abar0_b^T [Xs_b;Xq_b]: 256 x 2048 outputs in 256 x 64 tiles, contraction over 32 x 185 rows in 16 slabs, fp32 MFMA 32x32x2; "
+                               "vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                               "executed_bf16_tflops": round(ach * SPLIT_PRODUCTS, 1),
+                               "kernel": "xpanel_bwd256_sb_kernel (gW0 = sum_b Abar0_b^T [Xs_b;Xq_b]: 256 x 2048 outputs in 256 x 64 tiles, contraction over 32 x 185 rows "
+                                         "in 16 slabs; fp32 operands split exactly into three bf16 pieces, six piece products per fp32 product on v_mfma_f32_32x32x16_bf16 with "
+                                         "fp32 accumulation -- `achieved` counts the ALGORITHMIC fp32 flops, `peak` is the dense bf16 MFMA peak / 6; "
                                          "the launch also carries the hypernetwork backward as 40 rider workgroups, hyper_bwd.h: its 0.09 GFLOP are counted, its ~5 us stretch the launch)",
                                "avg_us": round(dur * 1e6, 2), "launches": n,
                                "timed": f"HIP events around every {prof_every}th launch of the timed region"}

@@ -681,9 +681,8 @@ __global__ __launch_bounds__(512) void xpanel_bwd256_kernel(XPanel p, const floa
 //   16-deep slabs (one MFMA k-step), double-buffered: 2 x (3 x 16 x 576 + 3 x 16 x 192) B = 72 KB -> two workgroups per CU.
 //   8 waves as 4 (M) x 2 (N), two 32x32 accumulators each; register ring of 2 slabs of global loads.
 constexpr int BSK = 16;
-constexpr int BRSA = 288, BRSB = 96;                  // ushorts per LDS row (576 B / 192 B)
-constexpr int BPA = BSK * BRSA, BPB = BSK * BRSB;     // ushorts per plane
-constexpr int BBUF = 3 * BPA + 3 * BPB;               // ushorts per buffer
+constexpr int BRSA = 288;                             // ushorts per LDS row of the A image (576 B)
+__host__ __device__ constexpr int bsb_buf_ushorts(int nb, int sk) { return 3 * sk * BRSA + 3 * sk * (nb == 1 ? 96 : 160); }
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned short* a, int row4_ushorts) {
@@ -694,11 +693,19 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short* a, int row4_usho
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool RIDER, int NST>
-__global__ __launch_bounds__(512, 2) void xpanel_bwd256_sb_kernel(XPanel p, const float* __restrict__ Abar, float* __restrict__ slabs,
+// NB = 32-column blocks per wave in N: 1 -> 256 x 64 tiles (two workgroups per CU), 2 -> 256 x 128 tiles (half the re-reads of the
+// Abar0 panel, four accumulators per wave, 92 KB of LDS: one workgroup per CU)
+// SK = contraction rows per slab: 16 (one MFMA k-step; 72 KB of LDS at NB = 1: two workgroups per CU) or 32 (two k-steps between
+// barriers, 144 KB: one workgroup per CU)
+template <bool RIDER, int NST, int NB, int SK>
+__global__ __launch_bounds__(512, (NB == 1 && SK == 16) ? 2 : 1) void xpanel_bwd256_sb_kernel(XPanel p, const float* __restrict__ Abar, float* __restrict__ slabs,
                                                                    int kchunk, int nsplit, int tiles_n, int tiles_m, HyperBwdArgs rider) {
     extern __shared__ __attribute__((aligned(16))) float lds256[];
-    unsigned short* const L = (unsigned short*)lds256;            // [2][ A h|m|l : 16 x 288 | B h|m|l : 16 x 96 ]
+    unsigned short* const L = (unsigned short*)lds256;            // [2][ A h|m|l : 16 x 288 | B h|m|l : 16 x BRSB ]
+    constexpr int TN = 64 * NB;                                   // tile columns
+    constexpr int BRSB = NB == 1 ? 96 : 160;                      // ushorts per B row: 192 B / 320 B (both = 16 or 48 mod 64 dwords)
+    constexpr int BPA = SK * BRSA, BPB = SK * BRSB, BBUF = 3 * BPA + 3 * BPB;
+    constexpr int KS = SK / 16, NA = SK / 8;                      // MFMA k-steps per slab; A float4 per thread and slab
     int bid = blockIdx.x;
     if constexpr (RIDER) {
         if (bid < rider.nblk) { hyper_bwd_body(rider, bid, lds256); return; }
@@ -712,36 +719,38 @@ __global__ __launch_bounds__(512, 2) void xpanel_bwd256_sb_kernel(XPanel p, cons
     const int xcd = bid & 7, jq = bid >> 3;
     const int z = xcd + 8 * (jq / tiles), tl = jq % tiles;
     if (z >= nsplit) return;
-    const int m0 = (tl / tiles_n) * 256, n0 = (tl % tiles_n) * 64;
+    const int m0 = (tl / tiles_n) * 256, n0 = (tl % tiles_n) * TN;
     const long kbeg = (long)z * kchunk;
     const long kend = min(Ktot, kbeg + kchunk);
     float* C = slabs + (long)z * M * Nn;
 
-    // staging map: A float4 f = tid + 512 i (i < 2) -> contraction row f >> 6, columns (f & 63) * 4; B float4 tid (< 256) -> row
-    // tid >> 4, columns (tid & 15) * 4 (waves 4..7 carry no B element)
-    const int ac4 = (tid & 63) << 2, bc4 = (tid & 15) << 2;
-    const bool hasb = tid < 256;
+    // staging map: A float4 f = tid + 512 i (i < NA) -> contraction row f >> 6, columns (f & 63) * 4; B float4 tid -> row tid >> BL,
+    // columns (tid & (2^BL - 1)) * 4 (NB = 1: BL = 4 and waves 4..7 carry no B element; NB = 2: BL = 5, every thread has one)
+    constexpr int BL = NB == 1 ? 4 : 5;
+    const int ac4 = (tid & 63) << 2, bc4 = (tid & ((1 << BL) - 1)) << 2;
+    const int brow = tid >> BL;
+    const bool hasb = brow < SK;
     int gb, gr;
     {
-        const long g = kbeg + (tid >> 4);
+        const long g = kbeg + brow;
         gb = (int)(g / R); gr = (int)(g - (long)gb * R);
     }
-    const float* xp = xrow(p, (hasb && kbeg + (tid >> 4) < kend) ? gb : 0, (hasb && kbeg + (tid >> 4) < kend) ? gr : 0);
-    f32x4 ra[NST][2], rb[NST]; bool oka[NST][2], okb[NST];
+    const float* xp = xrow(p, (hasb && kbeg + brow < kend) ? gb : 0, (hasb && kbeg + brow < kend) ? gr : 0);
+    f32x4 ra[NST][NA], rb[NST]; bool oka[NST][NA], okb[NST];
     auto gload = [&](auto sc, long k0) {
         constexpr int ST = decltype(sc)::value;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const long g = k0 + (tid >> 6) + 8 * i;
             oka[ST][i] = g < kend;
             ra[ST][i] = *(const f32x4*)(Abar + (oka[ST][i] ? g : 0) * M + m0 + ac4);        // raw; masked when written to LDS
         }
-        const long g = k0 + (tid >> 4);
+        const long g = k0 + brow;
         okb[ST] = hasb && g < kend;
         rb[ST] = *(const f32x4*)(xp + n0 + bc4);
-        gr += BSK;
+        gr += SK;
         while (gr >= R) { gr -= R; ++gb; }
-        const bool okn = hasb && g + BSK < kend;
+        const bool okn = hasb && g + SK < kend;
         xp = xrow(p, okn ? gb : 0, okn ? gr : 0);
     };
     auto lstore = [&](auto sc, int buf) {
@@ -749,7 +758,7 @@ __global__ __launch_bounds__(512, 2) void xpanel_bwd256_sb_kernel(XPanel p, cons
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         unsigned short* Ab = L + buf * BBUF; unsigned short* Bb = Ab + 3 * BPA;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NA; ++i) {
             u32x2 h, m, l;
             split3(oka[ST][i] ? ra[ST][i] : zero4, h, m, l);
             const int off = ((tid >> 6) + 8 * i) * BRSA + ac4;
@@ -758,7 +767,7 @@ __global__ __launch_bounds__(512, 2) void xpanel_bwd256_sb_kernel(XPanel p, cons
         if (hasb) {
             u32x2 h, m, l;
             split3(okb[ST] ? rb[ST] : zero4, h, m, l);
-            const int off = (tid >> 4) * BRSB + bc4;
+            const int off = brow * BRSB + bc4;
             *(u32x2*)(Bb + off) = h; *(u32x2*)(Bb + BPB + off) = m; *(u32x2*)(Bb + 2 * BPB + off) = l;
         }
     };
@@ -767,36 +776,45 @@ __global__ __launch_bounds__(512, 2) void xpanel_bwd256_sb_kernel(XPanel p, cons
     const int grp = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
     const int arow = 8 * (grp >> 1) + fq;
     const int aoff = arow * BRSA + wm * 64 + 16 * (grp & 1) + 4 * fp;       // + 32 for the wave's second 32-row block
-    const int boff = arow * BRSB + wn * 32 + 16 * (grp & 1) + 4 * fp;
-    f32x16 acc0, acc1;
+    const int boff = arow * BRSB + wn * 32 * NB + 16 * (grp & 1) + 4 * fp;      // + 32 for the wave's second 32-column block (NB = 2)
+    f32x16 acc[2][NB];                                            // [m block][n block]
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    const int nslab = (int)((kend - kbeg + BSK - 1) / BSK);
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y_ = 0; y_ < NB; ++y_) acc[x][y_][i] = 0.f;
+    const int nslab = (int)((kend - kbeg + SK - 1) / SK);
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};     // piece pairs, smallest first: (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
     auto mma_slab = [&](int buf) {
         const unsigned short* Ab = L + buf * BBUF; const unsigned short* Bb = Ab + 3 * BPA;
-        bf16x8 a0[3], a1[3], b[3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            a0[pl] = tr_frag(Ab + pl * BPA + aoff, 4 * BRSA);
-            a1[pl] = tr_frag(Ab + pl * BPA + aoff + 32, 4 * BRSA);
-            b[pl] = tr_frag(Bb + pl * BPB + boff, 4 * BRSB);
-        }
-        // piece pairs in accumulation order (smallest first): (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
-        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 a[2][3], b[NB][3];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[PA[u]], b[PB[u]], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[PA[u]], b[PB[u]], acc1, 0, 0, 0);
+            for (int pl = 0; pl < 3; ++pl) {
+                a[0][pl] = tr_frag(Ab + pl * BPA + aoff + 16 * ks * BRSA, 4 * BRSA);
+                a[1][pl] = tr_frag(Ab + pl * BPA + aoff + 16 * ks * BRSA + 32, 4 * BRSA);
+#pragma unroll
+                for (int y_ = 0; y_ < NB; ++y_) b[y_][pl] = tr_frag(Bb + pl * BPB + boff + 16 * ks * BRSB + 32 * y_, 4 * BRSB);
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u)
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y_ = 0; y_ < NB; ++y_)
+                        acc[x][y_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][PA[u]], b[y_][PB[u]], acc[x][y_], 0, 0, 0);
         }
     };
     // prologue: slab 0 straight to LDS, slabs 1..NST into the ring (slot of slab q is (q - 1) % NST)
     if (nslab > 0) { gload(WgInt<0>{}, kbeg); lstore(WgInt<0>{}, 0); }
-    xp_static_for<0, NST>([&](auto ic) { if (decltype(ic)::value + 1 < nslab) gload(ic, kbeg + (long)(decltype(ic)::value + 1) * BSK); });
+    xp_static_for<0, NST>([&](auto ic) { if (decltype(ic)::value + 1 < nslab) gload(ic, kbeg + (long)(decltype(ic)::value + 1) * SK); });
     __syncthreads();
     auto slab = [&](auto sc, int s_) {
         const int cur = s_ & 1;
         if (s_ + 1 < nslab) lstore(sc, cur ^ 1);
-        if (s_ + 1 + NST < nslab) gload(sc, kbeg + (long)(s_ + 1 + NST) * BSK);
+        if (s_ + 1 + NST < nslab) gload(sc, kbeg + (long)(s_ + 1 + NST) * SK);
         mma_slab(cur);
         __syncthreads();
     };
@@ -808,43 +826,49 @@ __global__ __launch_bounds__(512, 2) void xpanel_bwd256_sb_kernel(XPanel p, cons
         const int cur = s_ & 1;
         const unsigned short* Ab = L + cur * BBUF; const unsigned short* Bb = Ab + 3 * BPA;
         unsigned short* An = L + (cur ^ 1) * BBUF; unsigned short* Bn = An + 3 * BPA;
-        bf16x8 a0[3], a1[3], b[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            a0[pl] = tr_frag(Ab + pl * BPA + aoff, 4 * BRSA);
-            a1[pl] = tr_frag(Ab + pl * BPA + aoff + 32, 4 * BRSA);
-            b[pl] = tr_frag(Bb + pl * BPB + boff, 4 * BRSB);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        unsigned hp[2], mp[2], lp[2];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {                          // float4 q of the staged slab: A row i = 0, 1, then B
-            const f32x4 v = q < 2 ? (oka[ST][q] ? ra[ST][q] : zero4) : (okb[ST] ? rb[ST] : zero4);
-            unsigned hp[2], mp[2], lp[2];
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 a[2][3], b[NB][3];
 #pragma unroll
-            for (int part = 0; part < 2; ++part) {
-                const int u = 2 * q + part;
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[PA[u]], b[PB[u]], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[PA[u]], b[PB[u]], acc1, 0, 0, 0);
-                split_pair(v[2 * part], v[2 * part + 1], hp[part], mp[part], lp[part]);
-                if (part == 1) {
-                    if (q < 2) {
-                        const int off = ((tid >> 6) + 8 * q) * BRSA + ac4;
-                        *(u32x2*)(An + off) = (u32x2){hp[0], hp[1]};
-                        *(u32x2*)(An + BPA + off) = (u32x2){mp[0], mp[1]};
-                        *(u32x2*)(An + 2 * BPA + off) = (u32x2){lp[0], lp[1]};
-                    } else if (hasb) {
-                        const int off = (tid >> 4) * BRSB + bc4;
-                        *(u32x2*)(Bn + off) = (u32x2){hp[0], hp[1]};
-                        *(u32x2*)(Bn + BPB + off) = (u32x2){mp[0], mp[1]};
-                        *(u32x2*)(Bn + 2 * BPB + off) = (u32x2){lp[0], lp[1]};
+            for (int pl = 0; pl < 3; ++pl) {
+                a[0][pl] = tr_frag(Ab + pl * BPA + aoff + 16 * ks * BRSA, 4 * BRSA);
+                a[1][pl] = tr_frag(Ab + pl * BPA + aoff + 16 * ks * BRSA + 32, 4 * BRSA);
+#pragma unroll
+                for (int y_ = 0; y_ < NB; ++y_) b[y_][pl] = tr_frag(Bb + pl * BPB + boff + 16 * ks * BRSB + 32 * y_, 4 * BRSB);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y_ = 0; y_ < NB; ++y_)
+                        acc[x][y_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][PA[u]], b[y_][PB[u]], acc[x][y_], 0, 0, 0);
+                // split pair j of the staged slab: float4 q = j / 2 (A rows i = 0 .. NA - 1, then B), its values 2 part, 2 part + 1
+                const int j = 6 * ks + u, q = j >> 1, part = j & 1;
+                if (q <= NA) {
+                    const f32x4 v = q < NA ? (oka[ST][q < NA ? q : 0] ? ra[ST][q < NA ? q : 0] : zero4) : (okb[ST] ? rb[ST] : zero4);
+                    split_pair(v[2 * part], v[2 * part + 1], hp[part], mp[part], lp[part]);
+                    if (part == 1) {
+                        if (q < NA) {
+                            const int off = ((tid >> 6) + 8 * q) * BRSA + ac4;
+                            *(u32x2*)(An + off) = (u32x2){hp[0], hp[1]};
+                            *(u32x2*)(An + BPA + off) = (u32x2){mp[0], mp[1]};
+                            *(u32x2*)(An + 2 * BPA + off) = (u32x2){lp[0], lp[1]};
+                        } else if (hasb) {
+                            const int off = brow * BRSB + bc4;
+                            *(u32x2*)(Bn + off) = (u32x2){hp[0], hp[1]};
+                            *(u32x2*)(Bn + BPB + off) = (u32x2){mp[0], mp[1]};
+                            *(u32x2*)(Bn + 2 * BPB + off) = (u32x2){lp[0], lp[1]};
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        gload(sc, kbeg + (long)(s_ + 1 + NST) * BSK);
+        gload(sc, kbeg + (long)(s_ + 1 + NST) * SK);
         __syncthreads();
     };
     int s_ = 0;
@@ -854,12 +878,15 @@ __global__ __launch_bounds__(512, 2) void xpanel_bwd256_sb_kernel(XPanel p, cons
     for (; s_ < nslab; s_ += NST)
         xp_static_for<0, NST>([&](auto ic) { if (s_ + decltype(ic)::value < nslab) slab(ic, s_ + decltype(ic)::value); });
     const int li = lane & 31, kh = lane >> 5;
-    const int n = n0 + wn * 32 + li;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        C[(long)m * Nn + n] = acc0[r];
-        C[(long)(m + 32) * Nn + n] = acc1[r];
+    for (int y_ = 0; y_ < NB; ++y_) {
+        const int n = n0 + wn * 32 * NB + 32 * y_ + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            C[(long)m * Nn + n] = acc[0][y_][r];
+            C[(long)(m + 32) * Nn + n] = acc[1][y_][r];
+        }
     }
 }
 
@@ -962,26 +989,24 @@ int launch_xpanel_bwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
         static const int ride = getenv("FUMI_XP_RIDER") ? atoi(getenv("FUMI_XP_RIDER")) : 1;     // 0: never carry the hypernetwork backward
         static const int bsb = getenv("FUMI_XPB_SB") ? atoi(getenv("FUMI_XPB_SB")) : 1;          // 0: the fp32-MFMA kernel
         if (bsb && kchunk % BSK == 0) {
-            const size_t lds_sb = 2 * (size_t)BBUF * sizeof(unsigned short);
-            static const int bnst = getenv("FUMI_XPB_NST") ? atoi(getenv("FUMI_XPB_NST")) : 2;    // ring depth (tuning knob)
-            if (ride && rider && rider_done && rider->nblk > 0 && rider->nblk % 8 == 0 &&
-                (size_t)hyper_bwd_lds_floats(rider->Dt, rider->H1) * 4 <= lds_sb) {
-                if (bnst >= 3) {
-                    FUMI_SET_DYN_LDS((xpanel_bwd256_sb_kernel<true, 3>), lds_sb);
-                    hipLaunchKernelGGL((xpanel_bwd256_sb_kernel<true, 3>), dim3(nwg + rider->nblk), dim3(512), lds_sb, st, p, Abar, slabs,
-                                       kchunk, nsplit, tn, tm, *rider);
-                } else {
-                    FUMI_SET_DYN_LDS((xpanel_bwd256_sb_kernel<true, 2>), lds_sb);
-                    hipLaunchKernelGGL((xpanel_bwd256_sb_kernel<true, 2>), dim3(nwg + rider->nblk), dim3(512), lds_sb, st, p, Abar, slabs,
-                                       kchunk, nsplit, tn, tm, *rider);
-                }
-                *rider_done = 1;
-            } else {
-                HyperBwdArgs none; memset(&none, 0, sizeof(none));
-                FUMI_SET_DYN_LDS((xpanel_bwd256_sb_kernel<false, 2>), lds_sb);
-                hipLaunchKernelGGL((xpanel_bwd256_sb_kernel<false, 2>), dim3(nwg), dim3(512), lds_sb, st, p, Abar, slabs,
-                                   kchunk, nsplit, tn, tm, none);
-            }
+            static const int bnb = getenv("FUMI_XPB_NB") ? atoi(getenv("FUMI_XPB_NB")) : 1;      // 2: 256 x 128 tiles
+            static const int bsk = getenv("FUMI_XPB_SK") ? atoi(getenv("FUMI_XPB_SK")) : 16;     // 32: two k-steps per slab (NB = 1)
+            const int NB = (bnb == 2 && D % 128 == 0) ? 2 : 1;
+            const int SKv = (NB == 1 && bsk == 32 && kchunk % 32 == 0) ? 32 : 16;
+            const size_t lds_sb = 2 * (size_t)bsb_buf_ushorts(NB, SKv) * sizeof(unsigned short);
+            const unsigned nwg2 = 8 * ((nsplit + 7) / 8) * (D / (64 * NB)) * tm;
+            const bool ridden = ride && rider && rider_done && rider->nblk > 0 && rider->nblk % 8 == 0 &&
+                                (size_t)hyper_bwd_lds_floats(rider->Dt, rider->H1) * 4 <= lds_sb;
+            HyperBwdArgs none; memset(&none, 0, sizeof(none));
+#define BSB_LAUNCH(RID_, NB_, SK_)                                                                                      \
+            do {                                                                                                        \
+                FUMI_SET_DYN_LDS((xpanel_bwd256_sb_kernel<RID_, 2, NB_, SK_>), lds_sb);                                  \
+                hipLaunchKernelGGL((xpanel_bwd256_sb_kernel<RID_, 2, NB_, SK_>), dim3(nwg2 + (RID_ ? rider->nblk : 0)), dim3(512), lds_sb, st, \
+                                   p, Abar, slabs, kchunk, nsplit, D / (64 * NB_), tm, RID_ ? *rider : none);            \
+            } while (0)
+            if (ridden) { if (NB == 2) BSB_LAUNCH(true, 2, 16); else if (SKv == 32) BSB_LAUNCH(true, 1, 32); else BSB_LAUNCH(true, 1, 16); *rider_done = 1; }
+            else { if (NB == 2) BSB_LAUNCH(false, 2, 16); else if (SKv == 32) BSB_LAUNCH(false, 1, 32); else BSB_LAUNCH(false, 1, 16); }
+#undef BSB_LAUNCH
             LAUNCH_CHECK();
             return FUMI_OK;
         }
