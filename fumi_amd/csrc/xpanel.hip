@@ -372,9 +372,11 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* 
     f32x4 ga[NST][2], gb[NST][2];
     const int li = lane & 31, hh = lane >> 5;
     const int aoff = (wm * 32 + li) * SROW + 8 * hh, boff = (wn * 32 + li) * SROW + 8 * hh;
-    f32x16 acc;
+    // two accumulators, one per 16-deep step of a slab: two independent MFMA chains per wave (a wave owns a single 32x32 block, and
+    // with two waves per SIMD a chain of twelve dependent MFMAs per slab left the matrix pipe waiting on its own results)
+    f32x16 acc2[2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 16; ++i) { acc2[0][i] = 0.f; acc2[1][i] = 0.f; }
     const int nslab = K / ks / SBK;
 
     auto gload = [&](auto sc, int k0) {
@@ -404,6 +406,7 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* 
             bf16x8 bh = __builtin_bit_cast(bf16x8, *(const f32x4*)(lds[buf][1][0] + boff + 16 * s));
             bf16x8 bm = __builtin_bit_cast(bf16x8, *(const f32x4*)(lds[buf][1][1] + boff + 16 * s));
             bf16x8 bl = __builtin_bit_cast(bf16x8, *(const f32x4*)(lds[buf][1][2] + boff + 16 * s));
+            f32x16& acc = acc2[s & 1];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);      // smallest terms first
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
@@ -445,8 +448,8 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* 
             unsigned hp[2], mp[2], lp[2];
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
-                const int u = 3 * q + part;                // MFMA number 0..11
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u / 6][PA[u % 6]], fb[u / 6][PB[u % 6]], acc, 0, 0, 0);
+                const int u = 3 * q + part;                // MFMA number 0..11: step u & 1, piece pair u >> 1
+                acc2[u & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][PA[u >> 1]], fb[u & 1][PB[u >> 1]], acc2[u & 1], 0, 0, 0);
                 if (part < 2) {
                     split_pair(v[2 * part], v[2 * part + 1], hp[part], mp[part], lp[part]);
                 } else {
@@ -470,6 +473,9 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* 
         xp_static_for<0, NST>([&](auto ic) { slab_main(ic, s + decltype(ic)::value); });
     for (; s < nslab; s += NST)
         xp_static_for<0, NST>([&](auto ic) { if (s + decltype(ic)::value < nslab) slab(ic, s + decltype(ic)::value); });
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = acc2[0][i] + acc2[1][i];
     const int n = n0 + wn * 32 + li;
     if (n < C) {
         float* base; long ld; int col;
