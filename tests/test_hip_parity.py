@@ -863,13 +863,17 @@ sys.path.insert(0, %r)
 from fumi_amd import hip
 dev = torch.device("cuda:0"); ws = hip.Workspace.get(dev)
 g = torch.Generator().manual_seed(9)
-B, S, Qn, D, h0 = 5, 25, 43, 256, 256                     # 340 contraction rows: a ragged last slab
-x_s = torch.randn(B, S, D, generator=g).abs(); x_q = torch.randn(B, Qn, D, generator=g) * 3.0
-Ab = torch.randn(B, S + Qn, h0, generator=g) * torch.rand(B, S + Qn, 1, generator=g)      # rows of very different scale
-gW = hip.xpanel_bwd(ws, x_s.to(dev), x_q.to(dev), Ab.to(dev))
-X = torch.cat([x_s, x_q], 1).double().reshape(-1, D)
-ref = Ab.double().reshape(-1, h0).T @ X
-print(json.dumps({"e": float((gW.cpu().double() - ref).abs().max() / ref.abs().max())}))
+worst = 0.0
+for B, S, Qn, D, h0 in [(5, 25, 43, 256, 256),            # 340 contraction rows: a ragged last slab
+                        (3, 10, 21, 128, 512),            # two 256-row tiles of gW0, two 64-column tiles
+                        (40, 25, 160, 192, 256)]:         # 7400 rows: many slabs, episodes straddling slab borders
+    x_s = torch.randn(B, S, D, generator=g).abs(); x_q = torch.randn(B, Qn, D, generator=g) * 3.0
+    Ab = torch.randn(B, S + Qn, h0, generator=g) * torch.rand(B, S + Qn, 1, generator=g)      # rows of very different scale
+    gW = hip.xpanel_bwd(ws, x_s.to(dev), x_q.to(dev), Ab.to(dev))
+    X = torch.cat([x_s, x_q], 1).double().reshape(-1, D)
+    ref = Ab.double().reshape(-1, h0).T @ X
+    worst = max(worst, float((gW.cpu().double() - ref).abs().max() / ref.abs().max()))
+print(json.dumps({"e": worst}))
 """
 
 
