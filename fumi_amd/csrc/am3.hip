@@ -525,7 +525,7 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     int hgq = 1;
     if (fast_head && B <= FUMI_HCNT) {
         if (hgq_env > 0) hgq = hgq_env > 16 ? 16 : hgq_env;
-        else while (hgq < 8 && B * hgq * 2 <= 256 && Qn / (hgq * 2) >= 2 * nwaves) hgq *= 2;
+        else while (hgq < 8 && B * hgq * 2 <= 256 && Qn / (hgq * 2) >= nwaves) hgq *= 2;      // (8 shares at 32 episodes x 160 rows: measured best)
     }
     if (hgq > 1) A((size_t)B * hgq * ((size_t)N * P + 2 + (size_t)N * N + P));
     if (need_grad) A((size_t)B * P);
