@@ -259,6 +259,7 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
                                                         const int64_t* y_s, int* status, int P) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ StageTab s_stg;
+    __shared__ int s_lab[128];                   // support labels (the LDS-resident form holds S <= 128 rows)
     // the buffer table (~100 pointers) is read from an LDS copy: as a kernel argument every pointer is a scalar load from the
     // argument block at its first use, each with its own wait, scattered over the phases (2.7 us of the step loop's preheader)
     __shared__ EpiBuf s_w;
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
     // labels and A0_s + b0 are loaded now: a load issued inside the step loop would wait for every older tape store
     // (vmcnt counts loads and stores together, in order)
     const int my_label = tid < S ? label(ys, tid, N, status) : 0;
+    if (tid < S && tid < 128) s_lab[tid] = my_label;          // (read by the soft-max lanes of a row: published by the barriers before the loop)
     // A0_s + b0 of the lane's 4x4 block of the layer-0 products (block = wave)
     f32x4 preZ[4];
     {
@@ -438,22 +440,31 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
         });
         wg_lds_barrier(); STAMP()
         {
+            // one lane per (row, class): G = 8 / 16 / 32 / 64 lanes per row, every lane walks its row's N logits through shuffles in
+            // class order -- the same max / sum, in the same order, as one thread per row computed, at 1 / N of the chain length
+            // (one thread per row: S = 25 lanes of the workgroup busy for ~500 dependent instructions, 3.3 us per inner step)
             float* tpp = w.tp + tp * S * N; float* tee = w.te + tp * S * N;
-            for (int s_ = tid; s_ < S; s_ += nt) {
-                const int yy = s_ == tid ? my_label : label(ys, s_, N, status);       // (S > blockDim only)
-                float* row = e_ + s_ * ldN;
-                float mx = row[0];
-                for (int n = 1; n < N; ++n) mx = fmaxf(mx, row[n]);
+            const int G = N <= 8 ? 8 : N <= 16 ? 16 : N <= 32 ? 32 : 64;
+            const int per = nt / G, gl = tid & (G - 1), base = (tid & 63) & ~(G - 1);
+            for (int s0 = 0; s0 < S; s0 += per) {
+                const int s_ = s0 + tid / G;
+                const bool rok = s_ < S, live = rok && gl < N;
+                float* row = e_ + (rok ? s_ : 0) * ldN;
+                const float x = live ? row[gl] : -INFINITY;
+                float mx = __shfl(x, base, 64);
+                for (int n = 1; n < N; ++n) mx = fmaxf(mx, __shfl(x, base + n, 64));
+                const float ex = live ? expf(x - mx) : 0.f;
                 float sum = 0.f;
-                for (int n = 0; n < N; ++n) sum += expf(row[n] - mx);
+                for (int n = 0; n < N; ++n) sum += __shfl(ex, base + n, 64);
                 const float inv = 1.f / sum;
-                for (int n = 0; n < N; ++n) {
-                    const float pv = expf(row[n] - mx) * inv;
-                    const float ev = (pv - (n == yy ? 1.f : 0.f)) / (float)S;
-                    row[n] = ev;
-                    if (d.taped && lead) { tpp[s_ * N + n] = pv; tee[s_ * N + n] = ev; }
+                if (live) {
+                    const int yy = s_lab[s_];
+                    const float pv = ex * inv;
+                    const float ev = (pv - (gl == yy ? 1.f : 0.f)) / (float)S;
+                    row[gl] = ev;
+                    if (d.taped && lead) { tpp[s_ * N + gl] = pv; tee[s_ * N + gl] = ev; }
                 }
-                for (int n = N; n < ldN - 4; ++n) row[n] = 0.f;                  // K padding of e (logits wrote bias-free zeros anyway)
+                if (rok) for (int n = gl; n < ldN - 4; n += G) if (n >= N) row[n] = 0.f;      // K padding of e
             }
         }
         wg_lds_barrier(); STAMP()
