@@ -703,7 +703,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short* a, int row4_usho
 // Abar0 panel, four accumulators per wave, 92 KB of LDS: one workgroup per CU)
 // SK = contraction rows per slab: 16 (one MFMA k-step; 72 KB of LDS at NB = 1: two workgroups per CU) or 32 (two k-steps between
 // barriers, 144 KB: one workgroup per CU)
-template <bool RIDER, int NST, int NB, int SK>
+// SWAP (narrow gradients, h0 = 64: AM3's image encoder): the 256-wide side of the tile is a block of X's COLUMNS (rows through xrow)
+// and the 64-wide side the plain matrix Abar [K, 64]; the tile is the transpose of a 64 x 256 block of gW and leaves through LDS
+// so that its rows are stored contiguously.  (NB = 1, SK = 16, no rider.)
+template <bool RIDER, int NST, int NB, int SK, bool SWAP = false>
 __global__ __launch_bounds__(512, (NB == 1 && SK == 16) ? 2 : 1) void xpanel_bwd256_sb_kernel(XPanel p, const float* __restrict__ Abar, float* __restrict__ slabs,
                                                                    int kchunk, int nsplit, int tiles_n, int tiles_m, HyperBwdArgs rider) {
     extern __shared__ __attribute__((aligned(16))) float lds256[];
@@ -719,7 +722,7 @@ __global__ __launch_bounds__(512, (NB == 1 && SK == 16) ? 2 : 1) void xpanel_bwd
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int R = p.S + p.Qn, M = p.h0, Nn = p.D;
+    const int R = p.S + p.Qn, M = SWAP ? p.D : p.h0, Nn = SWAP ? p.h0 : p.D;        // wide / narrow extents of the product
     const long Ktot = (long)p.B * R;
     const int tiles = tiles_n * tiles_m;
     const int xcd = bid & 7, jq = bid >> 3;
@@ -736,12 +739,17 @@ __global__ __launch_bounds__(512, (NB == 1 && SK == 16) ? 2 : 1) void xpanel_bwd
     const int ac4 = (tid & 63) << 2, bc4 = (tid & ((1 << BL) - 1)) << 2;
     const int brow = tid >> BL;
     const bool hasb = brow < SK;
-    int gb, gr;
-    {
-        const long g = kbeg + brow;
-        gb = (int)(g / R); gr = (int)(g - (long)gb * R);
+    // the virtual rows of X this thread fetches: its B row (brow), or with SWAP its NA A rows; tracked incrementally (+SK per slab)
+    constexpr int NXR = SWAP ? NA : 1;
+    int gb[NXR], gr[NXR]; const float* xp[NXR];
+#pragma unroll
+    for (int i = 0; i < NXR; ++i) {
+        const int row = SWAP ? (tid >> 6) + 8 * i : brow;
+        const long g = kbeg + row;
+        gb[i] = (int)(g / R); gr[i] = (int)(g - (long)gb[i] * R);
+        const bool ok = (SWAP || hasb) && g < kend;
+        xp[i] = xrow(p, ok ? gb[i] : 0, ok ? gr[i] : 0);
     }
-    const float* xp = xrow(p, (hasb && kbeg + brow < kend) ? gb : 0, (hasb && kbeg + brow < kend) ? gr : 0);
     f32x4 ra[NST][NA], rb[NST]; bool oka[NST][NA], okb[NST];
     auto gload = [&](auto sc, long k0) {
         constexpr int ST = decltype(sc)::value;
@@ -749,15 +757,21 @@ __global__ __launch_bounds__(512, (NB == 1 && SK == 16) ? 2 : 1) void xpanel_bwd
         for (int i = 0; i < NA; ++i) {
             const long g = k0 + (tid >> 6) + 8 * i;
             oka[ST][i] = g < kend;
-            ra[ST][i] = *(const f32x4*)(Abar + (oka[ST][i] ? g : 0) * M + m0 + ac4);        // raw; masked when written to LDS
+            if constexpr (SWAP) ra[ST][i] = *(const f32x4*)(xp[i] + m0 + ac4);
+            else ra[ST][i] = *(const f32x4*)(Abar + (oka[ST][i] ? g : 0) * M + m0 + ac4);        // raw; masked when written to LDS
         }
         const long g = k0 + brow;
         okb[ST] = hasb && g < kend;
-        rb[ST] = *(const f32x4*)(xp + n0 + bc4);
-        gr += SK;
-        while (gr >= R) { gr -= R; ++gb; }
-        const bool okn = hasb && g + SK < kend;
-        xp = xrow(p, okn ? gb : 0, okn ? gr : 0);
+        if constexpr (SWAP) rb[ST] = *(const f32x4*)(Abar + (okb[ST] ? g : 0) * Nn + n0 + bc4);
+        else rb[ST] = *(const f32x4*)(xp[0] + n0 + bc4);
+#pragma unroll
+        for (int i = 0; i < NXR; ++i) {
+            const int row = SWAP ? (tid >> 6) + 8 * i : brow;
+            gr[i] += SK;
+            while (gr[i] >= R) { gr[i] -= R; ++gb[i]; }
+            const bool okn = (SWAP || hasb) && k0 + row + SK < kend;
+            xp[i] = xrow(p, okn ? gb[i] : 0, okn ? gr[i] : 0);
+        }
     };
     auto lstore = [&](auto sc, int buf) {
         constexpr int ST = decltype(sc)::value;
@@ -884,6 +898,23 @@ __global__ __launch_bounds__(512, (NB == 1 && SK == 16) ? 2 : 1) void xpanel_bwd
     for (; s_ < nslab; s_ += NST)
         xp_static_for<0, NST>([&](auto ic) { if (s_ + decltype(ic)::value < nslab) slab(ic, s_ + decltype(ic)::value); });
     const int li = lane & 31, kh = lane >> 5;
+    if constexpr (SWAP) {
+        // transpose through LDS (the last slab's barrier has passed: every wave is done reading): T[n][m], rows of 256 + 4 floats
+        float* T = lds256;
+        constexpr int TLD = 256 + 4;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                T[(wn * 32 + li) * TLD + wm * 64 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * kh] = acc[x][0][r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int f = tid + 512 * j, row = f >> 6, c4 = (f & 63) << 2;
+            *(f32x4*)(C + (long)(n0 + row) * M + m0 + c4) = *(const f32x4*)(T + row * TLD + c4);
+        }
+        return;
+    }
 #pragma unroll
     for (int y_ = 0; y_ < NB; ++y_) {
         const int n = n0 + wn * 32 * NB + 32 * y_ + li;
@@ -966,9 +997,23 @@ static bool xpanel_bwd_wide(int D, int h0) {
     return !off && (h0 % 256 == 0) && (D % 64 == 0);
 }
 
+// narrow gradients (h0 = 64: AM3's image encoder) on the split-bf16 kernel with the roles of the operands swapped
+static bool xpanel_bwd_narrow(int D, int h0) {
+    static const int on = getenv("FUMI_XPB_SB") ? atoi(getenv("FUMI_XPB_SB")) : 1;
+    return on && h0 == 64 && D % 256 == 0;
+}
+
 int xpanel_bwd_nsplit(int B, int S, int Qn, int D, int h0, int* kchunk_out) {
     const long Ktot = (long)B * (S + Qn);
     const bool wide = xpanel_bwd_wide(D, h0);
+    if (xpanel_bwd_narrow(D, h0)) {                 // D / 256 tiles: one workgroup per CU
+        long ns = (256 + D / 256 - 1) / (D / 256);
+        if (ns > 32) ns = 32;
+        if (ns < 1) ns = 1;
+        long kc = ((Ktot + ns - 1) / ns + BK - 1) / BK * BK;
+        *kchunk_out = (int)kc;
+        return (int)((Ktot + kc - 1) / kc);
+    }
     const long tiles = wide ? (long)(h0 / 256) * (D / 64) : (long)((h0 + 63) / 64) * ((D + 63) / 64);
     static const int target = getenv("FUMI_XPB_WG") ? atoi(getenv("FUMI_XPB_WG")) : 0;
     const long want = target > 0 ? target : (wide ? 512 : 1024);   // workgroups: two 8-wave ones or four 4-wave ones per CU
@@ -988,6 +1033,16 @@ int launch_xpanel_bwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
     XPanel p{x_s, x_q, nullptr, B, S, Qn, D, h0, nullptr, nullptr, nullptr, 0, S};
     if (rows && rows->table) { p.table = rows->table; p.idx_s = rows->idx_s; p.idx_q = rows->idx_q; p.n_rows = rows->n_rows; p.x_s = p.x_q = rows->table; }
     const bool fast = (D % 64 == 0) && (h0 % 64 == 0) && al16(p.x_s) && al16(p.x_q) && al16(Abar);
+    if (fast && xpanel_bwd_narrow(D, h0) && kchunk % BSK == 0) {
+        const size_t lds_sb = 2 * (size_t)bsb_buf_ushorts(1, 16) * sizeof(unsigned short);      // (72 KB: also holds the 64 x 260 float transpose)
+        HyperBwdArgs none; memset(&none, 0, sizeof(none));
+        const int tm = D / 256;
+        FUMI_SET_DYN_LDS((xpanel_bwd256_sb_kernel<false, 2, 1, 16, true>), lds_sb);
+        hipLaunchKernelGGL((xpanel_bwd256_sb_kernel<false, 2, 1, 16, true>), dim3(8 * ((nsplit + 7) / 8) * tm), dim3(512), lds_sb, st,
+                           p, Abar, slabs, kchunk, nsplit, 1, tm, none);
+        LAUNCH_CHECK();
+        return FUMI_OK;
+    }
     if (fast && xpanel_bwd_wide(D, h0)) {
         const size_t lds_bytes = 2 * (32 * 256 + 32 * 64) * sizeof(float);
         const int tn = D / 64, tm = h0 / 256;
