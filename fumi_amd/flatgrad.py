@@ -32,3 +32,23 @@ class FlatGrads:
         for p, v in zip(self.params, self.views):
             if p.grad is not v:                  # stays attached from step to step: the engine overwrites the whole buffer
                 p.grad = v
+
+
+class ParamWatch:
+    """Cheap per-step check that a model's cached parameter views are still current: every parameter must still be the object
+    registered under its name in its owner module (``module._parameters``) and must still live at the same address
+    (``param.data = ...`` and ``.to()`` move it).  ~1 us for a dozen parameters."""
+
+    def __init__(self, module, params):
+        byid = {}
+        for m in module.modules():
+            for n, q in m._parameters.items():
+                if q is not None:
+                    byid[id(q)] = (m._parameters, n)
+        self.refs = [(byid[id(q)][0], byid[id(q)][1], q, q.data_ptr()) for q in params]
+
+    def valid(self):
+        for d, n, q, ptr in self.refs:
+            if d.get(n) is not q or q.data_ptr() != ptr:
+                return False
+        return True

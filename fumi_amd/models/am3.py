@@ -14,7 +14,7 @@ import torch.nn as nn
 from .. import dist as fdist
 from .. import engine as _engine
 from .. import lazy
-from ..flatgrad import FlatGrads
+from ..flatgrad import FlatGrads, ParamWatch
 from ..utils import utils as utils
 from ..utils.average_meter import AverageMeter
 from ..utils.wandb_compat import wandb
@@ -89,10 +89,10 @@ class AM3(nn.Module):
         """(detached weights, detached backbone tensors | None, flat gradient buffer | None) as objects that stay the SAME from
         step to step (hip.py validates a list once); rebuilt when a parameter object was replaced or moved (``_apply``)."""
         c = self._pcache
-        first = self.image_encoder.weight
-        if c is None or c[0] is not first or c[1] != first.data_ptr():
-            c = self._pcache = (first, first.data_ptr(), [p.detach() for p in self._w()],
-                                [p.detach() for p in self.conv.theta()] if self.conv is not None else None)
+        if c is None or not c[0].valid():
+            w, th = self._w(), (self.conv.theta() if self.conv is not None else [])
+            c = self._pcache = (ParamWatch(self, w + th), None, [p.detach() for p in w],
+                                [p.detach() for p in th] if self.conv is not None else None)
             self._flat = None
         fg = None
         if need_grad:

@@ -16,7 +16,7 @@ import torch.nn as nn
 from .. import dist as fdist
 from .. import lazy
 from .. import engine as _engine
-from ..flatgrad import FlatGrads
+from ..flatgrad import FlatGrads, ParamWatch
 from ..meta import MetaLinear, MetaSequential
 from ..utils import utils as utils
 from ..utils.average_meter import AverageMeter
@@ -130,17 +130,16 @@ class FUMI(nn.Module):
         (they share storage, so optimizer updates show through) and the FlatGrads.  Rebuilt when a parameter object was
         replaced or moved (``_apply``: .to() / .cuda() / .float())."""
         c = self._pcache
-        first = self.im_net.theta()[0] if self.im_encoder == "conv4" else self.im_net.linear0.weight
-        if c is None or c[0] is not first or c[1] is not self.hyper_net[0].weight or c[2] != first.data_ptr():
+        if c is None or not c[0].valid():
             theta, phi = self._theta(), self._phi()
-            c = self._pcache = (first, phi[0], first.data_ptr(), [p.detach() for p in theta], [p.detach() for p in phi])
+            c = self._pcache = (ParamWatch(self, theta + phi), [p.detach() for p in theta], [p.detach() for p in phi])
             self._flat = None
         fg = None
         if train:
             fg = self._flat
             if fg is None:
                 fg = self._flat_grads()
-        return c[3], c[4], fg
+        return c[1], c[2], fg
 
     def _apply(self, fn, recurse=True):
         self._pcache = None

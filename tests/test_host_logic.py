@@ -392,3 +392,28 @@ def test_clip_baseline_surface_and_cli_on_cpu(oracle_engine, tmp_path, monkeypat
     assert 0.0 <= res["test_acc"] <= 1.0
     runs = os.listdir(tmp_path / "res" / "runs")
     assert os.path.exists(tmp_path / "res" / "runs" / runs[0] / "ckpt.pth.tar")
+
+
+def test_cached_parameter_views_follow_replaced_parameters(oracle_engine):
+    """FUMI / AM3 hand the engine the SAME lists of detached parameter views every step (hip.py validates a list once); the cache
+    must notice a parameter object that was replaced, a ``param.data`` that was re-pointed and a module that was moved."""
+    from fumi_amd.models.am3 import AM3
+    from fumi_amd.models.fumi import FUMI
+    m = FUMI(n_way=3, im_emb_dim=16, im_hid_dim=[8, 4], text_encoder="BERT", text_emb_dim=6, text_hid_dim=8, dropout_rate=0.0)
+    th1, ph1, _ = m._step_params(False)
+    th2, ph2, _ = m._step_params(False)
+    assert th1 is th2 and ph1 is ph2                                   # stable list objects from step to step
+    m.hyper_net[2].weight = torch.nn.Parameter(torch.zeros_like(m.hyper_net[2].weight))
+    _, ph3, _ = m._step_params(False)
+    assert ph3 is not ph1 and ph3[2].data_ptr() == m.hyper_net[2].weight.data_ptr()
+    m.im_net.linear0.bias.data = torch.ones_like(m.im_net.linear0.bias)
+    th4, _, _ = m._step_params(False)
+    assert th4 is not th1 and th4[1].data_ptr() == m.im_net.linear0.bias.data_ptr() and float(th4[1][0]) == 1.0
+    m.double(); m.float()                                              # _apply: every tensor re-created
+    th5, _, _ = m._step_params(False)
+    assert th5[0].data_ptr() == m.im_net.linear0.weight.data_ptr()
+    a = AM3(im_encoder="precomputed", im_emb_dim=16, text_encoder="BERT", text_emb_dim=6, text_hid_dim=8, prototype_dim=4, dropout=0.0)
+    w1 = a._step_params(False, 3)[0]
+    a.g[3].bias = torch.nn.Parameter(torch.zeros_like(a.g[3].bias))
+    w2 = a._step_params(False, 3)[0]
+    assert w2 is not w1 and w2[5].data_ptr() == a.g[3].bias.data_ptr()
