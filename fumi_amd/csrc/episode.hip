@@ -666,13 +666,14 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
 // (query_layout().total <= QLDS_CAP), i.e. for the reference's [256, 64] image network and anything smaller.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int QLDS_CAP = 40000;         // floats of dynamic LDS (160 KiB = 40960 less the kernel's static arrays)
-struct QLay { int a[MAXL], W[MAXL], bi[MAXL], Wh, Gq, D, lq, b0, cs, pb0, bh, total; };
-__host__ __device__ inline void query_layout(QLay& y, int L, const int* h, int S, int N) {
+struct QLay { int a[MAXL], W[MAXL], bi[MAXL], Wh, Wh2, Gq, D, lq, b0, cs, pb0, bh, total; };
+__host__ __device__ inline void query_layout(QLay& y, int L, const int* h, int S, int N, bool fused = false) {
     int off = 0;
     for (int i = 0; i < MAXL; ++i) { y.a[i] = y.W[i] = y.bi[i] = 0; }
     for (int i = 0; i < L; ++i) { y.a[i] = off; off += QR * wg_ld(h[i]); }
     for (int i = 1; i < L; ++i) { y.W[i] = off; off += q_r16(h[i]) * wg_ld(h[i - 1]); y.bi[i] = off; off += q_r4(h[i]); }
     y.Wh = off; off += q_r16(N) * wg_ld(h[L - 1]);
+    y.Wh2 = off; if (fused) off += q_r16(N) * wg_ld(h[L - 1]);       // (fused inner step: the updated head next to the old one)
     y.Gq = off; off += QR * wg_ld(S);
     y.D = off; off += q_r4(S) * wg_ld(h[0]);
     y.lq = off; off += QR * wg_ld(N);
@@ -683,12 +684,21 @@ __host__ __device__ inline void query_layout(QLay& y, int L, const int* h, int S
     y.total = off;
 }
 
-__global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d, EpiBuf w, QLay y, const int64_t* y_q,
-                                                        float* logits_q, int64_t* preds_q, float* preds_f, int* status) {
+// FUSED (one inner step, two layers, S <= 32: the reference configuration): every query tile first runs the episode's inner step on
+// the support rows ITSELF -- redundantly in each of the episode's tiles, which costs nothing on a chip that the 32 one-workgroup
+// adapt launches left 7/8 idle -- so the adapt kernel, its launch and the round trip of the fast weights through memory go away.
+// The support activations borrow the tile's own images (a_0, a_1, lq) before the query rows are staged into them; the updated head
+// is built next to the old one (the backward through the head reads the old); tile 0 writes the tape the reverse sweep reads.
+template <bool FUSED>
+__global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, StageTab stg_sup, EpiDims d, EpiBuf w, QLay y, const int64_t* y_q,
+                                                        float* logits_q, int64_t* preds_q, float* preds_f, int* status,
+                                                        const int64_t* y_s) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float s_loss[QR];
     __shared__ float s_corr[QR];
-    __shared__ StageTab s_stg;
+    __shared__ StageTab s_stg2[2];
+    __shared__ int s_lab[QR];
+    StageTab& s_stg = s_stg2[0];
     const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
     int qi = 0;
 #define QSTAMP() if (w.trace && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) w.trace[64 + qi++] = __builtin_amdgcn_s_memrealtime();
@@ -703,9 +713,131 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d,
     // the row's label is loaded now: inside the chain it would wait for every older store (vmcnt is in order)
     const int my_label = tid < nr ? label(y_q + (long)b * Qn + r0, tid, N, status) : 0;
     // ---- zero the arena (padding must read as zero), then stage everything this tile needs in one batch (plan: host)
-    wg_stage_tab_to_lds(&s_stg, 1, (int)(sizeof(StageTab) + sizeof(EpiDims) + sizeof(EpiBuf) + sizeof(QLay) + 64));
+    const int my_label_s = (FUSED && tid < S) ? label(y_s + (long)b * S, tid, N, status) : 0;
+    if (FUSED && tid < S && tid < QR) s_lab[tid] = my_label_s;
+    wg_stage_tab_to_lds(s_stg2, 2, (int)(2 * sizeof(StageTab) + sizeof(EpiDims) + sizeof(EpiBuf) + sizeof(QLay) + 64));
     for (int i = tid * 4, tot = y.total; i < tot; i += nt * 4) *(f32x4*)(sm + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads(); QSTAMP()
+    int whq = y.Wh;                                                  // the head the query pass uses
+    if constexpr (FUSED) {
+        const bool lead = tile == 0 && d.taped;                      // one tile per episode writes the tape
+        const f32x4 z4s = {0.f, 0.f, 0.f, 0.f};
+        wg_stage_rows<20>(&s_stg2[1], b, 0, 0, 0, sm);               // A0_s rows -> a_0, W_1, b_1, the episode's head, b_0
+        wg_lds_barrier();
+        float* a0 = a(0); float* a1 = a(1); float* W1 = sm + y.W[1]; float* b1 = sm + y.bi[1];
+        float* Wh = sm + y.Wh; float* Wh2 = sm + y.Wh2; float* bh = sm + y.bh; float* Dl = sm + y.D; float* csl = sm + y.cs;
+        const float* b0l = sm + y.b0; float* e_ = sm + y.lq;
+        const int h1 = d.h[1], ld1 = wg_ld(h1);
+        const long tp = (long)b * w.ntape;                           // tape step 0
+        auto store_img = [&](float* dst, long drs, const float* img, int ld, int rows, int cols) {      // LDS image -> global rows
+            const int c4n = (cols + 3) >> 2;
+            for (int i = tid; i < rows * c4n; i += nt) {
+                const int r = i / c4n, cc = (i - r * c4n) << 2;
+                wg_st4(dst + (long)r * drs + cc, *(const f32x4*)(img + r * ld + cc), min(4, cols - cc));
+            }
+        };
+        if (lead) {                                                  // slot 0 of the tape: the initial fast weights
+            store_img(w.Wslot[1] + (long)b * w.nslot * ((long)h1 * h0), h0, W1, ld0, h1, h0);
+            store_img(w.Whslot + (long)b * w.nslot * N * H, H, Wh, ldH, N, H);
+        }
+        {   // 1. a_0 = relu(A0_s + b_0)   (D_0 = 0)
+            const unsigned key0 = drop_key(d, b, 0, 0);
+            float* ta0 = w.ta[0] + tp * S * h0;
+            const int c4n = h0 >> 2;
+            for (int i = tid; i < S * c4n; i += nt) {
+                const int m = i / c4n, n = (i - m * c4n) << 2;
+                float* p = a0 + m * ld0 + n;
+                const f32x4 v = drop_relu4(d, key0, (long)m * h0 + n, *(const f32x4*)p + *(const f32x4*)(b0l + n));
+                *(f32x4*)p = v;
+                if (lead) *(f32x4*)(ta0 + (long)m * h0 + n) = v;
+            }
+        }
+        wg_lds_barrier();
+        {   // 2. a_1
+            const unsigned key1 = drop_key(d, b, 0, 1);
+            float* ta1 = w.ta[1] + tp * S * h1;
+            wg_lmm<true, true>(S, h1, h0, a0, ld0, W1, ld0, [&](int m, int n, const f32x4& acc, int cnt) {
+                f32x4 o = drop_relu4(d, key1, (long)m * h1 + n, acc + *(const f32x4*)(b1 + n));
+#pragma unroll
+                for (int cc = 1; cc < 4; ++cc) if (cc >= cnt) o[cc] = 0.f;
+                *(f32x4*)(a1 + m * ld1 + n) = o;
+                if (lead) wg_st4(ta1 + (long)m * h1 + n, o, cnt);
+            });
+        }
+        wg_lds_barrier();
+        // 3. head logits (into e_), soft-max, e = (p - onehot) / S
+        wg_lmm<true, true>(S, N, H, a1, ld1, Wh, ldH, [&](int m, int n, const f32x4& acc, int) {
+            *(f32x4*)(e_ + m * ldq + n) = acc + *(const f32x4*)(bh + n);
+        });
+        wg_lds_barrier();
+        {
+            float* tpp = w.tp + tp * S * N; float* tee = w.te + tp * S * N;
+            const int G = N <= 8 ? 8 : N <= 16 ? 16 : N <= 32 ? 32 : 64;
+            const int per = nt / G, gl = tid & (G - 1), base = (tid & 63) & ~(G - 1);
+            for (int s0 = 0; s0 < S; s0 += per) {
+                const int s_ = s0 + tid / G;
+                const bool rok = s_ < S, live = rok && gl < N;
+                float* row = e_ + (rok ? s_ : 0) * ldq;
+                const float x = live ? row[gl] : -INFINITY;
+                float mx = __shfl(x, base, 64);
+                for (int n = 1; n < N; ++n) mx = fmaxf(mx, __shfl(x, base + n, 64));
+                const float ex = live ? expf(x - mx) : 0.f;
+                float sum = 0.f;
+                for (int n = 0; n < N; ++n) sum += __shfl(ex, base + n, 64);
+                const float inv = 1.f / sum;
+                if (live) {
+                    const float pv = ex * inv;
+                    const float ev = (pv - (gl == s_lab[s_] ? 1.f : 0.f)) / (float)S;
+                    row[gl] = ev;
+                    if (lead) { tpp[s_ * N + gl] = pv; tee[s_ * N + gl] = ev; }
+                }
+                if (rok) for (int n = gl; n < ldq - 4; n += G) if (n >= N) row[n] = 0.f;      // K padding of e
+            }
+        }
+        wg_lds_barrier();
+        // 4. updated head next to the old one: Wh' = Wh - alpha e^T a_1,  bh' = bh - alpha colsum(e)
+        wg_lmm_wide<false>(N, H, S, e_, ldq, a1, ld1, [&](int m, int n, const f32x4& acc, int, auto) {
+            *(f32x4*)(Wh2 + m * ldH + n) = *(const f32x4*)(Wh + m * ldH + n) - alpha * acc;
+        });
+        wg_lcolsum(S, N, e_, ldq, [&](int n, float s_) { bh[n] -= alpha * s_; });
+        wg_lds_barrier();
+        {   // 5. dz_1 = (e Wh) * relu'(a_1), in place of a_1 (reads the OLD head)
+            float* tdl = w.tdz[1] + tp * S * h1;
+            wg_lmm_wide<true>(S, H, N, e_, ldq, Wh, ldH, [&](int m, int n, const f32x4& acc, int cnt, auto) {
+                float* p = a1 + m * ld1 + n;
+                const f32x4 act = *(const f32x4*)p;
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = (c < cnt && act[c] > 0.f) ? acc[c] * d.mscale : 0.f;
+                *(f32x4*)p = o;
+                if (lead) wg_st4(tdl + (long)m * h1 + n, o, cnt);
+            });
+        }
+        wg_lds_barrier();
+        // 6. dz_0 = (dz_1 W_1) * relu'(a_0) = D_1
+        wg_lmm_wide<true>(S, h0, h1, a1, ld1, W1, ld0, [&](int m, int n, const f32x4& acc, int cnt, auto) {
+            const f32x4 act = *(const f32x4*)(a0 + m * ld0 + n);
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = (c < cnt && act[c] > 0.f) ? acc[c] * d.mscale : 0.f;
+            *(f32x4*)(Dl + m * ld0 + n) = o;
+        });
+        wg_lds_barrier();
+        // 7. W_1' = W_1 - alpha dz_1^T a_0 in place, b_1' = b_1 - alpha colsum(dz_1), colsum(D_1)
+        wg_lmm_wide<false>(h1, h0, S, a1, ld1, a0, ld0, [&](int m, int n, const f32x4& acc, int, auto) {
+            float* pw = W1 + m * ld0 + n;
+            *(f32x4*)pw = *(const f32x4*)pw - alpha * acc;
+        });
+        wg_lcolsum(S, h1, a1, ld1, [&](int n, float s_) { b1[n] -= alpha * s_; });
+        wg_lcolsum(S, h0, Dl, ld0, [&](int n, float s_) { csl[n] = s_; });
+        wg_lds_barrier();
+        whq = y.Wh2;
+        // the support rows' leftovers in the images the query pass contracts over (rows the tile does not overwrite)
+        for (int i = tid; i < QR * (ld0 >> 2); i += nt) { const int m = i / (ld0 >> 2); if (m >= nr) *(f32x4*)(a0 + m * ld0 + ((i - m * (ld0 >> 2)) << 2)) = z4s; }
+        for (int i = tid; i < QR * (ld1 >> 2); i += nt) { const int m = i / (ld1 >> 2); *(f32x4*)(a1 + m * ld1 + ((i - m * (ld1 >> 2)) << 2)) = z4s; }
+        for (int i = tid; i < QR * (ldq >> 2); i += nt) { const int m = i / (ldq >> 2); *(f32x4*)(e_ + m * ldq + ((i - m * (ldq >> 2)) << 2)) = z4s; }
+        wg_lds_barrier();
+    }
     wg_stage_rows<20>(&s_stg, b, tile, 0, nr, sm);
     wg_lds_barrier(); QSTAMP()
 
@@ -735,7 +867,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d,
     {
         float* lg = logits_q + ((long)b * Qn + r0) * N;
         const float* bhl = sm + y.bh;
-        wg_lmm<true, true>(nr, N, H, a(L - 1), ldH, sm + y.Wh, ldH, [&](int m, int n, const f32x4& acc, int cnt) {
+        wg_lmm<true, true>(nr, N, H, a(L - 1), ldH, sm + whq, ldH, [&](int m, int n, const f32x4& acc, int cnt) {
             const f32x4 v = acc + *(const f32x4*)(bhl + n);        // bh is zero-padded: columns past N stay 0
             *(f32x4*)(lq + m * ldq + n) = v;
             wg_st4(lg + m * N + n, v, cnt);
@@ -789,7 +921,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, EpiDims d,
     wg_lds_barrier(); QSTAMP()
     {
         float* zl = a(L - 1);
-        wg_lmm_wide<true>(nr, H, N, lbar, ldq, sm + y.Wh, ldH, [&](int m, int n, const f32x4& acc, int, auto) {
+        wg_lmm_wide<true>(nr, H, N, lbar, ldq, sm + whq, ldH, [&](int m, int n, const f32x4& acc, int, auto) {
             float* p = zl + m * ldH + n;
             *(f32x4*)p = relu_bwd4(*(const f32x4*)p, acc);
         });
@@ -1448,7 +1580,30 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     if (p.head_ready) HIP_TRY(hipStreamWaitEvent(st, p.head_ready, 0));       // `head` was produced on another stream
     EpiParams prm;
     for (int i = 0; i < MAXL; ++i) { prm.W[i] = i < p.L ? p.W[i] : nullptr; prm.b[i] = i < p.L ? p.b[i] : nullptr; }
-    {
+    // one inner step on a two-layer network with at most 32 support rows: every query tile runs the inner step itself
+    // (query_lds_kernel<true>), no adapt launch
+    static const int fuse_env = getenv("FUMI_EPI_FUSE") ? atoi(getenv("FUMI_EPI_FUSE")) : 1;
+    QLay qlf; StageTab tbq, tbs;
+    bool fuse_q = fuse_env && !getenv("FUMI_EPI_GLOBAL") && p.T == 1 && p.L == 2 && p.S <= QR && (h0 & 3) == 0 && p.head != nullptr;
+    if (fuse_q) {
+        query_layout(qlf, p.L, p.h, p.S, p.N, true);
+        fuse_q = qlf.total <= QLDS_CAP;
+    }
+    if (fuse_q) {
+        const long R = p.S + p.Qn, S = p.S, N = p.N, H = d.H;
+        const int h1 = p.h[1];
+        tbs.init(); tbq.init();
+        tbs.add(w.A0, R * h0, 0, 0, h0, p.S, p.S, h0, qlf.a[0], wg_ld(h0));                     // support rows of A0
+        tbs.add(p.W[1], 0, 0, 0, h0, h1, h1, h0, qlf.W[1], wg_ld(h0));                          // meta-parameters of layer 1
+        tbs.add(p.b[1], 0, 0, 0, h1, 1, 1, h1, qlf.bi[1], h1);
+        tbs.add(p.head, N * (H + 1), 0, 0, H + 1, p.N, p.N, (int)H, qlf.Wh, wg_ld((int)H));    // the episode's head [Wh | bh]
+        tbs.add(p.head + H, N * (H + 1), 0, 0, H + 1, p.N, p.N, 1, qlf.bh, 1);
+        tbs.add(p.b[0], 0, 0, 0, h0, 1, 1, h0, qlf.b0, h0);
+        tbq.add(w.A0 + S * h0, R * h0, (long)QR * h0, 0, h0, -1, QR, h0, qlf.a[0], wg_ld(h0));  // the tile's query rows of A0, G
+        tbq.add(w.G + S * S, R * S, (long)QR * S, 0, S, -1, QR, p.S, qlf.Gq, wg_ld(p.S));
+        fuse_q = !tbs.bad && !tbq.bad && tbs.nunits <= 64 * 8 && tbq.nunits <= 64 * 8;
+    }
+    if (!fuse_q) {
         ProfScope ps(ws, st, FUMI_PH_ADAPT);
         static const bool force_global_a = getenv("FUMI_EPI_GLOBAL") != nullptr;   // dev/test: take the generic kernels
         // column parts per episode (adapt_lds_kernel): the layer-0 columns can be split over AP workgroups that exchange the
@@ -1493,7 +1648,13 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
         }
         LAUNCH_CHECK();
     }
-    {
+    if (fuse_q) {
+        ProfScope ps(ws, st, FUMI_PH_QUERY);
+        FUMI_SET_DYN_LDS(query_lds_kernel<true>, qlf.total * 4);
+        hipLaunchKernelGGL(query_lds_kernel<true>, dim3(w.ntile, p.B), dim3(512), qlf.total * 4, st, tbq, tbs, d, w, qlf, p.y_q,
+                           p.logits_q, p.preds_q, p.preds_f, ws->status, p.y_s);
+        LAUNCH_CHECK();
+    } else {
         ProfScope ps(ws, st, FUMI_PH_QUERY);
         QLay ql; query_layout(ql, p.L, p.h, p.S, p.N);
         static const bool force_global = getenv("FUMI_EPI_GLOBAL") != nullptr;     // dev/test: take the generic kernels
@@ -1518,9 +1679,10 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
             lds_form = !tb.bad && tb.nunits <= 64 * 8;      // wg_stage_rows: one unit per lane and wave
         }
         if (lds_form) {
-            FUMI_SET_DYN_LDS(query_lds_kernel, ql.total * 4);
-            hipLaunchKernelGGL(query_lds_kernel, dim3(w.ntile, p.B), dim3(512), ql.total * 4, st, tb, d, w, ql, p.y_q,
-                               p.logits_q, p.preds_q, p.preds_f, ws->status);
+            StageTab none; none.init();
+            FUMI_SET_DYN_LDS(query_lds_kernel<false>, ql.total * 4);
+            hipLaunchKernelGGL(query_lds_kernel<false>, dim3(w.ntile, p.B), dim3(512), ql.total * 4, st, tb, none, d, w, ql, p.y_q,
+                               p.logits_q, p.preds_q, p.preds_f, ws->status, p.y_s);
         } else {
             FUMI_SET_DYN_LDS(query_kernel, w.lds_query * 4);
             hipLaunchKernelGGL(query_kernel, dim3(w.ntile, p.B), dim3(512), w.lds_query * 4, st, d, w, p.b[0], p.y_q, p.logits_q,
