@@ -722,7 +722,20 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, StageTab s
     if constexpr (FUSED) {
         const bool lead = tile == 0 && d.taped;                      // one tile per episode writes the tape
         const f32x4 z4s = {0.f, 0.f, 0.f, 0.f};
-        wg_stage_rows<20>(&s_stg2[1], b, 0, 0, 0, sm);               // A0_s rows -> a_0, W_1, b_1, the episode's head, b_0
+        // the tile's own A0 rows are requested NOW (4 float4 per thread: h0 <= 256) and written into a_0 when the support rows
+        // are done with it: their latency disappears behind the inner step
+        f32x4 qv[4]; bool qok[4];
+        {
+            const float* A0q = w.A0 + ((long)b * (S + Qn) + S + r0) * h0;
+            const int c4n = h0 >> 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = tid + 512 * i, m = f / c4n, n = (f - m * c4n) << 2;
+                qok[i] = m < nr;
+                qv[i] = *(const f32x4*)(A0q + (long)(qok[i] ? m : 0) * h0 + (qok[i] ? n : 0));
+            }
+        }
+        wg_stage_rows<20>(&s_stg2[1], b, tile, 0, nr, sm);           // A0_s rows -> a_0, W_1, b_1, the episode's head, b_0, the tile's G rows
         wg_lds_barrier();
         float* a0 = a(0); float* a1 = a(1); float* W1 = sm + y.W[1]; float* b1 = sm + y.bi[1];
         float* Wh = sm + y.Wh; float* Wh2 = sm + y.Wh2; float* bh = sm + y.bh; float* Dl = sm + y.D; float* csl = sm + y.cs;
@@ -832,14 +845,22 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, StageTab s
         wg_lcolsum(S, h0, Dl, ld0, [&](int n, float s_) { csl[n] = s_; });
         wg_lds_barrier();
         whq = y.Wh2;
-        // the support rows' leftovers in the images the query pass contracts over (rows the tile does not overwrite)
-        for (int i = tid; i < QR * (ld0 >> 2); i += nt) { const int m = i / (ld0 >> 2); if (m >= nr) *(f32x4*)(a0 + m * ld0 + ((i - m * (ld0 >> 2)) << 2)) = z4s; }
+        // the query rows replace the support rows in a_0 (rows past the tile: zeros); a_1 and the logits image are cleared
+        {
+            const int c4n = h0 >> 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = tid + 512 * i, m = f / c4n, n = (f - m * c4n) << 2;
+                if (m < QR) *(f32x4*)(a0 + m * ld0 + n) = qok[i] ? qv[i] : z4s;
+            }
+        }
         for (int i = tid; i < QR * (ld1 >> 2); i += nt) { const int m = i / (ld1 >> 2); *(f32x4*)(a1 + m * ld1 + ((i - m * (ld1 >> 2)) << 2)) = z4s; }
         for (int i = tid; i < QR * (ldq >> 2); i += nt) { const int m = i / (ldq >> 2); *(f32x4*)(e_ + m * ldq + ((i - m * (ldq >> 2)) << 2)) = z4s; }
-        wg_lds_barrier();
+        wg_lds_barrier(); QSTAMP()
+    } else {
+        wg_stage_rows<20>(&s_stg, b, tile, 0, nr, sm);
+        wg_lds_barrier(); QSTAMP()
     }
-    wg_stage_rows<20>(&s_stg, b, tile, 0, nr, sm);
-    wg_lds_barrier(); QSTAMP()
 
     // ---- forward (epilogues handle 4 consecutive columns of one row: wg_lmm)
     {
@@ -1599,9 +1620,8 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
         tbs.add(p.head, N * (H + 1), 0, 0, H + 1, p.N, p.N, (int)H, qlf.Wh, wg_ld((int)H));    // the episode's head [Wh | bh]
         tbs.add(p.head + H, N * (H + 1), 0, 0, H + 1, p.N, p.N, 1, qlf.bh, 1);
         tbs.add(p.b[0], 0, 0, 0, h0, 1, 1, h0, qlf.b0, h0);
-        tbq.add(w.A0 + S * h0, R * h0, (long)QR * h0, 0, h0, -1, QR, h0, qlf.a[0], wg_ld(h0));  // the tile's query rows of A0, G
-        tbq.add(w.G + S * S, R * S, (long)QR * S, 0, S, -1, QR, p.S, qlf.Gq, wg_ld(p.S));
-        fuse_q = !tbs.bad && !tbq.bad && tbs.nunits <= 64 * 8 && tbq.nunits <= 64 * 8;
+        tbs.add(w.G + S * S, R * S, (long)QR * S, 0, S, -1, QR, p.S, qlf.Gq, wg_ld(p.S));      // the tile's rows of G (its A0 rows: direct loads)
+        fuse_q = !tbs.bad && tbs.nunits <= 64 * 8 && h0 <= 256;
     }
     if (!fuse_q) {
         ProfScope ps(ws, st, FUMI_PH_ADAPT);
