@@ -67,7 +67,7 @@ int fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out) {
     if (device < 0 || device >= ndev) return FUMI_EINVAL;
     HIP_TRY(hipSetDevice(device));
     fumi_ws* ws = new fumi_ws();
-    ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr; ws->hcnt = nullptr; ws->acnt = nullptr; ws->pub_src = nullptr; ws->pub_dst = nullptr; ws->pub_n = 0; ws->pub_seq = 0;
+    ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr; ws->hcnt = nullptr; ws->acnt = nullptr; ws->w0p = nullptr; ws->w0p_cap = 0; ws->pub_src = nullptr; ws->pub_dst = nullptr; ws->pub_n = 0; ws->pub_seq = 0;
     ws->profiling = 0; ws->prof_every = 1; memset(ws->prof_seen, 0, sizeof(ws->prof_seen)); ws->recs = new std::vector<ProfRec>(); ws->pool = new std::vector<hipEvent_t>();
     ws->side = nullptr;
     for (auto& e : ws->ev) e = nullptr;
@@ -104,6 +104,7 @@ void fumi_hip_workspace_destroy(fumi_ws_t* ws) {
     if (ws->status) (void)hipFree(ws->status);
     if (ws->hcnt) (void)hipFree(ws->hcnt);
     if (ws->acnt) (void)hipFree(ws->acnt);
+    if (ws->w0p) (void)hipFree(ws->w0p);
     if (ws->status_host) (void)hipHostFree(ws->status_host);
     for (auto& r : *ws->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : *ws->pool) (void)hipEventDestroy(e);
@@ -449,7 +450,8 @@ int fumi_hip_xpanel_fwd(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int Q
     if (!ws || !x_s || !x_q || !W0 || !A0 || !G || B < 1 || S < 1 || Qn < 1 || D < 1 || h0 < 1) return FUMI_EINVAL;
     HIP_TRY(hipSetDevice(ws->device));
     ProfScope ps(ws, (hipStream_t)stream, FUMI_PH_XPANEL_FWD);
-    return launch_xpanel_fwd((hipStream_t)stream, B, S, Qn, D, h0, x_s, x_q, W0, A0, G);
+    return launch_xpanel_fwd((hipStream_t)stream, B, S, Qn, D, h0, x_s, x_q, W0, A0, G, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             xpanel_planes(ws, B, S, D, h0));
 }
 
 int fumi_hip_xpanel_bwd(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int Qn, int D, int h0,

@@ -25,6 +25,7 @@ struct fumi_ws {
     const float* pub_src; float* pub_dst; int pub_n; unsigned long long pub_seq;   // deferred publication (api: publish_scalars_deferred)
     int* acnt;           // [FUMI_ACNT] arrival counters of the split adapt kernel (reset by the query kernel of the same step)
     int* hcnt;           // [FUMI_HCNT] arrival counters of hyper_fwd_split_kernel, zero between launches
+    unsigned short* w0p; size_t w0p_cap;   // the layer-0 weight as three bf16 planes in MFMA fragment order (xpanel.hip), own allocation
     int profiling;       // bit p: record HIP events around phase p (bench only)
     int prof_every;      // ... at every prof_every-th occurrence of the phase
     unsigned prof_seen[16];
@@ -159,7 +160,11 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
                       const float* W0, float* A0 /*[B,S+Qn,h0]*/, float* G /*[B,S+Qn,S]*/, const XRows* rows = nullptr,
                       const HyperFwdArgs* rider = nullptr, int* rider_done = nullptr /* set to 1 when the rider was launched */,
                       float* parts = nullptr /* [xpanel_fwd_ksplit(), B, S+Qn, h0] partial products of a split contraction */,
-                      int* parts_unreduced = nullptr /* not NULL: the parts are NOT summed into A0; receives their number (0: A0 is final) */);
+                      int* parts_unreduced = nullptr /* not NULL: the parts are NOT summed into A0; receives their number (0: A0 is final) */,
+                      unsigned short* planes = nullptr /* xpanel_planes(): room for the column operand split once per launch (the fast forward needs it) */);
+// room for W0 [h0, D] and the support rows [B, S, D] split into three bf16 planes each (grown on demand, owned by the workspace);
+// NULL when the fast forward does not apply
+unsigned short* xpanel_planes(fumi_ws* ws, int B, int S, int D, int h0);
 int xpanel_fwd_ksplit(int B, int S, int Qn, int D, int h0, int with_gram);
 int xpanel_bwd_nsplit(int B, int S, int Qn, int D, int h0, int* kchunk_out);
 struct HyperBwdArgs;         // hyper_bwd.h: the hypernetwork backward, able to ride at the front of the backward X-panel launch

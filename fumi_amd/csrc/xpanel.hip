@@ -334,27 +334,16 @@ __device__ __forceinline__ void xp_static_for(F&& f) {
     if constexpr (I < N) { f(WgInt<I>{}); xp_static_for<I + 1, N>(f); }
 }
 
-// RIDER: the first rider.nblk workgroups (a multiple of 8, so the XCD grouping of the rest is unchanged) run the split
-// hypernetwork forward (hyper_fwd.h) in this kernel's LDS and leave; they are dispatched first and are done in ~10 us.
-template <int NST, bool RIDER>
-__global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* __restrict__ A0, float* __restrict__ G,
-                                                                int tiles_m, int tiles_n, HyperFwdArgs rider) {
-    __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][3][SPLANE];      // [buffer][operand][piece]
-    int bid = blockIdx.x;
-    if constexpr (RIDER) {
-        __shared__ int s_last;
-        if (bid < rider.nblk) { hyper_fwd_split_body<HF_RIDER_KS, true>(rider, bid, (float*)&lds[0][0][0][0], &s_last); return; }
-        bid -= rider.nblk;
-    }
+typedef unsigned short (*SbLds)[2][3][SPLANE];      // [buffer][operand][piece]
+
+// one 64 x 64 output tile (rows m0.., virtual columns n0..) of episode b, contraction part kz
+template <int NST>
+__device__ __forceinline__ void xpanel_fwd_sb_tile(const XPanel& p, float* __restrict__ A0, float* __restrict__ G, int b, int m0, int n0,
+                                                   int kz, SbLds lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int R = p.S + p.Qn, C = p.h0 + p.gcols, K = p.D;
-    const int tiles = tiles_m * tiles_n;
-    const int xcd = bid & 7, j = bid >> 3;
-    const int ks = p.ksplit, per = tiles * ks;
-    const int b = xcd + 8 * (j / per), tz = j % per, kz = tz / tiles, t = tz - kz * tiles;
-    if (b >= p.B) return;
-    const int m0 = (t / tiles_n) * 64, n0 = (t % tiles_n) * 64;
+    const int ks = p.ksplit;
     const int kbeg = kz * (K / ks);             // this part's first contraction column
 
     // staging map: float4 f = tid + 256 i  ->  tile row (f >> 3), k offset (f & 7) * 4
@@ -466,11 +455,19 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* 
     // prologue: slab 0 straight to LDS, slabs 1..NST into the ring (slot of slab q is (q-1) % NST)
     gload(WgInt<0>{}, 0);
     lstore(WgInt<0>{}, 0);
-    xp_static_for<0, NST>([&](auto ic) { if (decltype(ic)::value + 1 < nslab) gload(ic, (decltype(ic)::value + 1) * SBK); });
-    __syncthreads();
     int s = 0;
-    for (; s + 2 * NST < nslab; s += NST)                // every slab of this round has s' + 1 + NST < nslab
-        xp_static_for<0, NST>([&](auto ic) { slab_main(ic, s + decltype(ic)::value); });
+    if (nslab > 2 * NST) {
+        // The steady-state loop is entered ONLY behind unconditional ring loads: hipcc sizes every s_waitcnt vmcnt(n) of the loop for
+        // the worst way into it, and a load it must assume skipped counts as not issued -- with `if (q < nslab) gload(q)` in front,
+        // the loop waited for all but its newest load, i.e. the full memory latency every slab instead of a load issued NST slabs ago.
+        xp_static_for<0, NST>([&](auto ic) { gload(ic, (decltype(ic)::value + 1) * SBK); });
+        __syncthreads();
+        for (; s + 2 * NST < nslab; s += NST)            // every slab of this round has s' + 1 + NST < nslab
+            xp_static_for<0, NST>([&](auto ic) { slab_main(ic, s + decltype(ic)::value); });
+    } else {
+        xp_static_for<0, NST>([&](auto ic) { if (decltype(ic)::value + 1 < nslab) gload(ic, (decltype(ic)::value + 1) * SBK); });
+        __syncthreads();
+    }
     for (; s < nslab; s += NST)
         xp_static_for<0, NST>([&](auto ic) { if (s + decltype(ic)::value < nslab) slab(ic, s + decltype(ic)::value); });
     f32x16 acc;
@@ -486,6 +483,250 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* 
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (m < R) base[(long)m * ld + col] = acc[r];
         }
+    }
+}
+
+// RIDER: the first rider.nblk workgroups (a multiple of 8, so the XCD grouping of the rest is unchanged) run the split
+// hypernetwork forward (hyper_fwd.h) in this kernel's LDS and leave; they are dispatched first and are done in ~10 us.
+template <int NST, bool RIDER>
+__global__ __launch_bounds__(256, 2) void xpanel_fwd_sb_kernel(XPanel p, float* __restrict__ A0, float* __restrict__ G,
+                                                                int tiles_m, int tiles_n, HyperFwdArgs rider) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][3][SPLANE];
+    int bid = blockIdx.x;
+    if constexpr (RIDER) {
+        __shared__ int s_last;
+        if (bid < rider.nblk) { hyper_fwd_split_body<HF_RIDER_KS, true>(rider, bid, (float*)&lds[0][0][0][0], &s_last); return; }
+        bid -= rider.nblk;
+    }
+    const int tiles = tiles_m * tiles_n;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int per = tiles * p.ksplit;
+    const int b = xcd + 8 * (j / per), tz = j % per, kz = tz / tiles, t = tz - kz * tiles;
+    if (b >= p.B) return;
+    xpanel_fwd_sb_tile<NST>(p, A0, G, b, (t / tiles_n) * 64, (t % tiles_n) * 64, kz, lds);
+}
+
+// ---- forward with the column operand split ONCE ----------------------------------------------------------------------
+// In xpanel_fwd_sb_tile every 64 x 64 tile splits its 64 rows of X AND its 64 rows of the column operand into bf16 pieces, slab
+// by slab: the split (ten vector operations and three LDS writes per pair of values) and the LDS traffic of both operands cost
+// more than the matrix instructions they feed, and W0 -- the same for all episodes and row tiles -- is split 96 times over.
+// Here the column operand (W0, and each episode's support rows for the Gram block) is split once per step by
+// xpanel_presplit_kernel into three bf16 planes stored in the ORDER THE MATRIX INSTRUCTION READS ITS B OPERAND:
+//     [plane][16-deep step][32-column block][lane][8]   with lane l = column (l & 31), k = 16 step + 8 (l >> 5) .. + 7,
+// so a wave fetches a fragment with one fully coalesced 1 KiB global_load_dwordx4 straight into registers (3 MiB for W0 + 12 MiB
+// for the support rows of 32 episodes: L2 / MALL resident) -- no LDS, no vector work on the column side.  A workgroup computes
+// 32 RB rows x (32 columns per wave); every wave owns one 32-column block -- W0 columns or Gram columns alike -- and RB
+// accumulators that share each B fragment.  Only the slab of X is split and staged through LDS.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void xpanel_presplit_kernel(XPanel p, int cbg, unsigned short* __restrict__ Wp, unsigned short* __restrict__ Xp) {
+    const int bid = blockIdx.x;
+    // one wave = one fragment (32 columns x 16 k) in all three planes: lane l holds column (l & 31), k = 8 (l >> 5) .. + 7 -- the
+    // three 1 KiB stores are contiguous; consecutive waves take consecutive 16-deep steps of one column block (they share the
+    // 128-byte lines of the rows they read)
+    const int K = p.D, nks = K >> 4, CB = p.h0 >> 5;
+    const long gw = (long)bid * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, c = lane & 31, k8 = (lane >> 5) * 8;
+    const long blk = gw / nks; const int ks = (int)(gw - blk * nks);
+    const float* src; u32x4* dst; long plane;
+    if (blk < CB) {
+        src = p.W0 + ((long)blk * 32 + c) * K + ks * 16 + k8;
+        plane = (long)p.h0 * (K >> 3);
+        dst = (u32x4*)Wp + ((long)ks * CB + blk) * 64 + lane;
+    } else {
+        const long xb = blk - CB;
+        if (xb >= (long)p.B * cbg) return;
+        const int b = (int)(xb / cbg), g = (int)(xb - (long)b * cbg), col = g * 32 + c;
+        src = col < p.S ? xrow(p, b, col) + ks * 16 + k8 : nullptr;
+        plane = (long)cbg * 32 * (K >> 3);
+        dst = (u32x4*)Xp + (long)b * 3 * plane + ((long)ks * cbg + g) * 64 + lane;
+    }
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 v0 = src ? *(const f32x4*)src : z4, v1 = src ? *(const f32x4*)(src + 4) : z4;
+    u32x2 h0_, m0_, l0_, h1_, m1_, l1_;
+    split3(v0, h0_, m0_, l0_);
+    split3(v1, h1_, m1_, l1_);
+    dst[0] = (u32x4){h0_[0], h0_[1], h1_[0], h1_[1]};
+    dst[plane] = (u32x4){m0_[0], m0_[1], m1_[0], m1_[1]};
+    dst[2 * plane] = (u32x4){l0_[0], l0_[1], l1_[0], l1_[1]};
+}
+
+// One tile of xpanel_fwd_ps_kernel: 256 threads stage SR x 32 rows of X (from row m0) per slab; every wave owns RB 32-row blocks
+// (from tile row `wrow`) of ONE 32-column block whose fragments it reads at `bq` (+ plane per piece, + kstride per 16-deep step).
+// W0 tiles: RB = SR = 2, the four waves sit side by side on the same 64 rows.  Gram tiles: RB = 1, SR = 4, the four waves sit
+// one above the other on 128 rows of the same column block (equal work per wave either way: 12 RB MFMAs a slab).
+template <int NST, int RB, int SR>
+__device__ __forceinline__ void xpanel_ps_tile(const XPanel& p, int b, int m0, int wrow, const u32x4* __restrict__ bq, long plane, long kstride,
+                                               int kbeg, int nslab, unsigned short* lds, float* __restrict__ out, int ld, int n, bool nok) {
+    constexpr int PLN = SR * 32 * SROW;                         // ushorts per LDS plane; lds: [buffer][piece][row][k]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int R = p.S + p.Qn;
+    // X staging map: float4 f = tid + 256 i -> tile row (tid >> 3) + 32 i, k offset (tid & 7) * 4
+    const float* arow[SR];
+#pragma unroll
+    for (int i = 0; i < SR; ++i) {
+        const int r = m0 + (tid >> 3) + 32 * i;
+        arow[i] = xrow(p, b, r < R ? r : 0) + (((tid & 7) << 2) + kbeg);       // (rows past the panel: valid address, outputs not stored)
+    }
+    const int li = lane & 31, hh = lane >> 5;
+    const int aoff = (wrow + li) * SROW + 8 * hh;
+    f32x4 ga[NST][SR];
+    bf16x8 fb[2][2][3];                          // [slot = slab & 1][step][piece]
+    f32x16 acc[RB];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb][i] = 0.f;
+
+    auto gload = [&](auto sc, int k0) {
+        constexpr int ST = decltype(sc)::value;
+#pragma unroll
+        for (int i = 0; i < SR; ++i) ga[ST][i] = *(const f32x4*)(arow[i] + k0);
+    };
+    auto bload = [&](auto sc, auto stc, int slab_) {                             // the fragments of one 16-deep step of slab `slab_`
+        constexpr int SL = decltype(sc)::value & 1, st = decltype(stc)::value;
+        const u32x4* q = bq + (long)(2 * slab_ + st) * kstride;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) fb[SL][st][pl] = __builtin_bit_cast(bf16x8, q[pl * plane]);
+    };
+    auto lstore = [&](auto sc, int buf) {
+        constexpr int ST = decltype(sc)::value;
+#pragma unroll
+        for (int i = 0; i < SR; ++i) {
+            const int off = ((tid >> 3) + 32 * i) * SROW + ((tid & 7) << 2);
+            u32x2 h, m, l;
+            split3(ga[ST][i], h, m, l);
+            unsigned short* d = lds + buf * 3 * PLN + off;
+            *(u32x2*)d = h; *(u32x2*)(d + PLN) = m; *(u32x2*)(d + 2 * PLN) = l;
+        }
+    };
+    // piece pairs in accumulation order (smallest first): (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+    auto mma_slab = [&](auto sc, int buf) {
+        constexpr int SL = decltype(sc)::value & 1;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 f[RB][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    f[rb][pl] = __builtin_bit_cast(bf16x8, *(const f32x4*)(lds + (buf * 3 + pl) * PLN + aoff + rb * 32 * SROW + 16 * st));
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[rb][PA[q]], fb[SL][st][PB[q]], acc[rb], 0, 0, 0);
+        }
+    };
+    auto slab = [&](auto sc, int s) {                                            // the last slabs: nothing (or not everything) left to fetch
+        const int cur = s & 1;
+        if (s + 1 < nslab) lstore(sc, cur ^ 1);
+        if (s + 1 + NST < nslab) gload(sc, (s + 1 + NST) * SBK);
+        mma_slab(sc, cur);
+        if (s + 2 < nslab) { bload(sc, WgInt<0>{}, s + 2); bload(sc, WgInt<1>{}, s + 2); }
+        __syncthreads();
+    };
+    // steady state, issue order spelled out (see xpanel_fwd_sb_tile): 3 SR segments of 4 RB / SR MFMAs plus one third of the work
+    // that splits a float4 of the NEXT slab of X; when a step's last MFMA is out, the step's B registers are refilled for the
+    // slab after next
+    auto slab_main = [&](auto sc, int s) {
+        constexpr int ST = decltype(sc)::value, SL = ST & 1;
+        constexpr int NSEG = 3 * SR, MPS = 12 * RB / NSEG;
+        static_assert(MPS * NSEG == 12 * RB, "MFMAs per segment");
+        const int cur = s & 1, nxt = cur ^ 1;
+        bf16x8 fa[RB][2][3];
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    fa[rb][st][pl] = __builtin_bit_cast(bf16x8, *(const f32x4*)(lds + (cur * 3 + pl) * PLN + aoff + rb * 32 * SROW + 16 * st));
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned hp[2], mp[2], lp[2];
+        xp_static_for<0, NSEG>([&](auto gc) {                      // segment g: MFMAs MPS g .. + MPS - 1 of the slab's 12 RB, work item g
+            constexpr int g = decltype(gc)::value, q = g / 3, part = g % 3;
+#pragma unroll
+            for (int u = 0; u < MPS; ++u) {
+                const int m = MPS * g + u, st = m / (6 * RB), pr = (m / RB) % 6, rb = m % RB;
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[rb][st][PA[pr]], fb[SL][st][PB[pr]], acc[rb], 0, 0, 0);
+            }
+            const f32x4 v = ga[ST][q];
+            if constexpr (part < 2) {
+                split_pair(v[2 * part], v[2 * part + 1], hp[part], mp[part], lp[part]);
+            } else {
+                const int off = ((tid >> 3) + 32 * q) * SROW + ((tid & 7) << 2);
+                unsigned short* d = lds + nxt * 3 * PLN + off;
+                *(u32x2*)d = (u32x2){hp[0], hp[1]};
+                *(u32x2*)(d + PLN) = (u32x2){mp[0], mp[1]};
+                *(u32x2*)(d + 2 * PLN) = (u32x2){lp[0], lp[1]};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((6 * RB - 1) / MPS == g) { bload(sc, WgInt<0>{}, s + 2); __builtin_amdgcn_sched_barrier(0); }       // step 0's last MFMA is out
+            if constexpr ((12 * RB - 1) / MPS == g) { bload(sc, WgInt<1>{}, s + 2); __builtin_amdgcn_sched_barrier(0); }
+        });
+        gload(sc, (s + 1 + NST) * SBK);
+        __syncthreads();
+    };
+    // prologue.  The loads are issued in the ORDER THE STEADY STATE LEAVES THEM IN (..., B(s), X(s+NST-1), B(s+1), X(s+NST) at the
+    // top of slab s) and UNCONDITIONALLY (the launcher guarantees nslab > 2 NST): hipcc sizes every s_waitcnt vmcnt(n) in the loop
+    // for the worst way into it, and a load it must assume skipped counts as not issued -- the loop then waits for all but its
+    // newest load, i.e. the full memory latency every slab.
+    gload(WgInt<0>{}, 0);
+    bload(WgInt<0>{}, WgInt<0>{}, 0); bload(WgInt<0>{}, WgInt<1>{}, 0);
+    lstore(WgInt<0>{}, 0);
+    xp_static_for<0, NST - 1>([&](auto ic) { gload(ic, (decltype(ic)::value + 1) * SBK); });
+    bload(WgInt<1>{}, WgInt<0>{}, 1); bload(WgInt<1>{}, WgInt<1>{}, 1);
+    gload(WgInt<NST - 1>{}, NST * SBK);
+    __syncthreads();
+    int s = 0;
+    for (; s + 2 * NST < nslab; s += NST)
+        xp_static_for<0, NST>([&](auto ic) { slab_main(ic, s + decltype(ic)::value); });
+    for (; s < nslab; s += NST)
+        xp_static_for<0, NST>([&](auto ic) { if (s + decltype(ic)::value < nslab) slab(ic, s + decltype(ic)::value); });
+    if (!nok) return;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wrow + 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (m < R) out[(long)m * ld + n] = acc[rb][r];
+        }
+}
+
+// 256 threads.  Ids (after the XCD decode) per episode: tiles_m x (h0 / 128) x ksplit W0 tiles of 64 rows x 128 columns, then
+// tiles_g x cbg Gram tiles of 128 rows x 32 columns.  All W0 tiles of the launch come before all Gram tiles.
+// RIDER: the first rider.nblk workgroups (a multiple of 8, so the XCD grouping of the rest is unchanged) run the split hypernetwork
+// forward (hyper_fwd.h) in this kernel's LDS and leave; they are dispatched first and are done in ~10 us.
+template <int NST, bool RIDER>
+__global__ __launch_bounds__(256, 2) void xpanel_fwd_ps_kernel(XPanel p, const unsigned short* __restrict__ Wp, const unsigned short* __restrict__ Xp,
+                                                                float* __restrict__ A0, float* __restrict__ G, int tiles_m, int tiles_g, int cbg,
+                                                                HyperFwdArgs rider) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * 3 * 128 * SROW];
+    int bid = blockIdx.x;
+    if constexpr (RIDER) {
+        __shared__ int s_last;
+        if (bid < rider.nblk) { hyper_fwd_split_body<HF_RIDER_KS, true>(rider, bid, (float*)lds, &s_last); return; }
+        bid -= rider.nblk;
+    }
+    const int xcd = bid & 7, j = bid >> 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31;
+    const int R = p.S + p.Qn, K = p.D, CB = p.h0 >> 5, tiles_w = CB >> 2;
+    const int ks = p.ksplit, tw = tiles_m * tiles_w, heavy_per = tw * ks, nheavy = ((p.B + 7) >> 3) * heavy_per;
+    if (j < nheavy) {
+        const int b = xcd + 8 * (j / heavy_per), tz = j % heavy_per, kz = tz / tw, t = tz - kz * tw;
+        if (b >= p.B) return;
+        const int kbeg = kz * (K / ks), cb = (t % tiles_w) * 4 + wave;
+        xpanel_ps_tile<NST, 2, 2>(p, b, (t / tiles_w) * 64, 0, (const u32x4*)Wp + ((long)(kbeg >> 4) * CB + cb) * 64 + lane,
+                                  (long)p.h0 * (K >> 3), CB * 64L, kbeg, K / ks / SBK, lds,
+                                  A0 + kz * p.part_stride + (long)b * R * p.h0, p.h0, cb * 32 + li, true);
+    } else {
+        const int jj = j - nheavy, per = max(1, tiles_g * cbg);
+        const int b = xcd + 8 * (jj / per), t = jj % per, g = t % cbg;
+        if (b >= p.B) return;
+        const long plane = (long)cbg * 32 * (K >> 3);
+        xpanel_ps_tile<NST, 1, 4>(p, b, (t / cbg) * 128, wave * 32, (const u32x4*)Xp + (long)b * 3 * plane + (long)g * 64 + lane,
+                                  plane, cbg * 64L, 0, K / SBK, lds, G + (long)b * R * p.S, p.S, g * 32 + li, g * 32 + li < p.S);
     }
 }
 
@@ -829,8 +1070,6 @@ __global__ __launch_bounds__(512, (NB == 1 && SK == 16) ? 2 : 1) void xpanel_bwd
     };
     // prologue: slab 0 straight to LDS, slabs 1..NST into the ring (slot of slab q is (q - 1) % NST)
     if (nslab > 0) { gload(WgInt<0>{}, kbeg); lstore(WgInt<0>{}, 0); }
-    xp_static_for<0, NST>([&](auto ic) { if (decltype(ic)::value + 1 < nslab) gload(ic, kbeg + (long)(decltype(ic)::value + 1) * SK); });
-    __syncthreads();
     auto slab = [&](auto sc, int s_) {
         const int cur = s_ & 1;
         if (s_ + 1 < nslab) lstore(sc, cur ^ 1);
@@ -893,8 +1132,17 @@ __global__ __launch_bounds__(512, (NB == 1 && SK == 16) ? 2 : 1) void xpanel_bwd
     };
     int s_ = 0;
     static_assert(NST == 2 || NST == 3, "ring depth");
-    for (; s_ + 2 * NST < nslab; s_ += NST)                      // every slab of this round has s' + 1 + NST < nslab
-        xp_static_for<0, NST>([&](auto ic) { slab_main(ic, s_ + decltype(ic)::value); });
+    if (nslab > 2 * NST) {
+        // unconditional ring loads in front of the steady-state loop (see xpanel_fwd_sb_tile: the loop's s_waitcnt vmcnt(n) are sized
+        // for the worst way in)
+        xp_static_for<0, NST>([&](auto ic) { gload(ic, kbeg + (long)(decltype(ic)::value + 1) * SK); });
+        __syncthreads();
+        for (; s_ + 2 * NST < nslab; s_ += NST)                  // every slab of this round has s' + 1 + NST < nslab
+            xp_static_for<0, NST>([&](auto ic) { slab_main(ic, s_ + decltype(ic)::value); });
+    } else {
+        xp_static_for<0, NST>([&](auto ic) { if (decltype(ic)::value + 1 < nslab) gload(ic, kbeg + (long)(decltype(ic)::value + 1) * SK); });
+        __syncthreads();
+    }
     for (; s_ < nslab; s_ += NST)
         xp_static_for<0, NST>([&](auto ic) { if (s_ + decltype(ic)::value < nslab) slab(ic, s_ + decltype(ic)::value); });
     const int li = lane & 31, kh = lane >> 5;
@@ -948,9 +1196,30 @@ int xpanel_fwd_ksplit(int B, int S, int Qn, int D, int h0, int with_gram) {
     return ks;
 }
 
+constexpr int PS_MIN_SLABS = 2 * 4 + 1;          // xpanel_fwd_ps_kernel's prologue fetches NST + 1 <= 5 slabs unconditionally
+static bool xpanel_fwd_ps_ok(int D, int h0) {
+    static const int on = getenv("FUMI_XP_PS") ? atoi(getenv("FUMI_XP_PS")) : 1;       // 0: every tile splits its own column operand
+    static const int sb = getenv("FUMI_XP_SB") ? atoi(getenv("FUMI_XP_SB")) : 1;
+    return on && sb && h0 % 128 == 0 && D % SBK == 0;
+}
+static size_t ps_w0_bytes(int D, int h0) { return (size_t)3 * h0 * D * sizeof(unsigned short); }
+static size_t ps_xs_bytes(int B, int S, int D) { return (size_t)B * 3 * ((S + 31) / 32 * 32) * D * sizeof(unsigned short); }
+
+unsigned short* xpanel_planes(fumi_ws* ws, int B, int S, int D, int h0) {
+    if (!ws || !xpanel_fwd_ps_ok(D, h0)) return nullptr;
+    const size_t need = ps_w0_bytes(D, h0) + ps_xs_bytes(B, S, D);
+    if (ws->w0p_cap < need) {
+        if (ws->w0p) (void)hipFree(ws->w0p);          // (hipFree waits for the device: nothing in flight reads the old planes)
+        ws->w0p = nullptr; ws->w0p_cap = 0;
+        if (hipMalloc((void**)&ws->w0p, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // the 64 x 64 kernel still works
+        ws->w0p_cap = need;
+    }
+    return ws->w0p;
+}
+
 int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
                       const float* W0, float* A0, float* G, const XRows* rows, const HyperFwdArgs* rider, int* rider_done,
-                      float* parts, int* parts_unreduced) {
+                      float* parts, int* parts_unreduced, unsigned short* planes) {
     if (parts_unreduced) *parts_unreduced = 0;
     if (rider_done) *rider_done = 0;
     float* const A0_final = A0;
@@ -966,7 +1235,25 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
     static const int nst = getenv("FUMI_XP_NST") ? atoi(getenv("FUMI_XP_NST")) : 2;      // staging ring depth (tuning knob)
     // Default: the split-bf16 kernel (65 us at the bench shapes, error against fp64 below the fp32 MFMA kernel's: DESIGN.md).
     // FUMI_XP_SB=0 selects the fp32 MFMA kernel (78 us).
-    if (aligned && D % SBK == 0 && use_sb) {
+    if (aligned && planes && xpanel_fwd_ps_ok(D, h0) && D / p.ksplit / SBK >= PS_MIN_SLABS) {
+        // column operands split once (bf16 planes in fragment order), then tiles that
+        // only split X: 64 x 128 against W0, 128 x 32 against the support rows
+        static const int ride = getenv("FUMI_XP_RIDER") ? atoi(getenv("FUMI_XP_RIDER")) : 1;
+        const int cbg = (p.gcols + 31) / 32;
+        unsigned short* Wp = planes; unsigned short* Xp = planes + ps_w0_bytes(D, h0) / sizeof(unsigned short);
+        const long nfrag = ((long)h0 / 32 + (long)B * cbg) * (D / 16);      // one wave per fragment
+        hipLaunchKernelGGL(xpanel_presplit_kernel, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, st, p, cbg, Wp, Xp);
+        const int tm = (S + Qn + 63) / 64, tg = (S + Qn + 127) / 128;
+        const unsigned nwg = 8u * nper * (tm * (h0 / 128) * p.ksplit + tg * cbg);
+        HyperFwdArgs none; memset(&none, 0, sizeof(none));
+        if (ride && rider && rider_done && rider->nblk > 0 && rider->nblk % 8 == 0 && rider->d.Dt <= HF_RIDER_MAXDT &&
+            hyper_fwd_split_lds_bytes(rider->d.ldx) <= sizeof(unsigned short) * 2 * 3 * 128 * SROW) {
+            hipLaunchKernelGGL((xpanel_fwd_ps_kernel<2, true>), dim3(nwg + rider->nblk), dim3(256), 0, st, p, Wp, Xp, A0, G, tm, tg, cbg, *rider);
+            *rider_done = 1;
+        } else {
+            hipLaunchKernelGGL((xpanel_fwd_ps_kernel<2, false>), dim3(nwg), dim3(256), 0, st, p, Wp, Xp, A0, G, tm, tg, cbg, none);
+        }
+    } else if (aligned && D % SBK == 0 && use_sb) {
         static const int sbn = getenv("FUMI_XP_SBN") ? atoi(getenv("FUMI_XP_SBN")) : 2;          // ring depth (tuning knob)
         static const int ride = getenv("FUMI_XP_RIDER") ? atoi(getenv("FUMI_XP_RIDER")) : 1;     // 0: never carry the hypernetwork forward
         HyperFwdArgs none; memset(&none, 0, sizeof(none));
