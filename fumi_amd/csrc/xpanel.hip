@@ -556,9 +556,12 @@ __global__ __launch_bounds__(256) void xpanel_presplit_kernel(XPanel p, int cbg,
 // one above the other on 128 rows of the same column block (equal work per wave either way: 12 RB MFMAs a slab).
 template <int NST, int RB, int SR>
 __device__ __forceinline__ void xpanel_ps_tile(const XPanel& p, int b, int m0, int wrow, const u32x4* __restrict__ bq, long plane, long kstride,
-                                               int kbeg, int nslab, unsigned short* lds, float* __restrict__ out, int ld, int n, bool nok) {
+                                               int kbeg, int nslab, unsigned short* lds, float* __restrict__ out, int ld, int n, bool nok,
+                                               unsigned long long* trace) {
     constexpr int PLN = SR * 32 * SROW;                         // ushorts per LDS plane; lds: [buffer][piece][row][k]
     const int tid = threadIdx.x, lane = tid & 63;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;                  // dev tracing (tests/dev/trace_xpanel_wg.py): 100 MHz wall ticks
+    if (trace && tid == 0) t0 = __builtin_amdgcn_s_memrealtime();
     const int R = p.S + p.Qn;
     // X staging map: float4 f = tid + 256 i -> tile row (tid >> 3) + 32 i, k offset (tid & 7) * 4
     const float* arow[SR];
@@ -679,11 +682,19 @@ __device__ __forceinline__ void xpanel_ps_tile(const XPanel& p, int b, int m0, i
     bload(WgInt<1>{}, WgInt<0>{}, 1); bload(WgInt<1>{}, WgInt<1>{}, 1);
     gload(WgInt<NST - 1>{}, NST * SBK);
     __syncthreads();
+    if (trace && tid == 0) t1 = __builtin_amdgcn_s_memrealtime();
     int s = 0;
     for (; s + 2 * NST < nslab; s += NST)
         xp_static_for<0, NST>([&](auto ic) { slab_main(ic, s + decltype(ic)::value); });
     for (; s < nslab; s += NST)
         xp_static_for<0, NST>([&](auto ic) { if (s + decltype(ic)::value < nslab) slab(ic, s + decltype(ic)::value); });
+    if (trace && tid == 0) {
+        t2 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* t = trace + (long)blockIdx.x * 6;
+        t[0] = t0; t[1] = t1; t[2] = t2; t[3] = RB;
+        t[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+        t[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+    }
     if (!nok) return;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -701,7 +712,7 @@ __device__ __forceinline__ void xpanel_ps_tile(const XPanel& p, int b, int m0, i
 template <int NST, bool RIDER>
 __global__ __launch_bounds__(256, 2) void xpanel_fwd_ps_kernel(XPanel p, const unsigned short* __restrict__ Wp, const unsigned short* __restrict__ Xp,
                                                                 float* __restrict__ A0, float* __restrict__ G, int tiles_m, int tiles_g, int cbg,
-                                                                HyperFwdArgs rider) {
+                                                                HyperFwdArgs rider, unsigned long long* trace) {
     __shared__ __attribute__((aligned(16))) unsigned short lds[2 * 3 * 128 * SROW];
     int bid = blockIdx.x;
     if constexpr (RIDER) {
@@ -719,14 +730,14 @@ __global__ __launch_bounds__(256, 2) void xpanel_fwd_ps_kernel(XPanel p, const u
         const int kbeg = kz * (K / ks), cb = (t % tiles_w) * 4 + wave;
         xpanel_ps_tile<NST, 2, 2>(p, b, (t / tiles_w) * 64, 0, (const u32x4*)Wp + ((long)(kbeg >> 4) * CB + cb) * 64 + lane,
                                   (long)p.h0 * (K >> 3), CB * 64L, kbeg, K / ks / SBK, lds,
-                                  A0 + kz * p.part_stride + (long)b * R * p.h0, p.h0, cb * 32 + li, true);
+                                  A0 + kz * p.part_stride + (long)b * R * p.h0, p.h0, cb * 32 + li, true, trace);
     } else {
         const int jj = j - nheavy, per = max(1, tiles_g * cbg);
         const int b = xcd + 8 * (jj / per), t = jj % per, g = t % cbg;
         if (b >= p.B) return;
         const long plane = (long)cbg * 32 * (K >> 3);
         xpanel_ps_tile<NST, 1, 4>(p, b, (t / cbg) * 128, wave * 32, (const u32x4*)Xp + (long)b * 3 * plane + (long)g * 64 + lane,
-                                  plane, cbg * 64L, 0, K / SBK, lds, G + (long)b * R * p.S, p.S, g * 32 + li, g * 32 + li < p.S);
+                                  plane, cbg * 64L, 0, K / SBK, lds, G + (long)b * R * p.S, p.S, g * 32 + li, g * 32 + li < p.S, trace);
     }
 }
 
@@ -1248,10 +1259,10 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
         HyperFwdArgs none; memset(&none, 0, sizeof(none));
         if (ride && rider && rider_done && rider->nblk > 0 && rider->nblk % 8 == 0 && rider->d.Dt <= HF_RIDER_MAXDT &&
             hyper_fwd_split_lds_bytes(rider->d.ldx) <= sizeof(unsigned short) * 2 * 3 * 128 * SROW) {
-            hipLaunchKernelGGL((xpanel_fwd_ps_kernel<2, true>), dim3(nwg + rider->nblk), dim3(256), 0, st, p, Wp, Xp, A0, G, tm, tg, cbg, *rider);
+            hipLaunchKernelGGL((xpanel_fwd_ps_kernel<2, true>), dim3(nwg + rider->nblk), dim3(256), 0, st, p, Wp, Xp, A0, G, tm, tg, cbg, *rider, g_trace);
             *rider_done = 1;
         } else {
-            hipLaunchKernelGGL((xpanel_fwd_ps_kernel<2, false>), dim3(nwg), dim3(256), 0, st, p, Wp, Xp, A0, G, tm, tg, cbg, none);
+            hipLaunchKernelGGL((xpanel_fwd_ps_kernel<2, false>), dim3(nwg), dim3(256), 0, st, p, Wp, Xp, A0, G, tm, tg, cbg, none, g_trace);
         }
     } else if (aligned && D % SBK == 0 && use_sb) {
         static const int sbn = getenv("FUMI_XP_SBN") ? atoi(getenv("FUMI_XP_SBN")) : 2;          // ring depth (tuning knob)
