@@ -664,6 +664,14 @@ __device__ __forceinline__ void xpanel_ps_tile(const XPanel& p, int b, int m0, i
                 *(u32x2*)(d + PLN) = (u32x2){mp[0], mp[1]};
                 *(u32x2*)(d + 2 * PLN) = (u32x2){lp[0], lp[1]};
             }
+            if constexpr (MPS > 1) {            // inside a segment: one MFMA, then a share of the item's vector operations / LDS writes
+#pragma unroll
+                for (int u = 0; u < MPS; ++u) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if constexpr (part < 2) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr ((6 * RB - 1) / MPS == g) { bload(sc, WgInt<0>{}, s + 2); __builtin_amdgcn_sched_barrier(0); }       // step 0's last MFMA is out
             if constexpr ((12 * RB - 1) / MPS == g) { bload(sc, WgInt<1>{}, s + 2); __builtin_amdgcn_sched_barrier(0); }

@@ -604,6 +604,28 @@ def test_xpanel_fwd_split_bf16_has_fp32_accuracy(dev):
         assert errs["1"][k] < 1.5 * errs["0"][k] + 5e-8, errs
 
 
+@pytest.mark.parametrize("B,S,Qn,D,h0", [(3, 25, 43, 320, 128),      # 10 slabs (the pipelined loop's minimum + 1), ragged row tiles
+                                         (9, 40, 100, 512, 256),     # two Gram column blocks (S > 32), a partly filled XCD group
+                                         (2, 5, 15, 2048, 256)])     # fewer rows than one tile
+def test_xpanel_fwd_presplit_column_operand_has_fp32_accuracy(dev, ws, B, S, Qn, D, h0):
+    """h0 % 128 == 0 and >= 9 slabs of 32: W0 and the support rows are split once into bf16 planes in MFMA fragment order
+    (xpanel_presplit_kernel) and the tiles only split X (xpanel_fwd_ps_kernel, xpanel.hip).  Same six piece products per fp32
+    product as the per-tile split: the error against fp64 stays at the fp32 level, far inside the 1e-4 parity tolerance."""
+    from fumi_amd import hip
+    g = torch.Generator().manual_seed(B * 1000 + D)
+    x_s = torch.randn(B, S, D, generator=g).abs(); x_q = torch.randn(B, Qn, D, generator=g) * 3.0
+    W0 = torch.randn(h0, D, generator=g) * 0.05
+    A0, G = hip.xpanel_fwd(ws, x_s.to(dev), x_q.to(dev), W0.to(dev))
+    assert ws.read_status() == 0
+    X = torch.cat([x_s, x_q], 1).double()
+    A0r = X @ W0.double().T; Gr = X @ x_s.double().transpose(1, 2)
+    assert float((A0.cpu().double() - A0r).abs().max() / A0r.abs().max()) < 2e-6
+    assert float((G.cpu().double() - Gr).abs().max() / Gr.abs().max()) < 4e-6          # (all-positive support rows: truncated tails add up)
+    # the planes are rebuilt every call: a changed weight must show
+    A1, _ = hip.xpanel_fwd(ws, x_s.to(dev), x_q.to(dev), (2.0 * W0).to(dev))
+    assert float((A1.cpu().double() - 2.0 * A0r).abs().max() / A0r.abs().max()) < 4e-6
+
+
 def test_meta_batch_larger_than_the_chip_matches_chunks(dev, ws):
     """72 episodes at the reference sizes: the split reverse sweep launches 8*9*4 = 288 workgroups of one CU each (> 256
     CUs), so parts of an episode wait for partners that are dispatched later; T = 2 gives two exchange rounds.  Gradients
