@@ -421,7 +421,8 @@ def main():
                                    "second-order meta-gradient + Adam step; BASELINE.json configs[1]",
                        "episodes_per_gpu": c["B_per_gpu"], "global_meta_batch": Bg,
                        "layer0_fwd": "split-bf16x3 operands on the bf16 MFMA with fp32 accumulation (fp32-equivalent: error vs "
-                                     "fp64 below the fp32-MFMA kernel's, tests/test_hip_parity.py::test_xpanel_fwd_split_bf16_has_fp32_accuracy)",
+                                     "fp64 at the fp32-MFMA kernel's level, tests/test_hip_parity.py::test_xpanel_fwd_presplit_column_operand_has_fp32_accuracy"
+                                     " and ::test_xpanel_fwd_split_bf16_has_fp32_accuracy); W0 and the support rows are split once per step",
                        "layer0_bwd": "the same split for gW0 (test_xpanel_bwd_split_bf16_has_fp32_accuracy)",
                        "parallelism": f"episode-sharded x{world}, 1 all-reduce of the flat gradient"},
             "final_loss": float(last[0]), "final_acc": float(last[1]),
@@ -448,7 +449,7 @@ def main():
                                "algorithmic_bytes": int(bytes_dominant(c["B_per_gpu"])),
                                "vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                                "executed_bf16_tflops": round(ach * SPLIT_PRODUCTS, 1),
-                               "kernel": "xpanel_bwd256_sb_kernel (gW0 = sum_b Abar0_b^T [Xs_b;Xq_b]: 256 x 2048 outputs in 256 x 64 tiles, contraction over 32 x 185 rows "
+                               "kernel": "xpanel_bwd256_sb_kernel (gW0 = sum_b Abar0_b^T [Xs_b;Xq_b]: 256 x 2048 outputs in 256 x 128 tiles, contraction over 32 x 185 rows "
                                          "in 16 slabs; fp32 operands split exactly into three bf16 pieces, six piece products per fp32 product on v_mfma_f32_32x32x16_bf16 with "
                                          "fp32 accumulation -- `achieved` counts the ALGORITHMIC fp32 flops, `peak` is the dense bf16 MFMA peak / 6; "
                                          "the launch also carries the hypernetwork backward as 40 rider workgroups, hyper_bwd.h: its 0.09 GFLOP are counted, its ~5 us stretch the launch)",

@@ -1356,7 +1356,7 @@ int launch_xpanel_bwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
         static const int ride = getenv("FUMI_XP_RIDER") ? atoi(getenv("FUMI_XP_RIDER")) : 1;     // 0: never carry the hypernetwork backward
         static const int bsb = getenv("FUMI_XPB_SB") ? atoi(getenv("FUMI_XPB_SB")) : 1;          // 0: the fp32-MFMA kernel
         if (bsb && kchunk % BSK == 0) {
-            static const int bnb = getenv("FUMI_XPB_NB") ? atoi(getenv("FUMI_XPB_NB")) : 1;      // 2: 256 x 128 tiles
+            static const int bnb = getenv("FUMI_XPB_NB") ? atoi(getenv("FUMI_XPB_NB")) : 2;      // 2: 256 x 128 tiles (default), 1: 256 x 64
             static const int bsk = getenv("FUMI_XPB_SK") ? atoi(getenv("FUMI_XPB_SK")) : 16;     // 32: two k-steps per slab (NB = 1)
             const int NB = (bnb == 2 && D % 128 == 0) ? 2 : 1;
             const int SKv = (NB == 1 && bsk == 32 && kchunk % 32 == 0) ? 32 : 16;
