@@ -1254,7 +1254,7 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
     static const int nst = getenv("FUMI_XP_NST") ? atoi(getenv("FUMI_XP_NST")) : 2;      // staging ring depth (tuning knob)
     // Default: the split-bf16 kernel (65 us at the bench shapes, error against fp64 below the fp32 MFMA kernel's: DESIGN.md).
     // FUMI_XP_SB=0 selects the fp32 MFMA kernel (78 us).
-    if (aligned && planes && xpanel_fwd_ps_ok(D, h0) && D / p.ksplit / SBK >= PS_MIN_SLABS) {
+    if (aligned && planes && p.ksplit == 1 && xpanel_fwd_ps_ok(D, h0) && D / SBK >= PS_MIN_SLABS) {      // (split contractions: the 64 x 64 kernel)
         // column operands split once (bf16 planes in fragment order), then tiles that
         // only split X: 64 x 128 against W0, 128 x 32 against the support rows
         static const int ride = getenv("FUMI_XP_RIDER") ? atoi(getenv("FUMI_XP_RIDER")) : 1;
