@@ -7,9 +7,14 @@
 //   xpanel_bwd_kernel:  gW0 = sum_b Abar0_b^T [Xs_b ; Xq_b]   (autograd's AddmmBackward of layer 0 summed over every
 //        use inside the second-order graph, fumi/models/fumi.py:192), contraction over all B*R rows split into slabs.
 //
-// Both run on v_mfma_f32_32x32x2_f32 (exact fp32; 157 TFLOP/s peak).  Tiling: 64x64 output tile per 256-thread
-// workgroup (2x2 waves, one 32x32 accumulator each), 32-deep contraction slabs double-buffered in LDS with the next slab
-// prefetched into registers behind the MFMAs.  X is never copied: a "virtual row" r of episode b is read from
+// Kernels in this file, in the order they were written (the launchers at the end pick; DESIGN.md sections 5 and 12):
+//   fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32; 157 TFLOP/s peak): xpanel_fwd_generic / xpanel_fwd_kernel (64x64 tiles, 2x2 waves,
+//     32- / 64-deep slabs double-buffered in LDS, next slab prefetched into registers), xpanel_bwd_kernel, xpanel_bwd256_kernel;
+//   split-bf16 (every fp32 operand split exactly into three bf16 pieces, six piece products on v_mfma_f32_32x32x16_bf16, fp32
+//     accuracy at 2.7x the matrix rate): xpanel_fwd_sb_kernel (both operands split per tile), xpanel_presplit_kernel +
+//     xpanel_fwd_ps_kernel (the column operand split once per step into planes in MFMA fragment order: the default forward),
+//     xpanel_bwd256_sb_kernel (transposing LDS reads: the default backward).
+// X is never copied: a "virtual row" r of episode b is read from
 // x_s[b, r] (r < S) or x_q[b, r-S]; a virtual column c of the forward pass from W0[c] (c < h0) or x_s[b, c-h0].
 //
 // XCD-aware placement (forward): workgroup ids that are equal mod 8 share an XCD (round-robin dispatch), so episode
@@ -1252,11 +1257,11 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
     if (ks > 1 && parts && aligned && D % SBK == 0 && use_sb) { p.ksplit = ks; p.part_stride = (long)B * (S + Qn) * h0; A0 = parts; }
     const dim3 grid(8 * nper * tiles_m * tiles_n * p.ksplit);
     static const int nst = getenv("FUMI_XP_NST") ? atoi(getenv("FUMI_XP_NST")) : 2;      // staging ring depth (tuning knob)
-    // Default: the split-bf16 kernel (65 us at the bench shapes, error against fp64 below the fp32 MFMA kernel's: DESIGN.md).
-    // FUMI_XP_SB=0 selects the fp32 MFMA kernel (78 us).
+    // Default: split-bf16 (error against fp64 at the fp32 MFMA kernel's level: DESIGN.md) -- with the column operand split once per
+    // step where the shape allows (50 + 6 us at the bench shapes), else per tile (70 us).  FUMI_XP_SB=0: the fp32 MFMA kernel (78 us).
     if (aligned && planes && p.ksplit == 1 && xpanel_fwd_ps_ok(D, h0) && D / SBK >= PS_MIN_SLABS) {      // (split contractions: the 64 x 64 kernel)
-        // column operands split once (bf16 planes in fragment order), then tiles that
-        // only split X: 64 x 128 against W0, 128 x 32 against the support rows
+        // column operands split once (bf16 planes in fragment order), then tiles that only split X: 64 x 128 against W0, 128 x 32
+        // against the support rows
         static const int ride = getenv("FUMI_XP_RIDER") ? atoi(getenv("FUMI_XP_RIDER")) : 1;
         const int cbg = (p.gcols + 31) / 32;
         unsigned short* Wp = planes; unsigned short* Xp = planes + ps_w0_bytes(D, h0) / sizeof(unsigned short);
