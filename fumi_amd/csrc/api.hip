@@ -114,7 +114,7 @@ void fumi_hip_workspace_destroy(fumi_ws_t* ws) {
     delete ws;
 }
 
-size_t fumi_hip_workspace_bytes(const fumi_ws_t* ws) { return ws ? ws->cap : 0; }
+size_t fumi_hip_workspace_bytes(const fumi_ws_t* ws) { return ws ? ws->cap + ws->w0p_cap : 0; }      // slab + operand planes
 
 int fumi_hip_set_profiling(fumi_ws_t* ws, int on) {
     if (!ws) return FUMI_EINVAL;

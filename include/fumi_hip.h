@@ -54,6 +54,9 @@ int          fumi_hip_version(void);
 const char*  fumi_hip_strerror(int code);
 const char*  fumi_hip_last_hip_error(void);
 
+/* A workspace owns all device memory the library allocates for its device: the scratch slab (grown on demand, bump-allocated per
+ * call), a few small counters / the status word, and -- since round 2 -- the bf16 planes of the forward pass's column operand
+ * (W0 and the support rows split once per step, ~16 MB at the reference sizes; rebuilt by every step, nothing to keep coherent). */
 int   fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out);
 void  fumi_hip_workspace_destroy(fumi_ws_t* ws);
 size_t fumi_hip_workspace_bytes(const fumi_ws_t* ws);
