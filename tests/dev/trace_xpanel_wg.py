@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from fumi_amd import hip
 dev = torch.device("cuda:0"); ws = hip.Workspace.get(dev)
-B, S, Qn, D, h0 = 32, 25, 160, 2048, 256
+B, S, Qn, D, h0 = (int(sys.argv[1]) if len(sys.argv) > 1 else 32), 25, 160, 2048, 256
 g = torch.Generator(device=dev).manual_seed(0)
 xs = torch.randn(B, S, D, device=dev, generator=g); xq = torch.randn(B, Qn, D, device=dev, generator=g)
 W0 = torch.randn(h0, D, device=dev, generator=g) / 45
