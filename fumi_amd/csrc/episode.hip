@@ -720,7 +720,11 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, StageTab s
     __syncthreads(); QSTAMP()
     int whq = y.Wh;                                                  // the head the query pass uses
     if constexpr (FUSED) {
-        const bool lead = tile == 0 && d.taped;                      // one tile per episode writes the tape
+        // the tape (identical in every tile of the episode) is written by three of them: a_0 by tile 0, the initial fast weights by
+        // tile 1, the rest by tile 2 -- one tile writing all 105 KB was 1.5 us behind the others, and the launch lasts as long as it
+        const int nt_ = (Qn + QR - 1) / QR;
+        const bool lead = tile == 0 && d.taped;
+        const bool lead_w = tile == (nt_ > 1 ? 1 : 0) && d.taped, lead_r = tile == (nt_ > 2 ? 2 : 0) && d.taped;
         const f32x4 z4s = {0.f, 0.f, 0.f, 0.f};
         // the tile's own A0 rows are requested NOW (4 float4 per thread: h0 <= 256) and written into a_0 when the support rows
         // are done with it: their latency disappears behind the inner step
@@ -749,7 +753,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, StageTab s
                 wg_st4(dst + (long)r * drs + cc, *(const f32x4*)(img + r * ld + cc), min(4, cols - cc));
             }
         };
-        if (lead) {                                                  // slot 0 of the tape: the initial fast weights
+        if (lead_w) {                                                // slot 0 of the tape: the initial fast weights
             store_img(w.Wslot[1] + (long)b * w.nslot * ((long)h1 * h0), h0, W1, ld0, h1, h0);
             store_img(w.Whslot + (long)b * w.nslot * N * H, H, Wh, ldH, N, H);
         }
@@ -774,7 +778,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, StageTab s
 #pragma unroll
                 for (int cc = 1; cc < 4; ++cc) if (cc >= cnt) o[cc] = 0.f;
                 *(f32x4*)(a1 + m * ld1 + n) = o;
-                if (lead) wg_st4(ta1 + (long)m * h1 + n, o, cnt);
+                if (lead_r) wg_st4(ta1 + (long)m * h1 + n, o, cnt);
             });
         }
         wg_lds_barrier();
@@ -802,7 +806,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, StageTab s
                     const float pv = ex * inv;
                     const float ev = (pv - (gl == s_lab[s_] ? 1.f : 0.f)) / (float)S;
                     row[gl] = ev;
-                    if (lead) { tpp[s_ * N + gl] = pv; tee[s_ * N + gl] = ev; }
+                    if (lead_r) { tpp[s_ * N + gl] = pv; tee[s_ * N + gl] = ev; }
                 }
                 if (rok) for (int n = gl; n < ldq - 4; n += G) if (n >= N) row[n] = 0.f;      // K padding of e
             }
@@ -823,7 +827,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, StageTab s
 #pragma unroll
                 for (int c = 0; c < 4; ++c) o[c] = (c < cnt && act[c] > 0.f) ? acc[c] * d.mscale : 0.f;
                 *(f32x4*)p = o;
-                if (lead) wg_st4(tdl + (long)m * h1 + n, o, cnt);
+                if (lead_r) wg_st4(tdl + (long)m * h1 + n, o, cnt);
             });
         }
         wg_lds_barrier();
