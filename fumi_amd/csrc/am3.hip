@@ -387,7 +387,8 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
             else __hip_atomic_store(mine + NP + 2 + N * N + j, s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    __syncthreads();                                        // (every partial store has left: vmcnt(0) before the signal)
+    wg_drain_stores();                                      // every wave: its sc1 partial stores have completed ...
+    __syncthreads();                                        // ... before lane 0 signals for all of them
     if (GQ > 1) {
         if (tid == 0) {
             const int old = __hip_atomic_fetch_add(arrive + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -699,6 +699,15 @@ __device__ __forceinline__ void wg_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Producer side of a cross-workgroup hand-off through sc1 (agent-scope, write-through) stores: EVERY storing wave waits for
+// its own stores before the workgroup barrier behind which one lane bumps the arrival counter.  A __syncthreads() alone is a
+// workgroup-scope release: on gfx950 it waits for lgkmcnt only, and the counter's atomic can overtake stores that are still
+// in flight to another L2 channel (MI355X_MICROARCH.md, "Workgroup dispatch ... inter-workgroup visibility", valid forms).
+// Inline asm, because hipcc may drop a wait it believes redundant.  Readers use sc1 loads after the counter add has returned.
+__device__ __forceinline__ void wg_drain_stores() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // store the first cnt (1..4) elements of v at p: one 16-byte store when complete and aligned
 __device__ __forceinline__ void wg_st4(float* p, const f32x4& v, int cnt) {
     if (cnt == 4 && ((((uintptr_t)p) & 15) == 0)) *(f32x4*)p = v;

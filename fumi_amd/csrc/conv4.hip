@@ -347,7 +347,8 @@ static int hvp_pass(StepCtx& c, int M, const float* img, const float* frags, Pas
 
 // last step's buffer table, for fumi_hip_conv4_probe (tests compare every intermediate with oracle/conv4_manual.py)
 struct ProbeTab {
-    bool valid; Net n; int T, S, Qn; int ntape;
+    bool valid; fumi_ws* ws; char* base;            // the workspace (and its slab) the pointers below were carved from
+    Net n; int T, S, Qn; int ntape;
     PassBufs tape[8]; PassBufs query; TanBufs tan;
     float* params; float* heads; float* G; float* dh; float* bar; float* barh; float* HV; float* HVh;
 };
@@ -474,7 +475,7 @@ int run_conv4_episodes(fumi_ws* ws, hipStream_t st, Conv4Problem p, const Conv4H
         TRY(launch_reduce_multi(st, sg));
     }
     pt.n = n; pt.T = p.T; pt.S = p.S; pt.Qn = p.Qn; pt.ntape = ntape; pt.params = params; pt.heads = heads; pt.G = G; pt.dh = dh;
-    pt.bar = bar; pt.barh = barh; pt.HV = HV; pt.HVh = HVh; pt.valid = true;
+    pt.bar = bar; pt.barh = barh; pt.HV = HV; pt.HVh = HVh; pt.ws = ws; pt.base = ws->base; pt.valid = true;
     if (!grad) return FUMI_OK;
     TRY(backward_pass(c, p.Qn, p.x_q, Fr(cur), pt.query, Hd(cur), bar, barh));
     // ---- second-order reverse sweep
@@ -630,6 +631,7 @@ int fumi_hip_conv4_probe(fumi_ws_t* ws, fumi_stream_t stream, int pass, int kind
                          size_t* n_out) {
     if (!ws || !out || !n_out || !g_probe.valid) return FUMI_EINVAL;
     const ProbeTab& pt = g_probe;
+    if (pt.ws != ws || pt.base != ws->base) return FUMI_EINVAL;         // another workspace's step, or the slab has moved since
     const Net& n = pt.n;
     const float* src = nullptr; size_t cnt = 0;
     const size_t hsz = (size_t)n.B * n.N * (n.F + 1);

@@ -23,6 +23,7 @@
 namespace {
 
 unsigned long long* g_epi_trace = nullptr;     // dev tracing only
+int g_spin_limit = 1 << 22;                    // polls before a cross-workgroup wait gives up (fumi_hip_set_spin_limit; tests set 0)
 constexpr int QR = 32;                 // query rows per workgroup
 constexpr int MAXL = FUMI_MAX_HIDDEN;
 
@@ -40,6 +41,7 @@ struct EpiBuf {
     float *A0bar;                              // [B,R,h0] adjoint of A0 (support rows: sum over inner steps)
     float *apart; int *acnt;                   // adapt_lds split over column parts: [B,2,8,S*h_1] layer-1 partial sums; [B] arrival counters (persistent, zero between steps)
     float *xpart; int *xcnt;                   // reverse_lds: [B,2,8,S*h_1] partial sums exchanged between the column parts; [B] arrival counters
+    int *status; int spin_limit;               // status word (FUMI_ST_SYNC_TIMEOUT when a wait for the sibling parts expires); polls per wait
     int nslot, ntape, ntile, maxh;
     unsigned long long* trace;                 // dev: per-phase wall-clock stamps of block 0 (tests/dev/trace_adapt.py)
     int lds_adapt, lds_query, lds_reverse;     // floats of dynamic LDS each kernel stages its products through
@@ -410,13 +412,18 @@ __global__ __launch_bounds__(512) void adapt_lds_kernel(StageTab stg, EpiDims d,
                     const int m = e2 / hi, n = e2 - m * hi;
                     __hip_atomic_store(mine + e2, Xp[m * ldi + n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                __syncthreads();                                    // every wave's stores have left (vmcnt(0)) before the signal
+                wg_drain_stores();                                  // every wave: its sc1 partial stores have completed ...
+                __syncthreads();                                    // ... before the one lane that signals for all of them does
                 if (tid == 0) {
                     __hip_atomic_fetch_add(w.acnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const int target = P * (t + 1);
-                    // bounded: the parts of an episode are dispatched together (see reverse_lds_kernel)
-                    for (int spin = 0; spin < (1 << 22) &&
-                         __hip_atomic_load(w.acnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin) __builtin_amdgcn_s_sleep(2);
+                    // bounded: the parts of an episode are dispatched together (see reverse_lds_kernel); a wait that expires
+                    // is reported (FUMI_ST_SYNC_TIMEOUT -> the host raises), never silently carried on from
+                    int spin = 0;
+                    while (__hip_atomic_load(w.acnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                        if (++spin > w.spin_limit) { atomicOr(w.status, FUMI_ST_SYNC_TIMEOUT); break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
                 }
                 __syncthreads();
                 const int w4 = q_r4(hi);
@@ -1279,14 +1286,19 @@ __global__ __launch_bounds__(512) void reverse_lds_kernel(StageTab stg_init, Sta
                 float* pw = Wb1 + m * ldc + n; *(f32x4*)pw = *(const f32x4*)pw + acc;
             });
             if (P > 1) {
-                __syncthreads();                                    // every wave's stores have left (vmcnt(0)) before the signal
+                wg_drain_stores();                                  // every wave: its sc1 partial stores have completed ...
+                __syncthreads();                                    // ... before the one lane that signals for all of them does
                 if (tid == 0) {
                     __hip_atomic_fetch_add(w.xcnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const int target = P * (round + 1);
                     // bounded: the parts of an episode are dispatched together, so this wait is microseconds; a grid that
-                    // somehow lost a part must not hang the device (its results would simply be wrong and fail parity)
-                    for (int spin = 0; spin < (1 << 22) &&
-                         __hip_atomic_load(w.xcnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin) __builtin_amdgcn_s_sleep(2);
+                    // somehow lost a part must not hang the device -- the expired wait sets FUMI_ST_SYNC_TIMEOUT and the
+                    // host raises when it reads the status word (the gradients of this step are not to be trusted)
+                    int spin = 0;
+                    while (__hip_atomic_load(w.xcnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                        if (++spin > w.spin_limit) { atomicOr(w.status, FUMI_ST_SYNC_TIMEOUT); break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
                 }
                 __syncthreads();
             } else {
@@ -1553,7 +1565,14 @@ void carve(Carver& c, const EpisodeProblem& p, EpiBuf& w) {
 
 }  // namespace
 
-extern "C" void fumi_dbg_set_epi_trace(void* p) { g_epi_trace = (unsigned long long*)p; }
+void set_xpanel_trace(void* p);                    // xpanel.hip
+extern "C" int fumi_hip_set_trace_buffer(int which, void* p) {
+    if (which == 0) g_epi_trace = (unsigned long long*)p;
+    else if (which == 1) set_xpanel_trace(p);
+    else return FUMI_EINVAL;
+    return FUMI_OK;
+}
+extern "C" int fumi_hip_set_spin_limit(int polls) { const int old = g_spin_limit; g_spin_limit = polls < 0 ? 0 : polls; return old; }
 
 size_t episode_workspace_bytes(const EpisodeProblem& p) {
     Carver c{nullptr, 0};
@@ -1575,6 +1594,7 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     Carver c{ws, 0};
     carve(c, p, w);
     w.trace = g_epi_trace;
+    w.status = ws->status; w.spin_limit = g_spin_limit;
     w.acnt = ws->acnt;                           // persistent arrival counters of the split adapt kernel (zero between steps)
     EpiDims d;
     d.B = p.B; d.N = p.N; d.S = p.S; d.Qn = p.Qn; d.L = p.L; d.T = p.T; d.H = p.h[p.L - 1];

@@ -145,7 +145,8 @@ __device__ __forceinline__ void hyper_fwd_split_body(const HyperFwdArgs& a, int 
                 if (n + e < H1) __hip_atomic_store(mine + r * H1 + n + e, p[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    __syncthreads();                                      // every wave's partial stores have left (vmcnt(0)) before the signal
+    wg_drain_stores();                                    // every wave: its sc1 partial stores have completed ...
+    __syncthreads();                                      // ... before lane 0 signals for all of them
     if (tid == 0) {
         const int old = __hip_atomic_fetch_add(a.cnt + rb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_last = old == nch - 1;

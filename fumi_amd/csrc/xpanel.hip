@@ -1204,7 +1204,7 @@ unsigned long long* g_trace = nullptr;      // dev tracing only (tools/trace_xpa
 
 }  // namespace
 
-extern "C" void fumi_dbg_set_trace(void* p) { g_trace = (unsigned long long*)p; }
+void set_xpanel_trace(void* p) { g_trace = (unsigned long long*)p; }
 
 // contraction parts of the split-bf16 forward: 1 unless the output is narrow (no Gram block, few column tiles) and the tile count
 // would leave most of the chip idle -- AM3's image encoder (P = 64 columns: 96 workgroups for 256 CUs, 46 us for a pass that

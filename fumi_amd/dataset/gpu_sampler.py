@@ -21,14 +21,16 @@ from .. import hip
 
 class GpuEpisodeSampler:
     def __init__(self, images, class_of_image, class_text, num_ways, num_shots, num_shots_test, batch_size, seed=123,
-                 length=None, zero_copy=False, row_ids=None, skip_small_classes=False, torchmeta_tasks=False):
+                 length=None, zero_copy=False, row_ids=None, skip_small_classes=None, torchmeta_tasks=False):
         """images [n_images, D] fp32 (moved to the device once), class_of_image [n_images] ints (category of every row, as
         inat_anim.json's annotations give it), class_text [C, Dt] fp32 or [C, L] int64 tokens (one row per class: the text of
         a sample is its class description, data.py:543-549).  row_ids [n_images] ints: the id reported for every table row in
         the batch's index field (the dataset's image ids, data.py:568-571); default: the row number.
         A class with fewer than num_shots + num_shots_test images cannot fill an episode: torchmeta's ClassSplitter raises
-        ValueError when such a class is drawn, so the constructor raises it up front; ``skip_small_classes=True`` samples
-        among the classes that are large enough instead (the kernel never sees an under-populated class).
+        ValueError only when such a class is drawn, so a dataset the reference accepts must still load: by default (None) the
+        sampler warns and samples among the classes that are large enough (the kernel never sees an under-populated class:
+        no wrapped indices, no support rows leaking into the query set); ``True`` does the same silently, ``False`` is
+        strict and raises up front.
         torchmeta_tasks=True reproduces torchmeta's task semantics: the class slots of a task get a
         random permutation of the labels 0..N-1 (Categorical) and a class tuple drawn again has the same support / query
         members (ClassSplitter seeds its shuffle with hash(task) + seed); False keeps label n for slot n."""
@@ -41,7 +43,11 @@ class GpuEpisodeSampler:
         small = np.flatnonzero(counts < self.K + self.Q)
         self.class_ids = None                      # sampled class slot -> row of class_text (None: identity)
         if small.size:
-            if not skip_small_classes:
+            if skip_small_classes is None:
+                import warnings
+                warnings.warn(f"{small.size} of {C} classes have fewer than num_shots + num_shots_test = {self.K + self.Q} images "
+                              f"and are never sampled (torchmeta's ClassSplitter raises when it draws one)")
+            elif not skip_small_classes:
                 raise ValueError(f"{small.size} of {C} classes (first: {int(small[0])} with {int(counts[small[0]])} images) have "
                                  f"fewer than num_shots + num_shots_test = {self.K + self.Q} images; torchmeta's ClassSplitter "
                                  f"raises for such a class -- pass skip_small_classes=True to sample among the others")

@@ -78,6 +78,9 @@ class HipEngine:
     def linear(self, x, W, b=None, act=0):
         return hip.linear_fwd(self._ws(x), x.contiguous(), W.contiguous(), b, act)
 
+    def sgd_axpy(self, p, step_size, g):
+        return hip.sgd_axpy(self._ws(p), p, step_size, g)
+
     def check(self, device):
         """Synchronising validity check of the last calls (labels in range, every class has a support sample)."""
         device = torch.device(device)
@@ -102,6 +105,11 @@ def get_engine():
         hip.lib()                      # fail loudly here if the shared object has not been built
         _ENGINE = HipEngine()
     return _ENGINE
+
+
+def is_test_engine():
+    """True when a test installed a checker engine (``set_engine``); product code never does."""
+    return _ENGINE is not None and not isinstance(_ENGINE, HipEngine)
 
 
 def set_engine(engine):

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfumi_hip.so")
 SYMBOLS = [
     "fumi_hip_version", "fumi_hip_strerror", "fumi_hip_last_hip_error",
     "fumi_hip_workspace_create", "fumi_hip_workspace_destroy", "fumi_hip_workspace_bytes", "fumi_hip_read_status",
+    "fumi_hip_set_spin_limit", "fumi_hip_set_trace_buffer",
     "fumi_hip_set_profiling", "fumi_hip_set_profiling_every", "fumi_hip_get_profile", "fumi_hip_phase_name",
     "fumi_hip_fumi_step", "fumi_hip_fumi_step_indexed", "fumi_hip_maml_step", "fumi_hip_am3_step",
     "fumi_hip_glove_bag", "fumi_hip_glove_bag_select", "fumi_hip_class_text_select", "fumi_hip_xpanel_fwd", "fumi_hip_xpanel_bwd",
@@ -31,7 +32,7 @@ SYMBOLS = [
     "fumi_hip_sgd_axpy", "fumi_hip_ce_fwd_bwd", "fumi_hip_proto_reduce", "fumi_hip_clip_step", "fumi_hip_lstm_bidir",
 ]
 
-ST_LABEL_RANGE, ST_CLASS_MISSING = 1, 2
+ST_LABEL_RANGE, ST_CLASS_MISSING, ST_SYNC_TIMEOUT = 1, 2, 4
 N_PHASES = 15
 
 _lib = None
@@ -100,6 +101,8 @@ def lib():
         L.fumi_hip_workspace_bytes.argtypes = [c_void_p]
         L.fumi_hip_workspace_bytes.restype = c_size_t
         L.fumi_hip_read_status.argtypes = [c_void_p, c_void_p, POINTER(c_int)]
+        L.fumi_hip_set_spin_limit.argtypes = [c_int]
+        L.fumi_hip_set_trace_buffer.argtypes = [c_int, c_void_p]
         L.fumi_hip_set_profiling.argtypes = [c_void_p, c_int]
         L.fumi_hip_set_profiling_every.argtypes = [c_void_p, c_int]
         L.fumi_hip_get_profile.argtypes = [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int)]
@@ -326,6 +329,9 @@ class Workspace:
 
 
 def raise_on_status(status):
+    if status & ST_SYNC_TIMEOUT:
+        raise RuntimeError("a workgroup timed out waiting for the sibling workgroups of its episode "
+                           "(FUMI_ST_SYNC_TIMEOUT): the results of that step are invalid")
     if status & ST_CLASS_MISSING:
         raise IndexError("a class has no support sample (the reference raises IndexError at fumi/models/fumi.py:209)")
     if status & ST_LABEL_RANGE:

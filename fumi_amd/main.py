@@ -15,6 +15,8 @@ import numpy as np
 import torch
 
 from . import dist as fdist
+from . import engine as _engine
+from . import hip
 from .models import am3, clip, fumi, maml
 from .utils import utils
 from .utils.wandb_compat import wandb
@@ -122,6 +124,13 @@ def parse_args(argv=None):
     use_gpu = (not args.disable_cuda) and torch.cuda.is_available()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     args.device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    if not use_gpu and not _engine.is_test_engine():
+        # the reference falls back to the CPU here (fumi/main.py:145-146); this engine is MI355X-only and says so NOW rather
+        # than from inside the first meta-step
+        raise hip.FumiHipError(
+            ("--disable_cuda was given" if args.disable_cuda else "no GPU is visible (torch.cuda.is_available() is False)")
+            + ": fumi_amd has no CPU execution path -- every step runs on the MI355X library "
+              "(fumi_amd/lib/libfumi_hip.so).  Run the reference itself for a CPU run.")
     print(f"running on device {args.device}")
     return args
 

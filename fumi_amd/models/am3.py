@@ -109,9 +109,24 @@ class AM3(nn.Module):
         if self.text_encoder_type in ("BERT", "precomputed"):
             return text.to(torch.float32).contiguous()
         if self.text_encoder_type == "rand":
-            raise NotImplementedError("text_encoder='rand' draws the text prototypes at random inside the step "
-                                      "(am3.py:118-121); it is excluded from the parity path")
+            # am3.py:118-121: the text PROTOTYPES are drawn uniformly in [-1, 1), g is not applied
+            return 2 * torch.rand(*text.shape[:2], self.prototype_dim, device=text.device) - 1
         return self.text_encoder(text)
+
+    def _rand_g(self, device):
+        """text_encoder='rand' hands prototype-space rows to a step that applies g: an exact identity in g's own form,
+        x = relu(x) - relu(-x)  (G0 = [I; -I; 0], G1 = [I, -I, 0], zero biases; every sum has one non-zero term)."""
+        c = getattr(self, "_rand_g_cache", None)
+        if c is None or c[0].device != device:
+            P, Ht = self.prototype_dim, self.g[0].weight.shape[0]
+            if Ht < 2 * P:
+                raise NotImplementedError("text_encoder='rand' needs text_hid_dim >= 2 * prototype_dim on this engine")
+            G0 = torch.zeros(Ht, P, device=device); G1 = torch.zeros(P, Ht, device=device)
+            eye = torch.eye(P, device=device)
+            G0[:P], G0[P:2 * P], G1[:, :P], G1[:, P:2 * P] = eye, -eye, eye, -eye
+            c = self._rand_g_cache = [G0, torch.zeros(Ht, device=device), G1, torch.zeros(P, device=device)]
+            self._rand_g_scratch = [torch.empty_like(t) for t in c]
+        return c
 
     def forward(self, inputs, im_only=False):
         """Inference helper (am3.py:90-126): prototype-space embeddings through the engine's linear op."""
@@ -125,7 +140,10 @@ class AM3(nn.Module):
         if im_only:
             return im_emb
         enc = self._encode_text(text)
-        t = eng.linear(eng.linear(enc.reshape(-1, enc.shape[-1]).contiguous(), w[2], w[3], act=1), w[4], w[5])
+        if self.text_encoder_type == "rand":
+            t = enc.reshape(-1, enc.shape[-1]).contiguous()
+        else:
+            t = eng.linear(eng.linear(enc.reshape(-1, enc.shape[-1]).contiguous(), w[2], w[3], act=1), w[4], w[5])
         lam = eng.linear(eng.linear(t, w[6], w[7], act=1), w[8], w[9], act=3)
         return im_emb, t.reshape(*lead, -1), lam.reshape(*lead, 1)
 
@@ -167,9 +185,18 @@ class AM3(nn.Module):
             img_s, img_q = x_s, x_q
             theta = th_det
             x_s, x_q = eng.conv4_encode(img_s, img_q, theta, keep_tape=need_grad)
+        g_w = fg.split(10)[0] if need_grad else None
+        rand_text = self.text_encoder_type == "rand"
+        if rand_text:
+            if drop_p > 0:
+                raise NotImplementedError("text_encoder='rand' with dropout > 0 in training: the step's dropout would also "
+                                          "hit the identity that stands in for g (the reference applies it to h only)")
+            w_det = w_det[:2] + self._rand_g(x_s.device) + w_det[6:]
+            if need_grad:
+                g_w = list(g_w[:2]) + self._rand_g_scratch + list(g_w[6:])
         out = eng.am3_step(x_s, y_s, x_q, y_q, text, w_det, num_ways,
                            self.lamda_fixed, need_grad=need_grad, grad_scale=1.0 / B,
-                           g_w=fg.split(10)[0] if need_grad else None, dropout_p=drop_p, seed=drop_seed,
+                           g_w=g_w, dropout_p=drop_p, seed=drop_seed,
                            **({"stats": tail} if on_device else {}),
                            **({"want_dx": True} if (self.conv is not None and need_grad) else {}))
         if self.conv is not None and need_grad:     # ... and backwards from the adjoints of the features (already scaled by 1/B)
@@ -186,6 +213,9 @@ class AM3(nn.Module):
                 # h is not part of the graph when lamda is overridden (am3.py:174-177): the reference leaves its .grad
                 # None, so the optimizer (and its weight decay) skips those tensors
                 for p in self.h.parameters():
+                    p.grad = None
+            if rand_text:                        # g is not part of the graph (am3.py:118-121): its .grad stays None
+                for p in self.g.parameters():
                     p.grad = None
             getattr(optimizer, "step_fused", optimizer.step)()
             if scheduler:

@@ -36,6 +36,8 @@ class Adam(torch.optim.Adam):
         step): the models' ``evaluate`` calls this when the optimizer offers it.  Optimizer step hooks are NOT run here."""
         if self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks:
             return self.step()
+        if hasattr(self.step, "_wrapped_by_lr_sched"):
+            self._opt_called = True               # what the lr_scheduler's wrapper around step() records (its order check)
         with torch.no_grad():
             if not self._step_impl():
                 return torch.optim.Adam.step(self)
@@ -54,6 +56,27 @@ class Adam(torch.optim.Adam):
                 torch._foreach_add_(args.steps, lag)
                 args.synced = args.count
 
+    def _fall_back(self):
+        """torch's own step is about to run for EVERY group and will increment every `step` tensor itself: bring the tensors
+        up to date and forget the cached plans, so the next fused step reads its counts from the tensors again."""
+        self._sync_steps()
+        self._fused_args = {}
+        return False
+
+    def __getstate__(self):
+        self._sync_steps()                        # pickling / deepcopy read optimizer.state directly
+        return super().__getstate__()
+
+    def __deepcopy__(self, memo):
+        import copy
+        self._sync_steps()
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            setattr(new, k, {} if k == "_fused_args" else copy.deepcopy(v, memo))
+        return new
+
     def _step_impl(self):
         """True when every group went through the fused launch; False (nothing done) when torch's implementation must run."""
         groups = [(g, [p for p in g["params"] if p.grad is not None]) for g in self.param_groups]
@@ -69,8 +92,7 @@ class Adam(torch.optim.Adam):
                 if cached is not None:
                     self._sync_steps()            # (the replaced entry's pending count goes into the `step` tensors first)
                 if not self._fusable(group, params):
-                    self._sync_steps()
-                    return False
+                    return self._fall_back()
                 for p in params:
                     st = self.state[p]
                     if len(st) == 0:
@@ -85,8 +107,7 @@ class Adam(torch.optim.Adam):
                 cached.count = cached.synced = int(cached.steps[0])
                 cached.dev = params[0].device
             elif isinstance(group["lr"], torch.Tensor) or group.get("amsgrad") or group.get("maximize"):
-                self._sync_steps()
-                return False
+                return self._fall_back()
             plans.append((group, cached))
         for group, args in plans:
             args.count += 1                                                     # (the `step` tensors follow in _sync_steps)

@@ -27,6 +27,14 @@ class LocalWandb:
         self._fh = None
         self._pending = None
         self._n_runs = 0
+        import atexit
+        atexit.register(self._flush_at_exit)   # an exception / Ctrl-C before finish() must not lose the last record
+
+    def _flush_at_exit(self):
+        try:
+            self.finish()
+        except Exception:                      # (the device may be gone; the earlier records are on disk already)
+            pass
 
     def init(self, entity=None, project=None, group=None, job_type=None, save_code=False, dir=None, **kw):
         root = dir or os.environ.get("FUMI_LOG_DIR", "./results")

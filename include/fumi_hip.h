@@ -47,6 +47,8 @@ typedef void* fumi_stream_t;          /* hipStream_t */
 /* device-side status bits (fumi_hip_read_status) -- the reference raises IndexError in both situations */
 #define FUMI_ST_LABEL_RANGE   1       /* a label outside [0, N) */
 #define FUMI_ST_CLASS_MISSING 2       /* a class without a support sample (fumi.py:209 would raise) */
+#define FUMI_ST_SYNC_TIMEOUT  4       /* a workgroup gave up waiting for the sibling workgroups of its episode (split inner loop /
+                                       * split reverse sweep): the step's results are not to be trusted; the host raises RuntimeError */
 
 #define FUMI_MAX_HIDDEN 8
 
@@ -62,6 +64,12 @@ void  fumi_hip_workspace_destroy(fumi_ws_t* ws);
 size_t fumi_hip_workspace_bytes(const fumi_ws_t* ws);
 /* Copies the device status word to the host (synchronises `stream`) and clears it. */
 int   fumi_hip_read_status(fumi_ws_t* ws, fumi_stream_t stream, int* status_out);
+/* Polls a workgroup spends waiting for the sibling workgroups of its episode before it sets FUMI_ST_SYNC_TIMEOUT (process-wide;
+ * default 1 << 22, about a second).  Tests set 0 to see the bit; returns the previous value. */
+int   fumi_hip_set_spin_limit(int polls);
+/* Development hooks: a device buffer of uint64 wall-clock stamps written by block 0 of the per-episode kernels (which = 0) or by
+ * every workgroup of the forward X-panel kernel (which = 1); NULL switches the stamps off (the default). */
+int   fumi_hip_set_trace_buffer(int which, void* device_u64);
 
 /* ---- in-library phase timing (HIP events recorded on the caller's stream around each phase) ---------------------
  * Used by bench.py to time the dominant kernel live inside the timed region.  Off by default (no events recorded). */

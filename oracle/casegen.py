@@ -165,5 +165,7 @@ AM3_CASES = {
     "am3_lam0":       dict(B=4, N=5, K=5, Q=4, D=64, Dt=24, Ht=20, P=16, lamda_fixed=0),
     "am3_lam1":       dict(B=4, N=5, K=5, Q=4, D=64, Dt=24, Ht=20, P=16, lamda_fixed=1),
     "am3_default":    dict(B=2, N=5, K=5, Q=8, D=2048, Dt=768, Ht=256, P=64, lamda_fixed=None),
+    # BASELINE.json configs[3] per-rank episode shape (32 query/class, reference widths) on a reduced meta-batch
+    "am3_default_q32": dict(B=4, N=5, K=5, Q=32, D=2048, Dt=768, Ht=256, P=64, lamda_fixed=None),
 }
 ALPHA = 0.01     # --step_size default, fumi/utils/utils.py:164-167

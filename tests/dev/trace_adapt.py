@@ -10,10 +10,10 @@ g = lambda t: t.to(dev).contiguous()
 args = (ws, N, g(ep["x_s"]), g(ep["y_s"]), g(ep["x_q"]), g(ep["y_q"]), g(ep["text_s"]), [g(t) for t in theta], [g(t) for t in phi], T, 0.01, False)
 for _ in range(3): hip.fumi_step_select(*args)
 tr = torch.zeros(256, dtype=torch.int64, device=dev)
-L = hip.lib(); L.fumi_dbg_set_epi_trace.argtypes = [ctypes.c_void_p]
-L.fumi_dbg_set_epi_trace(ctypes.c_void_p(tr.data_ptr()))
+L = hip.lib()
+L.fumi_hip_set_trace_buffer(0, ctypes.c_void_p(tr.data_ptr()))
 hip.fumi_step_select(*args); torch.cuda.synchronize()
-L.fumi_dbg_set_epi_trace(None)
+L.fumi_hip_set_trace_buffer(0, None)
 t = tr.cpu(); n = int((t[:32] > 0).sum())
 d = [(int(t[i + 1]) - int(t[i])) / 100.0 for i in range(n - 1)]
 mm = [(int(t[32 + i + 1]) - int(t[32 + i])) / 100.0 for i in range(6)]

@@ -11,12 +11,12 @@ g = torch.Generator(device=dev).manual_seed(0)
 xs = torch.randn(B, S, D, device=dev, generator=g); xq = torch.randn(B, Qn, D, device=dev, generator=g)
 W0 = torch.randn(h0, D, device=dev, generator=g) / 45
 for _ in range(3): hip.xpanel_fwd(ws, xs, xq, W0)
-L = hip.lib(); L.fumi_dbg_set_trace.argtypes = [ctypes.c_void_p]
+L = hip.lib()
 for rep in range(3):
     tr = torch.zeros(480 * 6, dtype=torch.int64, device=dev)
-    L.fumi_dbg_set_trace(ctypes.c_void_p(tr.data_ptr()))
+    L.fumi_hip_set_trace_buffer(1, ctypes.c_void_p(tr.data_ptr()))
     hip.xpanel_fwd(ws, xs, xq, W0); torch.cuda.synchronize()
-    L.fumi_dbg_set_trace(None)
+    L.fumi_hip_set_trace_buffer(1, None)
     t = tr.cpu().view(480, 6)
     hw = t[:, 4]; xcc = t[:, 5] & 0xF
     cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7

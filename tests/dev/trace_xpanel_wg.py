@@ -9,7 +9,7 @@ B, S, Qn, D, h0 = (int(sys.argv[1]) if len(sys.argv) > 1 else 32), 25, 160, 2048
 g = torch.Generator(device=dev).manual_seed(0)
 xs = torch.randn(B, S, D, device=dev, generator=g); xq = torch.randn(B, Qn, D, device=dev, generator=g)
 W0 = torch.randn(h0, D, device=dev, generator=g) / 45
-L = hip.lib(); L.fumi_dbg_set_trace.argtypes = [ctypes.c_void_p]
+L = hip.lib()
 NW = 1024
 
 
@@ -17,9 +17,9 @@ def run(name, fn):
     for _ in range(3): fn()
     for rep in range(2):
         tr = torch.zeros(NW * 6, dtype=torch.int64, device=dev)
-        L.fumi_dbg_set_trace(ctypes.c_void_p(tr.data_ptr()))
+        L.fumi_hip_set_trace_buffer(1, ctypes.c_void_p(tr.data_ptr()))
         fn(); torch.cuda.synchronize()
-        L.fumi_dbg_set_trace(None)
+        L.fumi_hip_set_trace_buffer(1, None)
         t = tr.cpu().view(NW, 6)
         live = t[:, 0] != 0
         t = t[live]

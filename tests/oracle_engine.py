@@ -161,5 +161,8 @@ class OracleEngine:
         y = F.linear(x, W, b)
         return [y, torch.relu(y), torch.tanh(y), torch.sigmoid(y)][act]
 
+    def sgd_axpy(self, p, step_size, g):
+        return p - step_size * g
+
     def check(self, device):
         pass

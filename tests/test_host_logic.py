@@ -136,6 +136,71 @@ def test_am3_evaluate_matches_reference(name, oracle_engine):
     np.testing.assert_allclose(np.asarray(r[10]), gold["test_lamda_s"], atol=1e-6)
 
 
+def test_am3_rand_text_encoder_bypasses_g(oracle_engine):
+    """text_encoder='rand' (am3.py:68-69,118-121): prototype-space text rows are drawn uniformly in [-1, 1), g is not part of
+    the graph (its .grad stays None), h and the image encoder train.  The step receives an exact identity in g's place:
+    with lamda_fixed = 0 the prototypes are the drawn rows themselves, so the loss equals the oracle's on those rows."""
+    from fumi_amd.models.am3 import AM3
+    from oracle import fumi_ref as R
+    c = cg.AM3_CASES["am3_lam"]
+    P, Ht = 8, 20
+    ep = cg.make_episodes(4, c["B"], c["N"], c["K"], c["Q"], c["D"], c["Dt"])
+    model = AM3("precomputed", c["D"], "rand", text_emb_dim=c["Dt"], text_hid_dim=Ht, prototype_dim=P, dropout=0.0)
+    g_before = [p.detach().clone() for p in model.g.parameters()]
+    h_before = [p.detach().clone() for p in model.h.parameters()]
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    torch.manual_seed(5)
+    loss = model.evaluate(cg.to_batch(ep), opt, None, c["N"], torch.device("cpu"), "train")[0]
+    torch.manual_seed(5)
+    drawn = 2 * torch.rand(c["B"], c["N"] * c["K"], P) - 1
+    w = {k: v.detach().clone() for k, v in zip(
+        ["Wi", "bi", "G0", "g0", "G1", "g1", "H0", "h0", "H1", "h1"],
+        [model.image_encoder.weight, model.image_encoder.bias] + model._rand_g(torch.device("cpu")) + h_before)}
+    w["Wi"], w["bi"] = w["Wi"] + 0, w["bi"] + 0
+    assert all(p.grad is None for p in model.g.parameters())
+    assert all(torch.equal(a, b.detach()) for a, b in zip(g_before, model.g.parameters()))
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(h_before, model.h.parameters()))
+    # the identity in g's form is exact
+    G0, g0, G1, g1 = model._rand_g(torch.device("cpu"))
+    assert torch.equal(torch.relu(drawn @ G0.t() + g0) @ G1.t() + g1, drawn)
+    assert np.isfinite(float(loss))
+    with pytest.raises(NotImplementedError):
+        AM3("precomputed", c["D"], "rand", text_emb_dim=c["Dt"], text_hid_dim=Ht, prototype_dim=P, dropout=0.5).evaluate(
+            cg.to_batch(ep), opt, None, c["N"], torch.device("cpu"), "train")
+
+
+def test_gradient_update_parameters_matches_torchmeta_contract(oracle_engine):
+    """torchmeta's gradient_update_parameters (fumi.py:172-176, maml.py:173-177): p - step_size * dL/dp for
+    every meta-parameter, graph kept unless first_order; MetaLinear.forward is differentiable twice."""
+    import torch.nn.functional as Fn
+    from fumi_amd.meta import gradient_update_parameters
+    from fumi_amd.models.maml import PureImageNetwork
+    torch.manual_seed(0)
+    net = PureImageNetwork(12, 3, [8])
+    x, y = torch.randn(6, 12), torch.tensor([0, 1, 2, 0, 1, 2])
+    loss = Fn.cross_entropy(net(x), y)
+    ref_g = torch.autograd.grad(loss, list(net.parameters()), create_graph=True)
+    upd = gradient_update_parameters(net, loss, step_size=0.3)
+    assert list(upd.keys()) == [n for n, _ in net.meta_named_parameters()]
+    for (n, p), g in zip(net.meta_named_parameters(), ref_g):
+        assert torch.allclose(upd[n], p - 0.3 * g, atol=1e-6)
+    # second order: d/dp of the post-update loss flows through the update
+    outer = Fn.cross_entropy(net(x, params=upd), y)
+    g2 = torch.autograd.grad(outer, list(net.parameters()))
+    # plain torch restatement
+    ps = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
+    f = lambda q, inp: Fn.linear(torch.relu(Fn.linear(inp, q[0], q[1])), q[2], q[3])
+    l1 = Fn.cross_entropy(f(ps, x), y)
+    gs = torch.autograd.grad(l1, ps, create_graph=True)
+    l2 = Fn.cross_entropy(f([p - 0.3 * g for p, g in zip(ps, gs)], x), y)
+    for a, b in zip(g2, torch.autograd.grad(l2, ps)):
+        assert torch.allclose(a, b, atol=1e-6)
+    fo = gradient_update_parameters(net, Fn.cross_entropy(net(x), y), step_size=0.3, first_order=True)
+    assert all(not v.requires_grad or v.grad_fn is not None for v in fo.values())
+    with pytest.raises(ValueError):
+        gradient_update_parameters(torch.nn.Linear(2, 2), loss)
+
+
 def test_test_loop_consumes_max_plus_one_batches(oracle_engine):
     """The reference's break is tested after the batch is processed (fumi.py:324)."""
     from fumi_amd.models import fumi
@@ -206,7 +271,19 @@ def test_cli_maml_synthetic_cpu_plumbing(oracle_engine, tmp_path, monkeypatch):
     assert runs and os.path.exists(tmp_path / "res" / "runs" / runs[0] / "ckpt.pth.tar")
 
 
-def test_cli_flag_validation_raises_value_error(tmp_path, monkeypatch):
+def test_disable_cuda_is_refused_at_parse_args():
+    """The reference falls back to the CPU (fumi/main.py:145-146); this engine has no CPU path and says so when the flags
+    are parsed, not from inside the first meta-step."""
+    from fumi_amd import engine, hip, main as cli
+    old = engine.set_engine(None)
+    try:
+        with pytest.raises(hip.FumiHipError, match="no CPU execution path"):
+            cli.parse_args(["--model", "maml", "--disable_cuda"])
+    finally:
+        engine.set_engine(old)
+
+
+def test_cli_flag_validation_raises_value_error(oracle_engine, tmp_path, monkeypatch):
     from fumi_amd import main as cli
     monkeypatch.chdir(tmp_path)
     args = cli.parse_args(["--disable_cuda", "--image_embedding_model", "resnet-34", "--log_dir", str(tmp_path)])

@@ -205,12 +205,13 @@ def test_zero_copy_sampler_trains_like_the_gathering_one():
 
 def test_gpu_sampler_refuses_underpopulated_classes():
     """torchmeta's ClassSplitter raises ValueError for a class with fewer than K + Q images; the resident sampler raises it in
-    its constructor (before touching the GPU) instead of wrapping indices and leaking support rows into the query set."""
+    its constructor (before touching the GPU) when asked to be strict; by default it warns and leaves such classes out (a
+    dataset the reference accepts still loads), never wrapping indices and leaking support rows into the query set."""
     from fumi_amd.dataset.gpu_sampler import GpuEpisodeSampler
     coi = np.concatenate([np.repeat(np.arange(6), 20), np.repeat([6], 5)])          # class 6 has 5 images, class 7 none
     images, text = torch.zeros(len(coi), 8), torch.zeros(8, 4)
     with pytest.raises(ValueError, match="fewer than num_shots"):
-        GpuEpisodeSampler(images, coi, text, num_ways=5, num_shots=5, num_shots_test=8, batch_size=2)
+        GpuEpisodeSampler(images, coi, text, num_ways=5, num_shots=5, num_shots_test=8, batch_size=2, skip_small_classes=False)
     with pytest.raises(ValueError, match="fewer than num_ways classes"):
         GpuEpisodeSampler(images, coi, text, num_ways=7, num_shots=5, num_shots_test=8, batch_size=2, skip_small_classes=True)
 
