@@ -303,6 +303,138 @@ def as_worded(dev, steps, warmup, cpu_budget_s, with_cpu):
     return out
 
 
+# ---- BASELINE.json configs[4]: FuMI 20-way 5-shot, ResNet-12 backbone in bf16, 5 inner steps, second-order outer gradients -----------
+C4 = dict(N=20, K=5, Q=15, C=3, H=84, E=768, Ht=256, T=5, B_per_gpu=64, alpha=0.01, channels=(64, 160, 320, 640))
+
+
+def resnet12_layer_flops():
+    """[(forward flops per image, has an input gradient)] of the 16 convolutions (3 x 3x3 + the 1x1 shortcut per block)."""
+    out, h, ci = [], C4["H"], C4["C"]
+    for l, c in enumerate(C4["channels"]):
+        for (cin, k) in ((ci, 9), (c, 9), (c, 9), (ci, 1)):
+            out.append((2.0 * h * h * k * cin * c, not (l == 0 and cin == ci)))
+        h //= 2; ci = c
+    return out
+
+
+def resnet12_flops_per_episode(T, S, Qn):
+    """Products per support image and inner step: forward 1, backward 2, tangent forward 2, tangent backward 4 = 9 (SURVEY.md 8d's
+    c_s); the two convolutions that read the image have no input gradient and no x' term: 4.  Query images: 3 (2)."""
+    f = resnet12_layer_flops()
+    full = sum(x for x, g in f if g); first = sum(x for x, g in f if not g)
+    return S * T * (9 * full + 4 * first) + Qn * (3 * full + 2 * first)
+
+
+def configs4_leg(dev, steps, warmup, with_cpu, episodes):
+    """One GPU's share of BASELINE.json configs[4] (512 / 8 = 64 episodes) through FUMI.evaluate(task='train') with
+    im_encoder='resnet12': class text rows (BERT width) -> hypernetwork -> [20, 641] heads; 5 inner steps over the 48 encoder
+    tensors + head on 100 support images; 300 query images; second-order meta-gradient; Adam step.  Episodes are processed in
+    chunks that fit the workspace budget (csrc/rn12.hip)."""
+    from fumi_amd import hip
+    from fumi_amd.models.fumi import FUMI
+    from fumi_amd.utils import utils as U
+    c = C4
+    B, S, Qn = episodes, c["N"] * c["K"], c["N"] * c["Q"]
+    torch.manual_seed(11)
+    model = FUMI(n_way=c["N"], im_encoder="resnet12", image_size=c["H"], image_channels=c["C"], text_encoder="BERT",
+                 text_emb_dim=c["E"], text_hid_dim=c["Ht"], dropout_rate=0.0, norm_hypernet=False).to(dev)
+    args = SimpleNamespace(device=dev, num_train_adapt_steps=c["T"], num_test_adapt_steps=c["T"], step_size=c["alpha"],
+                           first_order=False, optim="adam", lr=3e-5, weight_decay=5e-4, momentum=0.9, batch_size=B, num_ways=c["N"])
+    opt = U.init_optim(args, model)
+
+    def batch(seed, device, nb):
+        gg = torch.Generator(device=device).manual_seed(seed)
+        cg_ = torch.Generator().manual_seed(seed)
+        y_s = torch.stack([torch.arange(c["N"]).repeat_interleave(c["K"])[torch.randperm(S, generator=cg_)] for _ in range(nb)])
+        y_q = torch.stack([torch.arange(c["N"]).repeat_interleave(c["Q"])[torch.randperm(Qn, generator=cg_)] for _ in range(nb)])
+        cls = torch.randn(nb, c["N"], c["E"], generator=cg_)
+        text_s = torch.gather(cls, 1, y_s[..., None].expand(-1, -1, c["E"]))
+        text_q = torch.gather(cls, 1, y_q[..., None].expand(-1, -1, c["E"]))
+        x_s = torch.randn(nb, S, c["C"], c["H"], c["H"], device=device, generator=gg)
+        x_q = torch.randn(nb, Qn, c["C"], c["H"], c["H"], device=device, generator=gg)
+        to = lambda t: t.to(device)
+        return {'train': ([to(torch.arange(nb * S).view(nb, S)), to(text_s), x_s], to(y_s)),
+                'test': ([to(torch.arange(nb * Qn).view(nb, Qn)), to(text_q), x_q], to(y_q))}
+    bt = batch(4000, dev, B)
+    ws = hip.Workspace.get(dev)
+    for _ in range(warmup):
+        model.evaluate(args, bt, opt, "train")
+    hip.raise_on_status(ws.read_status())
+    ws.set_profiling(True, ["rn_conv", "rn_wgrad", "rn_ew"], every=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        last = model.evaluate(args, bt, opt, "train")
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    prof = ws.profile()
+    ws.set_profiling(False)
+    ms = el / steps * 1e3
+    f_ep = resnet12_flops_per_episode(c["T"], S, Qn)
+    lf = resnet12_layer_flops()
+    full = sum(x for x, g in lf if g); first = sum(x for x, g in lf if not g)
+    # the forward / input-gradient / tangent convolutions (rn_conv_kernel): 6 of a support step's 9 products, 2 of a query image's 3
+    conv_flops = B * (S * c["T"] * (6 * full + 2 * first) + Qn * (2 * full + first))
+    wgrad_flops = B * f_ep - conv_flops
+    out = {"workload": "FuMI 20-way 5-shot, 15 query/class, ResNet-12 (channels 64/160/320/640, 3 x conv3x3 . BN(batch stats) . "
+                       "LeakyReLU(0.1) + conv1x1 shortcut, maxpool2; global average pool -> 640) on 3x84x84 images in bf16 (fp32 "
+                       "accumulation, fp32 master weights), hypernetwork head [20,641] from 768-d class text rows, 5 inner steps "
+                       "over encoder + head, second-order meta-gradient + Adam step; BASELINE.json configs[4], one GPU's share "
+                       "(512 / 8 episodes) -- the reference has no ResNet-12: parity unpinned, oracle = oracle/resnet12_manual.py",
+           "value": round(B * steps / el, 3), "unit": "episodes/s", "ms_per_step": round(ms, 1), "steps": steps, "warmup": warmup,
+           "episodes_per_gpu": B, "dtype": "bf16", "data": "synthetic",
+           "tflop_per_episode_algorithmic": round(f_ep / 1e12, 3),
+           "step_tflops_algorithmic": round(B * f_ep / (ms * 1e-3) / 1e12, 1),
+           "final_loss": float(last[0]), "final_acc": float(last[1]), "workspace_GiB": round(ws.bytes() / 2 ** 30, 1)}
+    if "rn_conv" in prof:
+        tot, n = prof["rn_conv"]
+        per_step = tot / steps * 1e-3
+        ach = conv_flops / per_step / 1e12
+        # algorithmic HBM bytes of those launches: every source map read once and the output written once per product, bf16
+        h, ci, alg = c["H"], 16, 0.0
+        for l, ch in enumerate(c["channels"]):
+            px = (h + 2) ** 2 * 2.0
+            per_prod = [px * (ci + ch), px * 2 * ch, px * 2 * ch, px * (ci + ch)]          # c1, c2, c3, shortcut: input + output maps
+            nprod_s = [3 if l == 0 else 6, 6, 6, 3 if l == 0 else 6]                      # (tangent products read two sources: counted as products)
+            nprod_q = [1 if l == 0 else 2, 2, 2, 1 if l == 0 else 2]
+            alg += B * sum(pp * (S * c["T"] * ns + Qn * nq) for pp, ns, nq in zip(per_prod, nprod_s, nprod_q))
+            h //= 2; ci = ch
+        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None, "algorithmic_bytes": int(alg),
+                           "kernel": "rn_conv_kernel: forward / input-gradient convolutions and their tangent forms as implicit GEMMs "
+                                     "over shifted pixel slabs on v_mfma_f32_32x32x16_bf16 (csrc/rn12_conv.hip)",
+                           "flops_per_step": conv_flops, "ms_per_step": round(per_step * 1e3, 2), "launches_per_step": n // steps,
+                           "timed": "HIP events around every launch of the timed region"}
+        if "rn_wgrad" in prof:
+            wt = prof["rn_wgrad"][0] / steps * 1e-3
+            out["roofline_wgrad"] = {"bound": "mfma", "achieved": round(wgrad_flops / wt / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+                                     "unit": "TFLOP/s", "frac": round(wgrad_flops / wt / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                                     "kernel": "rn_wgrad_kernel (+ the reduction of its pixel-slab partial sums)",
+                                     "ms_per_step": round(wt * 1e3, 2)}
+        out["phase_ms_per_step"] = {k: round(v[0] / steps, 2) for k, v in prof.items()}
+    if with_cpu:
+        # bounded sample of the same workload on the host: one forward + first-order backward of one episode's 100 support images
+        # through oracle/resnet12_ref.py (autograd, fp32) = 300 of the episode's 5400 image-passes (S T 9 + Qn 3); extrapolated
+        from oracle import resnet12_ref as RR
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        theta = [p.detach().cpu().clone().requires_grad_(True) for p in model._theta()]
+        cb = batch(5000, torch.device("cpu"), 1)
+        x, y = cb['train'][0][2][0], cb['train'][1][0]
+        h0 = (torch.randn(c["N"], 641) * 0.05).requires_grad_(True)
+        t1 = time.perf_counter()
+        loss = torch.nn.functional.cross_entropy(RR.forward(x, theta, h0), y)
+        torch.autograd.grad(loss, theta + [h0])
+        el2 = time.perf_counter() - t1
+        units = S * c["T"] * 9 + Qn * 3
+        out["cpu_baseline"] = {"value": round(1.0 / (el2 * units / (3.0 * S)), 5), "unit": "episodes/s", "cores": torch.get_num_threads(),
+                               "kind": "port",
+                               "sample": f"one forward + first-order backward of one episode's {S} support images through "
+                                         f"oracle/resnet12_ref.py (eager PyTorch CPU, fp32 autograd): {el2:.1f} s for {3 * S} of the "
+                                         f"episode's {units} image-passes (S T 9 + Qn 3), extrapolated linearly"}
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start one fresh process per GPU through torch.distributed.run as a CHILD of
     this process (which has not touched the GPU and never will), let rank 0's JSON line through and hand back the child's exit
@@ -332,6 +464,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-as-worded", action="store_true", help="skip the Conv4-as-worded leg (runs at N = 1 only)")
     ap.add_argument("--as-worded-steps", type=int, default=10)
+    ap.add_argument("--no-configs4", action="store_true", help="skip the ResNet-12 / bf16 leg (BASELINE.json configs[4], N = 1 only)")
+    ap.add_argument("--configs4-episodes", type=int, default=C4["B_per_gpu"], help="episodes of the ResNet-12 leg (one GPU's share: 64)")
+    ap.add_argument("--configs4-steps", type=int, default=1)
     ap.add_argument("--no-phase-timing", action="store_true", help="do not record HIP events around the library's phases")
     ap.add_argument("--all-phases", action="store_true",
                     help="time every phase of the library (adds ~10 us of stream time per phase and step); default: only the "
@@ -465,6 +600,10 @@ def main():
             del batches
             torch.cuda.empty_cache()
             out["as_worded"] = as_worded(dev, a.as_worded_steps, 2, 20.0, not a.no_cpu_baseline)
+        if not a.no_configs4 and world == 1:
+            print("[bench] configs[4] (ResNet-12, bf16, 20-way, 5 inner steps) leg", file=sys.stderr, flush=True)
+            torch.cuda.empty_cache()
+            out["configs4"] = configs4_leg(dev, a.configs4_steps, 1, not a.no_cpu_baseline, a.configs4_episodes)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

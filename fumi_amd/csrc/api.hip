@@ -19,7 +19,7 @@ static hipEvent_t prof_event(fumi_ws* ws) {
 }
 
 ProfScope::ProfScope(fumi_ws* w, hipStream_t s, int phase) : ws(w), st(s), b(nullptr), on(w && ((w->profiling >> phase) & 1)) {
-    if (on && ws->prof_every > 1) on = (ws->prof_seen[phase & 15]++ % (unsigned)ws->prof_every) == 0;
+    if (on && ws->prof_every > 1) on = (ws->prof_seen[phase & 31]++ % (unsigned)ws->prof_every) == 0;
     if (!on) return;
     hipEvent_t a = prof_event(ws);
     b = prof_event(ws);
@@ -35,7 +35,9 @@ int ws_reserve(fumi_ws* ws, size_t bytes) {
     HIP_TRY(hipDeviceSynchronize());
     if (ws->base) HIP_TRY(hipFree(ws->base));
     ws->base = nullptr; ws->cap = 0;
-    size_t want = bytes + bytes / 4 + (1u << 20);
+    size_t head = bytes / 4;                                   // headroom, capped: ResNet-12 slabs are tens of GB
+    if (head > ((size_t)1 << 30)) head = (size_t)1 << 30;
+    size_t want = bytes + head + (1u << 20);
     hipError_t e = hipMalloc((void**)&ws->base, want);
     if (e != hipSuccess) { fumi_set_hip_error(e, "hipMalloc(workspace)"); ws->base = nullptr; return FUMI_ENOMEM; }
     ws->cap = want;
@@ -67,7 +69,7 @@ int fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out) {
     if (device < 0 || device >= ndev) return FUMI_EINVAL;
     HIP_TRY(hipSetDevice(device));
     fumi_ws* ws = new fumi_ws();
-    ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr; ws->hcnt = nullptr; ws->acnt = nullptr; ws->w0p = nullptr; ws->w0p_cap = 0; ws->pub_src = nullptr; ws->pub_dst = nullptr; ws->pub_n = 0; ws->pub_seq = 0;
+    ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr; ws->hcnt = nullptr; ws->acnt = nullptr; ws->w0p = nullptr; ws->w0p_cap = 0; ws->side_buf = nullptr; ws->side_cap = 0; ws->pub_src = nullptr; ws->pub_dst = nullptr; ws->pub_n = 0; ws->pub_seq = 0;
     ws->profiling = 0; ws->prof_every = 1; memset(ws->prof_seen, 0, sizeof(ws->prof_seen)); ws->recs = new std::vector<ProfRec>(); ws->pool = new std::vector<hipEvent_t>();
     ws->side = nullptr;
     for (auto& e : ws->ev) e = nullptr;
@@ -104,6 +106,7 @@ void fumi_hip_workspace_destroy(fumi_ws_t* ws) {
     if (ws->status) (void)hipFree(ws->status);
     if (ws->hcnt) (void)hipFree(ws->hcnt);
     if (ws->acnt) (void)hipFree(ws->acnt);
+    if (ws->side_buf) (void)hipFree(ws->side_buf);
     if (ws->w0p) (void)hipFree(ws->w0p);
     if (ws->status_host) (void)hipHostFree(ws->status_host);
     for (auto& r : *ws->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -151,7 +154,7 @@ int fumi_hip_get_profile(fumi_ws_t* ws, int phase, double* total_ms, int* count)
 
 const char* fumi_hip_phase_name(int phase) {
     static const char* names[FUMI_PH_COUNT] = {"class_text_select", "hyper_fwd", "enc_gemm_s", "enc_gemm_q", "xpanel_fwd",
-        "adapt", "query", "reverse", "reduce", "xpanel_bwd", "hyper_bwd", "am3_head", "conv_gemm", "conv_first", "conv_ew"};
+        "adapt", "query", "reverse", "reduce", "xpanel_bwd", "hyper_bwd", "am3_head", "conv_gemm", "conv_first", "conv_ew", "rn_conv", "rn_wgrad", "rn_ew"};
     return (phase >= 0 && phase < FUMI_PH_COUNT) ? names[phase] : "?";
 }
 

@@ -25,10 +25,11 @@ struct fumi_ws {
     const float* pub_src; float* pub_dst; int pub_n; unsigned long long pub_seq;   // deferred publication (api: publish_scalars_deferred)
     int* acnt;           // [FUMI_ACNT] arrival counters of the split adapt kernel (reset by the query kernel of the same step)
     int* hcnt;           // [FUMI_HCNT] arrival counters of hyper_fwd_split_kernel, zero between launches
+    float* side_buf; size_t side_cap;   // small allocation that survives slab rewinds (ResNet-12 chunk loop: heads of the whole meta-batch)
     unsigned short* w0p; size_t w0p_cap;   // the layer-0 weight as three bf16 planes in MFMA fragment order (xpanel.hip), own allocation
     int profiling;       // bit p: record HIP events around phase p (bench only)
     int prof_every;      // ... at every prof_every-th occurrence of the phase
-    unsigned prof_seen[16];
+    unsigned prof_seen[32];
     hipStream_t side;    // second stream: the text path (hypernetwork fwd / bwd) runs beside the two X-panel passes
     hipEvent_t ev[4];    // fork / join points (timing disabled)
     std::vector<ProfRec>* recs;

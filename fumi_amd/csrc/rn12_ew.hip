@@ -1,0 +1,590 @@
+// Element-wise passes of the bf16 ResNet-12 encoder (rn12.h): batch-statistic BN + LeakyReLU, the residual join + max-pool, their
+// first-order backward and the tangent (forward-over-reverse) forms of both -- formulas of oracle/resnet12_manual.py.  HBM-bound:
+// a thread owns 8 channels (16 bytes) of one padded pixel; per-(episode, channel) coefficients come from tables the coefficient
+// kernel builds from partial sums (all sums in fixed order, the final ones in double: no float atomics, bit-reproducible).
+#include "rn12.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct F8 { float v[8]; };
+
+__device__ __forceinline__ F8 unpack8(const u32x4& r) {
+    F8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o.v[2 * j] = __uint_as_float(r[j] << 16); o.v[2 * j + 1] = __uint_as_float(r[j] & 0xffff0000u); }
+    return o;
+}
+__device__ __forceinline__ u32x4 pack8(const F8& f) {
+    u32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = (unsigned)rn_f2bf(f.v[2 * j]) | ((unsigned)rn_f2bf(f.v[2 * j + 1]) << 16);
+    return r;
+}
+__device__ __forceinline__ F8 ldbf(const rbf16* p) { return unpack8(*(const u32x4*)p); }
+__device__ __forceinline__ F8 ldcf(const float* coef, int field, int C, int c) {
+    F8 o;
+    const f32x4 a = *(const f32x4*)(coef + (long)field * C + c), b = *(const f32x4*)(coef + (long)field * C + c + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o.v[j] = a[j]; o.v[4 + j] = b[j]; }
+    return o;
+}
+__device__ __forceinline__ float lmask(float v) { return v > 0.f ? 1.f : RN_SLOPE; }
+
+// pixel index within an episode -> interior flag (and padded coordinates)
+__device__ __forceinline__ bool interior_of(long p, const RnGeom& g, int& y, int& x) {
+    const unsigned q = (unsigned)(p % g.Pp);
+    y = q / (unsigned)g.Wp; x = q - y * g.Wp;
+    return y >= 1 && y <= g.H && x >= 1 && x <= g.W;
+}
+
+// ---- BN + LeakyReLU ----------------------------------------------------------------------------------------------------------------
+template <bool TAN>
+__global__ __launch_bounds__(256) void rn_act_kernel(RnMap m, const rbf16* u, const rbf16* ud, const float* coef, rbf16* out) {
+    const int b = blockIdx.y, nch = m.C >> 3;
+    const long npix = (long)m.M * m.g.Pp;
+    const long unit = (long)blockIdx.x * 256 + threadIdx.x;
+    if (unit >= npix * nch) return;
+    const long p = unit / nch; const int c = (int)(unit - p * nch) * 8;
+    const long off = ((long)b * npix + p) * m.C + c;
+    int y, x;
+    F8 o;
+    if (!interior_of(p, m.g, y, x)) {
+        *(u32x4*)(out + off) = (u32x4){0u, 0u, 0u, 0u};
+        return;
+    }
+    const float* cf = coef + (long)b * RCF_N * m.C;
+    const F8 uv = ldbf(u + off), A = ldcf(cf, RCF_A, m.C, c), C0 = ldcf(cf, RCF_C0, m.C, c);
+    if (!TAN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float v = A.v[j] * uv.v[j] + C0.v[j]; o.v[j] = v > 0.f ? v : RN_SLOPE * v; }
+    } else {
+        const F8 udv = ldbf(ud + off), MU = ldcf(cf, RCF_MU, m.C, c), R = ldcf(cf, RCF_R, m.C, c), TB = ldcf(cf, RCF_TB, m.C, c),
+                 TC = ldcf(cf, RCF_TC, m.C, c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = A.v[j] * uv.v[j] + C0.v[j];
+            const float xh = (uv.v[j] - MU.v[j]) * R.v[j];
+            o.v[j] = lmask(v) * (A.v[j] * udv.v[j] + TB.v[j] * xh + TC.v[j]);
+        }
+    }
+    *(u32x4*)(out + off) = pack8(o);
+}
+
+// partial sums over RB consecutive pixels per workgroup: thread (row group rg, chunk ch)
+template <bool TAN>
+__global__ __launch_bounds__(256) void rn_bwd_reduce_kernel(RnMap m, const rbf16* u, const rbf16* ud, const rbf16* da, const rbf16* dad,
+                                                            const float* coef, float* part, int RB) {
+    extern __shared__ float red[];                          // [nrg][K][C]
+    constexpr int K = TAN ? 3 : 2;
+    const int b = blockIdx.y, nch = m.C >> 3, nrg = 256 / nch;
+    const long npix = (long)m.M * m.g.Pp;
+    const int ch = threadIdx.x % nch, rg = threadIdx.x / nch, c = ch * 8;
+    float s[K][8];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[k][j] = 0.f;
+    if (rg < nrg) {
+        const float* cf = coef + (long)b * RCF_N * m.C;
+        const F8 A = ldcf(cf, RCF_A, m.C, c), C0 = ldcf(cf, RCF_C0, m.C, c), MU = ldcf(cf, RCF_MU, m.C, c), R = ldcf(cf, RCF_R, m.C, c);
+        F8 M1, M2;
+        if (TAN) { M1 = ldcf(cf, RCF_M1, m.C, c); M2 = ldcf(cf, RCF_M2, m.C, c); }
+        const long pbeg = (long)blockIdx.x * RB, pend = min(npix, pbeg + RB);
+        for (long p = pbeg + rg; p < pend; p += nrg) {
+            int y, x;
+            if (!interior_of(p, m.g, y, x)) continue;
+            const long off = ((long)b * npix + p) * m.C + c;
+            const F8 uv = ldbf(u + off), dav = ldbf(da + off);
+            F8 udv, dadv;
+            if (TAN) { udv = ldbf(ud + off); dadv = ldbf(dad + off); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = A.v[j] * uv.v[j] + C0.v[j], mk = lmask(v);
+                const float xh = (uv.v[j] - MU.v[j]) * R.v[j];
+                const float dv = dav.v[j] * mk;
+                if (!TAN) { s[0][j] += dv; s[1][j] += dv * xh; }
+                else {
+                    const float dvd = dadv.v[j] * mk;
+                    const float xhd = R.v[j] * (udv.v[j] - M1.v[j] - xh * M2.v[j]);
+                    s[0][j] += dvd; s[1][j] += dvd * xh; s[2][j] += dv * xhd;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[((long)rg * K + k) * m.C + c + j] = s[k][j];
+    }
+    __syncthreads();
+    float* dst = part + ((long)b * gridDim.x + blockIdx.x) * K * m.C;
+    for (int i = threadIdx.x; i < K * m.C; i += 256) {
+        float t = 0.f;
+        for (int g = 0; g < nrg; ++g) t += red[(long)g * K * m.C + i];
+        dst[i] = t;
+    }
+}
+
+template <bool TAN>
+__global__ __launch_bounds__(256) void rn_bwd_apply_kernel(RnMap m, const rbf16* u, const rbf16* ud, const rbf16* da, const rbf16* dad,
+                                                           const float* coef, rbf16* du) {
+    const int b = blockIdx.y, nch = m.C >> 3;
+    const long npix = (long)m.M * m.g.Pp;
+    const long unit = (long)blockIdx.x * 256 + threadIdx.x;
+    if (unit >= npix * nch) return;
+    const long p = unit / nch; const int c = (int)(unit - p * nch) * 8;
+    const long off = ((long)b * npix + p) * m.C + c;
+    int y, x;
+    if (!interior_of(p, m.g, y, x)) { *(u32x4*)(du + off) = (u32x4){0u, 0u, 0u, 0u}; return; }
+    const float* cf = coef + (long)b * RCF_N * m.C;
+    const F8 uv = ldbf(u + off), dav = ldbf(da + off);
+    const F8 A = ldcf(cf, RCF_A, m.C, c), C0 = ldcf(cf, RCF_C0, m.C, c), MU = ldcf(cf, RCF_MU, m.C, c), R = ldcf(cf, RCF_R, m.C, c),
+             D1 = ldcf(cf, RCF_D1, m.C, c), D2 = ldcf(cf, RCF_D2, m.C, c);
+    F8 o;
+    if (!TAN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = A.v[j] * uv.v[j] + C0.v[j];
+            const float xh = (uv.v[j] - MU.v[j]) * R.v[j];
+            o.v[j] = A.v[j] * (dav.v[j] * lmask(v) - D1.v[j] - xh * D2.v[j]);
+        }
+    } else {
+        const F8 udv = ldbf(ud + off), dadv = ldbf(dad + off);
+        const F8 M1 = ldcf(cf, RCF_M1, m.C, c), M2 = ldcf(cf, RCF_M2, m.C, c), K0 = ldcf(cf, RCF_K0, m.C, c),
+                 DD1 = ldcf(cf, RCF_DD1, m.C, c), E12 = ldcf(cf, RCF_E12, m.C, c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = A.v[j] * uv.v[j] + C0.v[j], mk = lmask(v);
+            const float xh = (uv.v[j] - MU.v[j]) * R.v[j];
+            const float xhd = R.v[j] * (udv.v[j] - M1.v[j] - xh * M2.v[j]);
+            const float dv = dav.v[j] * mk, dvd = dadv.v[j] * mk;
+            o.v[j] = K0.v[j] * (dv - D1.v[j] - xh * D2.v[j]) + A.v[j] * (dvd - DD1.v[j] - xhd * D2.v[j] - xh * E12.v[j]);
+        }
+    }
+    *(u32x4*)(du + off) = pack8(o);
+}
+
+// ---- residual join: s = BN3(u3) + BNs(us), o = maxpool2(lrelu(s)) ----------------------------------------------------------------------
+struct JoinCoef { F8 A3, C3, As, Cs; };
+__device__ __forceinline__ JoinCoef join_coef(const float* c3, const float* cs, int C, int c) {
+    JoinCoef k; k.A3 = ldcf(c3, RCF_A, C, c); k.C3 = ldcf(c3, RCF_C0, C, c); k.As = ldcf(cs, RCF_A, C, c); k.Cs = ldcf(cs, RCF_C0, C, c);
+    return k;
+}
+// s of the 2 x 2 window with top-left padded coordinates (y0, x0) of image `img`: sv[w][j]; returns per channel the FIRST arg-max of
+// lrelu(s) (monotone: the arg-max of s) in window order (dy, dx) row-major
+__device__ __forceinline__ void window_s(const RnJoin& J, const JoinCoef& k, long imgbase, int y0, int x0, int c, float sv[4][8], int arg[8]) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const long off = (imgbase + (long)(y0 + (w >> 1)) * J.m.g.Wp + x0 + (w & 1)) * J.m.C + c;
+        const F8 a = ldbf(J.u3 + off), s_ = ldbf(J.us + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sv[w][j] = (k.A3.v[j] * a.v[j] + k.C3.v[j]) + (k.As.v[j] * s_.v[j] + k.Cs.v[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int am = 0; float mx = sv[0][j];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) if (sv[w][j] > mx) { mx = sv[w][j]; am = w; }
+        arg[j] = am;
+    }
+}
+// tangent of s at one pixel
+__device__ __forceinline__ F8 s_tangent(const RnJoin& J, const float* c3, const float* cs, const JoinCoef& k, long off, int c) {
+    const int C = J.m.C;
+    const F8 u3 = ldbf(J.u3 + off), us = ldbf(J.us + off), u3d = ldbf(J.u3d + off), usd = ldbf(J.usd + off);
+    const F8 MU3 = ldcf(c3, RCF_MU, C, c), R3 = ldcf(c3, RCF_R, C, c), TB3 = ldcf(c3, RCF_TB, C, c), TC3 = ldcf(c3, RCF_TC, C, c);
+    const F8 MUs = ldcf(cs, RCF_MU, C, c), Rs = ldcf(cs, RCF_R, C, c), TBs = ldcf(cs, RCF_TB, C, c), TCs = ldcf(cs, RCF_TC, C, c);
+    F8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float xh3 = (u3.v[j] - MU3.v[j]) * R3.v[j], xhs = (us.v[j] - MUs.v[j]) * Rs.v[j];
+        o.v[j] = (k.A3.v[j] * u3d.v[j] + TB3.v[j] * xh3 + TC3.v[j]) + (k.As.v[j] * usd.v[j] + TBs.v[j] * xhs + TCs.v[j]);
+    }
+    return o;
+}
+
+template <bool TAN>
+__global__ __launch_bounds__(256) void rn_join_fwd_kernel(RnJoin J, rbf16* o) {
+    const int b = blockIdx.y, C = J.m.C, nch = C >> 3;
+    const long npo = (long)J.m.M * J.gn.Pp;                          // output pixels per episode (padded grid of the next block)
+    const long unit = (long)blockIdx.x * 256 + threadIdx.x;
+    if (unit >= npo * nch) return;
+    const long po = unit / nch; const int c = (int)(unit - po * nch) * 8;
+    const long ooff = ((long)b * npo + po) * C + c;
+    const long img = po / J.gn.Pp; const int q = (int)(po - img * J.gn.Pp);
+    const int yo = q / J.gn.Wp, xo = q - yo * J.gn.Wp;
+    if (yo < 1 || yo > J.Ho || xo < 1 || xo > J.Wo) { *(u32x4*)(o + ooff) = (u32x4){0u, 0u, 0u, 0u}; return; }
+    const float* c3 = J.coef3 + (long)b * RCF_N * C; const float* cs = J.coefs + (long)b * RCF_N * C;
+    const JoinCoef k = join_coef(c3, cs, C, c);
+    const long imgbase = ((long)b * J.m.M + img) * J.m.g.Pp;
+    const int y0 = 2 * (yo - 1) + 1, x0 = 2 * (xo - 1) + 1;
+    float sv[4][8]; int arg[8];
+    window_s(J, k, imgbase, y0, x0, c, sv, arg);
+    F8 r;
+    if (!TAN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float mx = sv[0][j];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) mx = sv[w][j] > mx ? sv[w][j] : mx;
+            r.v[j] = mx > 0.f ? mx : RN_SLOPE * mx;
+        }
+    } else {
+        F8 sd[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            sd[w] = s_tangent(J, c3, cs, k, (imgbase + (long)(y0 + (w >> 1)) * J.m.g.Wp + x0 + (w & 1)) * C + c, c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float sa = sv[0][j], da = sd[0].v[j];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) if (arg[j] == w) { sa = sv[w][j]; da = sd[w].v[j]; }
+            r.v[j] = lmask(sa) * da;
+        }
+    }
+    *(u32x4*)(o + ooff) = pack8(r);
+}
+
+// per conv-resolution pixel: ds (and ds') = the pooled gradient routed to the window's arg-max, times lrelu'(s)
+struct JoinPix { bool inside, covered; long off, doff; int sel[8]; float sself[8]; };
+__device__ __forceinline__ JoinPix join_pixel(const RnJoin& J, const JoinCoef& k, int b, long p, int c) {
+    JoinPix r; r.covered = false;
+    const long img = p / J.m.g.Pp; const int q = (int)(p - img * J.m.g.Pp);
+    const int y = q / J.m.g.Wp, x = q - y * J.m.g.Wp;
+    r.inside = y >= 1 && y <= J.m.g.H && x >= 1 && x <= J.m.g.W;
+    r.off = (((long)b * J.m.M + img) * J.m.g.Pp + q) * J.m.C + c;
+    if (!r.inside) return r;
+    const int wy = (y - 1) >> 1, wx = (x - 1) >> 1;
+    const F8 a = ldbf(J.u3 + r.off), s_ = ldbf(J.us + r.off);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { r.sself[j] = (k.A3.v[j] * a.v[j] + k.C3.v[j]) + (k.As.v[j] * s_.v[j] + k.Cs.v[j]); r.sel[j] = 0; }
+    if (wy >= J.Ho || wx >= J.Wo) return r;
+    r.covered = true;
+    float sv[4][8]; int arg[8];
+    window_s(J, k, ((long)b * J.m.M + img) * J.m.g.Pp, 2 * wy + 1, 2 * wx + 1, c, sv, arg);
+    const int me = ((y - 1) & 1) * 2 + ((x - 1) & 1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.sel[j] = arg[j] == me;
+    r.doff = (((long)b * J.m.M + img) * J.gn.Pp + (long)(wy + 1) * J.gn.Wp + wx + 1) * J.m.C + c;
+    return r;
+}
+
+template <bool TAN>
+__global__ __launch_bounds__(256) void rn_join_reduce_kernel(RnJoin J, const rbf16* dout, const rbf16* doutd, float* part, int RB) {
+    extern __shared__ float red[];
+    constexpr int K = TAN ? 5 : 3;
+    const int b = blockIdx.y, C = J.m.C, nch = C >> 3, nrg = 256 / nch;
+    const long npix = (long)J.m.M * J.m.g.Pp;
+    const int ch = threadIdx.x % nch, rg = threadIdx.x / nch, c = ch * 8;
+    float s[K][8];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[k][j] = 0.f;
+    if (rg < nrg) {
+        const float* c3 = J.coef3 + (long)b * RCF_N * C; const float* cs = J.coefs + (long)b * RCF_N * C;
+        const JoinCoef k = join_coef(c3, cs, C, c);
+        const F8 MU3 = ldcf(c3, RCF_MU, C, c), R3 = ldcf(c3, RCF_R, C, c), MUs = ldcf(cs, RCF_MU, C, c), Rs = ldcf(cs, RCF_R, C, c);
+        F8 M13, M23, M1s, M2s;
+        if (TAN) { M13 = ldcf(c3, RCF_M1, C, c); M23 = ldcf(c3, RCF_M2, C, c); M1s = ldcf(cs, RCF_M1, C, c); M2s = ldcf(cs, RCF_M2, C, c); }
+        const long pbeg = (long)blockIdx.x * RB, pend = min(npix, pbeg + RB);
+        for (long p = pbeg + rg; p < pend; p += nrg) {
+            const JoinPix px = join_pixel(J, k, b, p, c);
+            if (!px.inside || !px.covered) continue;           // (an uncovered interior pixel has ds = 0: contributes nothing)
+            const F8 dov = ldbf(dout + px.doff), u3 = ldbf(J.u3 + px.off), us = ldbf(J.us + px.off);
+            F8 dodv, u3d, usd;
+            if (TAN) { dodv = ldbf(doutd + px.doff); u3d = ldbf(J.u3d + px.off); usd = ldbf(J.usd + px.off); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float mk = px.sel[j] ? lmask(px.sself[j]) : 0.f;
+                const float ds = dov.v[j] * mk;
+                const float xh3 = (u3.v[j] - MU3.v[j]) * R3.v[j], xhs = (us.v[j] - MUs.v[j]) * Rs.v[j];
+                if (!TAN) { s[0][j] += ds; s[1][j] += ds * xh3; s[2][j] += ds * xhs; }
+                else {
+                    const float dsd = dodv.v[j] * mk;
+                    const float xh3d = R3.v[j] * (u3d.v[j] - M13.v[j] - xh3 * M23.v[j]);
+                    const float xhsd = Rs.v[j] * (usd.v[j] - M1s.v[j] - xhs * M2s.v[j]);
+                    s[0][j] += dsd; s[1][j] += dsd * xh3; s[2][j] += ds * xh3d; s[3][j] += dsd * xhs; s[4][j] += ds * xhsd;
+                }
+            }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < K; ++k2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[((long)rg * K + k2) * C + c + j] = s[k2][j];
+    }
+    __syncthreads();
+    float* dst = part + ((long)b * gridDim.x + blockIdx.x) * K * C;
+    for (int i = threadIdx.x; i < K * C; i += 256) {
+        float t = 0.f;
+        for (int g = 0; g < nrg; ++g) t += red[(long)g * K * C + i];
+        dst[i] = t;
+    }
+}
+
+template <bool TAN>
+__global__ __launch_bounds__(256) void rn_join_apply_kernel(RnJoin J, const rbf16* dout, const rbf16* doutd, rbf16* du3, rbf16* dus) {
+    const int b = blockIdx.y, C = J.m.C, nch = C >> 3;
+    const long npix = (long)J.m.M * J.m.g.Pp;
+    const long unit = (long)blockIdx.x * 256 + threadIdx.x;
+    if (unit >= npix * nch) return;
+    const long p = unit / nch; const int c = (int)(unit - p * nch) * 8;
+    const float* c3 = J.coef3 + (long)b * RCF_N * C; const float* cs = J.coefs + (long)b * RCF_N * C;
+    const JoinCoef k = join_coef(c3, cs, C, c);
+    const JoinPix px = join_pixel(J, k, b, p, c);
+    if (!px.inside) {
+        *(u32x4*)(du3 + px.off) = (u32x4){0u, 0u, 0u, 0u}; *(u32x4*)(dus + px.off) = (u32x4){0u, 0u, 0u, 0u};
+        return;
+    }
+    F8 dov, dodv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dov.v[j] = 0.f; dodv.v[j] = 0.f; }
+    if (px.covered) { dov = ldbf(dout + px.doff); if (TAN) dodv = ldbf(doutd + px.doff); }
+    const F8 u3 = ldbf(J.u3 + px.off), us = ldbf(J.us + px.off);
+    const F8 MU3 = ldcf(c3, RCF_MU, C, c), R3 = ldcf(c3, RCF_R, C, c), MUs = ldcf(cs, RCF_MU, C, c), Rs = ldcf(cs, RCF_R, C, c);
+    const F8 D13 = ldcf(c3, RCF_D1, C, c), D23 = ldcf(c3, RCF_D2, C, c), D1s = ldcf(cs, RCF_D1, C, c), D2s = ldcf(cs, RCF_D2, C, c);
+    F8 o3, os;
+    if (!TAN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float ds = px.sel[j] ? dov.v[j] * lmask(px.sself[j]) : 0.f;
+            const float xh3 = (u3.v[j] - MU3.v[j]) * R3.v[j], xhs = (us.v[j] - MUs.v[j]) * Rs.v[j];
+            o3.v[j] = k.A3.v[j] * (ds - D13.v[j] - xh3 * D23.v[j]);
+            os.v[j] = k.As.v[j] * (ds - D1s.v[j] - xhs * D2s.v[j]);
+        }
+    } else {
+        const F8 u3d = ldbf(J.u3d + px.off), usd = ldbf(J.usd + px.off);
+        const F8 M13 = ldcf(c3, RCF_M1, C, c), M23 = ldcf(c3, RCF_M2, C, c), M1s = ldcf(cs, RCF_M1, C, c), M2s = ldcf(cs, RCF_M2, C, c);
+        const F8 K03 = ldcf(c3, RCF_K0, C, c), DD13 = ldcf(c3, RCF_DD1, C, c), E3 = ldcf(c3, RCF_E12, C, c);
+        const F8 K0s = ldcf(cs, RCF_K0, C, c), DD1s = ldcf(cs, RCF_DD1, C, c), Es = ldcf(cs, RCF_E12, C, c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float mk = px.sel[j] ? lmask(px.sself[j]) : 0.f;
+            const float ds = dov.v[j] * mk, dsd = dodv.v[j] * mk;
+            const float xh3 = (u3.v[j] - MU3.v[j]) * R3.v[j], xhs = (us.v[j] - MUs.v[j]) * Rs.v[j];
+            const float xh3d = R3.v[j] * (u3d.v[j] - M13.v[j] - xh3 * M23.v[j]);
+            const float xhsd = Rs.v[j] * (usd.v[j] - M1s.v[j] - xhs * M2s.v[j]);
+            o3.v[j] = K03.v[j] * (ds - D13.v[j] - xh3 * D23.v[j]) + k.A3.v[j] * (dsd - DD13.v[j] - xh3d * D23.v[j] - xh3 * E3.v[j]);
+            os.v[j] = K0s.v[j] * (ds - D1s.v[j] - xhs * D2s.v[j]) + k.As.v[j] * (dsd - DD1s.v[j] - xhsd * D2s.v[j] - xhs * Es.v[j]);
+        }
+    }
+    *(u32x4*)(du3 + px.off) = pack8(o3);
+    *(u32x4*)(dus + px.off) = pack8(os);
+}
+
+// ---- coefficients from partial sums ----------------------------------------------------------------------------------------------
+// first stage for long lists of partials (a conv at 84 x 84 leaves one per 128-pixel tile: 17 000 per episode for 300 query images):
+// a workgroup adds PR_GRP consecutive slabs [K][C] in fixed order -> [B][ceil(nt / PR_GRP)][K][C]
+constexpr int PR_GRP = 64;
+__global__ __launch_bounds__(256) void rn_partial_reduce_kernel(int nt, int KC, const float* part, float* out) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.z, cl = threadIdx.x & 63, g4 = threadIdx.x >> 6, i = blockIdx.y * 64 + cl;
+    const int t0 = blockIdx.x * PR_GRP, t1 = min(nt, t0 + PR_GRP);
+    float s = 0.f;
+    if (i < KC) {
+        const float* base = part + (long)b * nt * KC + i;
+        for (int t = t0 + g4; t < t1; t += 4) s += base[(long)t * KC];
+    }
+    red[g4][cl] = s;
+    __syncthreads();
+    if (g4 == 0 && i < KC) out[((long)b * gridDim.x + blockIdx.x) * KC + i] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+__global__ __launch_bounds__(256) void rn_coef_kernel(RnCoefArgs a) {
+    __shared__ double red[4][3][64];
+    const int b = blockIdx.y, cl = threadIdx.x & 63, g4 = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const bool ok = c < a.C;
+    double s[3] = {0.0, 0.0, 0.0};
+    const int ks[3] = {a.k0, a.k1, a.k2};
+    const int nk = a.mode == RCM_TBWD ? 3 : 2;
+    if (ok) {
+        const float* base = a.part + (long)b * a.nt * a.K * a.C + c;
+        for (int t = g4; t < a.nt; t += 4)
+            for (int k = 0; k < nk; ++k) s[k] += (double)base[((long)t * a.K + ks[k]) * a.C];
+    }
+    for (int k = 0; k < 3; ++k) red[g4][k][cl] = s[k];
+    __syncthreads();
+    if (g4 || !ok) return;
+    for (int k = 0; k < 3; ++k) s[k] = red[0][k][cl] + red[1][k][cl] + red[2][k][cl] + red[3][k][cl];
+    float* cf = a.coef + (long)b * RCF_N * a.C + c;
+    const double n = a.n;
+    if (a.mode == RCM_FWD) {
+        const double mu = s[0] / n;
+        double var = s[1] / n - mu * mu;
+        var = var > 0.0 ? var : 0.0;
+        const double r = 1.0 / sqrt(var + (double)RN_EPS);
+        const double A = (double)a.g[(long)b * a.pstride + c] * r;
+        cf[RCF_MU * a.C] = (float)mu; cf[RCF_R * a.C] = (float)r; cf[RCF_A * a.C] = (float)A;
+        cf[RCF_C0 * a.C] = (float)((double)a.beta[(long)b * a.pstride + c] - mu * A);
+    } else if (a.mode == RCM_BWD) {
+        cf[RCF_D1 * a.C] = (float)(s[0] / n); cf[RCF_D2 * a.C] = (float)(s[1] / n);
+        a.dbeta[(long)b * a.gstride + c] = (float)s[0];
+        a.dg[(long)b * a.gstride + c] = (float)s[1];
+    } else if (a.mode == RCM_TFWD) {
+        const double mu = cf[RCF_MU * a.C], r = cf[RCF_R * a.C], A = cf[RCF_A * a.C];
+        const double m1 = s[0] / n, m2 = r * (s[1] - mu * s[0]) / n;
+        cf[RCF_M1 * a.C] = (float)m1; cf[RCF_M2 * a.C] = (float)m2;
+        cf[RCF_TB * a.C] = (float)((double)a.gd[(long)b * a.dstride + c] - A * m2);
+        cf[RCF_TC * a.C] = (float)((double)a.betad[(long)b * a.dstride + c] - A * m1);
+    } else {
+        const double r = cf[RCF_R * a.C], A = cf[RCF_A * a.C], m2 = cf[RCF_M2 * a.C];
+        cf[RCF_DD1 * a.C] = (float)(s[0] / n);
+        cf[RCF_E12 * a.C] = (float)((s[1] + s[2]) / n);
+        cf[RCF_K0 * a.C] = (float)((double)a.gd[(long)b * a.dstride + c] * r - A * r * m2);
+        a.dbeta[(long)b * a.gstride + c] = (float)s[0];
+        a.dg[(long)b * a.gstride + c] = (float)(s[1] + s[2]);
+    }
+}
+
+// ---- global average pool ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rn_avgpool_kernel(int C, RnGeom g, const rbf16* o, float* f) {
+    const long img = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int y = 1; y <= g.H; ++y)
+        for (int x = 1; x <= g.W; ++x) s += rn_bf2f(o[(img * g.Pp + y * g.Wp + x) * C + c]);
+    f[img * C + c] = s / (float)(g.H * g.W);
+}
+__global__ __launch_bounds__(256) void rn_avgpool_bwd_kernel(int C, RnGeom g, const float* df, rbf16* dout) {
+    const long img = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)g.Pp * C) return;
+    const int q = (int)(i / C), c = (int)(i - (long)q * C);
+    const int y = q / g.Wp, x = q - y * g.Wp;
+    const bool in = y >= 1 && y <= g.H && x >= 1 && x <= g.W;
+    dout[img * g.Pp * C + i] = in ? rn_f2bf(df[img * C + c] / (float)(g.H * g.W)) : (rbf16)0;
+}
+
+__global__ __launch_bounds__(256) void rn_img_prep_kernel(long BM, int Cin, RnGeom g, const float* img, rbf16* out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;             // one padded pixel
+    if (i >= BM * g.Pp) return;
+    const long im = i / g.Pp; const int q = (int)(i - im * g.Pp);
+    const int y = q / g.Wp, x = q - y * g.Wp;
+    F8 lo, hi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { lo.v[j] = 0.f; hi.v[j] = 0.f; }
+    if (y >= 1 && y <= g.H && x >= 1 && x <= g.W)
+        for (int c = 0; c < Cin && c < 8; ++c) lo.v[c] = img[((im * Cin + c) * g.H + (y - 1)) * g.W + (x - 1)];
+    *(u32x4*)(out + i * 16) = pack8(lo);
+    *(u32x4*)(out + i * 16 + 8) = pack8(hi);
+}
+
+}  // namespace
+size_t rn_coef_scratch_floats(int B, int nt, int K, int C) { return (size_t)B * ((nt + PR_GRP - 1) / PR_GRP) * K * C; }
+namespace {
+inline int red_rb(const RnMap& m) {
+    const long npix = (long)m.M * m.g.Pp;
+    long rb = npix * m.B / 2048;
+    rb = rb < 64 ? 64 : (rb > 1024 ? 1024 : rb);
+    return (int)rb;
+}
+
+}  // namespace
+
+int launch_rn_coef(hipStream_t st, const RnCoefArgs& a0, float* scratch) {
+    RnCoefArgs a = a0;
+    if (a.B < 1 || a.C < 8 || a.nt < 1) return FUMI_EINVAL;
+    if (a.nt > 2 * PR_GRP && scratch) {
+        const int nt2 = (a.nt + PR_GRP - 1) / PR_GRP, KC = a.K * a.C;
+        hipLaunchKernelGGL(rn_partial_reduce_kernel, dim3(nt2, (KC + 63) / 64, a.B), dim3(256), 0, st, a.nt, KC, a.part, scratch);
+        LAUNCH_CHECK();
+        a.part = scratch; a.nt = nt2;
+    }
+    hipLaunchKernelGGL(rn_coef_kernel, dim3((a.C + 63) / 64, a.B), dim3(256), 0, st, a);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+static inline dim3 unit_grid(const RnMap& m, long npix) { return dim3((unsigned)((npix * (m.C >> 3) + 255) / 256), m.B); }
+
+int launch_rn_act(hipStream_t st, const RnMap& m, const rbf16* u, const rbf16* ud, const float* coef, rbf16* out) {
+    const long npix = (long)m.M * m.g.Pp;
+    if (ud) hipLaunchKernelGGL(rn_act_kernel<true>, unit_grid(m, npix), dim3(256), 0, st, m, u, ud, coef, out);
+    else hipLaunchKernelGGL(rn_act_kernel<false>, unit_grid(m, npix), dim3(256), 0, st, m, u, ud, coef, out);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+int rn_red_nt(const RnMap& m) {
+    const long npix = (long)m.M * m.g.Pp;
+    const int rb = red_rb(m);
+    return (int)((npix + rb - 1) / rb);
+}
+
+int launch_rn_bwd_reduce(hipStream_t st, const RnMap& m, const rbf16* u, const rbf16* ud, const rbf16* da, const rbf16* dad,
+                         const float* coef, float* part, int tangent) {
+    if ((m.C >> 3) > 256) return FUMI_ENOTSUP;
+    const int nrg = 256 / (m.C >> 3), K = tangent ? 3 : 2;
+    const size_t lds = (size_t)nrg * K * m.C * 4;
+    const dim3 grid(rn_red_nt(m), m.B);
+    if (tangent) {
+        FUMI_SET_DYN_LDS(rn_bwd_reduce_kernel<true>, lds);
+        hipLaunchKernelGGL(rn_bwd_reduce_kernel<true>, grid, dim3(256), lds, st, m, u, ud, da, dad, coef, part, red_rb(m));
+    } else {
+        FUMI_SET_DYN_LDS(rn_bwd_reduce_kernel<false>, lds);
+        hipLaunchKernelGGL(rn_bwd_reduce_kernel<false>, grid, dim3(256), lds, st, m, u, ud, da, dad, coef, part, red_rb(m));
+    }
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+int launch_rn_bwd_apply(hipStream_t st, const RnMap& m, const rbf16* u, const rbf16* ud, const rbf16* da, const rbf16* dad,
+                        const float* coef, rbf16* du, int tangent) {
+    const long npix = (long)m.M * m.g.Pp;
+    if (tangent) hipLaunchKernelGGL(rn_bwd_apply_kernel<true>, unit_grid(m, npix), dim3(256), 0, st, m, u, ud, da, dad, coef, du);
+    else hipLaunchKernelGGL(rn_bwd_apply_kernel<false>, unit_grid(m, npix), dim3(256), 0, st, m, u, ud, da, dad, coef, du);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+int launch_rn_join_fwd(hipStream_t st, const RnJoin& j, rbf16* o, int tangent) {
+    const long npo = (long)j.m.M * j.gn.Pp;
+    if (tangent) hipLaunchKernelGGL(rn_join_fwd_kernel<true>, unit_grid(j.m, npo), dim3(256), 0, st, j, o);
+    else hipLaunchKernelGGL(rn_join_fwd_kernel<false>, unit_grid(j.m, npo), dim3(256), 0, st, j, o);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+int launch_rn_join_reduce(hipStream_t st, const RnJoin& j, const rbf16* dout, const rbf16* doutd, float* part, int tangent) {
+    if ((j.m.C >> 3) > 256) return FUMI_ENOTSUP;
+    const int nrg = 256 / (j.m.C >> 3), K = tangent ? 5 : 3;
+    const size_t lds = (size_t)nrg * K * j.m.C * 4;
+    const dim3 grid(rn_red_nt(j.m), j.m.B);
+    if (tangent) {
+        FUMI_SET_DYN_LDS(rn_join_reduce_kernel<true>, lds);
+        hipLaunchKernelGGL(rn_join_reduce_kernel<true>, grid, dim3(256), lds, st, j, dout, doutd, part, red_rb(j.m));
+    } else {
+        FUMI_SET_DYN_LDS(rn_join_reduce_kernel<false>, lds);
+        hipLaunchKernelGGL(rn_join_reduce_kernel<false>, grid, dim3(256), lds, st, j, dout, doutd, part, red_rb(j.m));
+    }
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+int launch_rn_join_apply(hipStream_t st, const RnJoin& j, const rbf16* dout, const rbf16* doutd, rbf16* du3, rbf16* dus, int tangent) {
+    const long npix = (long)j.m.M * j.m.g.Pp;
+    if (tangent) hipLaunchKernelGGL(rn_join_apply_kernel<true>, unit_grid(j.m, npix), dim3(256), 0, st, j, dout, doutd, du3, dus);
+    else hipLaunchKernelGGL(rn_join_apply_kernel<false>, unit_grid(j.m, npix), dim3(256), 0, st, j, dout, doutd, du3, dus);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+int launch_rn_avgpool(hipStream_t st, int BM, int C, const RnGeom& g, const rbf16* o, float* f) {
+    hipLaunchKernelGGL(rn_avgpool_kernel, dim3((C + 255) / 256, BM), dim3(256), 0, st, C, g, o, f);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+int launch_rn_avgpool_bwd(hipStream_t st, int BM, int C, const RnGeom& g, const float* df, rbf16* dout) {
+    hipLaunchKernelGGL(rn_avgpool_bwd_kernel, dim3((unsigned)(((long)g.Pp * C + 255) / 256), BM), dim3(256), 0, st, C, g, df, dout);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+int launch_rn_img_prep(hipStream_t st, long BM, int Cin, const RnGeom& g, const float* img, rbf16* out) {
+    if (Cin < 1 || Cin > 8) return FUMI_EINVAL;
+    hipLaunchKernelGGL(rn_img_prep_kernel, dim3((unsigned)((BM * g.Pp + 255) / 256)), dim3(256), 0, st, BM, Cin, g, img, out);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}

@@ -65,7 +65,7 @@ def get_synthetic(args):
         tokens = (V, L, 0)
         dictionary = {"PAD": 0}
         dictionary.update({f"tok{i}": i for i in range(1, V)})
-    shape = (args.image_channels, args.image_size, args.image_size) if getattr(args, "im_encoder", "") == "conv4" else None
+    shape = (args.image_channels, args.image_size, args.image_size) if getattr(args, "im_encoder", "") in ("conv4", "resnet12") else None
     mk = lambda split, q: SyntheticEpisodes(args.synthetic_classes, args.im_emb_dim, args.text_emb_dim, args.num_ways,
                                             args.num_shots, q, args.batch_size, args.seed, split, tokens, image_shape=shape)
     q_eval = int(100 / args.num_ways)                      # data.py:163-166,180-183

@@ -60,6 +60,21 @@ class HipEngine:
         return hip.maml_conv4_step(self._ws(x_s), x_s, y_s, x_q, y_q, params, T, alpha, first_order, need_grad=need_grad,
                                    grad_scale=grad_scale, g_params=g_params, stats=stats)
 
+    def fumi_resnet12_step(self, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head, need_grad, grad_scale,
+                           g_theta=None, g_phi=None, cls_text=None, stats=None):
+        """FuMI with the bf16 ResNet-12 encoder at the im_net seam (BASELINE.json configs[4])."""
+        return hip.fumi_resnet12_step(self._ws(x_s), n_way, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head, cls_text=cls_text,
+                                      text_s=text_s, need_grad=need_grad, grad_scale=grad_scale, g_theta=g_theta, g_phi=g_phi,
+                                      stats=stats)
+
+    def maml_resnet12_step(self, x_s, y_s, x_q, y_q, params, T, alpha, first_order, need_grad, grad_scale, g_params=None,
+                           stats=None):
+        return hip.maml_resnet12_step(self._ws(x_s), x_s, y_s, x_q, y_q, params, T, alpha, first_order, need_grad=need_grad,
+                                      grad_scale=grad_scale, g_params=g_params, stats=stats)
+
+    def resnet12_features(self, x, theta):
+        return hip.resnet12_features(self._ws(x), x, theta)
+
     def conv4_features(self, x, theta):
         return hip.conv4_features(self._ws(x), x, theta)
 

@@ -28,12 +28,14 @@ SYMBOLS = [
     "fumi_hip_publish_scalars_deferred", "fumi_hip_publish_flush", "fumi_hip_am3_metrics",
     "fumi_hip_conv4_feature_dim", "fumi_hip_fumi_conv4_step", "fumi_hip_maml_conv4_step", "fumi_hip_conv4_probe", "fumi_hip_conv4_features", "fumi_hip_conv4_set_option",
     "fumi_hip_conv4_encode", "fumi_hip_conv4_encode_bwd", "fumi_hip_am3_step_dx",
+    "fumi_hip_resnet12_set_budget", "fumi_hip_fumi_resnet12_step", "fumi_hip_maml_resnet12_step", "fumi_hip_resnet12_features",
+    "fumi_hip_rn12_conv", "fumi_hip_rn12_wgrad",
     "fumi_hip_conv3x3_fwd", "fumi_hip_conv3x3_bwd_data", "fumi_hip_conv3x3_bwd_weight",
     "fumi_hip_sgd_axpy", "fumi_hip_ce_fwd_bwd", "fumi_hip_proto_reduce", "fumi_hip_clip_step", "fumi_hip_lstm_bidir",
 ]
 
 ST_LABEL_RANGE, ST_CLASS_MISSING, ST_SYNC_TIMEOUT = 1, 2, 4
-N_PHASES = 15
+N_PHASES = 18
 
 _lib = None
 _lock = threading.Lock()
@@ -150,6 +152,17 @@ def lib():
             [c_void_p, c_void_p] + [c_int] * 8 + [c_int, c_float, c_int, c_int, c_float]
             + [c_void_p] * 4 + [PP] + [c_void_p] * 6 + [PP])
         L.fumi_hip_conv4_set_option.argtypes = [c_int, c_int]
+        PI = POINTER(c_int)
+        L.fumi_hip_resnet12_set_budget.argtypes = [ctypes.c_double]
+        L.fumi_hip_fumi_resnet12_step.argtypes = (
+            [c_void_p, c_void_p] + [c_int] * 8 + [PI, c_int, c_int] + [c_int, c_float, c_int, c_int, c_float, c_int]
+            + [c_void_p] * 6 + [PP, PP] + [c_void_p] * 6 + [PP, PP])
+        L.fumi_hip_maml_resnet12_step.argtypes = (
+            [c_void_p, c_void_p] + [c_int] * 8 + [PI] + [c_int, c_float, c_int, c_int, c_float, c_int]
+            + [c_void_p] * 4 + [PP] + [c_void_p] * 6 + [PP])
+        L.fumi_hip_resnet12_features.argtypes = [c_void_p, c_void_p] + [c_int] * 6 + [PI, c_void_p, PP, c_void_p]
+        L.fumi_hip_rn12_conv.argtypes = [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p] * 4
+        L.fumi_hip_rn12_wgrad.argtypes = [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p] * 3
         L.fumi_hip_conv4_features.argtypes = [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, PP, c_void_p]
         L.fumi_hip_conv4_encode.argtypes = [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p, PP, c_void_p, c_void_p, c_int]
         L.fumi_hip_conv4_encode_bwd.argtypes = [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p] * 4 + [c_float, PP]
@@ -802,6 +815,132 @@ def maml_conv4_step(ws, x_s, y_s, x_q, y_q, params, T, alpha, first_order=False,
         _f32(stats, "stats") if stats is not None else None, _parr(g_params, "g_params") if need_grad else None)
     _check(rc, "fumi_hip_maml_conv4_step")
     return dict(logits=logits, preds=preds, preds_f=preds_f, loss_b=loss_b, acc_b=acc_b, g_params=g_params, stats=stats)
+
+
+# ---- ResNet-12 (bf16) -----------------------------------------------------------------------------------------------
+def _resnet12_shapes(x_s, y_s, x_q, y_q, theta):
+    if x_s.dim() != 5 or x_q.dim() != 5:
+        raise FumiHipError("resnet12: images must be [B, rows, Cin, H, W]")
+    B, S, Cin, H, W = x_s.shape
+    Qn = x_q.shape[1]
+    if len(theta) % 12 or not theta:
+        raise FumiHipError("resnet12: theta must hold 12 tensors per block (W1,g1,b1, W2,g2,b2, W3,g3,b3, Ws,gs,bs)")
+    nblk = len(theta) // 12
+    _shape(x_q, (B, Qn, Cin, H, W), "x_q"); _shape(y_s, (B, S), "y_s"); _shape(y_q, (B, Qn), "y_q")
+    channels, ci = [], Cin
+    for l in range(nblk):
+        c = int(theta[12 * l].shape[0])
+        if c % 32:
+            raise FumiHipError("resnet12: channel counts must be multiples of 32")
+        for k, (cin, ks) in enumerate(((ci, 3), (c, 3), (c, 3), (ci, 1))):
+            _shape(theta[12 * l + 3 * k], (c, cin, ks, ks), f"theta[{12 * l + 3 * k}]")
+            _shape(theta[12 * l + 3 * k + 1], (c,), f"theta[{12 * l + 3 * k + 1}]")
+            _shape(theta[12 * l + 3 * k + 2], (c,), f"theta[{12 * l + 3 * k + 2}]")
+        channels.append(c); ci = c
+    if min(H, W) >> nblk < 1:
+        raise FumiHipError(f"resnet12: {H}x{W} images are too small for {nblk} blocks")
+    return B, S, Qn, Cin, H, W, nblk, channels
+
+
+def _ci(v):
+    return (c_int * len(v))(*[int(x) for x in v])
+
+
+def resnet12_set_budget(gigabytes):
+    """Workspace budget (GB) from which the episode chunk of the ResNet-12 steps is derived (0: default 200)."""
+    _check(lib().fumi_hip_resnet12_set_budget(float(gigabytes)), "fumi_hip_resnet12_set_budget")
+
+
+def fumi_resnet12_step(ws, n_way, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head, *, cls_text=None, text_s=None,
+                       need_grad=True, grad_scale=None, g_theta=None, g_phi=None, stats=None, chunk=0):
+    """FuMI meta-step with the bf16 ResNet-12 encoder (fumi/models/fumi.py:146-192 with im_net = ResNet-12)."""
+    dev = _dev(x_s)
+    B, S, Qn, Cin, H, W, nblk, channels = _resnet12_shapes(x_s, y_s, x_q, y_q, theta)
+    N, F = int(n_way), channels[-1]
+    Ht, Dt = int(phi[0].shape[0]), int(phi[0].shape[1])
+    _shape(phi[1], (Ht,), "phi[1]"); _shape(phi[2], (F + 1, Ht), "phi[2]"); _shape(phi[3], (F + 1,), "phi[3]")
+    if cls_text is not None:
+        _shape(cls_text, (B, N, Dt), "cls_text")
+    else:
+        _shape(text_s, (B, S, Dt), "text_s")
+    logits, preds, preds_f, loss_b, acc_b = _step_outputs(dev, B, Qn, N)
+    if need_grad:
+        g_theta = [torch.empty_like(t) for t in theta] if g_theta is None else g_theta
+        g_phi = [torch.empty_like(t) for t in phi] if g_phi is None else g_phi
+    rc = lib().fumi_hip_fumi_resnet12_step(
+        ws.handle, _stream(dev), B, N, S, Qn, Cin, H, W, nblk, _ci(channels), Dt, Ht, int(T), float(alpha), int(bool(tanh_head)),
+        int(bool(need_grad)), float(1.0 / B if grad_scale is None else grad_scale), int(chunk),
+        _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"),
+        _f32(cls_text, "cls_text") if cls_text is not None else None, _f32(text_s, "text_s") if text_s is not None else None,
+        _parr(theta, "theta"), _parr(phi, "phi"),
+        _f32(logits, "logits"), _i64(preds, "preds"), _f32(preds_f, "preds_f"), _f32(loss_b, "loss_b"), _f32(acc_b, "acc_b"),
+        _f32(stats, "stats") if stats is not None else None,
+        _parr(g_theta, "g_theta") if need_grad else None, _parr(g_phi, "g_phi") if need_grad else None)
+    _check(rc, "fumi_hip_fumi_resnet12_step")
+    return dict(logits=logits, preds=preds, preds_f=preds_f, loss_b=loss_b, acc_b=acc_b, g_theta=g_theta, g_phi=g_phi, stats=stats)
+
+
+def maml_resnet12_step(ws, x_s, y_s, x_q, y_q, params, T, alpha, first_order=False, *, need_grad=True, grad_scale=None,
+                       g_params=None, stats=None, chunk=0):
+    """MAML meta-step with the bf16 ResNet-12 encoder: params = theta (12 per block) + [lin_final W [N,F], b [N]]."""
+    dev = _dev(x_s)
+    B, S, Qn, Cin, H, W, nblk, channels = _resnet12_shapes(x_s, y_s, x_q, y_q, params[:-2])
+    N, F = int(params[-2].shape[0]), channels[-1]
+    _shape(params[-2], (N, F), "lin_final.weight"); _shape(params[-1], (N,), "lin_final.bias")
+    logits, preds, preds_f, loss_b, acc_b = _step_outputs(dev, B, Qn, N)
+    if need_grad:
+        g_params = [torch.empty_like(t) for t in params] if g_params is None else g_params
+    rc = lib().fumi_hip_maml_resnet12_step(
+        ws.handle, _stream(dev), B, N, S, Qn, Cin, H, W, nblk, _ci(channels), int(T), float(alpha), int(bool(first_order)),
+        int(bool(need_grad)), float(1.0 / B if grad_scale is None else grad_scale), int(chunk),
+        _f32(x_s, "x_s"), _i64(y_s, "y_s"), _f32(x_q, "x_q"), _i64(y_q, "y_q"), _parr(params, "params"),
+        _f32(logits, "logits"), _i64(preds, "preds"), _f32(preds_f, "preds_f"), _f32(loss_b, "loss_b"), _f32(acc_b, "acc_b"),
+        _f32(stats, "stats") if stats is not None else None, _parr(g_params, "g_params") if need_grad else None)
+    _check(rc, "fumi_hip_maml_resnet12_step")
+    return dict(logits=logits, preds=preds, preds_f=preds_f, loss_b=loss_b, acc_b=acc_b, g_params=g_params, stats=stats)
+
+
+def resnet12_features(ws, x, theta):
+    """feats [G, M, F] = ResNet12(x [G, M, Cin, H, W]); batch statistics per group of M images."""
+    dev = _dev(x)
+    G, M, Cin, H, W = x.shape
+    nblk = len(theta) // 12
+    channels = [int(theta[12 * l].shape[0]) for l in range(nblk)]
+    feats = torch.empty(G, M, channels[-1], device=dev, dtype=torch.float32)
+    _check(lib().fumi_hip_resnet12_features(ws.handle, _stream(dev), G, M, Cin, H, W, nblk, _ci(channels), _f32(x, "x"),
+                                            _parr(theta, "theta"), _f32(feats, "feats")), "fumi_hip_resnet12_features")
+    return feats
+
+
+def _bf16ptr(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
+        raise FumiHipError(f"{name}: expected a contiguous bfloat16 GPU tensor")
+    return c_void_p(t.data_ptr())
+
+
+def rn12_conv(ws, x, Wt, H, W, transpose=False, want_stats=False):
+    """Unit op: x [B, M*(H+2)*(W+2), Cx] bf16 padded channels-last, Wt [B, Cout, Cin, k, k] fp32 -> y bf16 (and [B,2,Cy] stats)."""
+    dev = _dev(x)
+    B, npix, Cx = x.shape
+    Cout, Cin, k = int(Wt.shape[1]), int(Wt.shape[2]), int(Wt.shape[3])
+    M = npix // ((H + 2) * (W + 2))
+    Cy = Cin if transpose else Cout
+    y = torch.empty(B, npix, Cy, device=dev, dtype=torch.bfloat16)
+    st = torch.empty(B, 2, Cy, device=dev, dtype=torch.float32) if want_stats else None
+    _check(lib().fumi_hip_rn12_conv(ws.handle, _stream(dev), B, M, H, W, Cin, Cout, k * k, int(bool(transpose)), _bf16ptr(x, "x"),
+                                    _f32(Wt, "Wt"), _bf16ptr(y, "y"), _f32(st, "stats") if st is not None else None), "fumi_hip_rn12_conv")
+    return (y, st) if want_stats else y
+
+
+def rn12_wgrad(ws, x, dy, H, W, k):
+    dev = _dev(x)
+    B, npix, Cin = x.shape
+    Cout = int(dy.shape[2])
+    M = npix // ((H + 2) * (W + 2))
+    dW = torch.empty(B, Cout, Cin, k, k, device=dev, dtype=torch.float32)
+    _check(lib().fumi_hip_rn12_wgrad(ws.handle, _stream(dev), B, M, H, W, Cin, Cout, k * k, _bf16ptr(x, "x"), _bf16ptr(dy, "dy"),
+                                     _f32(dW, "dW")), "fumi_hip_rn12_wgrad")
+    return dW
 
 
 def conv4_set_option(key, value):

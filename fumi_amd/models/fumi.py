@@ -38,8 +38,9 @@ class FUMI(nn.Module):
                  image_channels=3):
         super().__init__()
         # im_encoder (additive): "precomputed" / "resnet" = the reference's MLP over embeddings (fumi.py:89-100);
-        # "conv4" = the Conv4 encoder on raw images at the same seam (fumi_amd/models/conv4.py), im_hid_dim is then unused
-        if im_encoder not in ("precomputed", "resnet", "conv4"):
+        # "conv4" / "resnet12" = the Conv4 / bf16 ResNet-12 encoder on raw images at the same seam (fumi_amd/models/conv4.py,
+        # resnet12.py), im_hid_dim is then unused
+        if im_encoder not in ("precomputed", "resnet", "conv4", "resnet12"):
             raise NameError(f"{im_encoder} not allowed as image encoder")
         self.im_encoder = im_encoder
         self.n_way = n_way
@@ -82,6 +83,10 @@ class FUMI(nn.Module):
             from .conv4 import Conv4
             conv = Conv4(image_channels, 64, 4, image_size)
             self.im_hid_dim = [conv.feature_dim]          # the head the hypernetwork emits is [N, feature_dim + 1]
+        elif im_encoder == "resnet12":
+            from .resnet12 import ResNet12
+            conv = ResNet12(image_channels, image_size=image_size)
+            self.im_hid_dim = [conv.feature_dim]
 
         # hypernetwork: Linear . ReLU . Linear(H+1) [. Tanh]  (fumi.py:70-86,104-107)
         head = nn.Linear(self.text_hid_dim, self.im_hid_dim[-1] + 1)
@@ -108,7 +113,7 @@ class FUMI(nn.Module):
 
     # ---- parameter views handed to the engine --------------------------------------------------------------------
     def _theta(self):
-        if self.im_encoder == "conv4":
+        if self.im_encoder in ("conv4", "resnet12"):
             return self.im_net.theta()
         out = []
         for i in range(len(self.im_hid_dim)):
@@ -175,7 +180,7 @@ class FUMI(nn.Module):
     def im_forward(self, im_embeds, im_params, hyper_params):
         """logits [rows, N] = im_net(x; params) @ h[:, :-1].T + h[:, -1]  (fumi.py:214-218); inference helper."""
         eng = _engine.get_engine()
-        if self.im_encoder == "conv4":
+        if self.im_encoder in ("conv4", "resnet12"):
             x = self.im_net(im_embeds, params=im_params)
             h = hyper_params.detach()
             return eng.linear(x.reshape(-1, x.shape[-1]).contiguous(), h[:, :-1].contiguous(), h[:, -1].contiguous(), act=0)
@@ -233,10 +238,10 @@ class FUMI(nn.Module):
         g_th, g_ph = fg.split(nth) if train else (None, None)
         # [.. grads .. | sum loss / B | sum acc / B], written by the engine -> one all-reduce(sum) -> global means everywhere
         tail = fg.tail if train else torch.empty(2, device=x_s.device, dtype=torch.float32)
-        if self.im_encoder == "conv4":
-            out = eng.fumi_conv4_step(self.n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, args.step_size, self.norm_hypernet,
-                                      need_grad=train, grad_scale=1.0 / B,
-                                      g_theta=g_th, g_phi=g_ph, cls_text=cls_text, stats=tail)
+        if self.im_encoder in ("conv4", "resnet12"):
+            step = eng.fumi_conv4_step if self.im_encoder == "conv4" else eng.fumi_resnet12_step
+            out = step(self.n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, args.step_size, self.norm_hypernet,
+                       need_grad=train, grad_scale=1.0 / B, g_theta=g_th, g_phi=g_ph, cls_text=cls_text, stats=tail)
         else:
             out = eng.fumi_step(self.n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, args.step_size, self.norm_hypernet,
                                 need_grad=train, grad_scale=1.0 / B,

@@ -32,6 +32,11 @@ class PureImageNetwork(MetaModule):
             self.hidden_dims = None
             layers['features'] = Conv4(image_channels, 64, 4, image_size)
             d = layers['features'].feature_dim
+        elif im_encoder == "resnet12":
+            from .resnet12 import ResNet12
+            self.hidden_dims = None
+            layers['features'] = ResNet12(image_channels, image_size=image_size)
+            d = layers['features'].feature_dim
         for i, h in enumerate(self.hidden_dims or []):
             layers[f'lin_{i}'] = MetaLinear(d, h)
             layers[f'relu_{i}'] = nn.ReLU()
@@ -44,7 +49,7 @@ class PureImageNetwork(MetaModule):
         return self.net(inputs, params=self.get_subdict(params, 'net'))
 
     def _params(self):
-        if self.im_encoder == "conv4":
+        if self.im_encoder in ("conv4", "resnet12"):
             return self.net.features.theta() + [self.net.lin_final.weight, self.net.lin_final.bias]
         out = []
         for i in range(len(self.hidden_dims or [])):
@@ -75,7 +80,9 @@ def evaluate(args, model, batch, optimizer, task="train"):
     T = args.num_train_adapt_steps if train else args.num_test_adapt_steps
     fg = model._flat_grads() if train else None
     tail = fg.tail if train else torch.empty(2, device=x_s.device, dtype=torch.float32)
-    step = _engine.get_engine().maml_conv4_step if getattr(model, "im_encoder", "") == "conv4" else _engine.get_engine().maml_step
+    enc = getattr(model, "im_encoder", "")
+    eng = _engine.get_engine()
+    step = eng.maml_conv4_step if enc == "conv4" else eng.maml_resnet12_step if enc == "resnet12" else eng.maml_step
     step(x_s, y_s, x_q, y_q, [p.detach() for p in model._params()], T, args.step_size,
          bool(args.first_order), need_grad=train, grad_scale=1.0 / B, g_params=fg.views if train else None, stats=tail)
     fdist.all_reduce_sum_(fg.flat if train else tail)

@@ -42,7 +42,7 @@ _FLAGS = [
     # model
     ("--model", dict(type=str, default="fumi", help="Model to be trained")),
     ("--prototype_dim", dict(type=int, default=64, help="Dimension of latent space")),
-    ("--im_encoder", dict(type=str, default="precomputed", help="Type of vision feature extractor (resnet, precomputed; conv4 = Conv4 on raw images, this engine's extension at the im_net seam)")),
+    ("--im_encoder", dict(type=str, default="precomputed", help="Type of vision feature extractor (resnet, precomputed; conv4 / resnet12 = Conv4 / bf16 ResNet-12 on raw images, this engine's extensions at the im_net seam)")),
     ("--im_emb_dim", dict(type=int, default=2048, help="Dimension of image embedding (if precomputed)")),
     ("--im_hid_dim", dict(type=int, nargs="+", default=[256, 64], help="Hidden dimension of image model")),
     ("--text_encoder", dict(type=str, choices=["glove", "w2v", "RNN", "RNNhid", "BERT", "rand"], default="BERT",
@@ -92,7 +92,8 @@ def init_model(args, dictionary, watch=True):
     """Model factory (utils.py:232-274).  Unknown names fall through to AM3 exactly like the reference."""
     from ..models import am3, clip, fumi, maml
     if args.model == "maml":
-        conv = dict(im_encoder="conv4", image_size=args.image_size, image_channels=args.image_channels) if args.im_encoder == "conv4" else {}
+        conv = (dict(im_encoder=args.im_encoder, image_size=args.image_size, image_channels=args.image_channels)
+                if args.im_encoder in ("conv4", "resnet12") else {})
         model = maml.PureImageNetwork(im_embed_dim=args.im_emb_dim, n_way=args.num_ways, hidden_dims=args.im_hid_dim, **conv)
     elif args.model == "fumi":
         model = fumi.FUMI(n_way=args.num_ways, im_emb_dim=args.im_emb_dim, im_hid_dim=args.im_hid_dim,
@@ -100,8 +101,8 @@ def init_model(args, dictionary, watch=True):
                           text_hid_dim=args.text_hid_dim, dropout_rate=args.dropout, dictionary=dictionary,
                           pooling_strat=args.pooling_strat, init_all_layers=args.init_all_layers,
                           norm_hypernet=args.norm_hypernet, fine_tune=args.fine_tune, init_bias=args.hypernet_bias_init,
-                          **(dict(im_encoder="conv4", image_size=args.image_size, image_channels=args.image_channels)
-                             if args.im_encoder == "conv4" else {}))
+                          **(dict(im_encoder=args.im_encoder, image_size=args.image_size, image_channels=args.image_channels)
+                             if args.im_encoder in ("conv4", "resnet12") else {}))
     elif args.model == "clip":
         model = clip.CLIP(text_input_dim=args.text_emb_dim, image_input_dim=args.im_emb_dim, latent_dim=args.clip_latent_dim)
     else:

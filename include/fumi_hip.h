@@ -88,7 +88,10 @@ int   fumi_hip_set_trace_buffer(int which, void* device_u64);
 #define FUMI_PH_CONV_GEMM 12   /* Conv4: the 64 -> 64 channel products (forward, input-gradient, weight-gradient) on the MFMA */
 #define FUMI_PH_CONV_FIRST 13  /* Conv4: block 1 (Cin <= 3 -> 64: K = 27, bound by writing / reading its 84x84x64 maps)   */
 #define FUMI_PH_CONV_EW   14   /* Conv4: batch-norm / ReLU / max-pool passes, head, updates                               */
-#define FUMI_PH_COUNT     15
+#define FUMI_PH_RN_CONV   15   /* ResNet-12 (bf16): forward / input-gradient convolutions on v_mfma_f32_32x32x16_bf16       */
+#define FUMI_PH_RN_WGRAD  16   /* ResNet-12: weight-gradient products                                                     */
+#define FUMI_PH_RN_EW     17   /* ResNet-12: batch-norm / LeakyReLU / residual join / pooling passes, head, updates       */
+#define FUMI_PH_COUNT     18
 /* phase_mask: bit p set = record a HIP event pair around phase p (FUMI_PH_*) on the caller's stream; -1 = every phase,
  * 0 = off.  An event pair costs a few microseconds of stream time, so time only what is needed.  Also clears the records. */
 int          fumi_hip_set_profiling(fumi_ws_t* ws, int phase_mask);
@@ -242,6 +245,41 @@ int fumi_hip_conv4_encode_bwd(fumi_ws_t* ws, fumi_stream_t stream, int B, int S,
  * fumi_amd/csrc/conv4.hip, fumi_hip_conv4_probe).  *n_out = its size in floats; at most max_floats are copied. */
 int fumi_hip_conv4_probe(fumi_ws_t* ws, fumi_stream_t stream, int pass, int kind, int block, float* out, size_t max_floats,
         size_t* n_out);
+/* ---- ResNet-12 image encoder in bf16 at the im_net seam (fumi/models/fumi.py:89-100; BASELINE.json configs[4]) ----------------------
+ * Four residual blocks  a1 = lrelu(BN(conv3x3(x))), a2 = lrelu(BN(conv3x3(a1))), out = maxpool2(lrelu(BN(conv3x3(a2)) + BN(conv1x1(x))))
+ * with `channels[l]` output channels (multiples of 32), LeakyReLU slope 0.1, batch statistics, no conv bias; features = global
+ * average pool of the last block ([rows, channels[nblk-1]]).  Images x_s [B,S,Cin,H,W], x_q [B,Qn,Cin,H,W] fp32; theta = 12 tensors
+ * per block: W1 [C,Cin|C_prev,3,3], g1, b1, W2 [C,C,3,3], g2, b2, W3, g3, b3, Ws [C,Cin|C_prev,1,1], gs, bs (fp32 masters; every
+ * matrix product runs in bf16 with fp32 accumulation, maps are stored in bf16).  Second-order outer gradient (fumi.py:176);
+ * the reference has no such encoder: "parity unpinned", oracle = oracle/resnet12_manual.py / resnet12_ref.py.
+ * `chunk`: episodes processed per pass over the tape (0 = derived from the workspace budget, fumi_hip_resnet12_set_budget /
+ * FUMI_RN12_BUDGET_GB, default 200 GB): the meta-gradient is the sum over chunks. */
+int fumi_hip_resnet12_set_budget(double gigabytes);
+int fumi_hip_fumi_resnet12_step(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int Cin, int H, int W, int nblk, const int* channels, int Dt, int Ht,
+        int T, float alpha, int tanh_head, int need_grad, float grad_scale, int chunk,
+        const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
+        const float* cls_text, const float* text_s,
+        const float* const* theta, const float* const* phi,
+        float* logits_q, int64_t* preds_q, float* preds_q_f32, float* loss_b, float* acc_b, float* stats,
+        float* const* g_theta, float* const* g_phi);
+int fumi_hip_maml_resnet12_step(fumi_ws_t* ws, fumi_stream_t stream,
+        int B, int N, int S, int Qn, int Cin, int H, int W, int nblk, const int* channels,
+        int T, float alpha, int first_order, int need_grad, float grad_scale, int chunk,
+        const float* x_s, const int64_t* y_s, const float* x_q, const int64_t* y_q,
+        const float* const* params,
+        float* logits_q, int64_t* preds_q, float* preds_q_f32, float* loss_b, float* acc_b, float* stats,
+        float* const* g_params);
+/* Forward only: feats [G*M, channels[nblk-1]] fp32; batch statistics per group of M images. */
+int fumi_hip_resnet12_features(fumi_ws_t* ws, fumi_stream_t stream, int G, int M, int Cin, int H, int W, int nblk, const int* channels,
+        const float* x, const float* const* theta, float* feats);
+/* The matrix kernels on raw maps (unit parity tests): x, y, dy are bf16 "padded channels-last" [B][M (H+2)(W+2)][C] with zero
+ * borders, Wt / dW fp32 [B][Cout][Cin][k][k] (k = 3: ntaps 9, pad 1; k = 1: ntaps 1).  transpose != 0: the input-gradient
+ * product (x has Cout channels, y has Cin).  stats (optional) [B][2][C_y]: per-channel sum and sum of squares of the stored y. */
+int fumi_hip_rn12_conv(fumi_ws_t* ws, fumi_stream_t stream, int B, int M, int H, int W, int Cin, int Cout, int ntaps, int transpose,
+        const void* x, const float* Wt, void* y, float* stats);
+int fumi_hip_rn12_wgrad(fumi_ws_t* ws, fumi_stream_t stream, int B, int M, int H, int W, int Cin, int Cout, int ntaps,
+        const void* x, const void* dy, float* dW);
 /* The three 3x3 / pad 1 / stride 1 convolution products on 64 -> 64 channels (the set is closed under differentiation: the
  * second-order sweep uses nothing else).  Dense channels-last tensors x, y, dy [M,H,W,64]; weights W, dW [64,64,3,3] (OIHW). */
 int fumi_hip_conv3x3_fwd(fumi_ws_t* ws, fumi_stream_t stream, int M, int H, int W, const float* x, const float* Wt, float* y);

@@ -142,6 +142,38 @@ class OracleEngine:
         from oracle import conv4_ref as C
         return torch.stack([C.conv4_features(x[g], theta) for g in range(x.shape[0])])
 
+    def fumi_resnet12_step(self, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head, need_grad, grad_scale,
+                           g_theta=None, g_phi=None, cls_text=None, stats=None):
+        from oracle import resnet12_ref as C
+        B = x_s.shape[0]
+        if cls_text is not None:
+            text_s = torch.gather(cls_text, 1, y_s[..., None].expand(-1, -1, cls_text.shape[-1]))
+        th = [t.detach().clone().requires_grad_(True) for t in theta]
+        ph = [t.detach().clone().requires_grad_(True) for t in phi]
+        out = C.fumi_meta_step(th, ph, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha, tanh_head, need_grad=need_grad)
+        if need_grad:
+            for dst, g in zip(list(g_theta) + list(g_phi), out["g_theta"] + out["g_phi"]):
+                dst.copy_(g * (B * grad_scale))
+        if stats is not None:
+            stats.copy_(torch.stack([out["loss_b"].sum(), out["acc_b"].sum()]) * grad_scale)
+        return dict(logits=out["logits"], preds=out["preds"], preds_f=out["preds"].float(), loss_b=out["loss_b"], acc_b=out["acc_b"])
+
+    def maml_resnet12_step(self, x_s, y_s, x_q, y_q, params, T, alpha, first_order, need_grad, grad_scale, g_params=None, stats=None):
+        from oracle import resnet12_ref as C
+        B = x_s.shape[0]
+        p = [t.detach().clone().requires_grad_(True) for t in params]
+        out = C.maml_meta_step(p, x_s, y_s, x_q, y_q, T, alpha, first_order, need_grad=need_grad)
+        if need_grad:
+            for dst, g in zip(g_params, out["g_params"]):
+                dst.copy_(g * (B * grad_scale))
+        if stats is not None:
+            stats.copy_(torch.stack([out["loss_b"].sum(), out["acc_b"].sum()]) * grad_scale)
+        return dict(logits=out["logits"], preds=out["preds"], preds_f=out["preds"].float(), loss_b=out["loss_b"], acc_b=out["acc_b"])
+
+    def resnet12_features(self, x, theta):
+        from oracle import resnet12_ref as C
+        return torch.stack([C.features(x[g], theta) for g in range(x.shape[0])])
+
     def clip_step(self, text, image, w, need_loss=True, need_grad=True, g_w=None):
         ww = [t.detach().clone().requires_grad_(True) for t in w]
         if not need_loss:

@@ -402,6 +402,30 @@ def test_fumi_conv4_module_trains_through_evaluate(oracle_engine):
     assert torch.allclose(feats[1], C.conv4_features(ep["x_q"][1], [t.detach() for t in m.im_net.theta()]), atol=1e-6)
 
 
+def test_fumi_resnet12_module_trains_through_evaluate(oracle_engine):
+    """FUMI(im_encoder='resnet12') (BASELINE.json configs[4]'s backbone at the im_net seam): state_dict keys, the [N, 641] head, every
+    one of the 48 encoder tensors + 4 hypernetwork tensors trained through evaluate(), the feature helper."""
+    from fumi_amd.models.fumi import FUMI
+    from oracle import conv4_ref as C, resnet12_ref as RR
+    torch.manual_seed(0)
+    m = FUMI(n_way=3, im_encoder="resnet12", image_size=16, image_channels=3, text_emb_dim=12, text_hid_dim=8, norm_hypernet=False)
+    assert m.im_net.feature_dim == 640 and m.hyper_net[2].weight.shape == (641, 8) and len(m.im_net.theta()) == 48
+    keys = [k for k in m.state_dict() if k.startswith("im_net.block1.")]
+    assert keys[:3] == ["im_net.block1.conv1.weight", "im_net.block1.bn1.weight", "im_net.block1.bn1.bias"]
+    assert m.state_dict()["im_net.block1.shortcut.weight"].shape == (160, 64, 1, 1)
+    ep = C.make_image_episodes(3, 2, 3, 2, 2, 3, 16, 16, 12)
+    args = SimpleNamespace(device=torch.device("cpu"), num_train_adapt_steps=1, num_test_adapt_steps=1, step_size=0.05,
+                           first_order=False, num_ways=3, batch_size=2)
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    before = [p.detach().clone() for p in m.parameters()]
+    loss, acc, _, _ = m.evaluate(args, cg.to_batch(ep), opt, "train")
+    assert np.isfinite(float(loss)) and 0.0 <= float(acc) <= 1.0
+    assert all(not torch.equal(a, b.detach()) for a, b in zip(before, m.parameters()))
+    feats = m.im_net(ep["x_q"])
+    assert feats.shape == (2, 6, 640)
+    assert torch.allclose(feats[1], RR.features(ep["x_q"][1], [t.detach() for t in m.im_net.theta()]), atol=1e-5)
+
+
 def test_am3_conv4_module_trains_through_evaluate(oracle_engine):
     """AM3(im_encoder='conv4'): Conv4 features feed the reference's Linear into the prototype space; evaluate() fills .grad of the
     10 AM3 tensors and the 12 backbone tensors (through the step's image-row adjoints) and steps the optimizer."""
