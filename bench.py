@@ -435,16 +435,40 @@ def configs4_leg(dev, steps, warmup, with_cpu, episodes):
     return out
 
 
+def visible_gpus():
+    """GPUs of this node counted from the KFD topology in sysfs (a node with simd_count > 0 and a non-zero gfx target is a GPU),
+    narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set; None when sysfs cannot tell."""
+    import glob
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for f in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(f) if len(line.split()) >= 2)
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0")) > 0 and int(props.get("gfx_target_version", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start one fresh process per GPU through torch.distributed.run as a CHILD of
     this process (which has not touched the GPU and never will), let rank 0's JSON line through and hand back the child's exit
     code.  (Replacing this process with the launcher after a HIP call is what the pool forbids; a child process is not that.)"""
     import socket
     import subprocess
-    if os.environ.get("FUMI_BENCH_REHEARSAL", "0") != "1" and torch.cuda.device_count() < n:
-        print(f"bench.py: --gpus {n} needs {n} visible GPUs, found {torch.cuda.device_count()} "
-              f"(FUMI_BENCH_REHEARSAL=1 rehearses the N-rank code path on one GPU over gloo)", file=sys.stderr)
-        return 2
+    if os.environ.get("FUMI_BENCH_REHEARSAL", "0") != "1":
+        have = visible_gpus()                       # from sysfs: the parent makes no HIP / torch.cuda call at all
+        if have is not None and have < n:
+            print(f"bench.py: --gpus {n} needs {n} visible GPUs, found {have} "
+                  f"(FUMI_BENCH_REHEARSAL=1 rehearses the N-rank code path on one GPU over gloo)", file=sys.stderr)
+            return 2
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -541,7 +565,10 @@ def main():
             dist.all_reduce(buf)
         barrier()
         allreduce = {"bytes": int(flat.numel() * 4), "avg_us": round((time.perf_counter() - t1) / 20 * 1e6, 1),
-                     "backend": "gloo (rehearsal)" if rehearsal else "nccl (RCCL)", "per_step": 1}
+                     "backend": "gloo (rehearsal)" if rehearsal else "nccl (RCCL)", "per_step": 1, "overlapped": False,
+                     "why_not_overlapped": "the gradient is final only after the step's last reduction (gW0's split-K slabs and the "
+                                           "hypernetwork slabs leave the last matrix launch); what is ready earlier is 70 KB of the "
+                                           "3 MB, and a 3 MB ring all-reduce is latency-bound (DESIGN.md section 6)"}
     el = float(t.item())
 
     if rank == 0:

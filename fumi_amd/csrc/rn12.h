@@ -46,10 +46,13 @@ struct RnConvArgs {
     rbf16* out; long out_stride;
     float* stats;                                     // != NULL: [B][tiles][2][Cout] partial sums over interior pixels of (out, out * dot)
     const rbf16* dot; long dot_stride;                // NULL: out * out
+    int tiles, ncg, xcd, slab_rows, glds, tpi;         // tpi > 0: tiles restart at every image (tpi tiles per image)                   // set by the launcher: pixel tiles / column groups per episode, XCD-grouped ids,
+                                                      // rows of the input slab's LDS image
 };
-int rn_conv_tiles(long npix, int Cout);
+int rn_conv_tiles(long npix, int Cout);                // upper bound of the statistics slabs per episode (sizing)
 size_t rn_conv_lds_bytes(const RnGeom& g, int Cout);
-int launch_rn_conv(hipStream_t st, const RnConvArgs& a);
+// nt_out (optional): the number of statistics slabs per episode the launch wrote (its pixel tiles: 128 or 256 pixels each)
+int launch_rn_conv(hipStream_t st, const RnConvArgs& a, int* nt_out = nullptr);
 
 // dW[b][tap][co][ci] = sum over pairs s of sum_p dy_s[b][p][co] x_s[b][p + off_tap][ci]; pixels cut into nsplit slabs per episode
 struct RnWgradArgs {

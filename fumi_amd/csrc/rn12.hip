@@ -167,9 +167,10 @@ int conv_bn(RnCtx& c, int M, int l, int nsrc, const RnSrc* src, rbf16* out, cons
     for (int s = 0; s < 4; ++s) a.src[s] = src[s < nsrc ? s : 0];
     a.out = out; a.out_stride = (long)M * n.g[l].Pp * n.C[l];
     a.stats = c.sc.cpart; a.dot = dot; a.dot_stride = a.out_stride;
-    TRYP(FUMI_PH_RN_CONV, launch_rn_conv(c.st, a));
+    int nt = 0;
+    TRYP(FUMI_PH_RN_CONV, launch_rn_conv(c.st, a, &nt));
     RnCoefArgs ca; memset(&ca, 0, sizeof(ca));
-    ca.B = n.B; ca.C = n.C[l]; ca.mode = mode; ca.nt = rn_conv_tiles(a.npix, n.C[l]); ca.K = 2; ca.k0 = 0; ca.k1 = 1; ca.k2 = 0;
+    ca.B = n.B; ca.C = n.C[l]; ca.mode = mode; ca.nt = nt; ca.K = 2; ca.k0 = 0; ca.k1 = 1; ca.k2 = 0;
     ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
     ca.part = c.sc.cpart; ca.coef = coef;
     if (mode == RCM_FWD) { ca.g = g; ca.beta = beta; ca.pstride = pstride; }
@@ -695,8 +696,10 @@ int fumi_hip_rn12_conv(fumi_ws_t* ws, fumi_stream_t stream, int B, int M, int H,
     a.src[0].Cin = Cx; a.src[0].ntaps = ntaps;
     a.src[1] = a.src[2] = a.src[3] = a.src[0];
     a.out = (rbf16*)y; a.out_stride = npix * Cy; a.stats = stats ? part : nullptr;
-    TRY(launch_rn_conv(st, a));
-    if (stats) TRY(launch_reduce_batched(st, B, tiles, 2L * Cy, part, 1.f, stats, 2L * Cy));
+    HIP_TRY(hipMemsetAsync(y, 0, (size_t)B * npix * Cy * 2, st));      // the kernel writes interior pixels only (nothing reads the border of a conv output)
+    int nt = 0;
+    TRY(launch_rn_conv(st, a, &nt));
+    if (stats) TRY(launch_reduce_batched(st, B, nt, 2L * Cy, part, 1.f, stats, 2L * Cy));
     return FUMI_OK;
 }
 

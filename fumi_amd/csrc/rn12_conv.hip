@@ -2,6 +2,7 @@
 // copies of the flattened padded pixel axis, weight gradients as pixel-contracted products, all on v_mfma_f32_32x32x16_bf16 with
 // fp32 accumulation.  Hand-written for gfx950 (wave64, 160 KiB LDS, ds_read_b64_tr_b16).
 #include "rn12.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -10,10 +11,20 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *(const u32x4*)p; }
+// wave-uniform values that reach the kernel through LDS or lane arithmetic live in VGPRs unless told otherwise: these move them to SGPRs
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long uni(long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffL)), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (long)(((unsigned long)hi << 32) | lo);
+}
+template <class T> __device__ __forceinline__ const T* uni(const T* p) { return (const T*)uni((long)p); }
 
 // =====================================================================================================================================
 // convolution (forward and input-gradient)
-//   workgroup = 4 waves, tile = (128 MW) consecutive padded pixels x (32 NF) output channels; wave w owns pixels [32 MW w, 32 MW (w+1))
+//   workgroup = 4 waves, tile = (128 MW) consecutive INTERIOR pixels (image after image, row after row; the zero border of the padded
+//   layout is skipped: at 10 x 10 it would be 44 % of the matrix work) x (32 NF) output channels; wave w owns pixels [32 MW w, 32 MW (w+1)).
+//   The tile's pixels are not contiguous in the padded map (2 border pixels per row, 2 border rows per image), its INPUT slab is:
+//   padded pixels [first - halo, last + halo]; a lane keeps the slab row of each of its pixels, every tap is the same shift for all.
 //   for every 64-channel chunk of every source: the input slab (tile + halo on both sides) goes to LDS ONCE as [pixel][64 ch] bf16 with
 //   its 16-byte chunks XOR-ed by (pixel >> 1) & 7 (conflict-free ds_read_b128 for every tap shift); per tap the weight tile
 //   (4 k-steps x NF fragments x 1 KiB, already in MFMA B-fragment order in memory) is double-buffered through LDS -- the copy is linear,
@@ -23,31 +34,90 @@ __device__ __forceinline__ u32x4 ld16(const void* p) { return *(const u32x4*)p; 
 // =====================================================================================================================================
 constexpr int CV_KC = 64;                              // channels per staged chunk
 
-template <int NF, int MW>
+// padded pixel (within an episode) of the compact interior index c = (image, y, x) row-major
+__host__ __device__ inline long rn_pix_of(long c, const RnGeom& g) {
+    const int hw = g.H * g.W;
+    const long img = c / hw; const int r = (int)(c - img * hw);
+    const int y = r / g.W, x = r - y * g.W;
+    return img * g.Pp + (long)(y + 1) * g.Wp + x + 1;
+}
+// Large images (>= 4 tiles each): tiles restart at every image -- a tile never straddles the 2 border rows between two images, which
+// would put them (and for wide rows a lot of LDS) into its slab; the last tile of an image is partial (1.6 % at 84 x 84 / 256).
+inline bool rn_per_image(const RnGeom& g, int mt) { return (long)g.H * g.W >= 4L * mt; }
+// rows of the LDS image of a tile's input slab (without the halo): the largest span of mt consecutive interior pixels in padded pixels
+inline int rn_slab_span(const RnGeom& g, int mt) {
+    const int hw = g.H * g.W;
+    int best = 0;
+    if (rn_per_image(g, mt)) {
+        for (long c0 = 0; c0 < hw; c0 += mt) {
+            const long c1 = (c0 + mt < hw ? c0 + mt : hw) - 1;
+            const int span = (int)(rn_pix_of(c1, g) - rn_pix_of(c0, g)) + 1;
+            best = span > best ? span : best;
+        }
+        return best;
+    }
+    for (int k = 0; k < hw; ++k) {                                 // every phase of a tile start within an image (starts are k * mt)
+        const long c0 = (long)k * mt;
+        const int span = (int)(rn_pix_of(c0 + mt - 1, g) - rn_pix_of(c0, g)) + 1;
+        best = span > best ? span : best;
+        if (k > 4096) break;
+    }
+    return best;
+}
+
+template <int NF, int MW, int BKS>
 struct ConvCfg {
     static constexpr int MT = 128 * MW, NT = 32 * NF, NTP = NT + 8;            // NTP: padded row of the epilogue image (bf16)
-    static constexpr int BT = 4 * NF * 1024;                                     // bytes of one tap's weight tile (64 channels)
+    static constexpr int BT = BKS * NF * 1024;                                   // bytes of one weight tile (BKS k-steps of one tap)
     static constexpr int NCH = NT / 8, NRG = 256 / NCH;                          // epilogue: 16-byte chunks per row, row groups
-    static __host__ __device__ int a_bytes(int halo) { return (MT + 2 * halo) * 128; }
-    static __host__ __device__ int lds_bytes(int halo) {
-        const int main_ = a_bytes(halo) + 2 * BT;
-        const int epi = MT * NTP * 2 + NRG * NT * 2 * 4;
+    static int slab_rows(const RnGeom& g) { return (rn_slab_span(g, MT) + 2 * g.halo + 7) / 8 * 8; }
+    static int lds_bytes(const RnGeom& g) {
+        const int main_ = slab_rows(g) * 128 + 2 * BT;
+        const int epi = 128 * NTP * 2 + NRG * NT * 2 * 4;                        // the epilogue goes through LDS 128 rows at a time
         return (main_ > epi ? main_ : epi) + 16;
     }
 };
 
-template <int NF, int MW>
-__global__ __launch_bounds__(256) void rn_conv_kernel(RnConvArgs a) {
-    typedef ConvCfg<NF, MW> C;
+template <int NF, int MW, int BKS>
+__global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
+    typedef ConvCfg<NF, MW, BKS> C;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ RnSrc s_src[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z, cg = blockIdx.y;
-    const long p0 = (long)blockIdx.x * C::MT;
+    // workgroup id -> (pixel tile, column group, episode).  All tiles of one (episode, column group) stream the SAME weight slice
+    // (up to 1.8 MB): with a.xcd the ids are dealt so that such a group stays on one XCD (ids i and i + 8 share an XCD) and its
+    // slice stays in that XCD's L2; speed only -- any placement is correct
+    int tile, cg, b;
+    if (a.xcd) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int grp = (j / a.tiles) * 8 + xcd;
+        tile = j % a.tiles; cg = grp % a.ncg; b = grp / a.ncg;
+        if (b >= a.B) return;
+    } else {
+        tile = blockIdx.x % a.tiles;
+        const int r = blockIdx.x / a.tiles;
+        cg = r % a.ncg; b = r / a.ncg;
+    }
     const int halo = a.g.halo, Wp = a.g.Wp;
+    const long NC = a.npix / a.g.Pp * (a.g.H * a.g.W);             // interior pixels of the episode
+    long c0 = (long)tile * C::MT, cend = NC;
+    if (a.tpi) {                                                    // tiles restart at every image
+        const int hw = a.g.H * a.g.W;
+        const long img = tile / a.tpi;
+        c0 = img * hw + (long)(tile - img * a.tpi) * C::MT; cend = (img + 1) * hw;
+    }
+    const long clast = min(c0 + C::MT, cend) - 1;
+    const long pfirst = rn_pix_of(c0, a.g), plast = rn_pix_of(clast, a.g);
     if (tid == 0) { s_src[0] = a.src[0]; s_src[1] = a.src[1]; s_src[2] = a.src[2]; s_src[3] = a.src[3]; }
     unsigned char* const As = lds;
-    unsigned char* const Bs = lds + C::a_bytes(halo);
+    unsigned char* const Bs = lds + a.slab_rows * 128;            // (slab_rows: a multiple of 8, the granule of the LDS-direct loads)
+    int prow[MW];                                                   // this lane's pixels as rows of a halo-less slab
+#pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        long c = c0 + wave * 32 * MW + m * 32 + (lane & 31);
+        c = c > clast ? clast : c;                                  // (rows past the end compute a copy of the last pixel; never stored)
+        prow[m] = (int)(rn_pix_of(c, a.g) - pfirst);
+    }
     f32x16 acc[MW][NF];
 #pragma unroll
     for (int m = 0; m < MW; ++m)
@@ -59,126 +129,171 @@ __global__ __launch_bounds__(256) void rn_conv_kernel(RnConvArgs a) {
     const int CF = a.Cout >> 5;
     const int srow = tid >> 3, schunk = tid & 7;
     for (int s = 0; s < a.nsrc; ++s) {
-        const RnSrc S = s_src[s];
+        RnSrc S;                                                    // (wave-uniform: kept in scalar registers)
+        S.in = uni(s_src[s].in); S.in_stride = uni(s_src[s].in_stride); S.frag = uni(s_src[s].frag);
+        S.frag_stride = uni(s_src[s].frag_stride); S.Cin = uni(s_src[s].Cin); S.ntaps = uni(s_src[s].ntaps);
         const int hs = S.ntaps == 9 ? halo : 0;
-        const int rows = C::MT + 2 * hs;
+        const long p0 = pfirst;                                     // slab row r = padded pixel p0 - hs + r
+        const int rows = (int)(plast - pfirst) + 1 + 2 * hs;
         const int KS = S.Cin >> 4;
         const rbf16* in = S.in + (long)b * S.in_stride;
         const rbf16* frag = S.frag + (long)b * S.frag_stride;
         for (int c0 = 0; c0 < S.Cin; c0 += CV_KC) {
             const int kc = min(CV_KC, S.Cin - c0), nks = kc >> 4;
             __syncthreads();                                       // the previous chunk's products are done with As / Bs
-            // ---- input slab -> LDS (unconditional loads from clamped addresses, masked at the LDS write)
+            // ---- input slab -> LDS.  Default: LDS-direct loads (global_load_lds_dwordx4, no registers: every load of the slab is in
+            //      flight at once, ONE memory round trip per chunk instead of one per batch of 4).  A wave instruction fills 8 rows
+            //      (1 KiB, lane-linear): the chunk swizzle is applied to the SOURCE address.  Pixels outside the episode are clamped
+            //      to its first / last pixel -- both are border pixels of the padded layout, i.e. zeros, which is what a halo outside
+            //      the map must read as.  (k-steps past the chunk's width are never multiplied: their columns may hold anything.)
             const bool chok = schunk * 8 < kc;
             const int chs = chok ? schunk * 8 : 0;
-            for (int r0 = 0; r0 < rows; r0 += 128) {
-                u32x4 v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = r0 + 32 * i + srow;
+            if (a.glds) {
+                for (int r0 = wave * 8; r0 < rows; r0 += 32) {
+                    const int r = r0 + (lane >> 3);
                     long p = p0 - hs + r;
                     p = p < 0 ? 0 : (p >= a.npix ? a.npix - 1 : p);
-                    v[i] = ld16(in + p * S.Cin + c0 + chs);
+                    int chunk = (lane & 7) ^ ((r >> 1) & 7);
+                    chunk = chunk * 8 < kc ? chunk : 0;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + p * S.Cin + c0 + chunk * 8),
+                                                     (__attribute__((address_space(3))) void*)(As + r0 * 128), 16, 0, 0);
                 }
+            } else {
+                for (int r0 = 0; r0 < rows; r0 += 128) {
+                    u32x4 v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = r0 + 32 * i + srow;
-                    const long p = p0 - hs + r;
-                    const bool ok = chok && p >= 0 && p < a.npix;
-                    if (r < rows) *(u32x4*)(As + r * 128 + ((schunk ^ ((r >> 1) & 7)) << 4)) = ok ? v[i] : (u32x4){0u, 0u, 0u, 0u};
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = r0 + 32 * i + srow;
+                        long p = p0 - hs + r;
+                        p = p < 0 ? 0 : (p >= a.npix ? a.npix - 1 : p);
+                        v[i] = ld16(in + p * S.Cin + c0 + chs);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = r0 + 32 * i + srow;
+                        const long p = p0 - hs + r;
+                        const bool ok = chok && p >= 0 && p < a.npix;
+                        if (r < rows) *(u32x4*)(As + r * 128 + ((schunk ^ ((r >> 1) & 7)) << 4)) = ok ? v[i] : (u32x4){0u, 0u, 0u, 0u};
+                    }
                 }
             }
-            // ---- weight tiles: tap t's tile = nks x NF fragments of 1 KiB, contiguous per k-step
-            const int units = nks * NF * 64;                       // 16-byte units of a tile
-            u32x4 breg[NF];
-            auto bload = [&](int tap) {
+            // ---- weight tiles: tile i of the chunk = k-steps [BKS (i % npt), ...) of tap i / npt; NF fragments of 1 KiB per k-step,
+            //      contiguous in memory; double-buffered through LDS, one barrier per tile
+            const int npt = (nks + BKS - 1) / BKS;                 // tiles per tap
+            const int ntile = S.ntaps * npt;
+            constexpr int NLD = (BKS * NF + 3) / 4;
+            u32x4 bra[NLD], brb[NLD];                              // two register sets: a tile's loads are issued TWO tiles ahead
+            auto bload = [&](int i, u32x4* breg) {
+                const int tap = i / npt, k0 = (i - tap * npt) * BKS;
+                const int units = min(BKS, nks - k0) * NF * 64;    // 16-byte units of this tile
 #pragma unroll
-                for (int i = 0; i < NF; ++i) {
-                    int u = tid + 256 * i;
+                for (int j = 0; j < NLD; ++j) {
+                    int u = tid + 256 * j;
                     u = u < units ? u : units - 1;
                     const int ks = u / (NF * 64), rem = u - ks * (NF * 64);
-                    breg[i] = ld16(frag + (((long)tap * KS + (c0 >> 4) + ks) * CF + cg * NF) * 512 + rem * 8);
+                    breg[j] = ld16(frag + (((long)tap * KS + (c0 >> 4) + k0 + ks) * CF + cg * NF) * 512 + rem * 8);
                 }
             };
-            auto bstore = [&](int buf) {
+            auto bstore = [&](int buf, const u32x4* breg) {
 #pragma unroll
-                for (int i = 0; i < NF; ++i) {
-                    const int u = tid + 256 * i;
-                    if (u < units) *(u32x4*)(Bs + buf * C::BT + u * 16) = breg[i];
+                for (int j = 0; j < NLD; ++j) {
+                    const int u = tid + 256 * j;
+                    if (u < BKS * NF * 64) *(u32x4*)(Bs + buf * C::BT + u * 16) = breg[j];
                 }
             };
-            bload(0);
-            bstore(0);
-            __syncthreads();
-            for (int t = 0; t < S.ntaps; ++t) {
-                if (t + 1 < S.ntaps) bload(t + 1);
+            auto compute = [&](int i) {
+                const int t = i / npt, k0 = (i - t * npt) * BKS, kn = min(BKS, nks - k0);
                 const int toff = S.ntaps == 9 ? (t / 3 - 1) * Wp + (t % 3 - 1) : 0;
-                const unsigned char* Bt = Bs + (t & 1) * C::BT;
+                const unsigned char* Bt = Bs + (i & 1) * C::BT;
                 int arow[MW];
 #pragma unroll
-                for (int m = 0; m < MW; ++m) arow[m] = wave * 32 * MW + m * 32 + (lane & 31) + hs + toff;
-                for (int ks = 0; ks < nks; ++ks) {
+                for (int m = 0; m < MW; ++m) arow[m] = prow[m] + hs + toff;
+                // (a runtime loop on purpose: fully unrolled, hipcc hoists the next k-steps' fragment reads and spills -- 576 bytes of
+                //  scratch per lane at NF = 5, MW = 2 and 8.6x the time)
+                for (int ks = 0; ks < kn; ++ks) {
                     rbf16x8 bf[NF];
 #pragma unroll
                     for (int f = 0; f < NF; ++f) bf[f] = *(const rbf16x8*)(Bt + ((ks * NF + f) * 64 + lane) * 16);
 #pragma unroll
                     for (int m = 0; m < MW; ++m) {
-                        const int ch = ks * 2 + (lane >> 5);
+                        const int ch = (k0 + ks) * 2 + (lane >> 5);
                         const rbf16x8 af = *(const rbf16x8*)(As + arow[m] * 128 + ((ch ^ ((arow[m] >> 1) & 7)) << 4));
 #pragma unroll
                         for (int f = 0; f < NF; ++f) acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[f], acc[m][f], 0, 0, 0);
                     }
                 }
-                if (t + 1 < S.ntaps) bstore((t + 1) & 1);
+            };
+            bload(0, bra);
+            bstore(0, bra);
+            if (ntile > 1) bload(1, bra);
+            __syncthreads();
+            for (int i = 0; i < ntile; i += 2) {
+                if (i + 2 < ntile) bload(i + 2, brb);              // even tile: bra holds tile i + 1
+                compute(i);
+                if (i + 1 < ntile) bstore(1, bra);
+                __syncthreads();
+                if (i + 1 >= ntile) break;
+                if (i + 3 < ntile) bload(i + 3, bra);              // odd tile: brb holds tile i + 2
+                compute(i + 1);
+                if (i + 2 < ntile) bstore(0, brb);
                 __syncthreads();
             }
         }
     }
-    // ---- epilogue: fp32 tile -> bf16 image in LDS (rows of NTP elements: the two lane halves land 16 banks apart)
+    // ---- epilogue, 128 rows at a time: fp32 accumulators -> bf16 image in LDS (rows of NTP elements: the two lane halves land 16
+    //      banks apart), then rows leave with 16-byte stores and the statistics of the stored values are taken on the way
     rbf16* Ot = (rbf16*)lds;
-    float* red = (float*)(lds + C::MT * C::NTP * 2);
-#pragma unroll
-    for (int m = 0; m < MW; ++m)
-#pragma unroll
-        for (int f = 0; f < NF; ++f)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = wave * 32 * MW + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                Ot[row * C::NTP + f * 32 + (lane & 31)] = rn_f2bf(acc[m][f][i]);
-            }
-    __syncthreads();
+    float* red = (float*)(lds + 128 * C::NTP * 2);
     const int ch = tid % C::NCH, rg = tid / C::NCH;
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    if (rg < C::NRG) {
-        const unsigned Pp = a.g.Pp;
-        unsigned q = (unsigned)((p0 + rg) % Pp);
-        int y = q / (unsigned)Wp, x = q - y * Wp;
-        rbf16* out = a.out + (long)b * a.out_stride + (long)cg * C::NT + ch * 8;
-        const rbf16* dot = a.dot ? a.dot + (long)b * a.dot_stride + (long)cg * C::NT + ch * 8 : nullptr;
-        for (int row = rg; row < C::MT; row += C::NRG) {
-            const long p = p0 + row;
-            if (p < a.npix) {
-                const bool interior = y >= 1 && y <= a.g.H && x >= 1 && x <= a.g.W;
-                u32x4 v = *(const u32x4*)(Ot + row * C::NTP + ch * 8);
-                if (!interior) v = (u32x4){0u, 0u, 0u, 0u};
-                *(u32x4*)(out + p * a.Cout) = v;
-                if (a.stats && interior) {
-                    u32x4 d = v;
-                    if (dot) d = ld16(dot + p * a.Cout);
+    const long Pp = a.g.Pp;
+    rbf16* out = a.out + (long)b * a.out_stride + (long)cg * C::NT + ch * 8;
+    const rbf16* dot = a.dot ? a.dot + (long)b * a.dot_stride + (long)cg * C::NT + ch * 8 : nullptr;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float lo = __uint_as_float(v[j] << 16), hi = __uint_as_float(v[j] & 0xffff0000u);
-                        const float dl = __uint_as_float(d[j] << 16), dh = __uint_as_float(d[j] & 0xffff0000u);
-                        s1[2 * j] += lo; s1[2 * j + 1] += hi;
-                        s2[2 * j] += lo * dl; s2[2 * j + 1] += hi * dh;
+    for (int hq = 0; hq < MW; ++hq) {
+        // rows [128 hq, 128 hq + 128) of the tile belong to waves [2 hq / MW ...): with MW = 2 waves 2 hq, 2 hq + 1 (64 rows each)
+        if (hq) __syncthreads();
+        if (wave / (4 / MW) == hq || MW == 1) {
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = (wave * 32 * MW + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) - 128 * hq;
+                        Ot[row * C::NTP + f * 32 + (lane & 31)] = rn_f2bf(acc[m][f][i]);
+                    }
+        }
+        __syncthreads();
+        if (rg < C::NRG) {
+            // row -> interior pixel (image, y, x), walked incrementally in steps of NRG rows
+            const long cb = c0 + 128 * hq + rg;
+            const int hw = a.g.H * a.g.W;
+            long img = cb / hw; int rr = (int)(cb - img * hw);
+            int y = rr / a.g.W, x = rr - y * a.g.W;
+            for (int row = rg; row < 128; row += C::NRG) {
+                if (c0 + 128 * hq + row <= clast) {
+                    const long p = img * Pp + (long)(y + 1) * Wp + x + 1;
+                    const u32x4 v = *(const u32x4*)(Ot + row * C::NTP + ch * 8);
+                    *(u32x4*)(out + p * a.Cout) = v;
+                    if (a.stats) {
+                        u32x4 d = v;
+                        if (dot) d = ld16(dot + p * a.Cout);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float lo = __uint_as_float(v[j] << 16), hi = __uint_as_float(v[j] & 0xffff0000u);
+                            const float dl = __uint_as_float(d[j] << 16), dh = __uint_as_float(d[j] & 0xffff0000u);
+                            s1[2 * j] += lo; s1[2 * j + 1] += hi;
+                            s2[2 * j] += lo * dl; s2[2 * j + 1] += hi * dh;
+                        }
                     }
                 }
+                x += C::NRG;
+                while (x >= a.g.W) { x -= a.g.W; ++y; }
+                while (y >= a.g.H) { y -= a.g.H; ++img; }
             }
-            x += C::NRG;
-            while (x >= Wp) { x -= Wp; ++y; }
-            while (y >= a.g.Hp) y -= a.g.Hp;
         }
     }
     if (a.stats) {
@@ -193,22 +308,56 @@ __global__ __launch_bounds__(256) void rn_conv_kernel(RnConvArgs a) {
         if (tid < C::NT) {
             float t1 = 0.f, t2 = 0.f;
             for (int g = 0; g < C::NRG; ++g) { t1 += red[(g * C::NT + tid) * 2]; t2 += red[(g * C::NT + tid) * 2 + 1]; }
-            float* st = a.stats + (((long)b * gridDim.x + blockIdx.x) * 2) * a.Cout + cg * C::NT + tid;
+            float* st = a.stats + (((long)b * a.tiles + tile) * 2) * a.Cout + cg * C::NT + tid;
             st[0] = t1; st[a.Cout] = t2;
         }
     }
 }
 
-template <int NF, int MW>
-int conv_launch(hipStream_t st, const RnConvArgs& a) {
-    typedef ConvCfg<NF, MW> C;
-    const int lds = C::lds_bytes(a.g.halo);
+template <int NF, int MW, int BKS>
+int conv_launch(hipStream_t st, const RnConvArgs& a, int* nt_out) {
+    typedef ConvCfg<NF, MW, BKS> C;
+    const int lds = C::lds_bytes(a.g);
     if (lds > 160 * 1024) return FUMI_ENOTSUP;
-    FUMI_SET_DYN_LDS((rn_conv_kernel<NF, MW>), lds);
-    const dim3 grid((unsigned)((a.npix + C::MT - 1) / C::MT), a.Cout / C::NT, a.B);
-    hipLaunchKernelGGL((rn_conv_kernel<NF, MW>), grid, dim3(256), lds, st, a);
+    FUMI_SET_DYN_LDS((rn_conv_kernel<NF, MW, BKS>), lds);
+    RnConvArgs k = a;
+    const long NC = a.npix / a.g.Pp * ((long)a.g.H * a.g.W);
+    k.tiles = (int)((NC + C::MT - 1) / C::MT); k.ncg = a.Cout / C::NT; k.slab_rows = C::slab_rows(a.g); k.tpi = 0;
+    if (rn_per_image(a.g, C::MT)) {
+        k.tpi = (a.g.H * a.g.W + C::MT - 1) / C::MT;
+        k.tiles = (int)(a.npix / a.g.Pp) * k.tpi;
+    }
+    const int groups = k.ncg * a.B;
+    static const int xcd_env = getenv("FUMI_RN_XCD") ? atoi(getenv("FUMI_RN_XCD")) : 1;
+    k.xcd = xcd_env && groups >= 8 && groups % 8 == 0;
+    static const int glds_env = getenv("FUMI_RN_GLDS") ? atoi(getenv("FUMI_RN_GLDS")) : 1;
+    k.glds = glds_env;
+    const dim3 grid((unsigned)((long)k.tiles * groups));
+    hipLaunchKernelGGL((rn_conv_kernel<NF, MW, BKS>), grid, dim3(256), lds, st, k);
     LAUNCH_CHECK();
+    if (nt_out) *nt_out = k.tiles;
     return FUMI_OK;
+}
+
+// tile shape for a layer: 256-pixel tiles (each wave 64 pixels: every weight fragment feeds two MFMAs, 0.7 KiB of LDS reads per MFMA
+// instead of 1.2) whenever two workgroups still fit a CU's LDS -- with 4-k-step weight tiles, else with 2-k-step ones
+template <int NF>
+int conv_dispatch(hipStream_t st, const RnConvArgs& a, int* nt_out) {
+    // dev knobs: FUMI_RN_MW = 1 | 2 forces the pixels per wave (32 | 64), FUMI_RN_BKS = 2 | 4 the k-steps per weight tile (also
+    // when that leaves one workgroup per CU)
+    static const int force = getenv("FUMI_RN_MW") ? atoi(getenv("FUMI_RN_MW")) : 0;
+    static const int fbks = getenv("FUMI_RN_BKS") ? atoi(getenv("FUMI_RN_BKS")) : 0;
+    const long tiles256 = (a.npix + 255) / 256 * (a.Cout / (32 * NF)) * a.B;
+    const int two = 80 * 1024 - 256;                                  // two workgroups per CU
+    if (force != 1 && (tiles256 >= 256 || force == 2)) {
+        if (fbks == 4 && ConvCfg<NF, 2, 4>::lds_bytes(a.g) <= 160 * 1024) return conv_launch<NF, 2, 4>(st, a, nt_out);
+        if (fbks == 2 && ConvCfg<NF, 2, 2>::lds_bytes(a.g) <= 160 * 1024) return conv_launch<NF, 2, 2>(st, a, nt_out);
+        // (NF = 5 with 4-k-step tiles and two register sets of weight loads spills: 2-k-step tiles there)
+        if (NF < 5 && ConvCfg<NF, 2, 4>::lds_bytes(a.g) <= two) return conv_launch<NF, 2, 4>(st, a, nt_out);
+        if (ConvCfg<NF, 2, 2>::lds_bytes(a.g) <= two) return conv_launch<NF, 2, 2>(st, a, nt_out);
+    }
+    if (fbks == 2) return conv_launch<NF, 1, 2>(st, a, nt_out);
+    return conv_launch<NF, 1, 4>(st, a, nt_out);
 }
 
 // NF (32-column blocks per workgroup) for an output width: the widest of {5, 4, 3, 2, 1} that divides it
@@ -241,11 +390,25 @@ __device__ __forceinline__ rbf16x8 tr_frag(const unsigned char* img, int r0, int
 }
 
 template <int NTAP>
-__global__ __launch_bounds__(256) void rn_wgrad_kernel(RnWgradArgs a, int ci_tiles, int Ci32) {
+__global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(RnWgradArgs a, int ci_tiles, int Ci32, int xcd, int glds) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z, split = blockIdx.y;
-    const int co0 = (blockIdx.x / ci_tiles) * 64, ci0 = (blockIdx.x % ci_tiles) * 64;
+    // workgroup id -> (output tile, pixel slab, episode).  Every tile of one (slab, episode) walks through the SAME dy / x pixels at
+    // about the same time: with `xcd` such a group is dealt to one XCD (ids i and i + 8 share one), so those pixels are fetched into
+    // that XCD's L2 once instead of once per XCD (L2 hit rate 37 % without).  Speed only: any placement is correct.
+    const int ntile = ci_tiles * ((a.Cout + 63) / 64);
+    int tileid, split, b;
+    if (xcd) {
+        const int x8 = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int grp = (j / ntile) * 8 + x8;
+        tileid = j % ntile; split = grp % a.nsplit; b = grp / a.nsplit;
+        if (b >= a.B) return;
+    } else {
+        tileid = blockIdx.x % ntile;
+        const int r = blockIdx.x / ntile;
+        split = r % a.nsplit; b = r / a.nsplit;
+    }
+    const int co0 = (tileid / ci_tiles) * 64, ci0 = (tileid % ci_tiles) * 64;
     const int hs = NTAP == 9 ? a.g.halo : 0, Wp = a.g.Wp;
     unsigned char* const Dy = lds;                         // [128][128 B]
     unsigned char* const Xs = lds + WG_PK * 128;           // [128 + 2 hs][128 B]
@@ -267,6 +430,28 @@ __global__ __launch_bounds__(256) void rn_wgrad_kernel(RnWgradArgs a, int ci_til
         for (long c = cbeg; c < cend; ++c) {
             const long p0 = c * WG_PK;
             __syncthreads();
+            if (glds) {
+                // LDS-direct loads (no registers, everything in flight at once); a wave instruction fills 8 rows, the swizzle goes on
+                // the source address.  Pixels outside the episode are clamped to its first / last pixel: border pixels = zeros.
+                for (int r0 = wave * 8; r0 < WG_PK; r0 += 32) {
+                    const int r = r0 + (lane >> 3);
+                    long p = p0 + r;
+                    p = p >= a.npix ? a.npix - 1 : p;
+                    int chunk = (lane & 7) ^ (((r >> 1) & 1) << 2);
+                    chunk = co0 + chunk * 8 < a.Cout ? chunk : 0;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dy + p * a.Cout + co0 + chunk * 8),
+                                                     (__attribute__((address_space(3))) void*)(Dy + r0 * 128), 16, 0, 0);
+                }
+                for (int r0 = wave * 8; r0 < xrows; r0 += 32) {
+                    const int r = r0 + (lane >> 3);
+                    long p = p0 - hs + r;
+                    p = p < 0 ? 0 : (p >= a.npix ? a.npix - 1 : p);
+                    int chunk = (lane & 7) ^ (((r >> 1) & 1) << 2);
+                    chunk = ci0 + chunk * 8 < a.Cin ? chunk : 0;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + p * a.Cin + ci0 + chunk * 8),
+                                                     (__attribute__((address_space(3))) void*)(Xs + r0 * 128), 16, 0, 0);
+                }
+            } else {
             {   // dy stage: 128 rows x 8 chunks = 4 units per thread
                 u32x4 v[4];
 #pragma unroll
@@ -298,6 +483,7 @@ __global__ __launch_bounds__(256) void rn_wgrad_kernel(RnWgradArgs a, int ci_til
                     if (r < xrows) *(u32x4*)(Xs + r * 128 + ((sch * 16) ^ (((r >> 1) & 1) << 6))) = ok ? v[i] : (u32x4){0u, 0u, 0u, 0u};
                 }
             }
+            }
             __syncthreads();
 #pragma unroll 2
             for (int ks = 0; ks < WG_PK / 16; ++ks) {
@@ -322,20 +508,23 @@ __global__ __launch_bounds__(256) void rn_wgrad_kernel(RnWgradArgs a, int ci_til
         }
 }
 
+// thread = one (co, ci) pair: for every tap the reads of consecutive threads are consecutive floats of a slab row; the ntaps results
+// of a thread are ntaps consecutive floats of the OIHW tensor
 __global__ __launch_bounds__(256) void rn_wgrad_reduce_kernel(int nsplit, int ntaps, int Cout, int Ci32, int Cin_real, const float* part,
                                                               float* G, long gstride) {
     const int b = blockIdx.y;
-    const long n = (long)Cout * Cin_real * ntaps;
+    const long n = (long)Cout * Cin_real;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int tap = (int)(i % ntaps);
-    const long r = i / ntaps;
-    const int ci = (int)(r % Cin_real), co = (int)(r / Cin_real);
+    const int ci = (int)(i % Cin_real), co = (int)(i / Cin_real);
     const long slab = (long)ntaps * Cout * Ci32;
-    const float* p = part + (long)b * nsplit * slab + ((long)tap * Cout + co) * Ci32 + ci;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += p[(long)k * slab];
-    G[(long)b * gstride + i] = s;
+    const float* p = part + (long)b * nsplit * slab + (long)co * Ci32 + ci;
+    float* g = G + (long)b * gstride + i * ntaps;
+    for (int tap = 0; tap < ntaps; ++tap) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += p[(long)k * slab + (long)tap * Cout * Ci32];
+        g[tap] = s;
+    }
 }
 
 // fp32 OIHW master -> bf16 fragment copies
@@ -372,25 +561,25 @@ int rn_conv_tiles(long npix, int Cout) {
 
 size_t rn_conv_lds_bytes(const RnGeom& g, int Cout) {
     switch (conv_nf(Cout)) {
-        case 5: return ConvCfg<5, 1>::lds_bytes(g.halo);
-        case 4: return ConvCfg<4, 1>::lds_bytes(g.halo);
-        case 3: return ConvCfg<3, 1>::lds_bytes(g.halo);
-        case 2: return ConvCfg<2, 1>::lds_bytes(g.halo);
-        default: return ConvCfg<1, 1>::lds_bytes(g.halo);
+        case 5: return ConvCfg<5, 1, 4>::lds_bytes(g);
+        case 4: return ConvCfg<4, 1, 4>::lds_bytes(g);
+        case 3: return ConvCfg<3, 1, 4>::lds_bytes(g);
+        case 2: return ConvCfg<2, 1, 4>::lds_bytes(g);
+        default: return ConvCfg<1, 1, 4>::lds_bytes(g);
     }
 }
 
-int launch_rn_conv(hipStream_t st, const RnConvArgs& a) {
+int launch_rn_conv(hipStream_t st, const RnConvArgs& a, int* nt_out) {
     if (a.B < 1 || a.nsrc < 1 || a.nsrc > 4 || a.Cout < 32 || (a.Cout & 31) || a.npix < 1) return FUMI_EINVAL;
     for (int s = 0; s < a.nsrc; ++s)
         if (!a.src[s].in || !a.src[s].frag || a.src[s].Cin < 16 || (a.src[s].Cin & 15) || (a.src[s].ntaps != 9 && a.src[s].ntaps != 1))
             return FUMI_EINVAL;
     switch (conv_nf(a.Cout)) {
-        case 5: return conv_launch<5, 1>(st, a);
-        case 4: return conv_launch<4, 1>(st, a);
-        case 3: return conv_launch<3, 1>(st, a);
-        case 2: return conv_launch<2, 1>(st, a);
-        default: return conv_launch<1, 1>(st, a);
+        case 5: return conv_dispatch<5>(st, a, nt_out);
+        case 4: return conv_dispatch<4>(st, a, nt_out);
+        case 3: return conv_dispatch<3>(st, a, nt_out);
+        case 2: return conv_dispatch<2>(st, a, nt_out);
+        default: return conv_dispatch<1>(st, a, nt_out);
     }
 }
 
@@ -403,6 +592,7 @@ int rn_wgrad_nsplit(int B, long npix, int Cin, int Cout) {
     if (ns > chunks / 4) ns = chunks / 4;
     if (ns < 1) ns = 1;
     if (ns > 512) ns = 512;
+    if (ns * B >= 8 && B < 8 && 8 % B == 0) ns = (ns + 8 / B - 1) / (8 / B) * (8 / B);     // slabs x episodes in multiples of 8: XCD-grouped ids
     return (int)ns;
 }
 
@@ -414,13 +604,17 @@ int launch_rn_wgrad(hipStream_t st, const RnWgradArgs& a) {
     const int hs = a.ntaps == 9 ? a.g.halo : 0;
     const int lds = WG_PK * 128 + (WG_PK + 2 * hs) * 128 + 1024;       // (+ slack: transposing reads of the last k-step stay in bounds)
     if (lds > 160 * 1024) return FUMI_ENOTSUP;
-    const dim3 grid(co_tiles * ci_tiles, a.nsplit, a.B);
+    const int groups = a.nsplit * a.B;
+    static const int xcd_env = getenv("FUMI_RN_XCD") ? atoi(getenv("FUMI_RN_XCD")) : 1;
+    const int xcd = xcd_env && groups >= 8 && groups % 8 == 0;
+    static const int glds = getenv("FUMI_RN_GLDS") ? atoi(getenv("FUMI_RN_GLDS")) : 1;
+    const dim3 grid((unsigned)((long)co_tiles * ci_tiles * groups));
     if (a.ntaps == 9) {
         FUMI_SET_DYN_LDS(rn_wgrad_kernel<9>, lds);
-        hipLaunchKernelGGL(rn_wgrad_kernel<9>, grid, dim3(256), lds, st, a, ci_tiles, Ci32);
+        hipLaunchKernelGGL(rn_wgrad_kernel<9>, grid, dim3(256), lds, st, a, ci_tiles, Ci32, xcd, glds);
     } else {
         FUMI_SET_DYN_LDS(rn_wgrad_kernel<1>, lds);
-        hipLaunchKernelGGL(rn_wgrad_kernel<1>, grid, dim3(256), lds, st, a, ci_tiles, Ci32);
+        hipLaunchKernelGGL(rn_wgrad_kernel<1>, grid, dim3(256), lds, st, a, ci_tiles, Ci32, xcd, glds);
     }
     LAUNCH_CHECK();
     return FUMI_OK;
@@ -429,7 +623,7 @@ int launch_rn_wgrad(hipStream_t st, const RnWgradArgs& a) {
 int launch_rn_wgrad_reduce(hipStream_t st, int B, int nsplit, int ntaps, int Cout, int Cin, int Cin_real, const float* part,
                            float* G, long gstride) {
     const int Ci32 = (Cin + 31) / 32 * 32;
-    const long n = (long)Cout * Cin_real * ntaps;
+    const long n = (long)Cout * Cin_real;
     hipLaunchKernelGGL(rn_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, nsplit, ntaps, Cout, Ci32, Cin_real,
                        part, G, gstride);
     LAUNCH_CHECK();

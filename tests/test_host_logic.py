@@ -340,7 +340,8 @@ def test_bench_self_launches_one_process_per_gpu(monkeypatch, capsys):
         seen["cmd"], seen["env"] = cmd, env
         return subprocess.CompletedProcess(cmd, 7)
     monkeypatch.setattr(subprocess, "run", fake_run)
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 4)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: (_ for _ in ()).throw(AssertionError("the parent must not touch torch.cuda")))
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "1"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     with pytest.raises(SystemExit) as e:
@@ -350,7 +351,7 @@ def test_bench_self_launches_one_process_per_gpu(monkeypatch, capsys):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
     assert cmd[-6:] == ["--gpus", "4", "--steps", "5", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)          # not enough devices: refuse, exit code 2
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 1)               # not enough devices: refuse, exit code 2
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 2
