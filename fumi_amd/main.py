@@ -131,6 +131,11 @@ def parse_args(argv=None):
             ("--disable_cuda was given" if args.disable_cuda else "no GPU is visible (torch.cuda.is_available() is False)")
             + ": fumi_amd has no CPU execution path -- every step runs on the MI355X library "
               "(fumi_amd/lib/libfumi_hip.so).  Run the reference itself for a CPU run.")
+    if getattr(args, "fine_tune", False) and args.text_encoder in ("RNN", "RNNhid") and args.model in ("fumi", "am3"):
+        # the reference trains the bi-LSTM here (fumi/models/fumi.py:65-67, common.py:44-161); the engine's LSTM op is forward
+        # only, so this combination is refused when the flags are parsed instead of at the first training step
+        raise NotImplementedError("--fine_tune with --text_encoder RNN / RNNhid: the engine's bi-LSTM text encoder is forward only "
+                                  "(frozen LSTM weights are supported: drop --fine_tune)")
     print(f"running on device {args.device}")
     return args
 

@@ -283,6 +283,16 @@ def test_disable_cuda_is_refused_at_parse_args():
         engine.set_engine(old)
 
 
+def test_fine_tuning_the_lstm_is_refused_at_parse_args(oracle_engine):
+    """--fine_tune with RNN / RNNhid trains the bi-LSTM in the reference (fumi.py:65-67); the engine's LSTM op is forward only and
+    says so when the flags are parsed (frozen LSTM text encoders work: test_rnn_text_encoders_keep_the_reference_surface)."""
+    from fumi_amd import main as cli
+    for enc in ("RNN", "RNNhid"):
+        with pytest.raises(NotImplementedError, match="forward only"):
+            cli.parse_args(["--model", "fumi", "--disable_cuda", "--text_encoder", enc, "--fine_tune"])
+    cli.parse_args(["--model", "fumi", "--disable_cuda", "--text_encoder", "RNN"])          # frozen: accepted
+
+
 def test_cli_flag_validation_raises_value_error(oracle_engine, tmp_path, monkeypatch):
     from fumi_amd import main as cli
     monkeypatch.chdir(tmp_path)
