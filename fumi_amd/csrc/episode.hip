@@ -1566,9 +1566,11 @@ void carve(Carver& c, const EpisodeProblem& p, EpiBuf& w) {
 }  // namespace
 
 void set_xpanel_trace(void* p);                    // xpanel.hip
+void set_rn12_trace(void* p);                      // rn12_conv.hip
 extern "C" int fumi_hip_set_trace_buffer(int which, void* p) {
     if (which == 0) g_epi_trace = (unsigned long long*)p;
     else if (which == 1) set_xpanel_trace(p);
+    else if (which == 2) set_rn12_trace(p);
     else return FUMI_EINVAL;
     return FUMI_OK;
 }

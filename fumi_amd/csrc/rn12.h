@@ -46,6 +46,7 @@ struct RnConvArgs {
     rbf16* out; long out_stride;
     float* stats;                                     // != NULL: [B][tiles][2][Cout] partial sums over interior pixels of (out, out * dot)
     const rbf16* dot; long dot_stride;                // NULL: out * out
+    unsigned long long* trace;                        // dev: cycle stamps of one workgroup's wave 0 (fumi_hip_set_trace_buffer(2, ..))
     int tiles, ncg, xcd, slab_rows, glds, tpi;         // tpi > 0: tiles restart at every image (tpi tiles per image)                   // set by the launcher: pixel tiles / column groups per episode, XCD-grouped ids,
                                                       // rows of the input slab's LDS image
 };

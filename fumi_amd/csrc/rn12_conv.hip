@@ -4,6 +4,9 @@
 #include "rn12.h"
 #include <stdlib.h>
 
+unsigned long long* g_rn_trace = nullptr;          // dev tracing only (tests/dev/trace_rn12_conv.py)
+void set_rn12_trace(void* p) { g_rn_trace = (unsigned long long*)p; }
+
 namespace {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -34,12 +37,14 @@ template <class T> __device__ __forceinline__ const T* uni(const T* p) { return 
 // =====================================================================================================================================
 constexpr int CV_KC = 64;                              // channels per staged chunk
 
-// padded pixel (within an episode) of the compact interior index c = (image, y, x) row-major
+// padded pixel (within an episode) of the compact interior index c = (image, y, x) row-major.  32-bit arithmetic: an episode has
+// fewer than 2^31 pixels (the launcher checks), and a 64-bit division costs ~100 instructions in a prologue that a short tile
+// (block 1: 36 k-steps) feels -- 5 600 of its 31 000 cycles in the first trace
 __host__ __device__ inline long rn_pix_of(long c, const RnGeom& g) {
-    const int hw = g.H * g.W;
-    const long img = c / hw; const int r = (int)(c - img * hw);
-    const int y = r / g.W, x = r - y * g.W;
-    return img * g.Pp + (long)(y + 1) * g.Wp + x + 1;
+    const unsigned hw = (unsigned)(g.H * g.W), cu = (unsigned)c;
+    const unsigned img = cu / hw, r = cu - img * hw;
+    const unsigned y = r / (unsigned)g.W, x = r - y * (unsigned)g.W;
+    return (long)(img * (unsigned)g.Pp + (y + 1) * (unsigned)g.Wp + x + 1);
 }
 // Large images (>= 4 tiles each): tiles restart at every image -- a tile never straddles the 2 border rows between two images, which
 // would put them (and for wide rows a lot of LDS) into its slab; the last tile of an image is partial (1.6 % at 84 x 84 / 256).
@@ -99,11 +104,11 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
         cg = r % a.ncg; b = r / a.ncg;
     }
     const int halo = a.g.halo, Wp = a.g.Wp;
-    const long NC = a.npix / a.g.Pp * (a.g.H * a.g.W);             // interior pixels of the episode
+    const long NC = (long)((unsigned)a.npix / (unsigned)a.g.Pp) * (a.g.H * a.g.W);   // interior pixels of the episode
     long c0 = (long)tile * C::MT, cend = NC;
     if (a.tpi) {                                                    // tiles restart at every image
         const int hw = a.g.H * a.g.W;
-        const long img = tile / a.tpi;
+        const long img = (unsigned)tile / (unsigned)a.tpi;
         c0 = img * hw + (long)(tile - img * a.tpi) * C::MT; cend = (img + 1) * hw;
     }
     const long clast = min(c0 + C::MT, cend) - 1;
@@ -128,6 +133,10 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
     __syncthreads();
     const int CF = a.Cout >> 5;
     const int srow = tid >> 3, schunk = tid & 7;
+    // dev tracing: cycles per phase summed in registers (a store inside the loop would join the vmcnt queue the waits count)
+    const bool traced = a.trace && tid == 0 && blockIdx.x == gridDim.x / 2;
+    unsigned long long t_prev = traced ? __builtin_amdgcn_s_memtime() : 0, t_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RNSTAMP(k) if (traced) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_sum[k] += t_now - t_prev; t_prev = t_now; }
     for (int s = 0; s < a.nsrc; ++s) {
         RnSrc S;                                                    // (wave-uniform: kept in scalar registers)
         S.in = uni(s_src[s].in); S.in_stride = uni(s_src[s].in_stride); S.frag = uni(s_src[s].frag);
@@ -149,13 +158,17 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
             const bool chok = schunk * 8 < kc;
             const int chs = chok ? schunk * 8 : 0;
             if (a.glds) {
-                for (int r0 = wave * 8; r0 < rows; r0 += 32) {
+                // (32-bit arithmetic off a scalar base: the address math of these loops was 7 % of the kernel as 64-bit VALU code)
+                const int pbase = (int)p0 - hs + (lane >> 3), plim = (int)a.npix - 1;
+                const char* inb = (const char*)(in + c0);
+                for (int r0 = uni(wave * 8); r0 < rows; r0 += 32) {
                     const int r = r0 + (lane >> 3);
-                    long p = p0 - hs + r;
-                    p = p < 0 ? 0 : (p >= a.npix ? a.npix - 1 : p);
+                    int p = pbase + r0;
+                    p = p < 0 ? 0 : (p > plim ? plim : p);
                     int chunk = (lane & 7) ^ ((r >> 1) & 7);
                     chunk = chunk * 8 < kc ? chunk : 0;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + p * S.Cin + c0 + chunk * 8),
+                    const unsigned off = ((unsigned)p * (unsigned)S.Cin + (unsigned)(chunk * 8)) * 2u;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(inb + off),
                                                      (__attribute__((address_space(3))) void*)(As + r0 * 128), 16, 0, 0);
                 }
             } else {
@@ -178,36 +191,38 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                 }
             }
             // ---- weight tiles: tile i of the chunk = k-steps [BKS (i % npt), ...) of tap i / npt; NF fragments of 1 KiB per k-step,
-            //      contiguous in memory; double-buffered through LDS, one barrier per tile
+            //      contiguous in memory AND in the order the LDS image has them: LDS-direct loads (one wave instruction per KiB block,
+            //      no registers, no ds_write pass), double-buffered, requested one tile ahead, one barrier per tile.  Addresses: a
+            //      scalar base per tile (advanced by constants) + lane * 16
             const int npt = (nks + BKS - 1) / BKS;                 // tiles per tap
             const int ntile = S.ntaps * npt;
-            constexpr int NLD = (BKS * NF + 3) / 4;
-            u32x4 bra[NLD], brb[NLD];                              // two register sets: a tile's loads are issued TWO tiles ahead
-            auto bload = [&](int i, u32x4* breg) {
-                const int tap = i / npt, k0 = (i - tap * npt) * BKS;
-                const int units = min(BKS, nks - k0) * NF * 64;    // 16-byte units of this tile
-#pragma unroll
-                for (int j = 0; j < NLD; ++j) {
-                    int u = tid + 256 * j;
-                    u = u < units ? u : units - 1;
-                    const int ks = u / (NF * 64), rem = u - ks * (NF * 64);
-                    breg[j] = ld16(frag + (((long)tap * KS + (c0 >> 4) + k0 + ks) * CF + cg * NF) * 512 + rem * 8);
-                }
+            constexpr int NBL = (BKS * NF + 3) / 4;                // KiB blocks per wave and tile (4 waves); clamped duplicates past the end
+            const int nblk = min(BKS, nks) * NF;                   // KiB blocks of a tile (nks <= BKS, or a multiple of it)
+            const char* fragb = (const char*)(frag + ((long)(c0 >> 4) * CF + cg * NF) * 512) + lane * 16;
+            const long tap_stride = (long)KS * CF * 1024, part_stride = (long)BKS * CF * 1024;
+            // one KiB block of a weight tile: block wave + 4 j of the tile whose first block is at tbase (clamped duplicate past the end)
+            auto bissue1 = [&](const char* tbase, int buf, int j) {
+                int blk = uni(wave) + 4 * j;
+                blk = blk < nblk ? blk : nblk - 1;
+                const int ks = blk / NF, f = blk - ks * NF;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + ((long)ks * CF + f) * 1024),
+                                                 (__attribute__((address_space(3))) void*)(Bs + buf * C::BT + blk * 1024), 16, 0, 0);
             };
-            auto bstore = [&](int buf, const u32x4* breg) {
+            auto bissue = [&](const char* tbase, int buf) {
 #pragma unroll
-                for (int j = 0; j < NLD; ++j) {
-                    const int u = tid + 256 * j;
-                    if (u < BKS * NF * 64) *(u32x4*)(Bs + buf * C::BT + u * 16) = breg[j];
-                }
+                for (int j = 0; j < NBL; ++j) bissue1(tbase, buf, j);
             };
-            auto compute = [&](int i) {
-                const int t = i / npt, k0 = (i - t * npt) * BKS, kn = min(BKS, nks - k0);
+            // the k-steps of one tile; `nxt` != NULL: the NEXT tile's NBL load requests are placed one by one BETWEEN the groups of MFMAs
+            // (a wave issues in order: as a block in front of the k-steps they cost 880 cycles of a 2 300-cycle tile during which this
+            // wave fed the matrix pipe nothing; behind an MFMA they issue while the pipe works)
+            auto compute = [&](int t, int k0, int buf, const char* nxt) {
+                const int kn = min(BKS, nks - k0);
                 const int toff = S.ntaps == 9 ? (t / 3 - 1) * Wp + (t % 3 - 1) : 0;
-                const unsigned char* Bt = Bs + (i & 1) * C::BT;
+                const unsigned char* Bt = Bs + buf * C::BT;
                 int arow[MW];
 #pragma unroll
                 for (int m = 0; m < MW; ++m) arow[m] = prow[m] + hs + toff;
+                int slot = nxt ? 0 : NBL;
                 // (a runtime loop on purpose: fully unrolled, hipcc hoists the next k-steps' fragment reads and spills -- 576 bytes of
                 //  scratch per lane at NF = 5, MW = 2 and 8.6x the time)
                 for (int ks = 0; ks < kn; ++ks) {
@@ -220,26 +235,34 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                         const rbf16x8 af = *(const rbf16x8*)(As + arow[m] * 128 + ((ch ^ ((arow[m] >> 1) & 7)) << 4));
 #pragma unroll
                         for (int f = 0; f < NF; ++f) acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[f], acc[m][f], 0, 0, 0);
+                        if (slot < NBL) { bissue1(nxt, buf ^ 1, slot); ++slot; }
                     }
                 }
+                for (; slot < NBL; ++slot) bissue1(nxt, buf ^ 1, slot);      // (a short tile: the rest after it)
             };
-            bload(0, bra);
-            bstore(0, bra);
-            if (ntile > 1) bload(1, bra);
+            RNSTAMP(0)                                              // (prologue / between chunks + slab loads issued)
+            bissue(fragb, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            for (int i = 0; i < ntile; i += 2) {
-                if (i + 2 < ntile) bload(i + 2, brb);              // even tile: bra holds tile i + 1
-                compute(i);
-                if (i + 1 < ntile) bstore(1, bra);
-                __syncthreads();
-                if (i + 1 >= ntile) break;
-                if (i + 3 < ntile) bload(i + 3, bra);              // odd tile: brb holds tile i + 2
-                compute(i + 1);
-                if (i + 2 < ntile) bstore(0, brb);
-                __syncthreads();
+            RNSTAMP(1)                                              // (slab and first weight tile in LDS)
+            int gbuf = 0;
+            for (int t = 0; t < S.ntaps; ++t) {
+                const char* tapb = fragb + t * tap_stride;
+                for (int kp = 0; kp < npt; ++kp, gbuf ^= 1) {
+                    // request the next tile (next k-part of this tap, or the first of the next tap) into the other buffer
+                    const char* nxt = kp + 1 < npt ? tapb + (kp + 1) * part_stride : (t + 1 < S.ntaps ? tapb + tap_stride : nullptr);
+                    RNSTAMP(2)
+                    compute(t, kp * BKS, gbuf, nxt);
+                    RNSTAMP(3)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    RNSTAMP(4)
+                    __syncthreads();
+                    RNSTAMP(6)
+                }
             }
         }
     }
+    RNSTAMP(0)
     // ---- epilogue, 128 rows at a time: fp32 accumulators -> bf16 image in LDS (rows of NTP elements: the two lane halves land 16
     //      banks apart), then rows leave with 16-byte stores and the statistics of the stored values are taken on the way
     rbf16* Ot = (rbf16*)lds;
@@ -271,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
             // row -> interior pixel (image, y, x), walked incrementally in steps of NRG rows
             const long cb = c0 + 128 * hq + rg;
             const int hw = a.g.H * a.g.W;
-            long img = cb / hw; int rr = (int)(cb - img * hw);
+            long img = (long)((unsigned)cb / (unsigned)hw); int rr = (int)(cb - img * hw);
             int y = rr / a.g.W, x = rr - y * a.g.W;
             for (int row = rg; row < 128; row += C::NRG) {
                 if (c0 + 128 * hq + row <= clast) {
@@ -312,6 +335,10 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
             st[0] = t1; st[a.Cout] = t2;
         }
     }
+    if (traced) {
+        RNSTAMP(7)                                                  // (epilogue)
+        for (int k = 0; k < 8; ++k) a.trace[k] = t_sum[k];
+    }
 }
 
 template <int NF, int MW, int BKS>
@@ -331,7 +358,7 @@ int conv_launch(hipStream_t st, const RnConvArgs& a, int* nt_out) {
     static const int xcd_env = getenv("FUMI_RN_XCD") ? atoi(getenv("FUMI_RN_XCD")) : 1;
     k.xcd = xcd_env && groups >= 8 && groups % 8 == 0;
     static const int glds_env = getenv("FUMI_RN_GLDS") ? atoi(getenv("FUMI_RN_GLDS")) : 1;
-    k.glds = glds_env;
+    k.glds = glds_env; k.trace = g_rn_trace;
     const dim3 grid((unsigned)((long)k.tiles * groups));
     hipLaunchKernelGGL((rn_conv_kernel<NF, MW, BKS>), grid, dim3(256), lds, st, k);
     LAUNCH_CHECK();
@@ -570,6 +597,9 @@ size_t rn_conv_lds_bytes(const RnGeom& g, int Cout) {
 }
 
 int launch_rn_conv(hipStream_t st, const RnConvArgs& a, int* nt_out) {
+    if (a.npix >= (1L << 31) - 4096) return FUMI_ENOTSUP;            // (pixel indices are 32-bit inside the kernels)
+    for (int s = 0; s < a.nsrc; ++s)
+        if (a.npix * a.src[s].Cin * 2 >= (1L << 32) - 65536) return FUMI_ENOTSUP;      // (byte offsets within an episode's map: 32-bit)
     if (a.B < 1 || a.nsrc < 1 || a.nsrc > 4 || a.Cout < 32 || (a.Cout & 31) || a.npix < 1) return FUMI_EINVAL;
     for (int s = 0; s < a.nsrc; ++s)
         if (!a.src[s].in || !a.src[s].frag || a.src[s].Cin < 16 || (a.src[s].Cin & 15) || (a.src[s].ntaps != 9 && a.src[s].ntaps != 1))

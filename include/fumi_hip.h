@@ -68,7 +68,8 @@ int   fumi_hip_read_status(fumi_ws_t* ws, fumi_stream_t stream, int* status_out)
  * default 1 << 22, about a second).  Tests set 0 to see the bit; returns the previous value. */
 int   fumi_hip_set_spin_limit(int polls);
 /* Development hooks: a device buffer of uint64 wall-clock stamps written by block 0 of the per-episode kernels (which = 0) or by
- * every workgroup of the forward X-panel kernel (which = 1); NULL switches the stamps off (the default). */
+ * every workgroup of the forward X-panel kernel (which = 1), or cycle stamps of wave 0 of the middle workgroup of a ResNet-12
+ * convolution launch (which = 2); NULL switches the stamps off (the default). */
 int   fumi_hip_set_trace_buffer(int which, void* device_u64);
 
 /* ---- in-library phase timing (HIP events recorded on the caller's stream around each phase) ---------------------
