@@ -416,8 +416,11 @@ __device__ __forceinline__ rbf16x8 tr_frag(const unsigned char* img, int r0, int
     return __builtin_bit_cast(rbf16x8, v);
 }
 
+// (One stage buffer, two workgroups per CU covering each other's loads.  Double-buffering the stages inside ONE workgroup per CU --
+// next stage's loads in flight under this stage's 72 MFMAs per wave, one barrier per stage -- was built and measured: 194 vs 171 ms
+// per 8-episode step.)
 template <int NTAP>
-__global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(RnWgradArgs a, int ci_tiles, int Ci32, int xcd, int glds) {
+__global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(RnWgradArgs a, int ci_tiles, int Ci32, int xcd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // workgroup id -> (output tile, pixel slab, episode).  Every tile of one (slab, episode) walks through the SAME dy / x pixels at
@@ -437,92 +440,68 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(RnWgradArgs a, int ci_
     }
     const int co0 = (tileid / ci_tiles) * 64, ci0 = (tileid % ci_tiles) * 64;
     const int hs = NTAP == 9 ? a.g.halo : 0, Wp = a.g.Wp;
-    unsigned char* const Dy = lds;                         // [128][128 B]
-    unsigned char* const Xs = lds + WG_PK * 128;           // [128 + 2 hs][128 B]
+    const int xrows = WG_PK + 2 * hs;
+    const int xr8 = (xrows + 7) / 8 * 8;
+    const int stage_bytes = (WG_PK + xr8) * 128;           // one stage: dy [128][128 B] then x [128 + 2 hs (rounded to 8)][128 B]
     f32x16 acc[NTAP];
 #pragma unroll
     for (int t = 0; t < NTAP; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    const long nchunks = (a.npix + WG_PK - 1) / WG_PK;
-    const long cps = (nchunks + a.nsplit - 1) / a.nsplit;
-    const long cbeg = (long)split * cps, cend = min(nchunks, cbeg + cps);
-    const int srow = tid >> 3, sch = tid & 7;
-    const bool dyok = co0 + sch * 8 < a.Cout, xok = ci0 + sch * 8 < a.Cin;
-    const int dych = dyok ? co0 + sch * 8 : 0, xch = xok ? ci0 + sch * 8 : 0;
-    const int xrows = WG_PK + 2 * hs;
-    for (int pr = 0; pr < a.npair; ++pr) {
-        const rbf16* x = (pr ? a.x[1] : a.x[0]) + (long)b * a.x_stride;
-        const rbf16* dy = (pr ? a.dy[1] : a.dy[0]) + (long)b * a.dy_stride;
-        for (long c = cbeg; c < cend; ++c) {
-            const long p0 = c * WG_PK;
-            __syncthreads();
-            if (glds) {
-                // LDS-direct loads (no registers, everything in flight at once); a wave instruction fills 8 rows, the swizzle goes on
-                // the source address.  Pixels outside the episode are clamped to its first / last pixel: border pixels = zeros.
-                for (int r0 = wave * 8; r0 < WG_PK; r0 += 32) {
-                    const int r = r0 + (lane >> 3);
-                    long p = p0 + r;
-                    p = p >= a.npix ? a.npix - 1 : p;
-                    int chunk = (lane & 7) ^ (((r >> 1) & 1) << 2);
-                    chunk = co0 + chunk * 8 < a.Cout ? chunk : 0;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dy + p * a.Cout + co0 + chunk * 8),
-                                                     (__attribute__((address_space(3))) void*)(Dy + r0 * 128), 16, 0, 0);
-                }
-                for (int r0 = wave * 8; r0 < xrows; r0 += 32) {
-                    const int r = r0 + (lane >> 3);
-                    long p = p0 - hs + r;
-                    p = p < 0 ? 0 : (p >= a.npix ? a.npix - 1 : p);
-                    int chunk = (lane & 7) ^ (((r >> 1) & 1) << 2);
-                    chunk = ci0 + chunk * 8 < a.Cin ? chunk : 0;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + p * a.Cin + ci0 + chunk * 8),
-                                                     (__attribute__((address_space(3))) void*)(Xs + r0 * 128), 16, 0, 0);
-                }
-            } else {
-            {   // dy stage: 128 rows x 8 chunks = 4 units per thread
-                u32x4 v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    long p = p0 + 32 * i + srow;
-                    p = p >= a.npix ? a.npix - 1 : p;
-                    v[i] = ld16(dy + p * a.Cout + dych);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 32 * i + srow;
-                    const bool ok = dyok && p0 + r < a.npix;
-                    *(u32x4*)(Dy + r * 128 + ((sch * 16) ^ (((r >> 1) & 1) << 6))) = ok ? v[i] : (u32x4){0u, 0u, 0u, 0u};
-                }
-            }
-            for (int r0 = 0; r0 < xrows; r0 += 128) {
-                u32x4 v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    long p = p0 - hs + r0 + 32 * i + srow;
-                    p = p < 0 ? 0 : (p >= a.npix ? a.npix - 1 : p);
-                    v[i] = ld16(x + p * a.Cin + xch);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = r0 + 32 * i + srow;
-                    const long p = p0 - hs + r;
-                    const bool ok = xok && p >= 0 && p < a.npix;
-                    if (r < xrows) *(u32x4*)(Xs + r * 128 + ((sch * 16) ^ (((r >> 1) & 1) << 6))) = ok ? v[i] : (u32x4){0u, 0u, 0u, 0u};
-                }
-            }
-            }
-            __syncthreads();
+    const int nchunks = (int)((a.npix + WG_PK - 1) / WG_PK);
+    const int cps = (nchunks + a.nsplit - 1) / a.nsplit;
+    const int cbeg = split * cps, cend = min(nchunks, cbeg + cps);
+    const int nst = max(cend - cbeg, 0), Q = a.npair * nst;   // stages of this workgroup: (pair, pixel chunk)
+    const int lr = lane >> 3, plim = (int)a.npix - 1;
+    // LDS-direct loads of stage q (no registers, everything in flight at once); a wave instruction fills 8 rows, the swizzle goes on
+    // the source address; 32-bit byte offsets off the episode's base.  Pixels outside the episode are clamped to its first / last
+    // pixel: border pixels of the padded layout = zeros.
+    auto issue = [&](int q, int buf) {
+        const int pr = q >= nst ? 1 : 0;
+        const int p0 = (cbeg + q - pr * nst) * WG_PK;
+        const char* dyb = (const char*)((pr ? a.dy[1] : a.dy[0]) + (long)b * a.dy_stride + co0);
+        const char* xb = (const char*)((pr ? a.x[1] : a.x[0]) + (long)b * a.x_stride + ci0);
+        unsigned char* Dy = lds + buf * stage_bytes; unsigned char* Xs = Dy + WG_PK * 128;
+        for (int r0 = uni(wave * 8); r0 < WG_PK; r0 += 32) {
+            const int r = r0 + lr;
+            int p = p0 + r;
+            p = p > plim ? plim : p;
+            int chunk = (lane & 7) ^ (((r >> 1) & 1) << 2);
+            chunk = co0 + chunk * 8 < a.Cout ? chunk : 0;
+            const unsigned off = ((unsigned)p * (unsigned)a.Cout + (unsigned)(chunk * 8)) * 2u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dyb + off),
+                                             (__attribute__((address_space(3))) void*)(Dy + r0 * 128), 16, 0, 0);
+        }
+        for (int r0 = uni(wave * 8); r0 < xrows; r0 += 32) {
+            const int r = r0 + lr;
+            int p = p0 - hs + r;
+            p = p < 0 ? 0 : (p > plim ? plim : p);
+            int chunk = (lane & 7) ^ (((r >> 1) & 1) << 2);
+            chunk = ci0 + chunk * 8 < a.Cin ? chunk : 0;
+            const unsigned off = ((unsigned)p * (unsigned)a.Cin + (unsigned)(chunk * 8)) * 2u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off),
+                                             (__attribute__((address_space(3))) void*)(Xs + r0 * 128), 16, 0, 0);
+        }
+    };
+    auto compute = [&](int buf) {
+        const unsigned char* Dy = lds + buf * stage_bytes; const unsigned char* Xs = Dy + WG_PK * 128;
 #pragma unroll 2
-            for (int ks = 0; ks < WG_PK / 16; ++ks) {
-                const rbf16x8 af = tr_frag(Dy, ks * 16, (wave >> 1) * 32, lane);
+        for (int ks = 0; ks < WG_PK / 16; ++ks) {
+            const rbf16x8 af = tr_frag(Dy, ks * 16, (wave >> 1) * 32, lane);
 #pragma unroll
-                for (int t = 0; t < NTAP; ++t) {
-                    const int toff = NTAP == 9 ? (t / 3 - 1) * Wp + (t % 3 - 1) : 0;
-                    const rbf16x8 bf = tr_frag(Xs, ks * 16 + hs + toff, (wave & 1) * 32, lane);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
-                }
+            for (int t = 0; t < NTAP; ++t) {
+                const int toff = NTAP == 9 ? (t / 3 - 1) * Wp + (t % 3 - 1) : 0;
+                const rbf16x8 bf = tr_frag(Xs, ks * 16 + hs + toff, (wave & 1) * 32, lane);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
             }
         }
+    };
+    for (int q = 0; q < Q; ++q) {
+        __syncthreads();
+        issue(q, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        compute(0);
     }
     float* part = a.part + (((long)b * a.nsplit + split) * NTAP) * a.Cout * Ci32;
     const int ci = ci0 + (wave & 1) * 32 + (lane & 31);
@@ -629,22 +608,23 @@ int rn_wgrad_nsplit(int B, long npix, int Cin, int Cout) {
 int launch_rn_wgrad(hipStream_t st, const RnWgradArgs& a) {
     if (a.B < 1 || a.npair < 1 || a.npair > 2 || (a.Cin & 15) || (a.Cout & 31) || a.nsplit < 1 || (a.ntaps != 9 && a.ntaps != 1))
         return FUMI_EINVAL;
+    if (a.npix * (a.Cin > a.Cout ? a.Cin : a.Cout) * 2 >= (1L << 32) - 65536) return FUMI_ENOTSUP;   // (32-bit byte offsets inside the kernel)
     const int Ci32 = (a.Cin + 31) / 32 * 32;
     const int ci_tiles = (Ci32 + 63) / 64, co_tiles = (a.Cout + 63) / 64;
     const int hs = a.ntaps == 9 ? a.g.halo : 0;
-    const int lds = WG_PK * 128 + (WG_PK + 2 * hs) * 128 + 1024;       // (+ slack: transposing reads of the last k-step stay in bounds)
+    const int stage = (WG_PK + (WG_PK + 2 * hs + 7) / 8 * 8) * 128;
+    const int lds = stage + 64;
     if (lds > 160 * 1024) return FUMI_ENOTSUP;
     const int groups = a.nsplit * a.B;
     static const int xcd_env = getenv("FUMI_RN_XCD") ? atoi(getenv("FUMI_RN_XCD")) : 1;
     const int xcd = xcd_env && groups >= 8 && groups % 8 == 0;
-    static const int glds = getenv("FUMI_RN_GLDS") ? atoi(getenv("FUMI_RN_GLDS")) : 1;
     const dim3 grid((unsigned)((long)co_tiles * ci_tiles * groups));
     if (a.ntaps == 9) {
         FUMI_SET_DYN_LDS(rn_wgrad_kernel<9>, lds);
-        hipLaunchKernelGGL(rn_wgrad_kernel<9>, grid, dim3(256), lds, st, a, ci_tiles, Ci32, xcd, glds);
+        hipLaunchKernelGGL(rn_wgrad_kernel<9>, grid, dim3(256), lds, st, a, ci_tiles, Ci32, xcd);
     } else {
         FUMI_SET_DYN_LDS(rn_wgrad_kernel<1>, lds);
-        hipLaunchKernelGGL(rn_wgrad_kernel<1>, grid, dim3(256), lds, st, a, ci_tiles, Ci32, xcd, glds);
+        hipLaunchKernelGGL(rn_wgrad_kernel<1>, grid, dim3(256), lds, st, a, ci_tiles, Ci32, xcd);
     }
     LAUNCH_CHECK();
     return FUMI_OK;
