@@ -88,6 +88,19 @@ def flops_dominant(B):
     return 2.0 * B * (S + Qn) * c["hid"][0] * c["D"] + rider
 
 
+def flops_query(B):
+    """query_lds_kernel<true> (the longest launch of the step): per episode one inner step on the S support rows (G_ss D, layer 1
+    forward, head, their backward products and the fast-weight updates) + forward, cross-entropy and first-order backward of the Qn
+    query rows through the adapted layers (layer 0 in its low-rank form: A0 - alpha G D).  Algorithmic: the inner step is counted
+    once per episode although each of the episode's tiles re-runs it."""
+    c = CFG
+    S, Qn, N = c["N"] * c["K"], c["N"] * c["Q"], c["N"]
+    h0, h1 = c["hid"][0], c["hid"][1]
+    inner = 2.0 * S * (S * h0 + 3 * h0 * h1 + 3 * h1 * N)                      # G D; layer 1 fwd, dz0, dW1; head fwd, dz1, dWh
+    query = 2.0 * Qn * (2 * S * h0 + 3 * h0 * h1 + 3 * h1 * N)                 # G D and its adjoint; layer 1 / head fwd + two backward products
+    return B * (inner + query)
+
+
 def bytes_dominant(B):
     """xpanel_bwd algorithmic HBM bytes: X and Abar0 read once, gW0 written once."""
     c = CFG
@@ -157,6 +170,9 @@ def cpu_baseline(table, budget_s=12.0):
             t1 = time.perf_counter(); step(batches[i % 2], nb); ts.append(time.perf_counter() - t1)
             if warm > budget:
                 break
+        if len(ts) < 3:                                     # one or two samples are not a measurement: the line is dropped
+            print(f"[bench] cpu baseline, {nt_} threads: {len(ts)} sample(s) within {budget:.0f} s, not reported", file=sys.stderr, flush=True)
+            return None
         ts.sort()
         print(f"[bench] cpu baseline, {nt_} threads: {nb / ts[len(ts) // 2]:.1f} episodes/s ({len(ts)} samples)", file=sys.stderr, flush=True)
         return {"value": round(nb / ts[len(ts) // 2], 2), "cores": nt_,
@@ -171,11 +187,12 @@ def cpu_baseline(table, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 200:
             break
+    extra = {k: v for k, v in (("all_cores", all_cores), ("one_thread", one_thread)) if v is not None}
     return dict(value=round(n * B / el, 2), unit="episodes/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{n} meta-batches of {B} episodes ({el:.1f} s) of the same workload through oracle/fumi_ref.py "
                        f"(eager PyTorch CPU, {ncpu} logical CPUs visible) at the fastest of the probed thread counts "
                        f"(1, 8, 16, ncpu/2): the eager per-episode loop is dispatch-bound, more threads only add contention",
-                all_cores=all_cores, one_thread=one_thread)
+                **extra)
 
 
 # ---- BASELINE.json configs[1] AS WORDED: the same FuMI meta-step with the Conv4 encoder on 3 x 84 x 84 images ------------------
@@ -491,6 +508,7 @@ def main():
     ap.add_argument("--no-configs4", action="store_true", help="skip the ResNet-12 / bf16 leg (BASELINE.json configs[4], N = 1 only)")
     ap.add_argument("--configs4-episodes", type=int, default=C4["B_per_gpu"], help="episodes of the ResNet-12 leg (one GPU's share: 64)")
     ap.add_argument("--configs4-steps", type=int, default=1)
+    ap.add_argument("--no-extra", action="store_true", help="skip the per-rank lines of BASELINE.json configs[0], [2], [3] (N = 1 only)")
     ap.add_argument("--no-phase-timing", action="store_true", help="do not record HIP events around the library's phases")
     ap.add_argument("--all-phases", action="store_true",
                     help="time every phase of the library (adds ~10 us of stream time per phase and step); default: only the "
@@ -540,7 +558,7 @@ def main():
     if not a.no_phase_timing:
         # an event record is a ~6 us bubble on the stream: the roofline kernel is timed at every 8th step of the timed region
         prof_every = 1 if a.all_phases else max(1, min(PROF_EVERY, a.steps // 16))     # >= 16 samples from a short run too
-        ws.set_profiling(True, None if a.all_phases else ["xpanel_bwd"], every=prof_every)
+        ws.set_profiling(True, None if a.all_phases else ["xpanel_bwd", "query"], every=prof_every)
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -618,10 +636,33 @@ def main():
                                "avg_us": round(dur * 1e6, 2), "launches": n,
                                "timed": f"HIP events around every {prof_every}th launch of the timed region"}
             out["phase_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items()}
+        if "query" in prof and c["T"] == 1:
+            # the LONGEST launch of the step is not the kernel with the most flops: the per-episode chain (inner step + query tiles)
+            tot, n = prof["query"]
+            dur = tot / n * 1e-3
+            ach = flops_query(c["B_per_gpu"]) / dur / 1e12
+            out["roofline_longest"] = {"bound": "latency (a chain of ~25 dependent LDS-resident products per workgroup; priced against the fp32 MFMA peak)",
+                                       "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                                       "kernel": "query_lds_kernel<true> (inner step fused into the query tiles: 5 workgroups per episode, "
+                                                 "160 on 256 CUs; v_mfma_f32_16x16x4_f32 from LDS)",
+                                       "avg_us": round(dur * 1e6, 2), "launches": n,
+                                       "timed": f"HIP events around every {prof_every}th launch of the timed region"}
         if allreduce:
             out["allreduce"] = allreduce
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(table)
+        if not a.no_extra and world == 1:
+            # BASELINE.json's other embedding-input configurations at their per-rank shapes (one GPU's share), with the library's
+            # phases timed in a second loop: configs[0]'s shapes on the GPU, configs[2] (FuMI, BERT text, 5 inner steps), configs[3] (AM3)
+            print("[bench] extra legs: configs[0], [2], [3] at per-rank shapes", file=sys.stderr, flush=True)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_configs
+            del batches, model, opt
+            torch.cuda.empty_cache()
+            out["extra"] = {k: bench_configs.run_config(k, dev, steps=100, warmup=10, roofline=True)
+                            for k in ("maml_5w1s_b4_t5", "fumi_bert_t5_b32", "am3_b32")}
+            batches = None
         if not a.no_as_worded and world == 1:
             print("[bench] as-worded (Conv4, 84x84) leg", file=sys.stderr, flush=True)
             del batches

@@ -13,6 +13,7 @@
 //     the N classes, first arg-min, and the backward to every embedding in the same pass (per-wave slabs in LDS for the
 //     prototype adjoints: deterministic, no float atomics)
 #include "common.h"
+#include <optional>
 #include <stdlib.h>
 #include "hyper_fwd.h"
 #include "hyper_bwd.h"
@@ -637,7 +638,9 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
         if ((rc = launch_gemm(st, g, 0, 1))) return rc;
     }
 
-    ProfScope pb(ws, st, FUMI_PH_HYPER_BWD);
+    // (the phase ends before the image-encoder gradient starts: the text-MLP backward's time used to include that launch and the
+    // step's final reductions)
+    std::optional<ProfScope> pb; pb.emplace(ws, st, FUMI_PH_HYPER_BWD);
     ColsumJobs cj; cj.n = 0; cj.part_total = 0;
     // weight gradients of the text MLPs contract over all B*S rows with only a few output tiles: the contraction is cut into
     // 128-row slabs (one workgroup each) that the step's final reduction sums together with everything else
@@ -704,11 +707,15 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
         cj.add(t1b, (int)Rs, Ht, Ht, g_w[3]);
     }
     if ((rc = wgrad(Ht, Dt, t1b, Ht, text_s, Dt, g_w[2]))) return rc;                  // gG0 = t1bar^T text (800 x 768: 128-row slabs)
+    pb.reset();
     // image encoder: gWi = imbar_s^T Xs + imbar_q^T Xq (split over the contraction), gbi = colsum(imbar)
     {
         ProfScope pg(ws, st, FUMI_PH_XPANEL_BWD);
-        const long slab = (long)P * D;
         if ((rc = launch_xpanel_bwd(st, B, S, Qn, D, P, x_s, x_q, imb, slabs, xkc, xns))) return rc;
+    }
+    {
+        ProfScope pr(ws, st, FUMI_PH_REDUCE);
+        const long slab = (long)P * D;
         if (bias_bar) tail_.add(bias_bar, B, P, P, g_w[1]);        // the head kernel left the episodes' column sums of imbar
         else cj.add(imb, (int)(Rs + Rq), P, P, g_w[1]);
         // every bias gradient (column sums over all rows) and the image-encoder weight slabs: two launches in all

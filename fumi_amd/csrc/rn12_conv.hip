@@ -514,22 +514,41 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(RnWgradArgs a, int ci_
         }
 }
 
-// thread = one (co, ci) pair: for every tap the reads of consecutive threads are consecutive floats of a slab row; the ntaps results
-// of a thread are ntaps consecutive floats of the OIHW tensor
+// workgroup = 64 consecutive ci x 4 rows; a wave reads 256 contiguous bytes of one slab row per step.  SPLIT4 (long slab lists: the
+// 84 x 84 layers leave 128 slabs per episode and only 64 x 64 outputs -- a thread per output walking them one after the other was
+// latency-bound, 450 us): the four waves share one (tap, co) row, wave g adds slabs g, g + 4, .. and the four sums are added in
+// fixed order through LDS.  Otherwise the waves are four consecutive co rows.  Writes go to torch's OIHW order.
+template <bool SPLIT4>
 __global__ __launch_bounds__(256) void rn_wgrad_reduce_kernel(int nsplit, int ntaps, int Cout, int Ci32, int Cin_real, const float* part,
                                                               float* G, long gstride) {
-    const int b = blockIdx.y;
-    const long n = (long)Cout * Cin_real;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int ci = (int)(i % Cin_real), co = (int)(i / Cin_real);
-    const long slab = (long)ntaps * Cout * Ci32;
-    const float* p = part + (long)b * nsplit * slab + (long)co * Ci32 + ci;
-    float* g = G + (long)b * gstride + i * ntaps;
-    for (int tap = 0; tap < ntaps; ++tap) {
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += p[(long)k * slab + (long)tap * Cout * Ci32];
-        g[tap] = s;
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cib = (Cin_real + 63) / 64;
+    const int rows = ntaps * Cout;                                     // (tap, co) rows of a slab
+    int row, k0, kstep;
+    const int ci = (blockIdx.x % cib) * 64 + lane;
+    if (SPLIT4) { row = blockIdx.x / cib; k0 = wv; kstep = 4; }
+    else { row = (blockIdx.x / cib) * 4 + wv; k0 = 0; kstep = 1; }
+    const bool ok = row < rows && ci < Cin_real;
+    const long slab = (long)rows * Ci32;
+    float s = 0.f;
+    if (ok) {
+        const float* p = part + (long)b * nsplit * slab + (long)row * Ci32 + ci;
+        float s0 = 0.f, s1 = 0.f;
+        int k = k0;
+        for (; k + kstep < nsplit; k += 2 * kstep) { s0 += p[(long)k * slab]; s1 += p[(long)(k + kstep) * slab]; }
+        if (k < nsplit) s0 += p[(long)k * slab];
+        s = s0 + s1;
+    }
+    if (SPLIT4) {
+        red[wv][lane] = s;
+        __syncthreads();
+        if (wv) return;
+        s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    }
+    if (ok) {
+        const int tap = row / Cout, co = row - tap * Cout;
+        G[(long)b * gstride + ((long)co * Cin_real + ci) * ntaps + tap] = s;
     }
 }
 
@@ -633,9 +652,13 @@ int launch_rn_wgrad(hipStream_t st, const RnWgradArgs& a) {
 int launch_rn_wgrad_reduce(hipStream_t st, int B, int nsplit, int ntaps, int Cout, int Cin, int Cin_real, const float* part,
                            float* G, long gstride) {
     const int Ci32 = (Cin + 31) / 32 * 32;
-    const long n = (long)Cout * Cin_real;
-    hipLaunchKernelGGL(rn_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, nsplit, ntaps, Cout, Ci32, Cin_real,
-                       part, G, gstride);
+    const int cib = (Cin_real + 63) / 64, rows = ntaps * Cout;
+    if (nsplit >= 16)
+        hipLaunchKernelGGL(rn_wgrad_reduce_kernel<true>, dim3((unsigned)(rows * cib), B), dim3(256), 0, st, nsplit, ntaps, Cout, Ci32,
+                           Cin_real, part, G, gstride);
+    else
+        hipLaunchKernelGGL(rn_wgrad_reduce_kernel<false>, dim3((unsigned)((rows + 3) / 4 * cib), B), dim3(256), 0, st, nsplit, ntaps, Cout,
+                           Ci32, Cin_real, part, G, gstride);
     LAUNCH_CHECK();
     return FUMI_OK;
 }

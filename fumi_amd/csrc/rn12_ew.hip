@@ -245,36 +245,43 @@ __global__ __launch_bounds__(256) void rn_join_fwd_kernel(RnJoin J, rbf16* o) {
     *(u32x4*)(o + ooff) = pack8(r);
 }
 
-// per conv-resolution pixel: ds (and ds') = the pooled gradient routed to the window's arg-max, times lrelu'(s)
-struct JoinPix { bool inside, covered; long off, doff; int sel[8]; float sself[8]; };
-__device__ __forceinline__ JoinPix join_pixel(const RnJoin& J, const JoinCoef& k, int b, long p, int c) {
-    JoinPix r; r.covered = false;
-    const long img = p / J.m.g.Pp; const int q = (int)(p - img * J.m.g.Pp);
-    const int y = q / J.m.g.Wp, x = q - y * J.m.g.Wp;
-    r.inside = y >= 1 && y <= J.m.g.H && x >= 1 && x <= J.m.g.W;
-    r.off = (((long)b * J.m.M + img) * J.m.g.Pp + q) * J.m.C + c;
-    if (!r.inside) return r;
-    const int wy = (y - 1) >> 1, wx = (x - 1) >> 1;
-    const F8 a = ldbf(J.u3 + r.off), s_ = ldbf(J.us + r.off);
+// Backward of the join.  The pooled gradient goes to the window's arg-max only, so the unit of work is a pooling WINDOW: its four
+// pixels of u3 / us are loaded once (a thread per pixel re-read the whole window to find the arg-max: 4x the L1 / L2 traffic, 2.1-2.7
+// TB/s), the arg-max and lrelu'(s) at the arg-max are found per channel, then every pixel gets its ds.
+struct JoinWin { u32x4 u3[4], us[4]; int am[8]; float lm[8]; };
+__device__ __forceinline__ void join_window(const RnJoin& J, const JoinCoef& k, const long off[4], int c, JoinWin& w) {
+    float sv[4][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { r.sself[j] = (k.A3.v[j] * a.v[j] + k.C3.v[j]) + (k.As.v[j] * s_.v[j] + k.Cs.v[j]); r.sel[j] = 0; }
-    if (wy >= J.Ho || wx >= J.Wo) return r;
-    r.covered = true;
-    float sv[4][8]; int arg[8];
-    window_s(J, k, ((long)b * J.m.M + img) * J.m.g.Pp, 2 * wy + 1, 2 * wx + 1, c, sv, arg);
-    const int me = ((y - 1) & 1) * 2 + ((x - 1) & 1);
+    for (int q = 0; q < 4; ++q) { w.u3[q] = *(const u32x4*)(J.u3 + off[q]); w.us[q] = *(const u32x4*)(J.us + off[q]); }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r.sel[j] = arg[j] == me;
-    r.doff = (((long)b * J.m.M + img) * J.gn.Pp + (long)(wy + 1) * J.gn.Wp + wx + 1) * J.m.C + c;
-    return r;
+    for (int q = 0; q < 4; ++q) {
+        const F8 a = unpack8(w.u3[q]), s_ = unpack8(w.us[q]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sv[q][j] = (k.A3.v[j] * a.v[j] + k.C3.v[j]) + (k.As.v[j] * s_.v[j] + k.Cs.v[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int am = 0; float mx = sv[0][j];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) if (sv[q][j] > mx) { mx = sv[q][j]; am = q; }      // the FIRST maximum in window order, as window_s
+        w.am[j] = am; w.lm[j] = lmask(mx);
+    }
+}
+// offsets of the window (wy, wx) of image img: its four conv-resolution pixels and its pooled pixel
+__device__ __forceinline__ long join_offsets(const RnJoin& J, int b, unsigned img, int wy, int wx, int c, long off[4]) {
+    const long imgbase = ((long)b * J.m.M + img) * J.m.g.Pp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) off[q] = (imgbase + (long)(2 * wy + 1 + (q >> 1)) * J.m.g.Wp + 2 * wx + 1 + (q & 1)) * J.m.C + c;
+    return (((long)b * J.m.M + img) * J.gn.Pp + (long)(wy + 1) * J.gn.Wp + wx + 1) * J.m.C + c;
 }
 
+// thread (row group rg, chunk ch) walks windows wbeg + rg, + nrg, ..: per channel only the arg-max pixel has ds != 0
 template <bool TAN>
-__global__ __launch_bounds__(256) void rn_join_reduce_kernel(RnJoin J, const rbf16* dout, const rbf16* doutd, float* part, int RB) {
+__global__ __launch_bounds__(256) void rn_join_reduce_kernel(RnJoin J, const rbf16* dout, const rbf16* doutd, float* part, unsigned WB) {
     extern __shared__ float red[];
     constexpr int K = TAN ? 5 : 3;
     const int b = blockIdx.y, C = J.m.C, nch = C >> 3, nrg = 256 / nch;
-    const long npix = (long)J.m.M * J.m.g.Pp;
+    const unsigned nwi = (unsigned)J.Ho * J.Wo, nwin = (unsigned)J.m.M * nwi;
     const int ch = threadIdx.x % nch, rg = threadIdx.x / nch, c = ch * 8;
     float s[K][8];
 #pragma unroll
@@ -287,23 +294,45 @@ __global__ __launch_bounds__(256) void rn_join_reduce_kernel(RnJoin J, const rbf
         const F8 MU3 = ldcf(c3, RCF_MU, C, c), R3 = ldcf(c3, RCF_R, C, c), MUs = ldcf(cs, RCF_MU, C, c), Rs = ldcf(cs, RCF_R, C, c);
         F8 M13, M23, M1s, M2s;
         if (TAN) { M13 = ldcf(c3, RCF_M1, C, c); M23 = ldcf(c3, RCF_M2, C, c); M1s = ldcf(cs, RCF_M1, C, c); M2s = ldcf(cs, RCF_M2, C, c); }
-        const long pbeg = (long)blockIdx.x * RB, pend = min(npix, pbeg + RB);
-        for (long p = pbeg + rg; p < pend; p += nrg) {
-            const JoinPix px = join_pixel(J, k, b, p, c);
-            if (!px.inside || !px.covered) continue;           // (an uncovered interior pixel has ds = 0: contributes nothing)
-            const F8 dov = ldbf(dout + px.doff), u3 = ldbf(J.u3 + px.off), us = ldbf(J.us + px.off);
-            F8 dodv, u3d, usd;
-            if (TAN) { dodv = ldbf(doutd + px.doff); u3d = ldbf(J.u3d + px.off); usd = ldbf(J.usd + px.off); }
+        const unsigned wbeg = blockIdx.x * WB, wend = min(nwin, wbeg + WB);
+        for (unsigned wi = wbeg + rg; wi < wend; wi += nrg) {
+            const unsigned img = wi / nwi, r = wi - img * nwi;
+            const int wy = (int)(r / (unsigned)J.Wo), wx = (int)(r - (unsigned)wy * J.Wo);
+            long off[4];
+            const long doff = join_offsets(J, b, img, wy, wx, c, off);
+            JoinWin w;
+            join_window(J, k, off, c, w);
+            const F8 dov = ldbf(dout + doff);
+            F8 dodv; u32x4 u3d[4], usd[4];
+            if (TAN) {
+                dodv = ldbf(doutd + doff);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { u3d[q] = *(const u32x4*)(J.u3d + off[q]); usd[q] = *(const u32x4*)(J.usd + off[q]); }
+            }
+            // the arg-max pixel's values, per channel
+            F8 u3, us, u3t, ust;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float mk = px.sel[j] ? lmask(px.sself[j]) : 0.f;
-                const float ds = dov.v[j] * mk;
+                unsigned a3 = w.u3[0][j >> 1], as_ = w.us[0][j >> 1], a3d = 0, asd = 0;
+                if (TAN) { a3d = u3d[0][j >> 1]; asd = usd[0][j >> 1]; }
+#pragma unroll
+                for (int q = 1; q < 4; ++q) if (w.am[j] == q) {
+                    a3 = w.u3[q][j >> 1]; as_ = w.us[q][j >> 1];
+                    if (TAN) { a3d = u3d[q][j >> 1]; asd = usd[q][j >> 1]; }
+                }
+                const int sh = (j & 1) ? 0 : 16;                        // (low half = even channel)
+                u3.v[j] = __uint_as_float((a3 << sh) & 0xffff0000u); us.v[j] = __uint_as_float((as_ << sh) & 0xffff0000u);
+                if (TAN) { u3t.v[j] = __uint_as_float((a3d << sh) & 0xffff0000u); ust.v[j] = __uint_as_float((asd << sh) & 0xffff0000u); }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float ds = dov.v[j] * w.lm[j];
                 const float xh3 = (u3.v[j] - MU3.v[j]) * R3.v[j], xhs = (us.v[j] - MUs.v[j]) * Rs.v[j];
                 if (!TAN) { s[0][j] += ds; s[1][j] += ds * xh3; s[2][j] += ds * xhs; }
                 else {
-                    const float dsd = dodv.v[j] * mk;
-                    const float xh3d = R3.v[j] * (u3d.v[j] - M13.v[j] - xh3 * M23.v[j]);
-                    const float xhsd = Rs.v[j] * (usd.v[j] - M1s.v[j] - xhs * M2s.v[j]);
+                    const float dsd = dodv.v[j] * w.lm[j];
+                    const float xh3d = R3.v[j] * (u3t.v[j] - M13.v[j] - xh3 * M23.v[j]);
+                    const float xhsd = Rs.v[j] * (ust.v[j] - M1s.v[j] - xhs * M2s.v[j]);
                     s[0][j] += dsd; s[1][j] += dsd * xh3; s[2][j] += ds * xh3d; s[3][j] += dsd * xhs; s[4][j] += ds * xhsd;
                 }
             }
@@ -322,54 +351,91 @@ __global__ __launch_bounds__(256) void rn_join_reduce_kernel(RnJoin J, const rbf
     }
 }
 
+// du3 / dus of ONE pixel from its ds (ds' in the tangent pass)
 template <bool TAN>
-__global__ __launch_bounds__(256) void rn_join_apply_kernel(RnJoin J, const rbf16* dout, const rbf16* doutd, rbf16* du3, rbf16* dus) {
-    const int b = blockIdx.y, C = J.m.C, nch = C >> 3;
-    const long npix = (long)J.m.M * J.m.g.Pp;
-    const long unit = (long)blockIdx.x * 256 + threadIdx.x;
-    if (unit >= npix * nch) return;
-    const long p = unit / nch; const int c = (int)(unit - p * nch) * 8;
-    const float* c3 = J.coef3 + (long)b * RCF_N * C; const float* cs = J.coefs + (long)b * RCF_N * C;
-    const JoinCoef k = join_coef(c3, cs, C, c);
-    const JoinPix px = join_pixel(J, k, b, p, c);
-    if (!px.inside) {
-        *(u32x4*)(du3 + px.off) = (u32x4){0u, 0u, 0u, 0u}; *(u32x4*)(dus + px.off) = (u32x4){0u, 0u, 0u, 0u};
-        return;
-    }
-    F8 dov, dodv;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { dov.v[j] = 0.f; dodv.v[j] = 0.f; }
-    if (px.covered) { dov = ldbf(dout + px.doff); if (TAN) dodv = ldbf(doutd + px.doff); }
-    const F8 u3 = ldbf(J.u3 + px.off), us = ldbf(J.us + px.off);
+__device__ __forceinline__ void join_apply_pixel(const RnJoin& J, const float* c3, const float* cs, const JoinCoef& k, long off, int c,
+                                                 const F8& u3, const F8& us, const float ds[8], const float dsd[8], rbf16* du3, rbf16* dus) {
+    const int C = J.m.C;
     const F8 MU3 = ldcf(c3, RCF_MU, C, c), R3 = ldcf(c3, RCF_R, C, c), MUs = ldcf(cs, RCF_MU, C, c), Rs = ldcf(cs, RCF_R, C, c);
     const F8 D13 = ldcf(c3, RCF_D1, C, c), D23 = ldcf(c3, RCF_D2, C, c), D1s = ldcf(cs, RCF_D1, C, c), D2s = ldcf(cs, RCF_D2, C, c);
     F8 o3, os;
     if (!TAN) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float ds = px.sel[j] ? dov.v[j] * lmask(px.sself[j]) : 0.f;
             const float xh3 = (u3.v[j] - MU3.v[j]) * R3.v[j], xhs = (us.v[j] - MUs.v[j]) * Rs.v[j];
-            o3.v[j] = k.A3.v[j] * (ds - D13.v[j] - xh3 * D23.v[j]);
-            os.v[j] = k.As.v[j] * (ds - D1s.v[j] - xhs * D2s.v[j]);
+            o3.v[j] = k.A3.v[j] * (ds[j] - D13.v[j] - xh3 * D23.v[j]);
+            os.v[j] = k.As.v[j] * (ds[j] - D1s.v[j] - xhs * D2s.v[j]);
         }
     } else {
-        const F8 u3d = ldbf(J.u3d + px.off), usd = ldbf(J.usd + px.off);
+        const F8 u3d = ldbf(J.u3d + off), usd = ldbf(J.usd + off);
         const F8 M13 = ldcf(c3, RCF_M1, C, c), M23 = ldcf(c3, RCF_M2, C, c), M1s = ldcf(cs, RCF_M1, C, c), M2s = ldcf(cs, RCF_M2, C, c);
         const F8 K03 = ldcf(c3, RCF_K0, C, c), DD13 = ldcf(c3, RCF_DD1, C, c), E3 = ldcf(c3, RCF_E12, C, c);
         const F8 K0s = ldcf(cs, RCF_K0, C, c), DD1s = ldcf(cs, RCF_DD1, C, c), Es = ldcf(cs, RCF_E12, C, c);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float mk = px.sel[j] ? lmask(px.sself[j]) : 0.f;
-            const float ds = dov.v[j] * mk, dsd = dodv.v[j] * mk;
             const float xh3 = (u3.v[j] - MU3.v[j]) * R3.v[j], xhs = (us.v[j] - MUs.v[j]) * Rs.v[j];
             const float xh3d = R3.v[j] * (u3d.v[j] - M13.v[j] - xh3 * M23.v[j]);
             const float xhsd = Rs.v[j] * (usd.v[j] - M1s.v[j] - xhs * M2s.v[j]);
-            o3.v[j] = K03.v[j] * (ds - D13.v[j] - xh3 * D23.v[j]) + k.A3.v[j] * (dsd - DD13.v[j] - xh3d * D23.v[j] - xh3 * E3.v[j]);
-            os.v[j] = K0s.v[j] * (ds - D1s.v[j] - xhs * D2s.v[j]) + k.As.v[j] * (dsd - DD1s.v[j] - xhsd * D2s.v[j] - xhs * Es.v[j]);
+            o3.v[j] = K03.v[j] * (ds[j] - D13.v[j] - xh3 * D23.v[j]) + k.A3.v[j] * (dsd[j] - DD13.v[j] - xh3d * D23.v[j] - xh3 * E3.v[j]);
+            os.v[j] = K0s.v[j] * (ds[j] - D1s.v[j] - xhs * D2s.v[j]) + k.As.v[j] * (dsd[j] - DD1s.v[j] - xhsd * D2s.v[j] - xhs * Es.v[j]);
         }
     }
-    *(u32x4*)(du3 + px.off) = pack8(o3);
-    *(u32x4*)(dus + px.off) = pack8(os);
+    *(u32x4*)(du3 + off) = pack8(o3);
+    *(u32x4*)(dus + off) = pack8(os);
+}
+
+// thread = one 2 x 2 CELL of the padded grid x one 8-channel chunk.  Cells start at odd coordinates (cell (cy, cx) = padded pixels
+// y in {2 cy - 1, 2 cy}, x in {2 cx - 1, 2 cx}), so a cell is either a whole pooling window (1 <= cy <= Ho, 1 <= cx <= Wo) or lies
+// on the rim: border pixels (zeros) and interior pixels no window covers (odd H / W: ds = 0).
+template <bool TAN>
+__global__ __launch_bounds__(256) void rn_join_apply_kernel(RnJoin J, const rbf16* dout, const rbf16* doutd, rbf16* du3, rbf16* dus,
+                                                            int ncy, int ncx) {
+    const int b = blockIdx.y, C = J.m.C, nch = C >> 3;
+    const unsigned nci = (unsigned)ncy * ncx, ncell = (unsigned)J.m.M * nci;
+    const unsigned unit = blockIdx.x * 256u + threadIdx.x;
+    if (unit >= ncell * (unsigned)nch) return;
+    const unsigned cell = unit / (unsigned)nch; const int c = (int)(unit - cell * nch) * 8;
+    const unsigned img = cell / nci, q0 = cell - img * nci;
+    const int cy = (int)(q0 / (unsigned)ncx), cx = (int)(q0 - (unsigned)cy * ncx);
+    const float* c3 = J.coef3 + (long)b * RCF_N * C; const float* cs = J.coefs + (long)b * RCF_N * C;
+    const JoinCoef k = join_coef(c3, cs, C, c);
+    float ds[8], dsd[8];
+    if (cy >= 1 && cy <= J.Ho && cx >= 1 && cx <= J.Wo) {
+        long off[4];
+        const long doff = join_offsets(J, b, img, cy - 1, cx - 1, c, off);
+        JoinWin w;
+        join_window(J, k, off, c, w);
+        const F8 dov = ldbf(dout + doff);
+        F8 dodv;
+        if (TAN) dodv = ldbf(doutd + doff);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // (an opaque zero per pixel: without it the 22 coefficient vectors of the tangent form are hoisted over the four pixels --
+            // 264 VGPRs, one wave per SIMD; re-loading them per pixel from L1 keeps the occupancy)
+            int z;
+            asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float mk = w.am[j] == q ? w.lm[j] : 0.f;
+                ds[j] = dov.v[j] * mk; dsd[j] = TAN ? dodv.v[j] * mk : 0.f;
+            }
+            join_apply_pixel<TAN>(J, c3 + z, cs + z, k, off[q], c, unpack8(w.u3[q]), unpack8(w.us[q]), ds, dsd, du3, dus);
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ds[j] = 0.f; dsd[j] = 0.f; }
+    const long imgbase = ((long)b * J.m.M + img) * J.m.g.Pp;
+    for (int q = 0; q < 4; ++q) {
+        const int y = 2 * cy - 1 + (q >> 1), x = 2 * cx - 1 + (q & 1);
+        if (y < 0 || y >= J.m.g.Hp || x < 0 || x >= J.m.g.Wp) continue;
+        const long off = (imgbase + (long)y * J.m.g.Wp + x) * C + c;
+        if (y < 1 || y > J.m.g.H || x < 1 || x > J.m.g.W) {
+            *(u32x4*)(du3 + off) = (u32x4){0u, 0u, 0u, 0u}; *(u32x4*)(dus + off) = (u32x4){0u, 0u, 0u, 0u};
+            continue;
+        }
+        join_apply_pixel<TAN>(J, c3, cs, k, off, c, ldbf(J.u3 + off), ldbf(J.us + off), ds, dsd, du3, dus);
+    }
 }
 
 // ---- coefficients from partial sums ----------------------------------------------------------------------------------------------
@@ -550,22 +616,28 @@ int launch_rn_join_reduce(hipStream_t st, const RnJoin& j, const rbf16* dout, co
     if ((j.m.C >> 3) > 256) return FUMI_ENOTSUP;
     const int nrg = 256 / (j.m.C >> 3), K = tangent ? 5 : 3;
     const size_t lds = (size_t)nrg * K * j.m.C * 4;
-    const dim3 grid(rn_red_nt(j.m), j.m.B);
+    const int nt = rn_red_nt(j.m);                                    // (the coefficient pass is sized for this many slabs)
+    const long nwin = (long)j.m.M * j.Ho * j.Wo;
+    if (nwin >= (1L << 31)) return FUMI_ENOTSUP;
+    const unsigned wb = (unsigned)((nwin + nt - 1) / nt);             // windows per workgroup
+    const dim3 grid(nt, j.m.B);
     if (tangent) {
         FUMI_SET_DYN_LDS(rn_join_reduce_kernel<true>, lds);
-        hipLaunchKernelGGL(rn_join_reduce_kernel<true>, grid, dim3(256), lds, st, j, dout, doutd, part, red_rb(j.m));
+        hipLaunchKernelGGL(rn_join_reduce_kernel<true>, grid, dim3(256), lds, st, j, dout, doutd, part, wb);
     } else {
         FUMI_SET_DYN_LDS(rn_join_reduce_kernel<false>, lds);
-        hipLaunchKernelGGL(rn_join_reduce_kernel<false>, grid, dim3(256), lds, st, j, dout, doutd, part, red_rb(j.m));
+        hipLaunchKernelGGL(rn_join_reduce_kernel<false>, grid, dim3(256), lds, st, j, dout, doutd, part, wb);
     }
     LAUNCH_CHECK();
     return FUMI_OK;
 }
 
 int launch_rn_join_apply(hipStream_t st, const RnJoin& j, const rbf16* dout, const rbf16* doutd, rbf16* du3, rbf16* dus, int tangent) {
-    const long npix = (long)j.m.M * j.m.g.Pp;
-    if (tangent) hipLaunchKernelGGL(rn_join_apply_kernel<true>, unit_grid(j.m, npix), dim3(256), 0, st, j, dout, doutd, du3, dus);
-    else hipLaunchKernelGGL(rn_join_apply_kernel<false>, unit_grid(j.m, npix), dim3(256), 0, st, j, dout, doutd, du3, dus);
+    const int ncy = j.m.g.Hp / 2 + 1, ncx = j.m.g.Wp / 2 + 1;          // cells (2 cy - 1 .. 2 cy) cover padded rows 0 .. Hp - 1
+    const long ncell = (long)j.m.M * ncy * ncx;
+    if (ncell * (j.m.C >> 3) >= (1L << 32) - 256) return FUMI_ENOTSUP;
+    if (tangent) hipLaunchKernelGGL(rn_join_apply_kernel<true>, unit_grid(j.m, ncell), dim3(256), 0, st, j, dout, doutd, du3, dus, ncy, ncx);
+    else hipLaunchKernelGGL(rn_join_apply_kernel<false>, unit_grid(j.m, ncell), dim3(256), 0, st, j, dout, doutd, du3, dus, ncy, ncx);
     LAUNCH_CHECK();
     return FUMI_OK;
 }

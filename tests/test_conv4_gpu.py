@@ -350,6 +350,59 @@ def test_conv4_full_size_episode_84x84(dev, ws):
         assert e <= max(1e-2, 4 * e32), f"grad {n}: {e:.3e} from float64 (fp32 host oracle: {e32:.3e})"
 
 
+def test_conv4_as_worded_bench_shape_properties(dev, ws):
+    """BASELINE.json configs[1] AS WORDED at bench.py's full shape (32 episodes, 5-way 5-shot, 32 query images per class, 3 x 84 x 84,
+    1 inner step, second order): too large for the host oracle, so the size-independent properties of a meta-step are checked --
+      * episodes are independent: the meta-batch's outputs are the two half-batches' outputs, its meta-gradient the mean of
+        theirs (1e-5: tiles and split-K slabs group differently with the batch size);
+      * evaluation mode (need_grad = 0) computes the same logits / losses as the training step's forward;
+      * the meta-gradient is linear in grad_scale;
+      * the loss of every episode is the cross-entropy of its own logits (recomputed on the host in float64)."""
+    from fumi_amd import hip
+    B, N, K, Q, Cin, H, nblk, Dt, Ht, alpha, T = 32, 5, 5, 32, 3, 84, 4, 300, 256, 0.01, 1
+    S, Qn = N * K, N * Q
+    g = torch.Generator(device=dev).manual_seed(2024)
+    cgen = torch.Generator().manual_seed(2024)
+    y_s = torch.stack([torch.arange(N).repeat_interleave(K)[torch.randperm(S, generator=cgen)] for _ in range(B)]).to(dev)
+    y_q = torch.stack([torch.arange(N).repeat_interleave(Q)[torch.randperm(Qn, generator=cgen)] for _ in range(B)]).to(dev)
+    proto = torch.randn(B, N, Cin, H, H, device=dev, generator=g)                     # class means: the episodes are learnable
+    x_s = proto.gather(1, y_s[:, :, None, None, None].expand(-1, -1, Cin, H, H)) + 0.5 * torch.randn(B, S, Cin, H, H, device=dev, generator=g)
+    x_q = proto.gather(1, y_q[:, :, None, None, None].expand(-1, -1, Cin, H, H)) + 0.5 * torch.randn(B, Qn, Cin, H, H, device=dev, generator=g)
+    cls_text = torch.randn(B, N, Dt, device=dev, generator=g)
+    _, theta, Fd = _case(78, 1, N, 1, 1, Cin, 12, 12, nblk)
+    assert hip.conv4_feature_dim(nblk, H, H) == 1600
+    _, phi = cg.make_fumi_params(78, 8, [1600], Dt, Ht, head_scale=0.03)
+    theta, phi = [_g(t, dev) for t in theta], [_g(t, dev) for t in phi]
+
+    def run(sl, **kw):
+        o = hip.fumi_conv4_step(ws, N, x_s[sl].contiguous(), y_s[sl].contiguous(), x_q[sl].contiguous(), y_q[sl].contiguous(), theta, phi,
+                                T, alpha, False, cls_text=cls_text[sl].contiguous(), **kw)
+        assert ws.read_status() == 0
+        return {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in o.items() if v is not None}
+    full = run(slice(0, B))
+    lo, hi = run(slice(0, B // 2)), run(slice(B // 2, B))
+    halves = {k: torch.cat([lo[k], hi[k]]) for k in ("logits", "loss_b", "acc_b", "preds")}
+    assert rel_to_max(full["logits"].cpu(), halves["logits"].cpu()) <= 1e-5 and rel_to_max(full["loss_b"].cpu(), halves["loss_b"].cpu()) <= 1e-5
+    safe = safe_margin_mask(full["logits"].double().cpu(), MARGIN)
+    assert torch.equal(full["preds"].cpu()[safe], halves["preds"].cpu()[safe])
+    names = [f"theta{i}" for i in range(len(theta))] + [f"phi{i}" for i in range(4)]
+    for n, a, b0, b1 in zip(names, full["g_theta"] + full["g_phi"], lo["g_theta"] + lo["g_phi"], hi["g_theta"] + hi["g_phi"]):
+        assert torch.isfinite(a).all() and float(a.abs().max()) > 0, n
+        assert rel_to_max(a.cpu(), (0.5 * (b0 + b1)).cpu()) <= 1e-5, n
+    ev = run(slice(0, B), need_grad=False)
+    assert torch.equal(ev["logits"], full["logits"]) and torch.equal(ev["loss_b"], full["loss_b"])
+    sc = run(slice(0, B), grad_scale=3.0 / B)
+    for n, a, b in zip(names, sc["g_theta"] + sc["g_phi"], full["g_theta"] + full["g_phi"]):
+        assert rel_to_max(a.cpu(), 3.0 * b.cpu()) <= 1e-6, n
+    z = full["logits"].double().cpu()
+    ce = torch.stack([F.cross_entropy(z[b], y_q[b].cpu()) for b in range(B)])
+    assert rel_to_max(full["loss_b"].cpu().double(), ce) <= 1e-5
+    acc = (z.max(-1)[1] == y_q.cpu()).double().mean(-1)
+    mask = safe_margin_mask(z, MARGIN).all(-1)
+    assert torch.allclose(full["acc_b"].cpu().double()[mask], acc[mask], atol=1e-6)
+    assert float(acc.mean()) > 1.5 / N                  # one inner step on separable classes: clearly above chance
+
+
 # ---- the module surface (--im_encoder conv4) on the GPU -------------------------------------------------------------------
 def test_conv4_features_op(dev, ws):
     from fumi_amd import hip

@@ -49,6 +49,56 @@ def batches(a, dev, n=4):
     return out
 
 
+def run_config(name, dev, steps=100, warmup=10, roofline=False):
+    """One configuration at its per-rank shape on `dev`: the record tools/bench_configs.py prints (bench.py's `extra` legs call this)."""
+    argv = CONFIGS[name]
+    a = U.parser().parse_args(argv + ["--dropout", "0", "--dataset", "synthetic"])
+    a.device = dev
+    torch.manual_seed(1)
+    model = U.init_model(a, None, watch=False)
+    opt = U.init_optim(a, model)
+    bs = batches(a, dev)
+    opt_, sched = opt if type(opt) == tuple else (opt, None)
+
+    def step(b):
+        if a.model == "maml":
+            return maml_mod.evaluate(a, model, b, opt_, "train")
+        if a.model == "fumi":
+            return model.evaluate(a, b, opt_, "train")
+        return model.evaluate(b, opt_, sched, a.num_ways, dev, "train")
+    for i in range(warmup):
+        step(bs[i % len(bs)])
+    ws = hip.Workspace.get(dev)
+    hip.raise_on_status(ws.read_status())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        last = step(bs[i % len(bs)])
+    t_enq = time.perf_counter() - t0                          # host time to enqueue the steps (>= the total: host-bound)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    rec = {"config": name, "argv": " ".join(argv), "episodes_per_meta_batch": a.batch_size,
+           "ms_per_step": round(el / steps * 1e3, 4), "episodes_per_s": round(a.batch_size * steps / el, 1),
+           "host_enqueue_ms_per_step": round(t_enq / steps * 1e3, 4), "final_loss": float(last[0])}
+    if roofline:
+        ws.set_profiling(True, None, every=1)                 # every phase bracketed (adds event bubbles: separate loop)
+        for i in range(steps):
+            step(bs[i % len(bs)])
+        prof = ws.profile()
+        ws.set_profiling(False)
+        rec["phase_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items()}
+        if a.model == "am3" and "xpanel_fwd" in prof:
+            B, R, D, P = a.batch_size, a.num_ways * (a.num_shots + a.num_shots_test), a.im_emb_dim, a.prototype_dim
+            byt = 4.0 * (B * R * D + P * D + B * R * P)         # rows read once, encoder weight once, embeddings written once
+            dur = prof["xpanel_fwd"][0] / prof["xpanel_fwd"][1] * 1e-3
+            rec["roofline"] = {"bound": "hbm", "achieved": round(byt / dur / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                               "frac": round(byt / dur / 8e12, 4), "traffic": None, "algorithmic_bytes": int(byt),
+                               "kernel": "xpanel_fwd (AM3 image encoder: [B*(S+Qn), 2048] x [2048, 64] in one pass over the "
+                                         "episode panels; 4 FLOP/B: HBM-bound)", "avg_us": round(dur * 1e6, 2),
+                               "launches": prof["xpanel_fwd"][1], "timed": "HIP events around every launch"}
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=100)
@@ -60,54 +110,10 @@ def main():
     o = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    for name, argv in CONFIGS.items():
+    for name in CONFIGS:
         if o.only and name != o.only:
             continue
-        a = U.parser().parse_args(argv + ["--dropout", "0", "--dataset", "synthetic"])
-        a.device = dev
-        torch.manual_seed(1)
-        model = U.init_model(a, None, watch=False)
-        opt = U.init_optim(a, model)
-        bs = batches(a, dev)
-        opt_, sched = opt if type(opt) == tuple else (opt, None)
-
-        def step(b):
-            if a.model == "maml":
-                return maml_mod.evaluate(a, model, b, opt_, "train")
-            if a.model == "fumi":
-                return model.evaluate(a, b, opt_, "train")
-            return model.evaluate(b, opt_, sched, a.num_ways, dev, "train")
-        for i in range(o.warmup):
-            step(bs[i % len(bs)])
-        ws = hip.Workspace.get(dev)
-        hip.raise_on_status(ws.read_status())
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(o.steps):
-            last = step(bs[i % len(bs)])
-        t_enq = time.perf_counter() - t0                          # host time to enqueue the steps (>= the total: host-bound)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        rec = {"config": name, "argv": " ".join(argv), "episodes_per_meta_batch": a.batch_size,
-               "ms_per_step": round(el / o.steps * 1e3, 4), "episodes_per_s": round(a.batch_size * o.steps / el, 1),
-               "host_enqueue_ms_per_step": round(t_enq / o.steps * 1e3, 4), "final_loss": float(last[0])}
-        if o.roofline:
-            ws.set_profiling(True, None, every=1)                 # every phase bracketed (adds event bubbles: separate loop)
-            for i in range(o.steps):
-                step(bs[i % len(bs)])
-            prof = ws.profile()
-            ws.set_profiling(False)
-            rec["phase_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items()}
-            if a.model == "am3" and "xpanel_fwd" in prof:
-                B, R, D, P = a.batch_size, a.num_ways * (a.num_shots + a.num_shots_test), a.im_emb_dim, a.prototype_dim
-                byt = 4.0 * (B * R * D + P * D + B * R * P)         # rows read once, encoder weight once, embeddings written once
-                dur = prof["xpanel_fwd"][0] / prof["xpanel_fwd"][1] * 1e-3
-                rec["roofline"] = {"bound": "hbm", "achieved": round(byt / dur / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                                   "frac": round(byt / dur / 8e12, 4), "traffic": None, "algorithmic_bytes": int(byt),
-                                   "kernel": "xpanel_fwd (AM3 image encoder: [B*(S+Qn), 2048] x [2048, 64] in one pass over the "
-                                             "episode panels; 4 FLOP/B: HBM-bound)", "avg_us": round(dur * 1e6, 2),
-                                   "launches": prof["xpanel_fwd"][1], "timed": "HIP events around every launch"}
-        print(json.dumps(rec), flush=True)
+        print(json.dumps(run_config(name, dev, o.steps, o.warmup, o.roofline)), flush=True)
 
 
 if __name__ == "__main__":
