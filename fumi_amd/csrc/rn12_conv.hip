@@ -418,7 +418,10 @@ __device__ __forceinline__ rbf16x8 tr_frag(const unsigned char* img, int r0, int
 
 // (One stage buffer, two workgroups per CU covering each other's loads.  Double-buffering the stages inside ONE workgroup per CU --
 // next stage's loads in flight under this stage's 72 MFMAs per wave, one barrier per stage -- was built and measured: 194 vs 171 ms
-// per 8-episode step.)
+// per 8-episode step.  Contracting over INTERIOR pixels only (dy is zero on the border: 44 % of the padded pixels at 10 x 10) with a
+// gathered dy stage, a wider x slab and a 128-entry row table for the x fragments was built as well: 30 % fewer stages at 10 x 10, but
+// the index arithmetic in front of the loads and the table-dependent fragment addresses cost as much -- 155.8 vs 156.4 ms with it on
+// the 21 x 21 and 10 x 10 layers, 170.5 on all layers.)
 template <int NTAP>
 __global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(RnWgradArgs a, int ci_tiles, int Ci32, int xcd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -443,6 +446,8 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(RnWgradArgs a, int ci_
     const int xrows = WG_PK + 2 * hs;
     const int xr8 = (xrows + 7) / 8 * 8;
     const int stage_bytes = (WG_PK + xr8) * 128;           // one stage: dy [128][128 B] then x [128 + 2 hs (rounded to 8)][128 B]
+    // a wave whose 32 x 32 quadrant lies outside the matrix (Cout or Cin = 160: the last 64-tile is half empty) skips its products
+    const bool live = co0 + (wave >> 1) * 32 < a.Cout && ci0 + (wave & 1) * 32 < Ci32;
     f32x16 acc[NTAP];
 #pragma unroll
     for (int t = 0; t < NTAP; ++t)
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(RnWgradArgs a, int ci_
         issue(q, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        compute(0);
+        if (live) compute(0);
     }
     float* part = a.part + (((long)b * a.nsplit + split) * NTAP) * a.Cout * Ci32;
     const int ci = ci0 + (wave & 1) * 32 + (lane & 31);

@@ -105,6 +105,26 @@ def _run(c, dev, progress=None):
 
 
 @pytest.mark.gpu
+def test_trained_accuracy_full_size_short_training():
+    """BASELINE.json configs[1]'s own shapes (D = 2048, [256, 64], GloVe token text, meta-batch 32, 160 query rows per episode) in the
+    default GPU suite: 300 meta-steps (the full run's loss curve is flat from step ~75 on) and 512 held-out episodes with 5 test-time
+    inner steps -- about 40 s of the reference path on the host.  Result kept next to the long run's as
+    gpurun_out/accuracy_vs_reference_300.json."""
+    dev = torch.device("cuda:0")
+    c = dict(FULL, steps=300, test_batches=16)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    r = _run(c, dev, None)
+    with open(os.path.join(ROOT, "gpurun_out", "accuracy_vs_reference_300.json"), "w") as f:
+        json.dump(r, f, indent=1)
+    print(json.dumps({k: v for k, v in r.items() if k != "train_loss_curve_step_hip_ref"}))
+    first, last = r["train_loss_curve_step_hip_ref"][0], r["train_loss_curve_step_hip_ref"][-1]
+    assert last[1] < first[1] - 0.1 and last[2] < first[2] - 0.1
+    assert r["acc_hip"] > 1.5 / c["N"]
+    assert abs(r["acc_difference_pp"]) <= 0.2
+    assert r["predictions_agreeing"] >= 0.99
+
+
+@pytest.mark.gpu
 def test_trained_accuracy_matches_reference_path():
     dev = torch.device("cuda:0")
     full = os.environ.get("FUMI_ACC_FULL", "0") == "1"
