@@ -102,6 +102,7 @@ def test_two_rank_rccl_step_equals_single_process(kind, tmp_path):
     np.testing.assert_array_equal(r0["extra"], ref_extra)
 
 
+@pytest.mark.gpu
 def test_bench_rehearsal_runs_the_two_rank_code_path():
     """`FUMI_BENCH_REHEARSAL=1 python bench.py --gpus 2` (how the driver launches N > 1, on the one GPU of this box: both ranks on
     cuda:0, gloo carries the all-reduce): the self-launching parent, the per-rank sharding, the flat-gradient all-reduce and the
@@ -111,7 +112,7 @@ def test_bench_rehearsal_runs_the_two_rank_code_path():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FUMI_BENCH_REHEARSAL="1")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
-                        "--no-cpu-baseline", "--no-as-worded", "--no-configs4"], env=env, capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline", "--no-as-worded", "--no-configs4", "--no-extra"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
