@@ -139,7 +139,27 @@ size_t scratch_sizes(const RnNet& n, int S, int Qn, RnScratch& sc) {
 #define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 #define TRYP(phase, expr) do { ProfScope _ps(c.ws, c.st, phase); int _rc = (expr); if (_rc) return _rc; } while (0)
 
-struct RnCtx { fumi_ws* ws; hipStream_t st; RnNet n; RnScratch sc; };
+// `side` (the workspace's low-priority second stream, FUMI_RN_SIDE=0: off): the weight gradients are leaves of the backward chain
+// (nothing in the pass reads them), MFMA-bound, and a quarter of the step, while a quarter of the chain itself is HBM-bound
+// element-wise passes -- so they are forked off behind the map they read (ev[0]) and fill the matrix pipe under those passes;
+// the pass joins (ev[1]) before it returns.  Their partial-sum scratch is touched by that stream only.  Measured: 568.8 -> 551.7 ms
+// per 8-episode step (3 %: the convolutions and the weight gradients each hold 2 x 240 of a SIMD's 512 registers per lane, so the
+// element-wise waves cannot sit beside them -- the gain is the tails of the launches filling up, not true co-residency).
+struct RnCtx { fumi_ws* ws; hipStream_t st; RnNet n; RnScratch sc; hipStream_t side = nullptr; bool forked = false; };
+
+static hipStream_t rn_side_stream(fumi_ws* ws) {
+    static const int on = getenv("FUMI_RN_SIDE") ? atoi(getenv("FUMI_RN_SIDE")) : 1;
+    if (ws->profiling) return nullptr;              // phase timing (bench.py's roofline step): one stream, every phase on its own
+    return on ? ws->side : nullptr;
+}
+// main waits for everything forked so far
+static int rn_join(RnCtx& c) {
+    if (!c.forked) return FUMI_OK;
+    HIP_TRY(hipEventRecord(c.ws->ev[1], c.side));
+    HIP_TRY(hipStreamWaitEvent(c.st, c.ws->ev[1], 0));
+    c.forked = false;
+    return FUMI_OK;
+}
 
 // bf16 fragment copies of one parameter slot (every layer, forward and backward-data order)
 int frags_of_slot(hipStream_t st, const RnNet& n, const float* params, rbf16* frags) {
@@ -198,8 +218,15 @@ int wgrad(RnCtx& c, int M, int l, const RnLayer& y, int npair, const rbf16* x0, 
     a.x[0] = x0; a.dy[0] = dy0; a.x[1] = x1; a.dy[1] = dy1;
     a.x_stride = a.npix * y.Cin; a.dy_stride = a.npix * y.Cout;
     a.part = c.sc.wpart;
-    TRYP(FUMI_PH_RN_WGRAD, launch_rn_wgrad(c.st, a));
-    TRYP(FUMI_PH_RN_WGRAD, launch_rn_wgrad_reduce(c.st, n.B, a.nsplit, y.ntaps, y.Cout, y.Cin, y.Cin_real, c.sc.wpart, G + y.offW, n.PSZ));
+    hipStream_t st = c.st;
+    if (c.side) {                                   // everything this product reads has been launched on the main stream by now
+        HIP_TRY(hipEventRecord(c.ws->ev[0], c.st));
+        HIP_TRY(hipStreamWaitEvent(c.side, c.ws->ev[0], 0));
+        st = c.side; c.forked = true;
+    }
+    { ProfScope _ps(c.ws, st, FUMI_PH_RN_WGRAD); TRY(launch_rn_wgrad(st, a)); }
+    { ProfScope _ps(c.ws, st, FUMI_PH_RN_WGRAD);
+      TRY(launch_rn_wgrad_reduce(st, n.B, a.nsplit, y.ntaps, y.Cout, y.Cin, y.Cin_real, c.sc.wpart, G + y.offW, n.PSZ)); }
     return FUMI_OK;
 }
 
@@ -291,7 +318,7 @@ int backward_pass(RnCtx& c, int M, const rbf16* img16, const rbf16* frags, RnPas
             TRY(conv_plain(c, npix, n.g[l], n.C[l - 1], 2, s, pb.dout[l - 1]));
         }
     }
-    return FUMI_OK;
+    return rn_join(c);
 }
 
 // HV [B][PSZ], HVh [B][N][F+1] = Hessian of the support loss at the tape's parameters times (V, Vh)
@@ -368,7 +395,7 @@ int hvp_pass(RnCtx& c, int M, const rbf16* img16, const rbf16* frags, RnPass& pb
             TRY(conv_plain(c, npix, n.g[l], n.C[l - 1], 4, s, tb.doutd[l - 1]));
         }
     }
-    return FUMI_OK;
+    return rn_join(c);
 }
 
 size_t g_rn_budget = 0;                               // workspace budget in bytes for the episode chunking (0: default)
@@ -403,7 +430,7 @@ static size_t chunk_bytes(RnNet& n, int Bc, const Rn12Problem& p, RnScratch& sc)
 }
 
 int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
-    RnCtx c; c.ws = ws; c.st = st;
+    RnCtx c; c.ws = ws; c.st = st; c.side = rn_side_stream(ws);
     int rc = net_init(c.n, p.B, p.nblk, p.Cimg, p.N, p.H, p.W, p.channels);
     if (rc) return rc;
     RnNet& n = c.n;
