@@ -422,8 +422,19 @@ def configs4_leg(dev, steps, warmup, with_cpu, episodes):
             nprod_q = [1 if l == 0 else 2, 2, 2, 1 if l == 0 else 2]
             alg += B * sum(pp * (S * c["T"] * ns + Qn * nq) for pp, ns, nq in zip(per_prod, nprod_s, nprod_q))
             h //= 2; ci = ch
+        # HBM bytes of the conv launches from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE over `tools/bench_resnet12.py 8 1 5
+        # 15` = two 8-episode steps), scaled to this leg's episodes; not re-measured in this run
+        traffic, tsrc = None, None
+        import glob
+        for f_ in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "rn12_pmc_traffic.json")))[-1:]:
+            pk = json.load(open(f_))
+            tot_b = sum(e.get("hbm_bytes_all_launches", 0.0) for k_, e in pk["kernels"].items() if k_.startswith("rn_conv_kernel"))
+            if tot_b > 0:
+                traffic = int(tot_b / pk.get("steps", 2) * (B / pk.get("episodes", 8)))
+                tsrc = os.path.relpath(f_, ROOT)
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None, "algorithmic_bytes": int(alg),
+                           "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                           "algorithmic_bytes": int(alg),
                            "kernel": "rn_conv_kernel: forward / input-gradient convolutions and their tangent forms as implicit GEMMs "
                                      "over shifted pixel slabs on v_mfma_f32_32x32x16_bf16 (csrc/rn12_conv.hip)",
                            "flops_per_step": conv_flops, "ms_per_step": round(per_step * 1e3, 2), "launches_per_step": n // psteps,

@@ -47,8 +47,9 @@ struct RnConvArgs {
     float* stats;                                     // != NULL: [B][tiles][2][Cout] partial sums over interior pixels of (out, out * dot)
     const rbf16* dot; long dot_stride;                // NULL: out * out
     unsigned long long* trace;                        // dev: cycle stamps of one workgroup's wave 0 (fumi_hip_set_trace_buffer(2, ..))
-    int tiles, ncg, xcd, slab_rows, glds, tpi;         // tpi > 0: tiles restart at every image (tpi tiles per image)                   // set by the launcher: pixel tiles / column groups per episode, XCD-grouped ids,
-                                                      // rows of the input slab's LDS image
+    // set by the launcher: pixel tiles / column groups per episode, XCD-grouped ids, rows of the input slab's LDS image, LDS-direct
+    // slab loads, tiles per image (tpi > 0: the tiles restart at every image)
+    int tiles, ncg, xcd, slab_rows, glds, tpi;
 };
 int rn_conv_tiles(long npix, int Cout);                // upper bound of the statistics slabs per episode (sizing)
 size_t rn_conv_lds_bytes(const RnGeom& g, int Cout);

@@ -283,3 +283,72 @@ def test_full_size_20way_episode_pair_against_the_stored_sweep(dev, ws):
         num += float(((d[2:] - r[2:]) ** 2).sum()); den += float((r[2:] ** 2).sum())
     assert (num / den) ** 0.5 <= 0.9
     assert rel_l2(out["g_phi"], [torch.from_numpy(gold[f"bf16.g_phi.{i}"]) for i in range(4)]) <= 0.5
+
+
+# ---- the module surface (--im_encoder resnet12) on the GPU ----------------------------------------------------------------------
+def test_fumi_resnet12_evaluate_applies_the_engines_gradient(dev, ws):
+    """FUMI(im_encoder='resnet12').evaluate on the HIP engine: the plumbing around the step (parameter order of the 48 encoder
+    tensors and the four hypernetwork tensors, gradient views, the loss / accuracy read-back, the optimizer step) -- one SGD
+    training step must move every parameter by -lr x the meta-gradient a direct call of fumi_hip_fumi_resnet12_step returns for the
+    same inputs (same kernels: compared at fp32 round-off), and the host oracle (fp32 autograd, no bf16 rounding) must see the same
+    first-batch loss within bf16's forward error."""
+    from types import SimpleNamespace
+    from oracle import casegen as cg
+    from fumi_amd import engine, hip
+    from fumi_amd.models.fumi import FUMI
+    from oracle_engine import OracleEngine
+    N, Dt = 5, 12
+    ep = CR.make_image_episodes(8, 3, N, 2, 3, 3, 16, 16, Dt)
+    batch = cg.to_batch(ep)
+    torch.manual_seed(1)
+    m = FUMI(n_way=N, im_encoder="resnet12", image_size=16, text_emb_dim=Dt, text_hid_dim=16, norm_hypernet=False).to(dev)
+    args = SimpleNamespace(device=dev, num_train_adapt_steps=1, num_test_adapt_steps=1, step_size=0.05, first_order=False, num_ways=N,
+                           batch_size=3)
+    theta, phi, _ = m._step_params(False)
+    theta0, phi0 = [t.detach().clone() for t in theta], [t.detach().clone() for t in phi]
+    state0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    direct = hip.fumi_resnet12_step(ws, N, ep["x_s"].to(dev), ep["y_s"].to(dev), ep["x_q"].to(dev), ep["y_q"].to(dev), theta0, phi0, 1, 0.05,
+                                    False, text_s=ep["text_s"].to(dev))
+    g_direct = [g.clone() for g in direct["g_theta"] + direct["g_phi"]]
+    loss_direct = float(direct["loss_b"].mean())
+    lr = 0.02
+    opt = torch.optim.SGD(m.parameters(), lr=lr)
+    tr = m.evaluate(args, batch, opt, "train")
+    assert ws.read_status() == 0
+    assert abs(float(tr[0]) - loss_direct) <= 1e-5 * max(1.0, abs(loss_direct))
+    theta1, phi1, _ = m._step_params(False)
+    for i, (p0, p1, g) in enumerate(zip(theta0 + phi0, list(theta1) + list(phi1), g_direct)):
+        upd = (p1.detach() - p0).cpu()
+        assert torch.allclose(upd, -lr * g.cpu(), rtol=1e-4, atol=1e-7 + 1e-5 * float(g.abs().max()) * lr), f"parameter {i}"
+    te = m.evaluate(args, batch, None, "test")
+    assert np.isfinite(float(te[0])) and te[2].shape == (3, N * 3)
+    # the host oracle on the same initial parameters: forward agreement at bf16 level
+    old = engine.set_engine(OracleEngine())
+    try:
+        torch.manual_seed(1)
+        mc = FUMI(n_way=N, im_encoder="resnet12", image_size=16, text_emb_dim=Dt, text_hid_dim=16, norm_hypernet=False)
+        mc.load_state_dict({k: v.cpu() for k, v in state0.items()})
+        argc = SimpleNamespace(**{**vars(args), "device": torch.device("cpu")})
+        ref = mc.evaluate(argc, batch, None, "test")
+    finally:
+        engine.set_engine(old)
+    m.load_state_dict(state0)
+    te0 = m.evaluate(args, batch, None, "test")
+    assert abs(float(te0[0]) - float(ref[0])) <= 0.05 * max(1.0, abs(float(ref[0])))
+
+
+def test_cli_fumi_resnet12_end_to_end_on_gpu(dev, tmp_path, monkeypatch):
+    """`python -m fumi_amd.main --model fumi --im_encoder resnet12 --dataset synthetic` (BASELINE.json configs[4]'s model, shortened):
+    image loader -> ResNet-12 (bf16) + hypernetwork -> meta-training on the HIP engine -> checkpoint -> test."""
+    from fumi_amd import main as cli
+    monkeypatch.chdir(tmp_path)
+    argv = ["--model", "fumi", "--dataset", "synthetic", "--im_encoder", "resnet12", "--image_size", "16", "--text_encoder", "BERT",
+            "--text_emb_dim", "32", "--batch_size", "8", "--num_shots", "5", "--num_ways", "5", "--num_shots_test", "5",
+            "--epochs", "30", "--eval_freq", "15", "--num_ep_test", "16", "--num_train_adapt_steps", "1",
+            "--num_test_adapt_steps", "1", "--lr", "1e-3", "--step_size", "0.05", "--dropout", "0", "--log_dir", str(tmp_path / "res"),
+            "--synthetic_classes", "16", "--wandb_offline"]
+    args = cli.parse_args(argv)
+    assert args.device.type == "cuda"
+    res = cli.main(args)
+    assert np.isfinite(res["test_loss"]) and 0.0 <= res["test_acc"] <= 1.0
+    assert res["test_acc"] > 0.3                                        # chance = 0.2: the engine's gradients train the encoder
