@@ -117,4 +117,4 @@ def test_bench_rehearsal_runs_the_two_rank_code_path():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_meta_batch"] == 64 and out["value"] > 0
-    assert out["allreduce"]["bytes"] > 3_000_000 and out["allreduce"]["avg_us"] > 0 and "REHEARSAL" in out["data"]
+    assert out["allreduce"]["bytes"] > 2_000_000 and out["allreduce"]["avg_us"] > 0 and "REHEARSAL" in out["data"]
