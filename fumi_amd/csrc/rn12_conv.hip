@@ -83,6 +83,10 @@ struct ConvCfg {
     }
 };
 
+// (Weight tiles: two buffers, the next tile requested while this one is multiplied, s_waitcnt vmcnt(0) + one barrier per tile.  A
+// three-buffer ring with requests two tiles ahead and a COUNTED wait -- vmcnt(NBL): the newest tile may still be in flight -- was
+// built and measured: the wait for the loads halves (9.9 -> 5.3 % of a wave's time) and the barrier takes it over (3.6 -> 8.8 %):
+// 884 vs 889 us per launch, 558.6 vs 557.1 ms per step.)
 template <int NF, int MW, int BKS>
 __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
     typedef ConvCfg<NF, MW, BKS> C;
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
             // the k-steps of one tile; `nxt` != NULL: the NEXT tile's NBL load requests are placed one by one BETWEEN the groups of MFMAs
             // (a wave issues in order: as a block in front of the k-steps they cost 880 cycles of a 2 300-cycle tile during which this
             // wave fed the matrix pipe nothing; behind an MFMA they issue while the pipe works)
-            auto compute = [&](int t, int k0, int buf, const char* nxt) {
+            auto compute = [&](int t, int k0, int buf, const char* nxt, int nbuf) {
                 const int kn = min(BKS, nks - k0);
                 const int toff = S.ntaps == 9 ? (t / 3 - 1) * Wp + (t % 3 - 1) : 0;
                 const unsigned char* Bt = Bs + buf * C::BT;
@@ -223,9 +227,7 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
 #pragma unroll
                 for (int m = 0; m < MW; ++m) arow[m] = prow[m] + hs + toff;
                 int slot = nxt ? 0 : NBL;
-                // (a runtime loop on purpose: fully unrolled, hipcc hoists the next k-steps' fragment reads and spills -- 576 bytes of
-                //  scratch per lane at NF = 5, MW = 2 and 8.6x the time)
-                for (int ks = 0; ks < kn; ++ks) {
+                auto kstep = [&](int ks) {
                     rbf16x8 bf[NF];
 #pragma unroll
                     for (int f = 0; f < NF; ++f) bf[f] = *(const rbf16x8*)(Bt + ((ks * NF + f) * 64 + lane) * 16);
@@ -235,29 +237,40 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                         const rbf16x8 af = *(const rbf16x8*)(As + arow[m] * 128 + ((ch ^ ((arow[m] >> 1) & 7)) << 4));
 #pragma unroll
                         for (int f = 0; f < NF; ++f) acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[f], acc[m][f], 0, 0, 0);
-                        if (slot < NBL) { bissue1(nxt, buf ^ 1, slot); ++slot; }
+                        if (slot < NBL) { bissue1(nxt, nbuf, slot); ++slot; }
                     }
-                }
-                for (; slot < NBL; ++slot) bissue1(nxt, buf ^ 1, slot);      // (a short tile: the rest after it)
+                };
+                // (a runtime loop on purpose: fully unrolled, hipcc hoists the next k-steps' fragment reads and spills -- 576 bytes of
+                //  scratch per lane at NF = 5, MW = 2 and 8.6x the time; at NF = 2 it fits, 200 VGPRs, and is no faster: 950 vs 910 us)
+                for (int ks = 0; ks < kn; ++ks) kstep(ks);
+                for (; slot < NBL; ++slot) bissue1(nxt, nbuf, slot);         // (a short tile: the rest after it)
             };
             RNSTAMP(0)                                              // (prologue / between chunks + slab loads issued)
+            // the tile after the one being multiplied, walked in (tap, k-part) order: `ahead` is its address, (at, akp) its tap and
+            // k-part; nullptr past the chunk's last tile
+            int at = 0, akp = 0;
+            const char* ahead = fragb;
+            auto advance = [&]() {
+                if (++akp == npt) { akp = 0; ++at; }
+                ahead = at < S.ntaps ? fragb + at * tap_stride + akp * part_stride : nullptr;
+            };
             bissue(fragb, 0);
+            advance();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             RNSTAMP(1)                                              // (slab and first weight tile in LDS)
             int gbuf = 0;
             for (int t = 0; t < S.ntaps; ++t) {
-                const char* tapb = fragb + t * tap_stride;
                 for (int kp = 0; kp < npt; ++kp, gbuf ^= 1) {
-                    // request the next tile (next k-part of this tap, or the first of the next tap) into the other buffer
-                    const char* nxt = kp + 1 < npt ? tapb + (kp + 1) * part_stride : (t + 1 < S.ntaps ? tapb + tap_stride : nullptr);
+                    const char* nxt = ahead;                        // requested into the other buffer while this tile is multiplied
                     RNSTAMP(2)
-                    compute(t, kp * BKS, gbuf, nxt);
+                    compute(t, kp * BKS, gbuf, nxt, gbuf ^ 1);
                     RNSTAMP(3)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     RNSTAMP(4)
                     __syncthreads();
                     RNSTAMP(6)
+                    if (nxt) advance();
                 }
             }
         }

@@ -275,9 +275,15 @@ def test_expired_sibling_wait_sets_the_status_bit(dev, ws):
             [_g(t, dev) for t in theta], [_g(t, dev) for t in phi], T, cg.ALPHA, False)
     ws.read_status()
     old = hip.lib().fumi_hip_set_spin_limit(0)
+    st = 0
     try:
-        hip.fumi_step_select(*args)
-        st = ws.read_status()
+        # (a wait expires only if a sibling part has not arrived yet when it is first polled -- 64 workgroups exchanging partial sums
+        # make that all but certain in one step, but it is a race: up to 50 steps)
+        for _ in range(50):
+            hip.fumi_step_select(*args)
+            st |= ws.read_status()
+            if st & hip.ST_SYNC_TIMEOUT:
+                break
     finally:
         hip.lib().fumi_hip_set_spin_limit(old)
     assert st & hip.ST_SYNC_TIMEOUT, "no wait expired with a limit of 0 polls (is the split sweep in use?)"

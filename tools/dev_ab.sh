@@ -1,4 +1,4 @@
-timeout -k 10 500 python -m pytest tests -m gpu -q -x -k "am3 or AM3" 2>&1 | tail -4
-for cfg in "FUMI_XP_PS=1" "FUMI_XP_PS=0"; do
-  echo "== am3 $cfg"; env $cfg timeout -k 10 200 python tools/bench_configs.py --only am3_b32 --roofline 2>&1 | tail -1 | cut -c1-520
-done
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/r03f/gputest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r03f/gputest.log
+tail -6 gpurun_out/r03f/gputest.log
+python tests/dev/trace_rn12_conv.py 320 320 21 8 100 2>&1 | tail -12
+python tests/dev/trace_rn12_conv.py 64 64 84 8 100 2>&1 | tail -12
