@@ -152,6 +152,8 @@ static hipStream_t rn_side_stream(fumi_ws* ws) {
     if (ws->profiling) return nullptr;              // phase timing (bench.py's roofline step): one stream, every phase on its own
     return on ? ws->side : nullptr;
 }
+// a failed call may leave weight-gradient launches on the second stream: nothing else may touch the workspace before they are done
+static void rn_abandon(fumi_ws* ws) { if (ws && ws->side) (void)hipStreamSynchronize(ws->side); }
 // main waits for everything forked so far
 static int rn_join(RnCtx& c) {
     if (!c.forked) return FUMI_OK;
@@ -609,7 +611,7 @@ int fumi_hip_maml_resnet12_step(fumi_ws_t* ws, fumi_stream_t stream,
     float* h = side; float* hbar = side + al64(hsz);
     if ((rc = launch_broadcast_head(st, B, N, F, Wf, bf, h))) return rc;            // every episode starts from lin_final (maml.py:24-31)
     p.head = h; p.head_bar = hbar;
-    if ((rc = run_rn12_episodes(ws, st, p))) return rc;
+    if ((rc = run_rn12_episodes(ws, st, p))) { rn_abandon(ws); return rc; }
     if (!need_grad) return FUMI_OK;
     return launch_split_head_grad(st, B, N, F, hbar, grad_scale, g_params[12 * nblk], g_params[12 * nblk + 1]);
 }
@@ -650,7 +652,7 @@ int fumi_hip_fumi_resnet12_step(fumi_ws_t* ws, fumi_stream_t stream,
     g.bias = phi[3]; g.act = tanh_head ? 2 : 0;
     if ((rc = launch_gemm(st, g, 0, 0))) return rc;
     p.head = h; p.head_bar = hbar;
-    if ((rc = run_rn12_episodes(ws, st, p))) return rc;
+    if ((rc = run_rn12_episodes(ws, st, p))) { rn_abandon(ws); return rc; }
     if (!need_grad) return FUMI_OK;
     const float* hp = hbar;
     if (tanh_head) { if ((rc = launch_tanh_bwd(st, (long)R * H1, h, hbar, hpb))) return rc; hp = hpb; }
