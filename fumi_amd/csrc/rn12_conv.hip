@@ -629,15 +629,35 @@ int launch_rn_conv(hipStream_t st, const RnConvArgs& a, int* nt_out) {
     }
 }
 
-// slabs of the pixel axis per episode: enough workgroups to fill the chip a few times over, at least 4 stages each
+// slabs of the pixel axis per episode.  A launch is a few hundred to a few thousand LONG workgroups on 512 slots (256 CUs x 2): the
+// chip runs them in rounds, and 1080 workgroups cost three rounds where 1008 cost two -- so the count is chosen for the fullest
+// last round among the splits that fill the chip one to four times over (at least 4 stages per workgroup).
 int rn_wgrad_nsplit(int B, long npix, int Cin, int Cout) {
     const int Ci32 = (Cin + 31) / 32 * 32;
     const long tiles = (long)((Cout + 63) / 64) * ((Ci32 + 63) / 64) * B;
     const long chunks = (npix + WG_PK - 1) / WG_PK;
-    long ns = (1024 + tiles - 1) / tiles;
-    if (ns > chunks / 4) ns = chunks / 4;
+    static const int legacy = getenv("FUMI_RN_WSPLIT") ? atoi(getenv("FUMI_RN_WSPLIT")) : 0;     // dev knob: 1 = ceil(1024 / tiles)
+    long nsmax = chunks / 4;
+    nsmax = nsmax < 1 ? 1 : (nsmax > 512 ? 512 : nsmax);
+    long ns;
+    if (legacy) {
+        ns = (1024 + tiles - 1) / tiles;
+        ns = ns > nsmax ? nsmax : ns;
+    } else {
+        const long slots = 512;
+        auto eff = [&](long c) {
+            const long w = tiles * c, rounds = (w + slots - 1) / slots;
+            const double e = (double)w / (double)(rounds * slots);    // share of the rounds' slots that hold a workgroup
+            return rounds == 1 ? 0.9 * e : e;                         // (a single round leaves nothing to cover the launch's ramps)
+        };
+        long cmax = nsmax;
+        while (cmax > 1 && tiles * cmax > 6 * slots) --cmax;          // at most six rounds (every slab is reduced again afterwards)
+        double best = -1.0;
+        for (long c = 1; c <= cmax; ++c) best = eff(c) > best ? eff(c) : best;
+        ns = 1;
+        while (ns < cmax && eff(ns) < best - 0.03) ++ns;              // the fewest slabs within 3 % of the best fill
+    }
     if (ns < 1) ns = 1;
-    if (ns > 512) ns = 512;
     if (ns * B >= 8 && B < 8 && 8 % B == 0) ns = (ns + 8 / B - 1) / (8 / B) * (8 / B);     // slabs x episodes in multiples of 8: XCD-grouped ids
     return (int)ns;
 }
