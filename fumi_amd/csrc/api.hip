@@ -71,7 +71,7 @@ int fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out) {
     fumi_ws* ws = new fumi_ws();
     ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr; ws->hcnt = nullptr; ws->acnt = nullptr; ws->w0p = nullptr; ws->w0p_cap = 0; ws->side_buf = nullptr; ws->side_cap = 0; ws->pub_src = nullptr; ws->pub_dst = nullptr; ws->pub_n = 0; ws->pub_seq = 0;
     ws->profiling = 0; ws->prof_every = 1; memset(ws->prof_seen, 0, sizeof(ws->prof_seen)); ws->recs = new std::vector<ProfRec>(); ws->pool = new std::vector<hipEvent_t>();
-    ws->side = nullptr;
+    ws->side = nullptr; ws->lane = nullptr;
     for (auto& e : ws->ev) e = nullptr;
     // small persistent device buffers: status word, arrival counters (kept zero between launches by the kernels that use them)
     auto fail = [&](int code) { fumi_hip_workspace_destroy(ws); return code; };
@@ -113,6 +113,7 @@ void fumi_hip_workspace_destroy(fumi_ws_t* ws) {
     for (auto e : *ws->pool) (void)hipEventDestroy(e);
     for (auto e : ws->ev) if (e) (void)hipEventDestroy(e);
     if (ws->side) (void)hipStreamDestroy(ws->side);
+    if (ws->lane) (void)hipStreamDestroy(ws->lane);
     delete ws->recs; delete ws->pool;
     delete ws;
 }

@@ -31,6 +31,7 @@ struct fumi_ws {
     int prof_every;      // ... at every prof_every-th occurrence of the phase
     unsigned prof_seen[32];
     hipStream_t side;    // second stream: the text path (hypernetwork fwd / bwd) runs beside the two X-panel passes
+    hipStream_t lane;    // ResNet-12: the stream of the odd episode chunks (created on first use)
     hipEvent_t ev[4];    // fork / join points (timing disabled)
     std::vector<ProfRec>* recs;
     std::vector<hipEvent_t>* pool;

@@ -145,7 +145,8 @@ size_t scratch_sizes(const RnNet& n, int S, int Qn, RnScratch& sc) {
 // the pass joins (ev[1]) before it returns.  Their partial-sum scratch is touched by that stream only.  Measured: 568.8 -> 551.7 ms
 // per 8-episode step (3 %: the convolutions and the weight gradients each hold 2 x 240 of a SIMD's 512 registers per lane, so the
 // element-wise waves cannot sit beside them -- the gain is the tails of the launches filling up, not true co-residency).
-struct RnCtx { fumi_ws* ws; hipStream_t st; RnNet n; RnScratch sc; hipStream_t side = nullptr; bool forked = false; };
+struct RnCtx { fumi_ws* ws; hipStream_t st; RnNet n; RnScratch sc; hipStream_t side = nullptr; bool forked = false;
+               hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
 
 static hipStream_t rn_side_stream(fumi_ws* ws) {
     static const int on = getenv("FUMI_RN_SIDE") ? atoi(getenv("FUMI_RN_SIDE")) : 1;
@@ -153,12 +154,15 @@ static hipStream_t rn_side_stream(fumi_ws* ws) {
     return on ? ws->side : nullptr;
 }
 // a failed call may leave weight-gradient launches on the second stream: nothing else may touch the workspace before they are done
-static void rn_abandon(fumi_ws* ws) { if (ws && ws->side) (void)hipStreamSynchronize(ws->side); }
+static void rn_abandon(fumi_ws* ws) {
+    if (ws && ws->side) (void)hipStreamSynchronize(ws->side);
+    if (ws && ws->lane) (void)hipStreamSynchronize(ws->lane);
+}
 // main waits for everything forked so far
 static int rn_join(RnCtx& c) {
     if (!c.forked) return FUMI_OK;
-    HIP_TRY(hipEventRecord(c.ws->ev[1], c.side));
-    HIP_TRY(hipStreamWaitEvent(c.st, c.ws->ev[1], 0));
+    HIP_TRY(hipEventRecord(c.ev_join, c.side));
+    HIP_TRY(hipStreamWaitEvent(c.st, c.ev_join, 0));
     c.forked = false;
     return FUMI_OK;
 }
@@ -222,8 +226,8 @@ int wgrad(RnCtx& c, int M, int l, const RnLayer& y, int npair, const rbf16* x0, 
     a.part = c.sc.wpart;
     hipStream_t st = c.st;
     if (c.side) {                                   // everything this product reads has been launched on the main stream by now
-        HIP_TRY(hipEventRecord(c.ws->ev[0], c.st));
-        HIP_TRY(hipStreamWaitEvent(c.side, c.ws->ev[0], 0));
+        HIP_TRY(hipEventRecord(c.ev_fork, c.st));
+        HIP_TRY(hipStreamWaitEvent(c.side, c.ev_fork, 0));
         st = c.side; c.forked = true;
     }
     { ProfScope _ps(c.ws, st, FUMI_PH_RN_WGRAD); TRY(launch_rn_wgrad(st, a)); }
@@ -432,7 +436,15 @@ static size_t chunk_bytes(RnNet& n, int Bc, const Rn12Problem& p, RnScratch& sc)
 }
 
 int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
-    RnCtx c; c.ws = ws; c.st = st; c.side = rn_side_stream(ws);
+    // Two LANES: the meta-batch's chunks of episodes are independent until their meta-gradients are added, so odd chunks run on a
+    // second stream (ws->lane, own half of the workspace) beside the even ones on the caller's.  Each lane's kernels alternate between
+    // MFMA-bound (convolutions, weight gradients: 3/4 of the time) and HBM-bound (element-wise: 1/4) and leave partial last rounds
+    // of workgroups; two lanes out of phase fill both (measured with two processes of 4 episodes each against one of 8: 15.9 vs
+    // 14.1 episodes/s).  FUMI_RN_LANES=1 or phase timing: one lane (then the weight gradients fork onto ws->side instead).
+    static const int lanes_env = getenv("FUMI_RN_LANES") ? atoi(getenv("FUMI_RN_LANES")) : 2;
+    RnCtx cx[2];
+    for (int i = 0; i < 2; ++i) { cx[i].ws = ws; cx[i].st = st; }
+    RnCtx& c = cx[0];
     int rc = net_init(c.n, p.B, p.nblk, p.Cimg, p.N, p.H, p.W, p.channels);
     if (rc) return rc;
     RnNet& n = c.n;
@@ -440,25 +452,47 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
     const bool grad = p.need_grad != 0, second = grad && p.second_order && p.T > 0;
     if (second && p.T > 16) return FUMI_ENOTSUP;
     const int ntape = second ? p.T : 1, nslot = second ? p.T + 1 : 2;
-    // ---- chunk size: the largest number of episodes whose tape fits the budget
+    int lanes = (lanes_env >= 2 && !ws->profiling && p.B >= 2 && ws->side) ? 2 : 1;
+    // ---- chunk size: the largest number of episodes whose tapes (one per lane) fit the budget
     size_t budget = g_rn_budget;
     if (!budget) {
         const char* e = getenv("FUMI_RN12_BUDGET_GB");
         budget = (size_t)((e && atof(e) > 0 ? atof(e) : 200.0) * (double)(1ull << 30));
     }
-    int Bc = p.chunk > 0 ? (p.chunk < p.B ? p.chunk : p.B) : p.B;
+    int Bc = p.chunk > 0 ? (p.chunk < p.B ? p.chunk : p.B) : (lanes == 2 ? (p.B + 1) / 2 : p.B);
     if (p.chunk <= 0) {
-        while (Bc > 1 && chunk_bytes(n, Bc, p, c.sc) > budget) Bc = (Bc + 1) / 2;
+        while (Bc > 1 && lanes * chunk_bytes(n, Bc, p, c.sc) > budget) Bc = (Bc + 1) / 2;
     }
-    const size_t bytes = chunk_bytes(n, Bc, p, c.sc);
-    if ((rc = ws_reserve(ws, bytes))) return rc;
+    if (Bc >= p.B) lanes = 1;                                             // a single chunk
+    const size_t region = ws_align(chunk_bytes(n, Bc, p, c.sc));
+    if ((rc = ws_reserve(ws, lanes * region))) return rc;
+    if (lanes == 2) {
+        if (!ws->lane && hipStreamCreateWithFlags(&ws->lane, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ws->lane = nullptr; lanes = 1; }
+    }
+    // (one lane: its weight gradients fork onto ws->side; with two lanes a stream of weight gradients per lane added nothing --
+    // 530.5 vs 524.2 ms per 8-episode step -- and they stay in line)
+    if (lanes == 1) { c.side = rn_side_stream(ws); c.ev_fork = ws->ev[0]; c.ev_join = ws->ev[1]; }
+    if (lanes == 2) {
+        cx[1].n = n; cx[1].st = ws->lane;
+        HIP_TRY(hipEventRecord(ws->ev[2], st));                           // the lane starts behind everything already on the caller's stream
+        HIP_TRY(hipStreamWaitEvent(ws->lane, ws->ev[2], 0));
+    }
     const size_t F1 = (size_t)n.N * (n.F + 1);
-    float* gacc = nullptr;
-    for (int b0 = 0; b0 < p.B; b0 += Bc) {
+    float* gacc_lane[2] = {nullptr, nullptr};
+    int ck = 0;
+    // (the lanes start together and run the same kernel sequence; giving the second lane half a chunk first, so that one multiplies
+    // while the other is in its element-wise passes, was measured: 4409 vs 4350 ms per 64-episode step -- they drift apart anyway)
+    for (int b0 = 0; b0 < p.B; b0 += Bc, ++ck) {
         const int bc = p.B - b0 < Bc ? p.B - b0 : Bc;
+        const int lane = lanes == 2 ? (ck & 1) : 0;
+        RnCtx& c = cx[lane];
+        RnNet& n = c.n;
+        const hipStream_t st = c.st;                                      // (shadows: everything of this chunk goes to its lane's stream)
         (void)chunk_bytes(n, bc, p, c.sc);                               // (sets n.B = bc and the scratch sizes of this chunk)
-        ws->off = 0;
-        float* gsum = ws_f(ws, (size_t)n.PSZ); gacc = ws_f(ws, (size_t)n.PSZ);       // first carve: same address in every chunk
+        ws->off = (size_t)lane * region;
+        float* gsum = ws_f(ws, (size_t)n.PSZ); float* gacc = ws_f(ws, (size_t)n.PSZ);   // first carve: same address in every chunk of a lane
+        const bool first_of_lane = gacc_lane[lane] == nullptr;
+        gacc_lane[lane] = gacc;
         c.sc.cpart = ws_f(ws, c.sc.cpart_n); c.sc.rpart = ws_f(ws, c.sc.rpart_n); c.sc.wpart = ws_f(ws, c.sc.wpart_n);
         c.sc.rowl = ws_f(ws, c.sc.rowl_n); c.sc.c2 = ws_f(ws, c.sc.c2_n);
         rbf16* img_s = ws_h(ws, (size_t)bc * p.S * n.g[0].Pp * 16); rbf16* img_q = ws_h(ws, (size_t)bc * p.Qn * n.g[0].Pp * 16);
@@ -474,7 +508,7 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
         float* G = ws_f(ws, (size_t)bc * n.PSZ); float* bar = ws_f(ws, (size_t)bc * n.PSZ); float* HV = ws_f(ws, (size_t)bc * n.PSZ);
         float* dh = ws_f(ws, hsz); float* barh = ws_f(ws, hsz); float* HVh = ws_f(ws, hsz);
         rbf16* Vfrags = ws_h(ws, (size_t)bc * n.FSZ);
-        if (ws->off > ws->cap) return FUMI_ENOMEM;
+        if (ws->off > (size_t)(lane + 1) * region || ws->off > ws->cap) return FUMI_ENOMEM;
         auto P = [&](int s) { return params + (size_t)s * bc * n.PSZ; };
         auto Fr = [&](int s) { return frags + (size_t)s * bc * n.FSZ; };
         auto Hd = [&](int s) { return heads + (size_t)s * hsz; };
@@ -524,10 +558,16 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
         }
         // ---- meta-gradient of the chunk: scaled sum over its episodes, added to the running sum
         TRY(launch_reduce_batched(st, 1, bc, n.PSZ, bar, p.grad_scale, gsum, 0));
-        if (b0 == 0) HIP_TRY(hipMemcpyAsync(gacc, gsum, (size_t)n.PSZ * 4, hipMemcpyDeviceToDevice, st));
+        if (first_of_lane) HIP_TRY(hipMemcpyAsync(gacc, gsum, (size_t)n.PSZ * 4, hipMemcpyDeviceToDevice, st));
         else TRY(launch_axpy(st, n.PSZ, gacc, 1.f, gsum, gacc));
         HIP_TRY(hipMemcpyAsync(p.head_bar + (size_t)b0 * F1, barh, hsz * 4, hipMemcpyDeviceToDevice, st));
     }
+    if (lanes == 2) {                                                     // the caller's stream waits for the second lane
+        HIP_TRY(hipEventRecord(ws->ev[3], ws->lane));
+        HIP_TRY(hipStreamWaitEvent(st, ws->ev[3], 0));
+    }
+    float* gacc = gacc_lane[0];
+    if (grad && gacc_lane[1]) TRY(launch_axpy(st, n.PSZ, gacc, 1.f, gacc_lane[1], gacc));
     if (p.stats) {
         ReduceSegs sg; sg.n = 0; sg.scale = p.grad_scale;
         sg.add(p.loss_b, p.B, 1, 1, p.stats); sg.add(p.acc_b, p.B, 1, 1, p.stats + 1);
