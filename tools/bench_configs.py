@@ -27,6 +27,9 @@ CONFIGS = {
     # configs[1] with the other text path, for comparison with bench.py's GloVe line
     "fumi_bert_t1_b32": ["--model", "fumi", "--text_encoder", "BERT", "--text_emb_dim", "768", "--batch_size", "32",
                          "--num_train_adapt_steps", "1"],
+    # half of configs[1]'s per-rank meta-batch (dev: what two concurrent half-batches could give)
+    "fumi_bert_t1_b16": ["--model", "fumi", "--text_encoder", "BERT", "--text_emb_dim", "768", "--batch_size", "16",
+                         "--num_train_adapt_steps", "1"],
 }
 
 
