@@ -467,6 +467,7 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
     const size_t region = ws_align(chunk_bytes(n, Bc, p, c.sc));
     if ((rc = ws_reserve(ws, lanes * region))) return rc;
     if (lanes == 2) {
+        // (a high-priority lane stream and GPU_MAX_HW_QUEUES=8 were tried: 1082 / 1068 vs 1063 ms per 16 episodes)
         if (!ws->lane && hipStreamCreateWithFlags(&ws->lane, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ws->lane = nullptr; lanes = 1; }
     }
     // (one lane: its weight gradients fork onto ws->side; with two lanes a stream of weight gradients per lane added nothing --
@@ -479,20 +480,18 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
     }
     const size_t F1 = (size_t)n.N * (n.F + 1);
     float* gacc_lane[2] = {nullptr, nullptr};
-    int ck = 0;
-    // (the lanes start together and run the same kernel sequence; giving the second lane half a chunk first, so that one multiplies
-    // while the other is in its element-wise passes, was measured: 4409 vs 4350 ms per 64-episode step -- they drift apart anyway)
-    for (int b0 = 0; b0 < p.B; b0 += Bc, ++ck) {
-        const int bc = p.B - b0 < Bc ? p.B - b0 : Bc;
-        const int lane = lanes == 2 ? (ck & 1) : 0;
+    fumi_ws* const ws_real = ws;
+    // one chunk of episodes [b0, b0 + bc) on its lane's stream, in its lane's half of the workspace
+    auto chunk_body = [&](int lane, int b0, int bc, bool first_of_lane, float** gacc_out) -> int {
         RnCtx& c = cx[lane];
         RnNet& n = c.n;
         const hipStream_t st = c.st;                                      // (shadows: everything of this chunk goes to its lane's stream)
+        fumi_ws view = *ws_real;                                          // (a private bump pointer per chunk)
+        fumi_ws* ws = &view;
         (void)chunk_bytes(n, bc, p, c.sc);                               // (sets n.B = bc and the scratch sizes of this chunk)
-        ws->off = (size_t)lane * region;
+        ws->off = (size_t)lane * region;                                 // (ws: this thread's carving view of the workspace)
         float* gsum = ws_f(ws, (size_t)n.PSZ); float* gacc = ws_f(ws, (size_t)n.PSZ);   // first carve: same address in every chunk of a lane
-        const bool first_of_lane = gacc_lane[lane] == nullptr;
-        gacc_lane[lane] = gacc;
+        *gacc_out = gacc;
         c.sc.cpart = ws_f(ws, c.sc.cpart_n); c.sc.rpart = ws_f(ws, c.sc.rpart_n); c.sc.wpart = ws_f(ws, c.sc.wpart_n);
         c.sc.rowl = ws_f(ws, c.sc.rowl_n); c.sc.c2 = ws_f(ws, c.sc.c2_n);
         rbf16* img_s = ws_h(ws, (size_t)bc * p.S * n.g[0].Pp * 16); rbf16* img_q = ws_h(ws, (size_t)bc * p.Qn * n.g[0].Pp * 16);
@@ -545,7 +544,7 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
         // ---- query pass with the adapted parameters
         TRY(forward_pass(c, p.Qn, img_q, P(cur), Fr(cur), query, Hd(cur), y_q, 1.f / p.Qn, p.logits_q + (size_t)b0 * p.Qn * n.N,
                          p.preds_q + (size_t)b0 * p.Qn, p.preds_f ? p.preds_f + (size_t)b0 * p.Qn : nullptr, p.loss_b + b0, p.acc_b + b0));
-        if (!grad) continue;
+        if (!grad) return FUMI_OK;
         HIP_TRY(hipMemsetAsync(bar, 0, (size_t)bc * n.PSZ * 4, st));
         TRY(backward_pass(c, p.Qn, img_q, Fr(cur), query, Hd(cur), bar, barh));
         if (second) {
@@ -561,6 +560,18 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
         if (first_of_lane) HIP_TRY(hipMemcpyAsync(gacc, gsum, (size_t)n.PSZ * 4, hipMemcpyDeviceToDevice, st));
         else TRY(launch_axpy(st, n.PSZ, gacc, 1.f, gsum, gacc));
         HIP_TRY(hipMemcpyAsync(p.head_bar + (size_t)b0 * F1, barh, hsz * 4, hipMemcpyDeviceToDevice, st));
+        return FUMI_OK;
+    };
+    // chunk k belongs to lane k & 1; the chunks are enqueued in order, alternating lanes (a second host thread enqueuing lane 1 on
+    // its own changed nothing: 1071 vs 1073 ms per 16 episodes)
+    {
+        bool first[2] = {true, true};
+        int ck = 0;
+        for (int b0 = 0; b0 < p.B; b0 += Bc, ++ck) {
+            const int bc = p.B - b0 < Bc ? p.B - b0 : Bc, lane = lanes == 2 ? (ck & 1) : 0;
+            TRY(chunk_body(lane, b0, bc, first[lane], &gacc_lane[lane]));
+            first[lane] = false;
+        }
     }
     if (lanes == 2) {                                                     // the caller's stream waits for the second lane
         HIP_TRY(hipEventRecord(ws->ev[3], ws->lane));
