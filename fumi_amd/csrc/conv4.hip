@@ -407,95 +407,154 @@ struct Conv4Hooks {
 
 int run_conv4_episodes(fumi_ws* ws, hipStream_t st, Conv4Problem p, const Conv4Hooks& hooks) {
     const size_t extra_bytes = ws_align(hooks.extra_bytes);
-    StepCtx c; c.ws = ws; c.st = st;
-    int rc = net_init(c.n, p.B, p.nblk, p.Cin, p.N, p.H, p.W);
+    // Two LANES (as rn12.hip): the two halves of the meta-batch are independent until their meta-gradients are added, so the second
+    // half runs on ws->lane in its own half of the workspace beside the first on the caller's stream -- the MFMA-bound GEMMs of one
+    // fill the HBM-bound element-wise passes and partial last rounds of the other (two processes of 16 episodes against one of 32:
+    // 617.8 vs 573.3 episodes/s).  From 8 episodes up; FUMI_CV_LANES=1, phase timing or a smaller batch: one lane, and only then the
+    // probe table (fumi_hip_conv4_probe) is filled.
+    static const int lanes_env = getenv("FUMI_CV_LANES") ? atoi(getenv("FUMI_CV_LANES")) : 2;
+    int lanes = (lanes_env >= 2 && !ws->profiling && p.B >= 8 && ws->side) ? 2 : 1;
+    StepCtx cx[2];
+    for (int i = 0; i < 2; ++i) { cx[i].ws = ws; cx[i].st = st; }
+    const int Bc = lanes == 2 ? (p.B + 1) / 2 : p.B;                  // episodes per lane
+    int rc = net_init(cx[0].n, Bc, p.nblk, p.Cin, p.N, p.H, p.W);
     if (rc) return rc;
-    const Net& n = c.n;
     if (p.T < 0 || p.S < 1 || p.Qn < 1) return FUMI_EINVAL;
     const bool grad = p.need_grad != 0, second = grad && p.second_order && p.T > 0;
     if (second && p.T > 8) return FUMI_ENOTSUP;                      // taped inner steps (the probe table holds 8)
-    c.S = p.S; c.Qn = p.Qn; c.img_s = p.x_s; c.img_q = p.x_q; c.y_s = p.y_s; c.y_q = p.y_q;
     const int ntape = second ? p.T : 1;
     const int nslot = second ? p.T + 1 : 2;
-    const size_t hsz = (size_t)n.B * n.N * (n.F + 1);
-    // ---- workspace
-    size_t bytes = extra_bytes + conv4_scratch_sizes(n, p.S, p.Qn, c.sc);
-    bytes += (size_t)ntape * pass_bytes(n, p.S, true) + pass_bytes(n, p.Qn, grad);
-    if (second) bytes += tan_bytes(n, p.S);
-    bytes += (size_t)nslot * (ws_align((size_t)n.B * n.PSZ * 4) + ws_align((size_t)n.B * n.FSZ * 4) + ws_align(hsz * 4));
-    bytes += 4 * ws_align((size_t)n.B * n.PSZ * 4) + 4 * ws_align(hsz * 4) + ws_align((size_t)n.B * n.FSZ * 4);   // G, bar, HV, tmp | dh, barh, HVh | Vfrags
-    bytes += ws_align((size_t)n.B * (2048 + 4096) * 4) + ws_align((size_t)(n.nblk) * 36864 * 4) + ws_align((size_t)n.PSZ * 4);
-    if ((rc = ws_reserve(ws, bytes))) return rc;
+    const size_t F1 = (size_t)cx[0].n.N * (cx[0].n.F + 1);
+    // ---- workspace: the caller's region, then one region per lane (sized for Bc episodes)
+    auto lane_bytes = [&](const Net& n, Scratch& sc) {
+        const size_t hsz = (size_t)n.B * F1;
+        size_t bytes = conv4_scratch_sizes(n, p.S, p.Qn, sc);
+        bytes += (size_t)ntape * pass_bytes(n, p.S, true) + pass_bytes(n, p.Qn, grad);
+        if (second) bytes += tan_bytes(n, p.S);
+        bytes += (size_t)nslot * (ws_align((size_t)n.B * n.PSZ * 4) + ws_align((size_t)n.B * n.FSZ * 4) + ws_align(hsz * 4));
+        bytes += 4 * ws_align((size_t)n.B * n.PSZ * 4) + 4 * ws_align(hsz * 4) + ws_align((size_t)n.B * n.FSZ * 4);   // G, bar, HV, tmp | dh, barh, HVh | Vfrags
+        bytes += ws_align((size_t)n.B * (2048 + 4096) * 4) + ws_align((size_t)(n.nblk) * 36864 * 4) + ws_align((size_t)n.PSZ * 4);
+        return ws_align(bytes + 4096);
+    };
+    const size_t region = lane_bytes(cx[0].n, cx[0].sc);
+    if ((rc = ws_reserve(ws, extra_bytes + lanes * region))) return rc;
     char* extra = ws->base + ws->off;
     ws->off += extra_bytes;                                           // (the caller's buffers: head, hypernetwork activations)
+    const size_t lane0_off = ws->off;
     TRY(hooks.prepare(extra, &p.head, &p.head_bar));
-    c.sc.cpart = ws_f(ws, c.sc.cpart_n); c.sc.wpart = ws_f(ws, c.sc.wpart_n); c.sc.rpart = ws_f(ws, c.sc.rpart_n);
-    c.sc.dsum = (double*)ws_f(ws, c.sc.dsum_n * 2); c.sc.rowl = ws_f(ws, c.sc.rowl_n);
+    if (lanes == 2) {
+        if (!ws->lane && hipStreamCreateWithFlags(&ws->lane, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ws->lane = nullptr; lanes = 1; }
+    }
+    if (lanes == 2) {
+        cx[1].st = ws->lane;
+        HIP_TRY(hipEventRecord(ws->ev[2], st));                       // the lane starts behind the head's producer on the caller's stream
+        HIP_TRY(hipStreamWaitEvent(ws->lane, ws->ev[2], 0));
+    } else if (Bc != p.B) {
+        return FUMI_EHIP;                                             // (no second stream after all: cannot happen once the reserve is sized)
+    }
     ProbeTab& pt = g_probe;
     pt.valid = false;
-    for (int t = 0; t < ntape; ++t) pass_carve(ws, n, p.S, true, pt.tape[t]);
-    pass_carve(ws, n, p.Qn, grad, pt.query);
-    if (second) tan_carve(ws, n, p.S, pt.tan);
-    float* params = ws_f(ws, (size_t)nslot * n.B * n.PSZ);
-    float* frags = ws_f(ws, (size_t)nslot * n.B * n.FSZ);
-    float* heads = ws_f(ws, (size_t)nslot * hsz);
-    float* G = ws_f(ws, (size_t)n.B * n.PSZ); float* bar = ws_f(ws, (size_t)n.B * n.PSZ); float* HV = ws_f(ws, (size_t)n.B * n.PSZ);
-    float* dh = ws_f(ws, hsz); float* barh = ws_f(ws, hsz); float* HVh = ws_f(ws, hsz);
-    float* Vfrags = ws_f(ws, (size_t)n.B * n.FSZ);
-    float* tmp1 = ws_f(ws, (size_t)n.B * (2048 + 4096));
-    float* toi_tmp = ws_f(ws, (size_t)n.nblk * 36864);
-    float* gsum = ws_f(ws, (size_t)n.PSZ);
-    auto P = [&](int s) { return params + (size_t)s * n.B * n.PSZ; };
-    auto Fr = [&](int s) { return frags + (size_t)s * n.B * n.FSZ; };
-    auto Hd = [&](int s) { return heads + (size_t)s * hsz; };
+    float* gsum_lane[2] = {nullptr, nullptr};
+    fumi_ws* const ws_real = ws;
+    // episodes [b0, b0 + bc) on lane `lane`
+    auto chunk_body = [&](int lane, int b0, int bc) -> int {
+        StepCtx& c = cx[lane];
+        const hipStream_t st = c.st;                                  // (shadows: everything of this half goes to its lane's stream)
+        int r = net_init(c.n, bc, p.nblk, p.Cin, p.N, p.H, p.W);
+        if (r) return r;
+        const Net& n = c.n;
+        const size_t hsz = (size_t)n.B * F1;
+        (void)lane_bytes(n, c.sc);                                    // (the scratch sizes of this half)
+        fumi_ws view = *ws_real;                                      // (a private bump pointer)
+        fumi_ws* ws = &view;
+        ws->off = lane0_off + (size_t)lane * region;
+        const float* x_s = p.x_s + (size_t)b0 * p.S * p.Cin * p.H * p.W; const float* x_q = p.x_q + (size_t)b0 * p.Qn * p.Cin * p.H * p.W;
+        const int64_t* y_s = p.y_s + (size_t)b0 * p.S; const int64_t* y_q = p.y_q + (size_t)b0 * p.Qn;
+        c.S = p.S; c.Qn = p.Qn; c.img_s = x_s; c.img_q = x_q; c.y_s = y_s; c.y_q = y_q;
+        c.sc.cpart = ws_f(ws, c.sc.cpart_n); c.sc.wpart = ws_f(ws, c.sc.wpart_n); c.sc.rpart = ws_f(ws, c.sc.rpart_n);
+        c.sc.dsum = (double*)ws_f(ws, c.sc.dsum_n * 2); c.sc.rowl = ws_f(ws, c.sc.rowl_n);
+        PassBufs tape_l[8]; PassBufs query_l; TanBufs tan_l;
+        PassBufs* tape = lanes == 1 ? pt.tape : tape_l; PassBufs& query = lanes == 1 ? pt.query : query_l; TanBufs& tan = lanes == 1 ? pt.tan : tan_l;
+        for (int t = 0; t < ntape; ++t) pass_carve(ws, n, p.S, true, tape[t]);
+        pass_carve(ws, n, p.Qn, grad, query);
+        if (second) tan_carve(ws, n, p.S, tan);
+        float* params = ws_f(ws, (size_t)nslot * n.B * n.PSZ);
+        float* frags = ws_f(ws, (size_t)nslot * n.B * n.FSZ);
+        float* heads = ws_f(ws, (size_t)nslot * hsz);
+        float* G = ws_f(ws, (size_t)n.B * n.PSZ); float* bar = ws_f(ws, (size_t)n.B * n.PSZ); float* HV = ws_f(ws, (size_t)n.B * n.PSZ);
+        float* dh = ws_f(ws, hsz); float* barh = ws_f(ws, hsz); float* HVh = ws_f(ws, hsz);
+        float* Vfrags = ws_f(ws, (size_t)n.B * n.FSZ);
+        float* tmp1 = ws_f(ws, (size_t)n.B * (2048 + 4096));
+        float* toi_tmp = ws_f(ws, (size_t)n.nblk * 36864);
+        float* gsum = ws_f(ws, (size_t)n.PSZ);
+        gsum_lane[lane] = gsum;
+        if (ws->off > lane0_off + (size_t)(lane + 1) * region || ws->off > ws->cap) return FUMI_ENOMEM;
+        auto P = [&](int s_) { return params + (size_t)s_ * n.B * n.PSZ; };
+        auto Fr = [&](int s_) { return frags + (size_t)s_ * n.B * n.FSZ; };
+        auto Hd = [&](int s_) { return heads + (size_t)s_ * hsz; };
 
-    // ---- slot 0: the meta-parameters, one copy per episode (canonical layouts), and the caller's head
-    TRY(slot0_from_theta(st, n, p.theta, P(0), toi_tmp));
-    TRY(frags_of_slot(st, n, P(0), Fr(0), tmp1));
-    HIP_TRY(hipMemcpyAsync(Hd(0), p.head, hsz * 4, hipMemcpyDeviceToDevice, st));
+        // ---- slot 0: the meta-parameters, one copy per episode (canonical layouts), and the caller's head
+        TRY(slot0_from_theta(st, n, p.theta, P(0), toi_tmp));
+        TRY(frags_of_slot(st, n, P(0), Fr(0), tmp1));
+        HIP_TRY(hipMemcpyAsync(Hd(0), p.head + (size_t)b0 * F1, hsz * 4, hipMemcpyDeviceToDevice, st));
 
-    // ---- inner loop on the support set
-    int cur = 0;
-    for (int t = 0; t < p.T; ++t) {
-        PassBufs& pb = pt.tape[second ? t : 0];
-        const int nxt = second ? t + 1 : cur ^ 1;
-        TRY(forward_pass(c, p.S, p.x_s, P(cur), Fr(cur), pb, Hd(cur), p.y_s, 1.f / p.S, nullptr, nullptr, nullptr, nullptr, nullptr));
-        TRY(backward_pass(c, p.S, p.x_s, Fr(cur), pb, Hd(cur), G, dh));
-        TRY(launch_axpy(st, (long)n.B * n.PSZ, P(cur), -p.alpha, G, P(nxt)));
-        TRY(launch_axpy(st, (long)hsz, Hd(cur), -p.alpha, dh, Hd(nxt)));
-        TRY(frags_of_slot(st, n, P(nxt), Fr(nxt), tmp1));
-        cur = nxt;
+        // ---- inner loop on the support set
+        int cur = 0;
+        for (int t = 0; t < p.T; ++t) {
+            PassBufs& pb = tape[second ? t : 0];
+            const int nxt = second ? t + 1 : cur ^ 1;
+            TRY(forward_pass(c, p.S, x_s, P(cur), Fr(cur), pb, Hd(cur), y_s, 1.f / p.S, nullptr, nullptr, nullptr, nullptr, nullptr));
+            TRY(backward_pass(c, p.S, x_s, Fr(cur), pb, Hd(cur), G, dh));
+            TRY(launch_axpy(st, (long)n.B * n.PSZ, P(cur), -p.alpha, G, P(nxt)));
+            TRY(launch_axpy(st, (long)hsz, Hd(cur), -p.alpha, dh, Hd(nxt)));
+            TRY(frags_of_slot(st, n, P(nxt), Fr(nxt), tmp1));
+            cur = nxt;
+        }
+        // ---- query pass with the adapted parameters
+        TRY(forward_pass(c, p.Qn, x_q, P(cur), Fr(cur), query, Hd(cur), y_q, 1.f / p.Qn, p.logits_q + (size_t)b0 * p.Qn * n.N,
+                         p.preds_q + (size_t)b0 * p.Qn, p.preds_f ? p.preds_f + (size_t)b0 * p.Qn : nullptr, p.loss_b + b0, p.acc_b + b0));
+        if (lanes == 1) {
+            pt.n = n; pt.T = p.T; pt.S = p.S; pt.Qn = p.Qn; pt.ntape = ntape; pt.params = params; pt.heads = heads; pt.G = G; pt.dh = dh;
+            pt.bar = bar; pt.barh = barh; pt.HV = HV; pt.HVh = HVh; pt.ws = ws_real; pt.base = ws_real->base; pt.valid = true;
+        }
+        if (!grad) return FUMI_OK;
+        TRY(backward_pass(c, p.Qn, x_q, Fr(cur), query, Hd(cur), bar, barh));
+        // ---- second-order reverse sweep
+        if (second) {
+            for (int t = p.T - 1; t >= 0; --t) {
+                TRY(frags_of_slot(st, n, bar, Vfrags, tmp1));
+                TRY(hvp_pass(c, p.S, x_s, Fr(t), tape[t], tan, Hd(t), bar, Vfrags, barh, 1.f / p.S, HV, HVh));
+                TRY(launch_axpy(st, (long)n.B * n.PSZ, bar, -p.alpha, HV, bar));
+                TRY(launch_axpy(st, (long)hsz, barh, -p.alpha, HVh, barh));
+            }
+        }
+        // ---- this half's meta-gradient: scaled sum over its episodes
+        TRY(launch_reduce_batched(st, 1, n.B, n.PSZ, bar, p.grad_scale, gsum, 0));
+        HIP_TRY(hipMemcpyAsync(p.head_bar + (size_t)b0 * F1, barh, hsz * 4, hipMemcpyDeviceToDevice, st));
+        return FUMI_OK;
+    };
+    TRY(chunk_body(0, 0, lanes == 2 ? Bc : p.B));
+    if (lanes == 2) {
+        TRY(chunk_body(1, Bc, p.B - Bc));
+        HIP_TRY(hipEventRecord(ws->ev[3], ws->lane));                 // the caller's stream waits for the second lane
+        HIP_TRY(hipStreamWaitEvent(st, ws->ev[3], 0));
     }
-    // ---- query pass with the adapted parameters
-    TRY(forward_pass(c, p.Qn, p.x_q, P(cur), Fr(cur), pt.query, Hd(cur), p.y_q, 1.f / p.Qn, p.logits_q, p.preds_q, p.preds_f,
-                     p.loss_b, p.acc_b));
+    const Net& n = cx[0].n;
     if (p.stats) {
         ReduceSegs sg; sg.n = 0; sg.scale = p.grad_scale;
-        sg.add(p.loss_b, n.B, 1, 1, p.stats); sg.add(p.acc_b, n.B, 1, 1, p.stats + 1);
+        sg.add(p.loss_b, p.B, 1, 1, p.stats); sg.add(p.acc_b, p.B, 1, 1, p.stats + 1);
         TRY(launch_reduce_multi(st, sg));
     }
-    pt.n = n; pt.T = p.T; pt.S = p.S; pt.Qn = p.Qn; pt.ntape = ntape; pt.params = params; pt.heads = heads; pt.G = G; pt.dh = dh;
-    pt.bar = bar; pt.barh = barh; pt.HV = HV; pt.HVh = HVh; pt.ws = ws; pt.base = ws->base; pt.valid = true;
     if (!grad) return FUMI_OK;
-    TRY(backward_pass(c, p.Qn, p.x_q, Fr(cur), pt.query, Hd(cur), bar, barh));
-    // ---- second-order reverse sweep
-    if (second) {
-        for (int t = p.T - 1; t >= 0; --t) {
-            TRY(frags_of_slot(st, n, bar, Vfrags, tmp1));
-            TRY(hvp_pass(c, p.S, p.x_s, Fr(t), pt.tape[t], pt.tan, Hd(t), bar, Vfrags, barh, 1.f / p.S, HV, HVh));
-            TRY(launch_axpy(st, (long)n.B * n.PSZ, bar, -p.alpha, HV, bar));
-            TRY(launch_axpy(st, (long)hsz, barh, -p.alpha, HVh, barh));
-        }
-    }
-    // ---- meta-gradients: scaled sum over the episodes, back to the parameters' own layouts
-    TRY(launch_reduce_batched(st, 1, n.B, n.PSZ, bar, p.grad_scale, gsum, 0));
+    // ---- meta-gradients: the lanes' sums added, back to the parameters' own layouts
+    float* gsum = gsum_lane[0];
+    if (gsum_lane[1]) TRY(launch_axpy(st, n.PSZ, gsum, 1.f, gsum_lane[1], gsum));
     TRY(launch_w1_from_canon(st, n.Cin, gsum + n.offW[0], p.g_theta[0], 1.f));
     for (int l = 0; l < n.nblk; ++l) {
         if (l) TRY(launch_toi_to_oihw(st, 1, gsum + n.offW[l], p.g_theta[3 * l], 1.f));
         HIP_TRY(hipMemcpyAsync(p.g_theta[3 * l + 1], gsum + n.offG[l], 64 * 4, hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(p.g_theta[3 * l + 2], gsum + n.offB[l], 64 * 4, hipMemcpyDeviceToDevice, st));
     }
-    HIP_TRY(hipMemcpyAsync(p.head_bar, barh, hsz * 4, hipMemcpyDeviceToDevice, st));
     return FUMI_OK;
 }
 
@@ -557,7 +616,7 @@ int fumi_hip_maml_conv4_step(fumi_ws_t* ws, fumi_stream_t stream,
         *head = h; *head_bar = hbar;
         return launch_broadcast_head(st, B, N, F, Wf, bf, h);            // every episode starts from lin_final (maml.py:24-31)
     };
-    if ((rc = run_conv4_episodes(ws, st, p, hk))) return rc;
+    if ((rc = run_conv4_episodes(ws, st, p, hk))) { if (ws->lane) (void)hipStreamSynchronize(ws->lane); return rc; }
     if (!need_grad) return FUMI_OK;
     return launch_split_head_grad(st, B, N, F, hbar, grad_scale, g_params[3 * nblk], g_params[3 * nblk + 1]);
 }
@@ -605,7 +664,7 @@ int fumi_hip_fumi_conv4_step(fumi_ws_t* ws, fumi_stream_t stream,
         *head = h; *head_bar = hbar;
         return FUMI_OK;
     };
-    if ((rc = run_conv4_episodes(ws, st, p, hk))) return rc;
+    if ((rc = run_conv4_episodes(ws, st, p, hk))) { if (ws->lane) (void)hipStreamSynchronize(ws->lane); return rc; }
     if (!need_grad) return FUMI_OK;
     const float* hp = hbar;
     if (tanh_head) { if ((rc = launch_tanh_bwd(st, (long)R * H1, h, hbar, hpb))) return rc; hp = hpb; }

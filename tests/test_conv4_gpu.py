@@ -389,14 +389,17 @@ def test_conv4_as_worded_bench_shape_properties(dev, ws):
     safe = safe_margin_mask(full["logits"].double().cpu(), 1e-2)
     assert float(safe.float().mean()) > 0.8 and torch.equal(full["preds"].cpu()[safe], halves["preds"].cpu()[safe])
     names = [f"theta{i}" for i in range(len(theta))] + [f"phi{i}" for i in range(4)]
+    # (a tensor whose gradient cancels to fp32 noise -- the head's bias row sums to zero over the classes -- is held to the scale of
+    # the largest gradient, not to its own)
+    floor = 1e-3 * max(float(t.abs().max()) for t in full["g_theta"] + full["g_phi"])
     for n, a, b0, b1 in zip(names, full["g_theta"] + full["g_phi"], lo["g_theta"] + lo["g_phi"], hi["g_theta"] + hi["g_phi"]):
-        assert torch.isfinite(a).all() and float(a.abs().max()) > 0, n
-        assert rel_to_max(a.cpu(), (0.5 * (b0 + b1)).cpu()) <= 2e-2, n
+        assert torch.isfinite(a).all(), n
+        assert rel_to_max(a.cpu(), (0.5 * (b0 + b1)).cpu(), floor) <= 2e-2, n
     ev = run(slice(0, B), need_grad=False)                              # same batch size, same forward kernels
     assert rel_to_max(ev["logits"].cpu(), full["logits"].cpu()) <= 1e-5 and rel_to_max(ev["loss_b"].cpu(), full["loss_b"].cpu()) <= 1e-5
     sc = run(slice(0, B), grad_scale=3.0 / B)
     for n, a, b in zip(names, sc["g_theta"] + sc["g_phi"], full["g_theta"] + full["g_phi"]):
-        assert rel_to_max(a.cpu(), 3.0 * b.cpu()) <= 1e-5, n
+        assert rel_to_max(a.cpu(), 3.0 * b.cpu(), 3.0 * floor) <= 1e-5, n
     z = full["logits"].double().cpu()
     ce = torch.stack([F.cross_entropy(z[b], y_q[b].cpu()) for b in range(B)])
     assert rel_to_max(full["loss_b"].cpu().double(), ce) <= 1e-5

@@ -1,7 +1,5 @@
-echo "== one process B=32"; python tools/bench_conv4.py 32 20 1 32 2>&1 | tail -1
-echo "== one process B=16"; python tools/bench_conv4.py 16 20 1 32 2>&1 | tail -1
-echo "== two processes B=16 concurrently"
-(python tools/bench_conv4.py 16 400 1 32 2>&1 | tail -1 > gpurun_out/h1.txt; date +%s.%N >> gpurun_out/h1.txt) &
-(python tools/bench_conv4.py 16 400 1 32 2>&1 | tail -1 > gpurun_out/h2.txt; date +%s.%N >> gpurun_out/h2.txt) &
-wait
-cat gpurun_out/h1.txt gpurun_out/h2.txt
+mkdir -p gpurun_out/r03f
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/r03f/gputest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r03f/gputest.log
+tail -4 gpurun_out/r03f/gputest.log
+timeout -k 10 600 python bench.py > gpurun_out/r03f/bench.json 2> gpurun_out/r03f/bench.err; echo "bench rc=$?"
+python tools/bench_am3_conv4.py 2>&1 | tail -2
