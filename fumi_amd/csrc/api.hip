@@ -44,6 +44,19 @@ int ws_reserve(fumi_ws* ws, size_t bytes) {
     return FUMI_OK;
 }
 
+hipStream_t ws_lane_stream(fumi_ws* ws, int i) {
+    if (!ws || i < 1 || i > 3) return nullptr;
+    hipStream_t& s = ws->lanes[i - 1];
+    if (!s) {
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); s = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&ws->lane_ev[i - 1], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError(); (void)hipStreamDestroy(s); s = nullptr; ws->lane_ev[i - 1] = nullptr; return nullptr;
+        }
+        if (i == 1) ws->lane = s;
+    }
+    return s;
+}
+
 extern "C" {
 
 int fumi_hip_version(void) { return 100; }
@@ -72,6 +85,7 @@ int fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out) {
     ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr; ws->hcnt = nullptr; ws->acnt = nullptr; ws->w0p = nullptr; ws->w0p_cap = 0; ws->side_buf = nullptr; ws->side_cap = 0; ws->pub_src = nullptr; ws->pub_dst = nullptr; ws->pub_n = 0; ws->pub_seq = 0;
     ws->profiling = 0; ws->prof_every = 1; memset(ws->prof_seen, 0, sizeof(ws->prof_seen)); ws->recs = new std::vector<ProfRec>(); ws->pool = new std::vector<hipEvent_t>();
     ws->side = nullptr; ws->lane = nullptr;
+    for (int i = 0; i < 3; ++i) { ws->lanes[i] = nullptr; ws->lane_ev[i] = nullptr; }
     for (auto& e : ws->ev) e = nullptr;
     // small persistent device buffers: status word, arrival counters (kept zero between launches by the kernels that use them)
     auto fail = [&](int code) { fumi_hip_workspace_destroy(ws); return code; };
@@ -113,7 +127,10 @@ void fumi_hip_workspace_destroy(fumi_ws_t* ws) {
     for (auto e : *ws->pool) (void)hipEventDestroy(e);
     for (auto e : ws->ev) if (e) (void)hipEventDestroy(e);
     if (ws->side) (void)hipStreamDestroy(ws->side);
-    if (ws->lane) (void)hipStreamDestroy(ws->lane);
+    for (int i = 0; i < 3; ++i) {
+        if (ws->lanes[i]) (void)hipStreamDestroy(ws->lanes[i]);
+        if (ws->lane_ev[i]) (void)hipEventDestroy(ws->lane_ev[i]);
+    }
     delete ws->recs; delete ws->pool;
     delete ws;
 }

@@ -31,11 +31,15 @@ struct fumi_ws {
     int prof_every;      // ... at every prof_every-th occurrence of the phase
     unsigned prof_seen[32];
     hipStream_t side;    // second stream: the text path (hypernetwork fwd / bwd) runs beside the two X-panel passes
-    hipStream_t lane;    // ResNet-12: the stream of the odd episode chunks (created on first use)
+    hipStream_t lane;    // ResNet-12 / Conv4: the stream of the second lane of episodes (created on first use); = lanes[0]
+    hipStream_t lanes[3]; hipEvent_t lane_ev[3];   // streams of lanes 1..3 and their join events (ws_lane_stream)
     hipEvent_t ev[4];    // fork / join points (timing disabled)
     std::vector<ProfRec>* recs;
     std::vector<hipEvent_t>* pool;
 };
+
+// stream of lane i (1..3) of a multi-lane step, created on first use together with its join event; nullptr when that fails
+hipStream_t ws_lane_stream(fumi_ws* ws, int i);
 
 // RAII phase timer: two hipEventRecords on the caller's stream when profiling is on, nothing otherwise
 struct ProfScope {

@@ -407,16 +407,24 @@ struct Conv4Hooks {
 
 int run_conv4_episodes(fumi_ws* ws, hipStream_t st, Conv4Problem p, const Conv4Hooks& hooks) {
     const size_t extra_bytes = ws_align(hooks.extra_bytes);
-    // Two LANES (as rn12.hip): the two halves of the meta-batch are independent until their meta-gradients are added, so the second
-    // half runs on ws->lane in its own half of the workspace beside the first on the caller's stream -- the MFMA-bound GEMMs of one
-    // fill the HBM-bound element-wise passes and partial last rounds of the other (two processes of 16 episodes against one of 32:
-    // 617.8 vs 573.3 episodes/s).  From 8 episodes up; FUMI_CV_LANES=1, phase timing or a smaller batch: one lane, and only then the
-    // probe table (fumi_hip_conv4_probe) is filled.
-    static const int lanes_env = getenv("FUMI_CV_LANES") ? atoi(getenv("FUMI_CV_LANES")) : 2;
-    int lanes = (lanes_env >= 2 && !ws->profiling && p.B >= 8 && ws->side) ? 2 : 1;
-    StepCtx cx[2];
-    for (int i = 0; i < 2; ++i) { cx[i].ws = ws; cx[i].st = st; }
-    const int Bc = lanes == 2 ? (p.B + 1) / 2 : p.B;                  // episodes per lane
+    // LANES (as rn12.hip): the parts of the meta-batch are independent until their meta-gradients are added, so parts 1.. run on
+    // streams of their own (ws_lane_stream), each in its own part of the workspace, beside part 0 on the caller's stream -- the
+    // MFMA-bound GEMMs of one fill the HBM-bound element-wise passes and partial last rounds of the others (proxy: one process of
+    // 32 episodes 573.3, two of 16 617.8, four of 8 645 episodes/s; in one process 1 / 2 / 3 / 4 lanes: 571.4 / 616.5 / 625.5 /
+    // 594.5, whatever GPU_MAX_HW_QUEUES says).  Up to three lanes of at least 4 episodes by default; FUMI_CV_LANES=n (<= 4) caps
+    // them; phase timing or a small batch: one lane, and only then the probe table (fumi_hip_conv4_probe) is filled.
+    constexpr int MAXLANES = 4;
+    static const int lanes_env = getenv("FUMI_CV_LANES") ? atoi(getenv("FUMI_CV_LANES")) : 3;
+    int lanes = 1;
+    if (lanes_env >= 2 && !ws->profiling && ws->side) {
+        lanes = p.B / 4;
+        lanes = lanes < 1 ? 1 : (lanes > MAXLANES ? MAXLANES : lanes);
+        lanes = lanes > lanes_env ? lanes_env : lanes;
+    }
+    for (int i = 1; i < lanes; ++i) if (!ws_lane_stream(ws, i)) { lanes = 1; break; }
+    StepCtx cx[MAXLANES];
+    for (int i = 0; i < MAXLANES; ++i) { cx[i].ws = ws; cx[i].st = i ? ws->lanes[i - 1] : st; }
+    const int Bc = (p.B + lanes - 1) / lanes;                         // episodes per lane
     int rc = net_init(cx[0].n, Bc, p.nblk, p.Cin, p.N, p.H, p.W);
     if (rc) return rc;
     if (p.T < 0 || p.S < 1 || p.Qn < 1) return FUMI_EINVAL;
@@ -442,19 +450,13 @@ int run_conv4_episodes(fumi_ws* ws, hipStream_t st, Conv4Problem p, const Conv4H
     ws->off += extra_bytes;                                           // (the caller's buffers: head, hypernetwork activations)
     const size_t lane0_off = ws->off;
     TRY(hooks.prepare(extra, &p.head, &p.head_bar));
-    if (lanes == 2) {
-        if (!ws->lane && hipStreamCreateWithFlags(&ws->lane, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ws->lane = nullptr; lanes = 1; }
-    }
-    if (lanes == 2) {
-        cx[1].st = ws->lane;
-        HIP_TRY(hipEventRecord(ws->ev[2], st));                       // the lane starts behind the head's producer on the caller's stream
-        HIP_TRY(hipStreamWaitEvent(ws->lane, ws->ev[2], 0));
-    } else if (Bc != p.B) {
-        return FUMI_EHIP;                                             // (no second stream after all: cannot happen once the reserve is sized)
+    if (lanes > 1) {
+        HIP_TRY(hipEventRecord(ws->ev[2], st));                       // the lanes start behind the head's producer on the caller's stream
+        for (int i = 1; i < lanes; ++i) HIP_TRY(hipStreamWaitEvent(ws->lanes[i - 1], ws->ev[2], 0));
     }
     ProbeTab& pt = g_probe;
     pt.valid = false;
-    float* gsum_lane[2] = {nullptr, nullptr};
+    float* gsum_lane[MAXLANES] = {nullptr, nullptr, nullptr, nullptr};
     fumi_ws* const ws_real = ws;
     // episodes [b0, b0 + bc) on lane `lane`
     auto chunk_body = [&](int lane, int b0, int bc) -> int {
@@ -533,11 +535,13 @@ int run_conv4_episodes(fumi_ws* ws, hipStream_t st, Conv4Problem p, const Conv4H
         HIP_TRY(hipMemcpyAsync(p.head_bar + (size_t)b0 * F1, barh, hsz * 4, hipMemcpyDeviceToDevice, st));
         return FUMI_OK;
     };
-    TRY(chunk_body(0, 0, lanes == 2 ? Bc : p.B));
-    if (lanes == 2) {
-        TRY(chunk_body(1, Bc, p.B - Bc));
-        HIP_TRY(hipEventRecord(ws->ev[3], ws->lane));                 // the caller's stream waits for the second lane
-        HIP_TRY(hipStreamWaitEvent(st, ws->ev[3], 0));
+    for (int i = 0; i < lanes; ++i) {
+        const int b0 = i * Bc, bc = p.B - b0 < Bc ? p.B - b0 : Bc;
+        if (bc > 0) TRY(chunk_body(i, b0, bc));
+    }
+    for (int i = 1; i < lanes; ++i) {                                 // the caller's stream waits for the other lanes
+        HIP_TRY(hipEventRecord(ws->lane_ev[i - 1], ws->lanes[i - 1]));
+        HIP_TRY(hipStreamWaitEvent(st, ws->lane_ev[i - 1], 0));
     }
     const Net& n = cx[0].n;
     if (p.stats) {
@@ -548,7 +552,7 @@ int run_conv4_episodes(fumi_ws* ws, hipStream_t st, Conv4Problem p, const Conv4H
     if (!grad) return FUMI_OK;
     // ---- meta-gradients: the lanes' sums added, back to the parameters' own layouts
     float* gsum = gsum_lane[0];
-    if (gsum_lane[1]) TRY(launch_axpy(st, n.PSZ, gsum, 1.f, gsum_lane[1], gsum));
+    for (int i = 1; i < lanes; ++i) if (gsum_lane[i]) TRY(launch_axpy(st, n.PSZ, gsum, 1.f, gsum_lane[i], gsum));
     TRY(launch_w1_from_canon(st, n.Cin, gsum + n.offW[0], p.g_theta[0], 1.f));
     for (int l = 0; l < n.nblk; ++l) {
         if (l) TRY(launch_toi_to_oihw(st, 1, gsum + n.offW[l], p.g_theta[3 * l], 1.f));
@@ -616,7 +620,7 @@ int fumi_hip_maml_conv4_step(fumi_ws_t* ws, fumi_stream_t stream,
         *head = h; *head_bar = hbar;
         return launch_broadcast_head(st, B, N, F, Wf, bf, h);            // every episode starts from lin_final (maml.py:24-31)
     };
-    if ((rc = run_conv4_episodes(ws, st, p, hk))) { if (ws->lane) (void)hipStreamSynchronize(ws->lane); return rc; }
+    if ((rc = run_conv4_episodes(ws, st, p, hk))) { for (int i = 0; i < 3; ++i) if (ws->lanes[i]) (void)hipStreamSynchronize(ws->lanes[i]); return rc; }
     if (!need_grad) return FUMI_OK;
     return launch_split_head_grad(st, B, N, F, hbar, grad_scale, g_params[3 * nblk], g_params[3 * nblk + 1]);
 }
@@ -664,7 +668,7 @@ int fumi_hip_fumi_conv4_step(fumi_ws_t* ws, fumi_stream_t stream,
         *head = h; *head_bar = hbar;
         return FUMI_OK;
     };
-    if ((rc = run_conv4_episodes(ws, st, p, hk))) { if (ws->lane) (void)hipStreamSynchronize(ws->lane); return rc; }
+    if ((rc = run_conv4_episodes(ws, st, p, hk))) { for (int i = 0; i < 3; ++i) if (ws->lanes[i]) (void)hipStreamSynchronize(ws->lanes[i]); return rc; }
     if (!need_grad) return FUMI_OK;
     const float* hp = hbar;
     if (tanh_head) { if ((rc = launch_tanh_bwd(st, (long)R * H1, h, hbar, hpb))) return rc; hp = hpb; }

@@ -156,7 +156,7 @@ static hipStream_t rn_side_stream(fumi_ws* ws) {
 // a failed call may leave weight-gradient launches on the second stream: nothing else may touch the workspace before they are done
 static void rn_abandon(fumi_ws* ws) {
     if (ws && ws->side) (void)hipStreamSynchronize(ws->side);
-    if (ws && ws->lane) (void)hipStreamSynchronize(ws->lane);
+    for (int i = 0; ws && i < 3; ++i) if (ws->lanes[i]) (void)hipStreamSynchronize(ws->lanes[i]);
 }
 // main waits for everything forked so far
 static int rn_join(RnCtx& c) {
@@ -468,7 +468,7 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
     if ((rc = ws_reserve(ws, lanes * region))) return rc;
     if (lanes == 2) {
         // (a high-priority lane stream and GPU_MAX_HW_QUEUES=8 were tried: 1082 / 1068 vs 1063 ms per 16 episodes)
-        if (!ws->lane && hipStreamCreateWithFlags(&ws->lane, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ws->lane = nullptr; lanes = 1; }
+        if (!ws_lane_stream(ws, 1)) lanes = 1;
     }
     // (one lane: its weight gradients fork onto ws->side; with two lanes a stream of weight gradients per lane added nothing --
     // 530.5 vs 524.2 ms per 8-episode step -- and they stay in line)
@@ -574,8 +574,8 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
         }
     }
     if (lanes == 2) {                                                     // the caller's stream waits for the second lane
-        HIP_TRY(hipEventRecord(ws->ev[3], ws->lane));
-        HIP_TRY(hipStreamWaitEvent(st, ws->ev[3], 0));
+        HIP_TRY(hipEventRecord(ws->lane_ev[0], ws->lane));
+        HIP_TRY(hipStreamWaitEvent(st, ws->lane_ev[0], 0));
     }
     float* gacc = gacc_lane[0];
     if (grad && gacc_lane[1]) TRY(launch_axpy(st, n.PSZ, gacc, 1.f, gacc_lane[1], gacc));
