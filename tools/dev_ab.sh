@@ -1,3 +1,5 @@
-for cfg in "FUMI_CV_LANES=4 GPU_MAX_HW_QUEUES=8" "FUMI_CV_LANES=3 GPU_MAX_HW_QUEUES=8" "FUMI_CV_LANES=2 GPU_MAX_HW_QUEUES=8" "FUMI_CV_LANES=4 GPU_MAX_HW_QUEUES=16"; do
-  echo "== $cfg"; env $cfg python tools/bench_conv4.py 32 30 1 32 2>&1 | tail -1
-done
+mkdir -p gpurun_out/r03f
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/r03f/gputest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r03f/gputest.log
+tail -4 gpurun_out/r03f/gputest.log
+timeout -k 10 600 python bench.py > gpurun_out/r03f/bench.json 2> gpurun_out/r03f/bench.err; echo "bench rc=$?"
+python tools/bench_conv4.py 32 10 5 32 2>&1 | tail -1
