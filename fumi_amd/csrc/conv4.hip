@@ -778,8 +778,8 @@ int fumi_hip_conv4_features(fumi_ws_t* ws, fumi_stream_t stream, int G, int M, i
 // the identical layout again (same arguments) and walks it backwards -- so `ws` must not serve any other call in between (give the
 // encoder a workspace of its own: fumi_hip_workspace_create).  A token records what was laid out; a mismatch is FUMI_EINVAL.
 namespace {
-struct EncodeToken { bool valid; fumi_ws* ws; char* base; int B, S, Qn, Cin, H, W, nblk; };
-EncodeToken g_enc = {false, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
+struct EncodeToken { bool valid; fumi_ws* ws; char* base; int B, S, Qn, Cin, H, W, nblk, lanes; };
+EncodeToken g_enc = {false, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 1};
 struct EncodeBufs { PassBufs ps, pq; float *params, *frags, *tmp1, *toi_tmp, *Gs, *Gq, *gsum; };
 
 size_t encode_bytes(const Net& n, int S, int Qn, Scratch& sc) {
@@ -800,26 +800,78 @@ void encode_carve(fumi_ws* ws, StepCtx& c, int S, int Qn, EncodeBufs& e) {
 }
 }  // namespace
 
+// lanes of the encoder calls (as run_conv4_episodes: parts of the episodes on streams of their own, each with its own carve).
+// AM3 + Conv4 at 32 episodes with 1 / 2 / 3 lanes: 741.8 / 790.2 / 751.5 episodes/s -- two by default here.
+static int encode_lanes(fumi_ws* ws, int B) {
+    static const int lanes_env = getenv("FUMI_CV_LANES") ? atoi(getenv("FUMI_CV_LANES")) : 2;
+    int lanes = 1;
+    if (lanes_env >= 2 && !ws->profiling && ws->side) {
+        lanes = B / 4;
+        lanes = lanes < 1 ? 1 : (lanes > 4 ? 4 : lanes);
+        lanes = lanes > lanes_env ? lanes_env : lanes;
+    }
+    for (int i = 1; i < lanes; ++i) if (!ws_lane_stream(ws, i)) return 1;
+    return lanes;
+}
+static void encode_abandon(fumi_ws* ws) { for (int i = 0; i < 3; ++i) if (ws->lanes[i]) (void)hipStreamSynchronize(ws->lanes[i]); }
+
+// shared frame of the two encoder calls: `lanes` parts of the episodes, part i carved at i * region and run on its lane's stream by
+// body(ctx, bufs, b0, bc); fork after everything on the caller's stream, join before the caller's stream goes on
+typedef std::function<int(StepCtx&, EncodeBufs&, int, int, int)> EncodeBody;
+static int encode_on_lanes(fumi_ws* ws, hipStream_t st, int lanes, int B, int S, int Qn, int Cin, int H, int W, int nblk,
+                           const EncodeBody& body) {
+    const int Bc = (B + lanes - 1) / lanes;
+    StepCtx c0; c0.ws = ws; c0.st = st;
+    int rc = net_init(c0.n, Bc, nblk, Cin, 1, H, W);
+    if (rc) return rc;
+    const size_t region = ws_align(encode_bytes(c0.n, S, Qn, c0.sc) + 4096);
+    if ((rc = ws_reserve(ws, lanes * region))) return rc;
+    if (lanes > 1) {
+        HIP_TRY(hipEventRecord(ws->ev[2], st));
+        for (int i = 1; i < lanes; ++i) HIP_TRY(hipStreamWaitEvent(ws->lanes[i - 1], ws->ev[2], 0));
+    }
+    for (int i = 0; i < lanes; ++i) {
+        const int b0 = i * Bc, bc = B - b0 < Bc ? B - b0 : Bc;
+        if (bc <= 0) continue;
+        StepCtx c; c.ws = ws; c.st = i ? ws->lanes[i - 1] : st;
+        if ((rc = net_init(c.n, bc, nblk, Cin, 1, H, W))) return rc;
+        (void)encode_bytes(c.n, S, Qn, c.sc);
+        fumi_ws view = *ws;
+        view.off = (size_t)i * region;
+        EncodeBufs e; encode_carve(&view, c, S, Qn, e);
+        if (view.off > (size_t)(i + 1) * region || view.off > ws->cap) return FUMI_ENOMEM;
+        if ((rc = body(c, e, i, b0, bc))) return rc;
+    }
+    for (int i = 1; i < lanes; ++i) {
+        HIP_TRY(hipEventRecord(ws->lane_ev[i - 1], ws->lanes[i - 1]));
+        HIP_TRY(hipStreamWaitEvent(st, ws->lane_ev[i - 1], 0));
+    }
+    return FUMI_OK;
+}
+
 int fumi_hip_conv4_encode(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int Qn, int Cin, int H, int W, int nblk,
         const float* x_s, const float* x_q, const float* const* theta, float* feats_s, float* feats_q, int keep_tape) {
     if (!ws || !x_s || !x_q || !theta || !feats_s || !feats_q || B < 1 || S < 1 || Qn < 1) return FUMI_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ws->device));
-    StepCtx c; c.ws = ws; c.st = st;
-    int rc = net_init(c.n, B, nblk, Cin, 1, H, W);
-    if (rc) return rc;
-    const Net& n = c.n;
     for (int i = 0; i < 3 * nblk; ++i) if (!theta[i]) return FUMI_EINVAL;
     g_enc.valid = false; g_probe.valid = false;
-    if ((rc = ws_reserve(ws, encode_bytes(n, S, Qn, c.sc)))) return rc;
-    EncodeBufs e; encode_carve(ws, c, S, Qn, e);
-    TRY(slot0_from_theta(st, n, theta, e.params, e.toi_tmp));
-    TRY(frags_of_slot(st, n, e.params, e.frags, e.tmp1));
-    TRY(forward_pass(c, S, x_s, e.params, e.frags, e.ps, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr));
-    TRY(forward_pass(c, Qn, x_q, e.params, e.frags, e.pq, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr));
-    HIP_TRY(hipMemcpyAsync(feats_s, e.ps.x[n.nblk - 1], (size_t)B * S * n.F * 4, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(feats_q, e.pq.x[n.nblk - 1], (size_t)B * Qn * n.F * 4, hipMemcpyDeviceToDevice, st));
-    if (keep_tape) g_enc = EncodeToken{true, ws, ws->base, B, S, Qn, Cin, H, W, nblk};
+    const int lanes = encode_lanes(ws, B);
+    const size_t img = (size_t)Cin * H * W;
+    int rc = encode_on_lanes(ws, st, lanes, B, S, Qn, Cin, H, W, nblk, [&](StepCtx& c, EncodeBufs& e, int, int b0, int bc) -> int {
+        const Net& n = c.n;
+        const hipStream_t st = c.st;
+        const float* xs = x_s + (size_t)b0 * S * img; const float* xq = x_q + (size_t)b0 * Qn * img;
+        TRY(slot0_from_theta(st, n, theta, e.params, e.toi_tmp));
+        TRY(frags_of_slot(st, n, e.params, e.frags, e.tmp1));
+        TRY(forward_pass(c, S, xs, e.params, e.frags, e.ps, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr));
+        TRY(forward_pass(c, Qn, xq, e.params, e.frags, e.pq, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr));
+        HIP_TRY(hipMemcpyAsync(feats_s + (size_t)b0 * S * n.F, e.ps.x[n.nblk - 1], (size_t)bc * S * n.F * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(feats_q + (size_t)b0 * Qn * n.F, e.pq.x[n.nblk - 1], (size_t)bc * Qn * n.F * 4, hipMemcpyDeviceToDevice, st));
+        return FUMI_OK;
+    });
+    if (rc) { encode_abandon(ws); return rc; }
+    if (keep_tape) g_enc = EncodeToken{true, ws, ws->base, B, S, Qn, Cin, H, W, nblk, lanes};
     return FUMI_OK;
 }
 
@@ -827,31 +879,42 @@ int fumi_hip_conv4_encode(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int
 int fumi_hip_conv4_encode_bwd(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int Qn, int Cin, int H, int W, int nblk,
         const float* x_s, const float* x_q, const float* dfeats_s, const float* dfeats_q, float scale, float* const* g_theta) {
     if (!ws || !x_s || !x_q || !dfeats_s || !dfeats_q || !g_theta) return FUMI_EINVAL;
-    const EncodeToken& t = g_enc;
+    const EncodeToken t = g_enc;
     if (!t.valid || t.ws != ws || t.base != ws->base || t.B != B || t.S != S || t.Qn != Qn || t.Cin != Cin || t.H != H || t.W != W ||
         t.nblk != nblk) return FUMI_EINVAL;                       // no tape of this shape in this workspace
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ws->device));
-    StepCtx c; c.ws = ws; c.st = st;
-    int rc = net_init(c.n, B, nblk, Cin, 1, H, W);
-    if (rc) return rc;
-    const Net& n = c.n;
     for (int i = 0; i < 3 * nblk; ++i) if (!g_theta[i]) return FUMI_EINVAL;
     g_enc.valid = false;                                           // the backward pass overwrites parts of the tape
-    if ((rc = ws_reserve(ws, encode_bytes(n, S, Qn, c.sc)))) return rc;
-    if (ws->base != t.base) return FUMI_EINVAL;
-    EncodeBufs e; encode_carve(ws, c, S, Qn, e);
-    HIP_TRY(hipMemcpyAsync(e.ps.dx[n.nblk - 1], dfeats_s, (size_t)B * S * n.F * 4, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(e.pq.dx[n.nblk - 1], dfeats_q, (size_t)B * Qn * n.F * 4, hipMemcpyDeviceToDevice, st));
-    TRY(backward_pass(c, S, x_s, e.frags, e.ps, nullptr, e.Gs, nullptr));
-    TRY(backward_pass(c, Qn, x_q, e.frags, e.pq, nullptr, e.Gq, nullptr));
-    // Gs and Gq are adjacent [B][PSZ] slabs: one sum over 2 B parameter slabs
-    TRY(launch_reduce_batched(st, 1, 2 * n.B, n.PSZ, e.Gs, scale, e.gsum, 0));
-    TRY(launch_w1_from_canon(st, n.Cin, e.gsum + n.offW[0], g_theta[0], 1.f));
+    const int lanes = t.lanes;                                     // the layout the forward call left
+    for (int i = 1; i < lanes; ++i) if (!ws_lane_stream(ws, i)) return FUMI_EHIP;
+    const size_t img = (size_t)Cin * H * W;
+    float* gsum_lane[4] = {nullptr, nullptr, nullptr, nullptr};
+    Net n0;
+    int rc = encode_on_lanes(ws, st, lanes, B, S, Qn, Cin, H, W, nblk, [&](StepCtx& c, EncodeBufs& e, int lane, int b0, int bc) -> int {
+        const Net& n = c.n;
+        const hipStream_t st = c.st;
+        if (ws->base != t.base) return FUMI_EINVAL;
+        const float* xs = x_s + (size_t)b0 * S * img; const float* xq = x_q + (size_t)b0 * Qn * img;
+        HIP_TRY(hipMemcpyAsync(e.ps.dx[n.nblk - 1], dfeats_s + (size_t)b0 * S * n.F, (size_t)bc * S * n.F * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(e.pq.dx[n.nblk - 1], dfeats_q + (size_t)b0 * Qn * n.F, (size_t)bc * Qn * n.F * 4, hipMemcpyDeviceToDevice, st));
+        TRY(backward_pass(c, S, xs, e.frags, e.ps, nullptr, e.Gs, nullptr));
+        TRY(backward_pass(c, Qn, xq, e.frags, e.pq, nullptr, e.Gq, nullptr));
+        // Gs and Gq are adjacent [bc][PSZ] slabs: one sum over 2 bc parameter slabs
+        TRY(launch_reduce_batched(st, 1, 2 * n.B, n.PSZ, e.Gs, scale, e.gsum, 0));
+        gsum_lane[lane] = e.gsum;
+        if (lane == 0) n0 = n;
+        return FUMI_OK;
+    });
+    if (rc) { encode_abandon(ws); return rc; }
+    const Net& n = n0;
+    float* gsum = gsum_lane[0];
+    for (int i = 1; i < lanes; ++i) if (gsum_lane[i]) TRY(launch_axpy(st, n.PSZ, gsum, 1.f, gsum_lane[i], gsum));
+    TRY(launch_w1_from_canon(st, n.Cin, gsum + n.offW[0], g_theta[0], 1.f));
     for (int l = 0; l < n.nblk; ++l) {
-        if (l) TRY(launch_toi_to_oihw(st, 1, e.gsum + n.offW[l], g_theta[3 * l], 1.f));
-        HIP_TRY(hipMemcpyAsync(g_theta[3 * l + 1], e.gsum + n.offG[l], 64 * 4, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(g_theta[3 * l + 2], e.gsum + n.offB[l], 64 * 4, hipMemcpyDeviceToDevice, st));
+        if (l) TRY(launch_toi_to_oihw(st, 1, gsum + n.offW[l], g_theta[3 * l], 1.f));
+        HIP_TRY(hipMemcpyAsync(g_theta[3 * l + 1], gsum + n.offG[l], 64 * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(g_theta[3 * l + 2], gsum + n.offB[l], 64 * 4, hipMemcpyDeviceToDevice, st));
     }
     return FUMI_OK;
 }
