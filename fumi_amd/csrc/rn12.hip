@@ -440,10 +440,12 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
     // second stream (ws->lane, own half of the workspace) beside the even ones on the caller's.  Each lane's kernels alternate between
     // MFMA-bound (convolutions, weight gradients: 3/4 of the time) and HBM-bound (element-wise: 1/4) and leave partial last rounds
     // of workgroups; two lanes out of phase fill both (measured with two processes of 4 episodes each against one of 8: 15.9 vs
-    // 14.1 episodes/s).  FUMI_RN_LANES=1 or phase timing: one lane (then the weight gradients fork onto ws->side instead).
+    // 14.1 episodes/s; in one process at 24 episodes 2 / 3 / 4 lanes: 14.46 / 14.81 / 14.24 -- two by default, FUMI_RN_LANES=n <= 4).
+    // FUMI_RN_LANES=1 or phase timing: one lane (then the weight gradients fork onto ws->side instead).
     static const int lanes_env = getenv("FUMI_RN_LANES") ? atoi(getenv("FUMI_RN_LANES")) : 2;
-    RnCtx cx[2];
-    for (int i = 0; i < 2; ++i) { cx[i].ws = ws; cx[i].st = st; }
+    constexpr int MAXLANES = 4;
+    RnCtx cx[MAXLANES];
+    for (int i = 0; i < MAXLANES; ++i) { cx[i].ws = ws; cx[i].st = st; }
     RnCtx& c = cx[0];
     int rc = net_init(c.n, p.B, p.nblk, p.Cimg, p.N, p.H, p.W, p.channels);
     if (rc) return rc;
@@ -452,34 +454,35 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
     const bool grad = p.need_grad != 0, second = grad && p.second_order && p.T > 0;
     if (second && p.T > 16) return FUMI_ENOTSUP;
     const int ntape = second ? p.T : 1, nslot = second ? p.T + 1 : 2;
-    int lanes = (lanes_env >= 2 && !ws->profiling && p.B >= 2 && ws->side) ? 2 : 1;
+    int lanes = (lanes_env >= 2 && !ws->profiling && p.B >= 2 && ws->side) ? (lanes_env > MAXLANES ? MAXLANES : lanes_env) : 1;
+    if (lanes > p.B) lanes = p.B;
     // ---- chunk size: the largest number of episodes whose tapes (one per lane) fit the budget
     size_t budget = g_rn_budget;
     if (!budget) {
         const char* e = getenv("FUMI_RN12_BUDGET_GB");
         budget = (size_t)((e && atof(e) > 0 ? atof(e) : 200.0) * (double)(1ull << 30));
     }
-    int Bc = p.chunk > 0 ? (p.chunk < p.B ? p.chunk : p.B) : (lanes == 2 ? (p.B + 1) / 2 : p.B);
+    int Bc = p.chunk > 0 ? (p.chunk < p.B ? p.chunk : p.B) : (p.B + lanes - 1) / lanes;
     if (p.chunk <= 0) {
         while (Bc > 1 && lanes * chunk_bytes(n, Bc, p, c.sc) > budget) Bc = (Bc + 1) / 2;
     }
     if (Bc >= p.B) lanes = 1;                                             // a single chunk
     const size_t region = ws_align(chunk_bytes(n, Bc, p, c.sc));
     if ((rc = ws_reserve(ws, lanes * region))) return rc;
-    if (lanes == 2) {
-        // (a high-priority lane stream and GPU_MAX_HW_QUEUES=8 were tried: 1082 / 1068 vs 1063 ms per 16 episodes)
-        if (!ws_lane_stream(ws, 1)) lanes = 1;
-    }
+    // (a high-priority lane stream and GPU_MAX_HW_QUEUES=8 were tried: 1082 / 1068 vs 1063 ms per 16 episodes)
+    for (int i = 1; i < lanes; ++i) if (!ws_lane_stream(ws, i)) { lanes = 1; break; }
     // (one lane: its weight gradients fork onto ws->side; with two lanes a stream of weight gradients per lane added nothing --
     // 530.5 vs 524.2 ms per 8-episode step -- and they stay in line)
     if (lanes == 1) { c.side = rn_side_stream(ws); c.ev_fork = ws->ev[0]; c.ev_join = ws->ev[1]; }
-    if (lanes == 2) {
-        cx[1].n = n; cx[1].st = ws->lane;
-        HIP_TRY(hipEventRecord(ws->ev[2], st));                           // the lane starts behind everything already on the caller's stream
-        HIP_TRY(hipStreamWaitEvent(ws->lane, ws->ev[2], 0));
+    if (lanes > 1) {
+        HIP_TRY(hipEventRecord(ws->ev[2], st));                           // the lanes start behind everything already on the caller's stream
+        for (int i = 1; i < lanes; ++i) {
+            cx[i].n = n; cx[i].st = ws->lanes[i - 1];
+            HIP_TRY(hipStreamWaitEvent(ws->lanes[i - 1], ws->ev[2], 0));
+        }
     }
     const size_t F1 = (size_t)n.N * (n.F + 1);
-    float* gacc_lane[2] = {nullptr, nullptr};
+    float* gacc_lane[MAXLANES] = {nullptr, nullptr, nullptr, nullptr};
     fumi_ws* const ws_real = ws;
     // one chunk of episodes [b0, b0 + bc) on its lane's stream, in its lane's half of the workspace
     auto chunk_body = [&](int lane, int b0, int bc, bool first_of_lane, float** gacc_out) -> int {
@@ -562,23 +565,23 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
         HIP_TRY(hipMemcpyAsync(p.head_bar + (size_t)b0 * F1, barh, hsz * 4, hipMemcpyDeviceToDevice, st));
         return FUMI_OK;
     };
-    // chunk k belongs to lane k & 1; the chunks are enqueued in order, alternating lanes (a second host thread enqueuing lane 1 on
+    // chunk k belongs to lane k mod lanes; the chunks are enqueued in order, alternating lanes (a second host thread enqueuing lane 1 on
     // its own changed nothing: 1071 vs 1073 ms per 16 episodes)
     {
-        bool first[2] = {true, true};
+        bool first[MAXLANES] = {true, true, true, true};
         int ck = 0;
         for (int b0 = 0; b0 < p.B; b0 += Bc, ++ck) {
-            const int bc = p.B - b0 < Bc ? p.B - b0 : Bc, lane = lanes == 2 ? (ck & 1) : 0;
+            const int bc = p.B - b0 < Bc ? p.B - b0 : Bc, lane = ck % lanes;
             TRY(chunk_body(lane, b0, bc, first[lane], &gacc_lane[lane]));
             first[lane] = false;
         }
     }
-    if (lanes == 2) {                                                     // the caller's stream waits for the second lane
-        HIP_TRY(hipEventRecord(ws->lane_ev[0], ws->lane));
-        HIP_TRY(hipStreamWaitEvent(st, ws->lane_ev[0], 0));
+    for (int i = 1; i < lanes; ++i) {                                     // the caller's stream waits for the other lanes
+        HIP_TRY(hipEventRecord(ws->lane_ev[i - 1], ws->lanes[i - 1]));
+        HIP_TRY(hipStreamWaitEvent(st, ws->lane_ev[i - 1], 0));
     }
     float* gacc = gacc_lane[0];
-    if (grad && gacc_lane[1]) TRY(launch_axpy(st, n.PSZ, gacc, 1.f, gacc_lane[1], gacc));
+    for (int i = 1; i < lanes; ++i) if (grad && gacc_lane[i]) TRY(launch_axpy(st, n.PSZ, gacc, 1.f, gacc_lane[i], gacc));
     if (p.stats) {
         ReduceSegs sg; sg.n = 0; sg.scale = p.grad_scale;
         sg.add(p.loss_b, p.B, 1, 1, p.stats); sg.add(p.acc_b, p.B, 1, 1, p.stats + 1);
