@@ -1,4 +1,4 @@
-timeout -k 10 600 python -m pytest tests/test_conv4_gpu.py -q -x 2>&1 | tail -3
-for cfg in "FUMI_CV_LANES=1" "FUMI_CV_LANES=2" "FUMI_CV_LANES=3"; do
-  echo "== $cfg"; env $cfg python tools/bench_am3_conv4.py 2>&1 | tail -1
-done
+mkdir -p gpurun_out/r03f
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/r03f/gputest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r03f/gputest.log
+tail -4 gpurun_out/r03f/gputest.log
+timeout -k 10 600 python bench.py > gpurun_out/r03f/bench.json 2> gpurun_out/r03f/bench.err; echo "bench rc=$?"
