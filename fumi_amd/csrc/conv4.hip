@@ -15,6 +15,7 @@
 
 namespace {
 
+static int g_cv_lanes = 0;      // fumi_hip_conv4_set_option(1, n): lanes of the meta-steps and encoder calls (0: the defaults)
 static int g_c1_fused = 1;     // block 1 without its full-resolution maps (conv_first.hip); 0 = the plain passes (probe tests)
 
 struct Net {
@@ -414,7 +415,8 @@ int run_conv4_episodes(fumi_ws* ws, hipStream_t st, Conv4Problem p, const Conv4H
     // 594.5, whatever GPU_MAX_HW_QUEUES says).  Up to three lanes of at least 4 episodes by default; FUMI_CV_LANES=n (<= 4) caps
     // them; phase timing or a small batch: one lane, and only then the probe table (fumi_hip_conv4_probe) is filled.
     constexpr int MAXLANES = 4;
-    static const int lanes_env = getenv("FUMI_CV_LANES") ? atoi(getenv("FUMI_CV_LANES")) : 3;
+    static const int lanes_env0 = getenv("FUMI_CV_LANES") ? atoi(getenv("FUMI_CV_LANES")) : 3;
+    const int lanes_env = g_cv_lanes > 0 ? g_cv_lanes : lanes_env0;
     int lanes = 1;
     if (lanes_env >= 2 && !ws->profiling && ws->side) {
         lanes = p.B / 4;
@@ -587,6 +589,7 @@ extern "C" {
 
 int fumi_hip_conv4_set_option(int key, int value) {
     if (key == 0) { g_c1_fused = value ? 1 : 0; return FUMI_OK; }
+    if (key == 1) { if (value < 0 || value > 4) return FUMI_EINVAL; g_cv_lanes = value; return FUMI_OK; }
     return FUMI_EINVAL;
 }
 
@@ -803,7 +806,8 @@ void encode_carve(fumi_ws* ws, StepCtx& c, int S, int Qn, EncodeBufs& e) {
 // lanes of the encoder calls (as run_conv4_episodes: parts of the episodes on streams of their own, each with its own carve).
 // AM3 + Conv4 at 32 episodes with 1 / 2 / 3 lanes: 741.8 / 790.2 / 751.5 episodes/s -- two by default here.
 static int encode_lanes(fumi_ws* ws, int B) {
-    static const int lanes_env = getenv("FUMI_CV_LANES") ? atoi(getenv("FUMI_CV_LANES")) : 2;
+    static const int lanes_env0 = getenv("FUMI_CV_LANES") ? atoi(getenv("FUMI_CV_LANES")) : 2;
+    const int lanes_env = g_cv_lanes > 0 ? g_cv_lanes : lanes_env0;
     int lanes = 1;
     if (lanes_env >= 2 && !ws->profiling && ws->side) {
         lanes = B / 4;

@@ -213,7 +213,9 @@ int fumi_hip_linear_bwd_weight(fumi_ws_t* ws, fumi_stream_t stream, int M, int N
  * Outputs / gradient conventions as fumi_hip_fumi_step / fumi_hip_maml_step.  Second order needs T <= 8 taped inner steps. */
 int fumi_hip_conv4_feature_dim(int nblk, int H, int W);
 /* Process-wide switches of the Conv4 path.  key 0: 1 (default) = block 1 recomputed band by band from the image, its 64-channel
- * full-resolution maps never stored (csrc/conv_first.hip); 0 = every block through the plain passes (what the probe tests read). */
+ * full-resolution maps never stored (csrc/conv_first.hip); 0 = every block through the plain passes (what the probe tests read).
+ * key 1: lanes -- parts of the meta-batch on concurrent streams of the workspace -- of the Conv4 meta-steps and encoder calls:
+ * 0 (default) = the library's choice (up to 3 from 8 episodes; 2 for the encoder calls), 1 = one stream, n <= 4 = at most n. */
 int fumi_hip_conv4_set_option(int key, int value);
 int fumi_hip_fumi_conv4_step(fumi_ws_t* ws, fumi_stream_t stream,
         int B, int N, int S, int Qn, int Cin, int H, int W, int nblk, int Dt, int Ht,

@@ -409,6 +409,33 @@ def test_conv4_as_worded_bench_shape_properties(dev, ws):
     assert float(acc.mean()) > 1.5 / N                  # one inner step on separable classes: clearly above chance
 
 
+def test_lanes_give_the_single_stream_step(dev, ws):
+    """The parts of a meta-batch run on concurrent streams (lanes, csrc/conv4.hip) -- with one, two and three lanes the same meta-step
+    must come out: per-episode outputs to fp32 summation order (a lane of 4 episodes tiles its maps differently from a batch of 12),
+    meta-gradients to 1e-3 of the largest gradient."""
+    from fumi_amd import hip
+    B, N, K, Q, Cin, H, W, nblk, Dt, Ht, alpha, T = 12, 5, 2, 3, 3, 20, 20, 4, 12, 16, 0.05, 2
+    ep, theta, Fd = _case(91, B, N, K, Q, Cin, H, W, nblk)
+    _, phi = cg.make_fumi_params(91, 8, [Fd], Dt, Ht, head_scale=0.3)
+    th, ph = [_g(t, dev) for t in theta], [_g(t, dev) for t in phi]
+    args = (ws, N, _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev), th, ph, T, alpha, True)
+    outs = []
+    try:
+        for lanes in (1, 2, 3):
+            hip.conv4_set_option(1, lanes)
+            o = hip.fumi_conv4_step(*args, text_s=_g(ep["text_s"], dev))
+            assert ws.read_status() == 0
+            outs.append({k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in o.items() if v is not None})
+    finally:
+        hip.conv4_set_option(1, 0)
+    one = outs[0]
+    gmax = max(float(t.abs().max()) for t in one["g_theta"] + one["g_phi"])
+    for o in outs[1:]:
+        assert rel_to_max(o["logits"].cpu(), one["logits"].cpu()) <= 1e-4 and rel_to_max(o["loss_b"].cpu(), one["loss_b"].cpu()) <= 1e-4
+        for a, b in zip(o["g_theta"] + o["g_phi"], one["g_theta"] + one["g_phi"]):
+            assert rel_to_max(a.cpu(), b.cpu(), 1e-1 * gmax) <= 1e-2
+
+
 # ---- the module surface (--im_encoder conv4) on the GPU -------------------------------------------------------------------
 def test_conv4_features_op(dev, ws):
     from fumi_amd import hip
