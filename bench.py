@@ -211,12 +211,12 @@ def conv4_flops_per_episode(T, S, Qn):
     return S * T * (4 * u[0] + 9 * sum(u[1:])) + Qn * (2 * u[0] + 3 * sum(u[1:]))
 
 
-def as_worded(dev, steps, warmup, cpu_budget_s, with_cpu):
+def as_worded(dev, steps, warmup, cpu_budget_s, with_cpu, T=None):
     from fumi_amd import hip
     from fumi_amd.models import common
     from fumi_amd.models.fumi import FUMI
     from fumi_amd.utils import utils as U
-    c = CW
+    c = dict(CW, T=T) if T else CW
     B, S, Qn = c["B_per_gpu"], c["N"] * c["K"], c["N"] * c["Q"]
     torch.manual_seed(7)
     g = torch.Generator().manual_seed(7)
@@ -288,6 +288,8 @@ def as_worded(dev, steps, warmup, cpu_budget_s, with_cpu):
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "conv4_pmc_traffic.json")))[-1:]:
             ks = json.load(open(f))["per_step"]
             traffic = int(sum(v["hbm_bytes"] for k, v in ks.items() if k.startswith("conv64_kernel") or k.startswith("wgrad64_kernel")))
+        if c["T"] != 1:
+            traffic = None                                           # (the committed passes are of the 1-step form)
         # algorithmic bytes: every map (padded channels-last: (H+2)^2 x 64 floats per image) read or written once per product
         maps = [256.0 * (hh + 2) ** 2 for hh in (42, 21, 10)]
         alg = sum(m * (pix[0] * (2 + 2 + 3 + 3 + 2 + 4) + pix[1] * (2 + 2 + 2)) for m in maps)
@@ -690,6 +692,11 @@ def main():
             del batches
             torch.cuda.empty_cache()
             out["as_worded"] = as_worded(dev, a.as_worded_steps, 2, 20.0, not a.no_cpu_baseline)
+            # configs[2]'s inner-loop depth (the reference's default: 5 steps) on the same images -- the as-worded form of configs[2]
+            # up to its text encoder (GloVe token text here, BERT rows there: the hypernetwork's input width, not the encoder's work)
+            out["as_worded_t5"] = as_worded(dev, max(2, a.as_worded_steps // 3), 1, 0.0, False, T=5)
+            out["as_worded_t5"]["workload"] = out["as_worded_t5"]["workload"].replace("1 inner step", "5 inner steps").replace(
+                "BASELINE.json configs[1] as worded", "BASELINE.json configs[2] as worded, GloVe instead of BERT text rows")
         if not a.no_configs4 and world == 1:
             print("[bench] configs[4] (ResNet-12, bf16, 20-way, 5 inner steps) leg", file=sys.stderr, flush=True)
             torch.cuda.empty_cache()
