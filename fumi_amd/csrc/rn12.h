@@ -24,6 +24,7 @@ constexpr float RN_EPS = 1e-5f;
 constexpr float RN_SLOPE = 0.1f;
 constexpr int RN_MAXBLK = 4;
 constexpr int RN_NCONV = 4;                           // convolutions per block: c1, c2, c3 (3x3) and the 1x1 shortcut cs
+constexpr int RN_BREF = 4;                            // episodes per chunk the launch geometry is priced for (configs[4]: two lanes of 4)
 
 struct RnGeom { int H, W, Hp, Wp, Pp, halo; };
 static inline RnGeom rn_geom(int H, int W) { RnGeom g; g.H = H; g.W = W; g.Hp = H + 2; g.Wp = W + 2; g.Pp = g.Hp * g.Wp; g.halo = g.Wp + 1; return g; }
@@ -51,7 +52,7 @@ struct RnConvArgs {
     // slab loads, tiles per image (tpi > 0: the tiles restart at every image)
     int tiles, ncg, xcd, slab_rows, glds, tpi;
 };
-int rn_conv_tiles(long npix, int Cout);                // upper bound of the statistics slabs per episode (sizing)
+int rn_conv_tiles(long npix, const RnGeom& g);          // upper bound of the statistics slabs per episode (sizing)
 size_t rn_conv_lds_bytes(const RnGeom& g, int Cout);
 // nt_out (optional): the number of statistics slabs per episode the launch wrote (its pixel tiles: 128 or 256 pixels each)
 int launch_rn_conv(hipStream_t st, const RnConvArgs& a, int* nt_out = nullptr);

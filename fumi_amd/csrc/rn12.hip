@@ -119,7 +119,7 @@ size_t scratch_sizes(const RnNet& n, int S, int Qn, RnScratch& sc) {
     for (int mi = 0; mi < 2; ++mi)
         for (int l = 0; l < n.nblk; ++l) {
             const long npix = (long)Ms[mi] * n.g[l].Pp;
-            const size_t c1 = (size_t)n.B * rn_conv_tiles(npix, n.C[l]) * 2 * n.C[l];
+            const size_t c1 = (size_t)n.B * rn_conv_tiles(npix, n.g[l]) * 2 * n.C[l];
             cp = c1 > cp ? c1 : cp;
             RnMap m; m.B = n.B; m.M = Ms[mi]; m.C = n.C[l]; m.g = n.g[l];
             const size_t r1 = (size_t)n.B * rn_red_nt(m) * 5 * n.C[l];
@@ -195,6 +195,7 @@ int conv_bn(RnCtx& c, int M, int l, int nsrc, const RnSrc* src, rbf16* out, cons
     a.stats = c.sc.cpart; a.dot = dot; a.dot_stride = a.out_stride;
     int nt = 0;
     TRYP(FUMI_PH_RN_CONV, launch_rn_conv(c.st, a, &nt));
+    if ((size_t)n.B * nt * 2 * n.C[l] > c.sc.cpart_n) return FUMI_ENOMEM;        // (cannot happen: scratch_sizes bounds the tiles)
     RnCoefArgs ca; memset(&ca, 0, sizeof(ca));
     ca.B = n.B; ca.C = n.C[l]; ca.mode = mode; ca.nt = nt; ca.K = 2; ca.k0 = 0; ca.k1 = 1; ca.k2 = 0;
     ca.n = (float)((double)M * n.g[l].H * n.g[l].W);
@@ -406,6 +407,23 @@ int hvp_pass(RnCtx& c, int M, const rbf16* img16, const rbf16* frags, RnPass& pb
 
 size_t g_rn_budget = 0;                               // workspace budget in bytes for the episode chunking (0: default)
 
+// ---- test hooks (fumi_hip_resnet12_set_option / fumi_hip_rn12_probe) -------------------------------------------------------------------
+// probe mode: one lane, and when the meta-batch is a single chunk the buffer table of the step is kept so that tests can read EVERY
+// stored intermediate (tests/test_resnet12_probe.py feeds each stage of oracle/resnet12_manual.py the engine's own upstream maps and
+// compares that stage's output alone: bf16 decorrelation cannot accumulate).  In this mode the gradient of every inner step and the
+// direction of the last Hessian-vector product are kept too (they are overwritten otherwise).  hvp_stop = k: the reverse sweep ends
+// after inner step k (its tangent maps, HV and V stay in place for the probe); 0 = the whole sweep.
+int g_rn_probe = 0, g_rn_hvp_stop = 0;
+constexpr int RN_MAXTAPE = 16;
+struct RnProbeTab {
+    bool valid; fumi_ws* ws; char* base;
+    RnNet n; int T, S, Qn, ntape, nslot, second;
+    RnPass tape[RN_MAXTAPE]; RnPass query; RnTan tan;
+    float* params; float* heads; float* G; float* dh; float* bar; float* barh; float* HV; float* HVh;
+    float* Gsave; float* dhsave; float* Vsave; float* Vhsave; rbf16* img_s; rbf16* img_q;
+};
+RnProbeTab g_rn_tab;
+
 }  // namespace
 
 struct Rn12Problem {
@@ -432,6 +450,7 @@ static size_t chunk_bytes(RnNet& n, int Bc, const Rn12Problem& p, RnScratch& sc)
     b += (size_t)nslot * (ws_align((size_t)Bc * n.PSZ * 4) + ws_align((size_t)Bc * n.FSZ * 2) + ws_align(hsz * 4));
     b += 3 * ws_align((size_t)Bc * n.PSZ * 4) + 3 * ws_align(hsz * 4) + ws_align((size_t)Bc * n.FSZ * 2);        // G, bar, HV | dh, barh, HVh | Vfrags
     b += 2 * ws_align((size_t)n.PSZ * 4);                                                                           // gsum, gacc
+    if (g_rn_probe) b += (size_t)(ntape + 1) * (ws_align((size_t)Bc * n.PSZ * 4) + ws_align(hsz * 4));             // Gsave, dhsave | Vsave, Vhsave
     return b + (1u << 16);
 }
 
@@ -452,10 +471,11 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
     RnNet& n = c.n;
     if (p.T < 0 || p.S < 1 || p.Qn < 1) return FUMI_EINVAL;
     const bool grad = p.need_grad != 0, second = grad && p.second_order && p.T > 0;
-    if (second && p.T > 16) return FUMI_ENOTSUP;
+    if (second && p.T > RN_MAXTAPE) return FUMI_ENOTSUP;
     const int ntape = second ? p.T : 1, nslot = second ? p.T + 1 : 2;
-    int lanes = (lanes_env >= 2 && !ws->profiling && p.B >= 2 && ws->side) ? (lanes_env > MAXLANES ? MAXLANES : lanes_env) : 1;
+    int lanes = (lanes_env >= 2 && !ws->profiling && !g_rn_probe && p.B >= 2 && ws->side) ? (lanes_env > MAXLANES ? MAXLANES : lanes_env) : 1;
     if (lanes > p.B) lanes = p.B;
+    g_rn_tab.valid = false;
     // ---- chunk size: the largest number of episodes whose tapes (one per lane) fit the budget
     size_t budget = g_rn_budget;
     if (!budget) {
@@ -510,7 +530,22 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
         float* G = ws_f(ws, (size_t)bc * n.PSZ); float* bar = ws_f(ws, (size_t)bc * n.PSZ); float* HV = ws_f(ws, (size_t)bc * n.PSZ);
         float* dh = ws_f(ws, hsz); float* barh = ws_f(ws, hsz); float* HVh = ws_f(ws, hsz);
         rbf16* Vfrags = ws_h(ws, (size_t)bc * n.FSZ);
+        float* Gsave = nullptr; float* dhsave = nullptr; float* Vsave = nullptr; float* Vhsave = nullptr;
+        if (g_rn_probe) {
+            Gsave = ws_f(ws, (size_t)ntape * bc * n.PSZ); dhsave = ws_f(ws, (size_t)ntape * hsz);
+            Vsave = ws_f(ws, (size_t)bc * n.PSZ); Vhsave = ws_f(ws, hsz);
+        }
         if (ws->off > (size_t)(lane + 1) * region || ws->off > ws->cap) return FUMI_ENOMEM;
+        if (g_rn_probe && bc == p.B) {                                   // the whole meta-batch in one chunk: keep the buffer table
+            RnProbeTab& pt = g_rn_tab;
+            pt.ws = ws_real; pt.base = ws_real->base; pt.n = n; pt.T = p.T; pt.S = p.S; pt.Qn = p.Qn; pt.ntape = ntape; pt.nslot = nslot;
+            pt.second = second ? 1 : 0;
+            for (int t = 0; t < ntape; ++t) pt.tape[t] = tape[t];
+            pt.query = query; pt.tan = tan; pt.params = params; pt.heads = heads; pt.G = G; pt.dh = dh; pt.bar = bar; pt.barh = barh;
+            pt.HV = HV; pt.HVh = HVh; pt.Gsave = Gsave; pt.dhsave = dhsave; pt.Vsave = Vsave; pt.Vhsave = Vhsave;
+            pt.img_s = img_s; pt.img_q = img_q;
+            pt.valid = true;
+        }
         auto P = [&](int s) { return params + (size_t)s * bc * n.PSZ; };
         auto Fr = [&](int s) { return frags + (size_t)s * bc * n.FSZ; };
         auto Hd = [&](int s) { return heads + (size_t)s * hsz; };
@@ -539,6 +574,11 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
             const int nxt = second ? t + 1 : cur ^ 1;
             TRY(forward_pass(c, p.S, img_s, P(cur), Fr(cur), pb, Hd(cur), y_s, 1.f / p.S, nullptr, nullptr, nullptr, nullptr, nullptr));
             TRY(backward_pass(c, p.S, img_s, Fr(cur), pb, Hd(cur), G, dh));
+            if (Gsave) {
+                const int ts = second ? t : 0;
+                HIP_TRY(hipMemcpyAsync(Gsave + (size_t)ts * bc * n.PSZ, G, (size_t)bc * n.PSZ * 4, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(dhsave + (size_t)ts * hsz, dh, hsz * 4, hipMemcpyDeviceToDevice, st));
+            }
             TRYP(FUMI_PH_RN_EW, launch_axpy(st, (long)bc * n.PSZ, P(cur), -p.alpha, G, P(nxt)));
             TRYP(FUMI_PH_RN_EW, launch_axpy(st, (long)hsz, Hd(cur), -p.alpha, dh, Hd(nxt)));
             TRY(frags_of_slot(st, n, P(nxt), Fr(nxt)));
@@ -551,7 +591,12 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
         HIP_TRY(hipMemsetAsync(bar, 0, (size_t)bc * n.PSZ * 4, st));
         TRY(backward_pass(c, p.Qn, img_q, Fr(cur), query, Hd(cur), bar, barh));
         if (second) {
-            for (int t = p.T - 1; t >= 0; --t) {
+            const int t_stop = g_rn_probe && g_rn_hvp_stop > 0 && g_rn_hvp_stop < p.T ? g_rn_hvp_stop : 0;
+            for (int t = p.T - 1; t >= t_stop; --t) {
+                if (Vsave) {
+                    HIP_TRY(hipMemcpyAsync(Vsave, bar, (size_t)bc * n.PSZ * 4, hipMemcpyDeviceToDevice, st));
+                    HIP_TRY(hipMemcpyAsync(Vhsave, barh, hsz * 4, hipMemcpyDeviceToDevice, st));
+                }
                 TRY(frags_of_slot(st, n, bar, Vfrags));
                 TRY(hvp_pass(c, p.S, img_s, Fr(t), tape[t], tan, Hd(t), bar, Vfrags, barh, 1.f / p.S, HV, HVh));
                 TRYP(FUMI_PH_RN_EW, launch_axpy(st, (long)bc * n.PSZ, bar, -p.alpha, HV, bar));
@@ -639,6 +684,91 @@ size_t al64(size_t n) { return (n + 63) / 64 * 64; }
 }  // namespace
 
 extern "C" {
+
+// Test hooks.  key 0: probe mode (one lane; a single-chunk step keeps its buffer table for fumi_hip_rn12_probe and the per-step
+// gradients / the last Hessian-vector product's direction).  key 1: the reverse sweep stops after inner step `value` (probe mode).
+int fumi_hip_resnet12_set_option(int key, int value) {
+    if (key == 0) { g_rn_probe = value ? 1 : 0; if (!value) g_rn_tab.valid = false; return FUMI_OK; }
+    if (key == 1) { if (value < 0) return FUMI_EINVAL; g_rn_hvp_stop = value; return FUMI_OK; }
+    return FUMI_EINVAL;
+}
+
+// Copies one stored intermediate of the LAST single-chunk ResNet-12 step run in probe mode out of the workspace.
+//   pass 0 .. T-1: the tape of support step `pass` (first order / T = 0: only the last step's tape exists, pass 0);  pass T: the
+//   query pass;  pass T + 1: the tangent maps of the last Hessian-vector product (inner step hvp_stop);  pass -1: parameter space.
+//   kind (pass >= 0): 0 u[block][idx 0..3: c1, c2, c3, shortcut], 1 a[block][idx 0..1], 2 out[block], 3 du[block][idx], 4 da[block][idx],
+//     5 dout[block] (bf16 padded channels-last maps [B][M (H+2)(W+2)][C]); 6 coef[block][idx] fp32 [B][RCF_N][C]; 7 f, 8 df fp32 [B][M][F];
+//     9 z, 10 p, 11 dz fp32 [B][M][N] (9 of the query pass: the caller's logits hold it).  The tangent pass has kinds 0-5, 7, 8, 11.
+//   kind (pass -1): 0 parameter slot idx [B][PSZ], 1 head slot idx [B][N][F+1], 2 G / 3 dh of inner step idx, 4 bar, 5 bar_h, 6 HV,
+//     7 HV_h, 8 V / 9 V_h (direction of the last Hessian-vector product), 10 / 11 prepared support / query images bf16 [B][M Pp][16].
+// *n_bytes = its size, *is_bf16 = element type; at most max_bytes are copied.
+int fumi_hip_rn12_probe(fumi_ws_t* ws, fumi_stream_t stream, int pass, int kind, int block, int idx, void* out, size_t max_bytes,
+                        size_t* n_bytes, int* is_bf16) {
+    if (!ws || !out || !n_bytes || !is_bf16 || !g_rn_tab.valid) return FUMI_EINVAL;
+    const RnProbeTab& pt = g_rn_tab;
+    if (pt.ws != ws || pt.base != ws->base) return FUMI_EINVAL;           // another workspace's step, or the slab has moved since
+    const RnNet& n = pt.n;
+    const void* src = nullptr; size_t bytes = 0; int bf = 0;
+    const size_t hsz = (size_t)n.B * n.N * (n.F + 1), psz = (size_t)n.B * n.PSZ;
+    if (pass == -1) {
+        switch (kind) {
+            case 0: if (idx < 0 || idx >= pt.nslot) return FUMI_EINVAL; src = pt.params + (size_t)idx * psz; bytes = psz * 4; break;
+            case 1: if (idx < 0 || idx >= pt.nslot) return FUMI_EINVAL; src = pt.heads + (size_t)idx * hsz; bytes = hsz * 4; break;
+            case 2: if (idx < 0 || idx >= pt.ntape) return FUMI_EINVAL; src = pt.Gsave + (size_t)idx * psz; bytes = psz * 4; break;
+            case 3: if (idx < 0 || idx >= pt.ntape) return FUMI_EINVAL; src = pt.dhsave + (size_t)idx * hsz; bytes = hsz * 4; break;
+            case 4: src = pt.bar; bytes = psz * 4; break;
+            case 5: src = pt.barh; bytes = hsz * 4; break;
+            case 6: src = pt.HV; bytes = psz * 4; break;
+            case 7: src = pt.HVh; bytes = hsz * 4; break;
+            case 8: src = pt.Vsave; bytes = psz * 4; break;
+            case 9: src = pt.Vhsave; bytes = hsz * 4; break;
+            case 10: src = pt.img_s; bytes = (size_t)n.B * pt.S * n.g[0].Pp * 16 * 2; bf = 1; break;
+            case 11: src = pt.img_q; bytes = (size_t)n.B * pt.Qn * n.g[0].Pp * 16 * 2; bf = 1; break;
+            default: return FUMI_EINVAL;
+        }
+    } else if (pass == pt.T + 1) {
+        if (!pt.second || block < 0 || block >= n.nblk) return FUMI_EINVAL;
+        const int M = pt.S;
+        const RnTan& tb = pt.tan;
+        switch (kind) {
+            case 0: if (idx < 0 || idx > 3) return FUMI_EINVAL; src = tb.ud[block][idx]; bytes = map_el(n, M, block) * 2; bf = 1; break;
+            case 1: if (idx < 0 || idx > 1) return FUMI_EINVAL; src = tb.ad[block][idx]; bytes = map_el(n, M, block) * 2; bf = 1; break;
+            case 2: src = tb.outd[block]; bytes = out_el(n, M, block) * 2; bf = 1; break;
+            case 3: if (idx < 0 || idx > 3) return FUMI_EINVAL; src = tb.dud[block][idx]; bytes = map_el(n, M, block) * 2; bf = 1; break;
+            case 4: if (idx < 0 || idx > 1) return FUMI_EINVAL; src = tb.dad[block][idx]; bytes = map_el(n, M, block) * 2; bf = 1; break;
+            case 5: src = tb.doutd[block]; bytes = out_el(n, M, block) * 2; bf = 1; break;
+            case 7: src = tb.fd; bytes = (size_t)n.B * M * n.F * 4; break;
+            case 8: src = tb.dfd; bytes = (size_t)n.B * M * n.F * 4; break;
+            case 11: src = tb.dzd; bytes = (size_t)n.B * M * n.N * 4; break;
+            default: return FUMI_EINVAL;
+        }
+    } else {
+        if (pass < 0 || pass > pt.T || block < 0 || block >= n.nblk) return FUMI_EINVAL;
+        if (pass < pt.T && pass >= pt.ntape) return FUMI_EINVAL;
+        const RnPass& pb = pass == pt.T ? pt.query : pt.tape[pass];
+        const int M = pb.M;
+        switch (kind) {
+            case 0: if (idx < 0 || idx > 3) return FUMI_EINVAL; src = pb.u[block][idx]; bytes = map_el(n, M, block) * 2; bf = 1; break;
+            case 1: if (idx < 0 || idx > 1) return FUMI_EINVAL; src = pb.a[block][idx]; bytes = map_el(n, M, block) * 2; bf = 1; break;
+            case 2: src = pb.out[block]; bytes = out_el(n, M, block) * 2; bf = 1; break;
+            case 3: if (idx < 0 || idx > 3) return FUMI_EINVAL; src = pb.du[block][idx]; bytes = map_el(n, M, block) * 2; bf = 1; break;
+            case 4: if (idx < 0 || idx > 1) return FUMI_EINVAL; src = pb.da[block][idx]; bytes = map_el(n, M, block) * 2; bf = 1; break;
+            case 5: src = pb.dout[block]; bytes = out_el(n, M, block) * 2; bf = 1; break;
+            case 6: if (idx < 0 || idx > 3) return FUMI_EINVAL; src = pb.coef[block][idx]; bytes = (size_t)n.B * RCF_N * n.C[block] * 4; break;
+            case 7: src = pb.f; bytes = (size_t)n.B * M * n.F * 4; break;
+            case 8: src = pb.df; bytes = (size_t)n.B * M * n.F * 4; break;
+            case 9: src = pb.z; bytes = (size_t)n.B * M * n.N * 4; break;
+            case 10: src = pb.p; bytes = (size_t)n.B * M * n.N * 4; break;
+            case 11: src = pb.dz; bytes = (size_t)n.B * M * n.N * 4; break;
+            default: return FUMI_EINVAL;
+        }
+    }
+    if (!src) return FUMI_ENOTSUP;                                        // (a forward-only pass has no gradient maps)
+    *n_bytes = bytes; *is_bf16 = bf;
+    const size_t k = bytes < max_bytes ? bytes : max_bytes;
+    if (k) HIP_TRY(hipMemcpyAsync(out, src, k, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return FUMI_OK;
+}
 
 int fumi_hip_resnet12_set_budget(double gigabytes) { g_rn_budget = gigabytes > 0 ? (size_t)(gigabytes * (double)(1ull << 30)) : 0; return FUMI_OK; }
 
@@ -737,6 +867,7 @@ int fumi_hip_resnet12_features(fumi_ws_t* ws, fumi_stream_t stream, int G, int M
     size_t bytes = scratch_sizes(n, M, M, c.sc) + pass_bytes(n, M, false) + ws_align((size_t)G * M * n.g[0].Pp * 16 * 2) +
                    ws_align((size_t)G * n.PSZ * 4) + ws_align((size_t)G * n.FSZ * 2);
     if ((rc = ws_reserve(ws, bytes))) return rc;
+    g_rn_tab.valid = false;
     c.sc.cpart = ws_f(ws, c.sc.cpart_n); c.sc.rpart = ws_f(ws, c.sc.rpart_n); c.sc.wpart = ws_f(ws, c.sc.wpart_n); c.sc.rowl = ws_f(ws, c.sc.rowl_n); c.sc.c2 = ws_f(ws, c.sc.c2_n);
     RnPass pb; pass_carve(ws, n, M, false, pb);
     rbf16* img = ws_h(ws, (size_t)G * M * n.g[0].Pp * 16);
@@ -768,7 +899,7 @@ int fumi_hip_rn12_conv(fumi_ws_t* ws, fumi_stream_t stream, int B, int M, int H,
     const long npix = (long)M * g.Pp;
     const int Cy = transpose ? Cin : Cout, Cx = transpose ? Cout : Cin;
     const long fe = (long)ntaps * Cin * Cout;
-    const int tiles = rn_conv_tiles(npix, Cy);
+    const int tiles = rn_conv_tiles(npix, g);
     int rc = ws_reserve(ws, 2 * ws_align((size_t)B * fe * 2) + ws_align((size_t)B * tiles * 2 * Cy * 4));
     if (rc) return rc;
     rbf16* ff = ws_h(ws, (size_t)B * fe); rbf16* fb = ws_h(ws, (size_t)B * fe); float* part = ws_f(ws, (size_t)B * tiles * 2 * Cy);

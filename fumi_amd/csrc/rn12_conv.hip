@@ -387,7 +387,9 @@ int conv_dispatch(hipStream_t st, const RnConvArgs& a, int* nt_out) {
     // when that leaves one workgroup per CU)
     static const int force = getenv("FUMI_RN_MW") ? atoi(getenv("FUMI_RN_MW")) : 0;
     static const int fbks = getenv("FUMI_RN_BKS") ? atoi(getenv("FUMI_RN_BKS")) : 0;
-    const long tiles256 = (a.npix + 255) / 256 * (a.Cout / (32 * NF)) * a.B;
+    // (the tile shape is chosen from per-episode quantities -- priced for RN_BREF episodes per chunk, the production chunk -- so that an
+    // episode's results do not depend on how many episodes share its chunk)
+    const long tiles256 = (a.npix + 255) / 256 * (a.Cout / (32 * NF)) * RN_BREF;
     const int two = 80 * 1024 - 256;                                  // two workgroups per CU
     if (force != 1 && (tiles256 >= 256 || force == 2)) {
         if (fbks == 4 && ConvCfg<NF, 2, 4>::lds_bytes(a.g) <= 160 * 1024) return conv_launch<NF, 2, 4>(st, a, nt_out);
@@ -597,9 +599,11 @@ __global__ __launch_bounds__(256) void rn_wprep_kernel(int Cout, int Cin, int Ci
 
 }  // namespace
 
-int rn_conv_tiles(long npix, int Cout) {
-    (void)Cout;
-    return (int)((npix + 127) / 128);
+// upper bound of the statistics slabs a convolution writes per episode: one per pixel tile (128 or 256 interior pixels); with tiles
+// that restart at every image (rn_per_image) that is M * ceil(H W / 128), which can exceed ceil(M Pp / 128) (23 x 23: 5 M vs 4.88 M)
+int rn_conv_tiles(long npix, const RnGeom& g) {
+    const long M = npix / g.Pp, per_image = M * (((long)g.H * g.W + 127) / 128), flat = (npix + 127) / 128;
+    return (int)(per_image > flat ? per_image : flat);
 }
 
 size_t rn_conv_lds_bytes(const RnGeom& g, int Cout) {
@@ -632,7 +636,11 @@ int launch_rn_conv(hipStream_t st, const RnConvArgs& a, int* nt_out) {
 // slabs of the pixel axis per episode.  A launch is a few hundred to a few thousand LONG workgroups on 512 slots (256 CUs x 2): the
 // chip runs them in rounds, and 1080 workgroups cost three rounds where 1008 cost two -- so the count is chosen for the fullest
 // last round among the splits that fill the chip one to four times over (at least 4 stages per workgroup).
-int rn_wgrad_nsplit(int B, long npix, int Cin, int Cout) {
+int rn_wgrad_nsplit(int B_chunk, long npix, int Cin, int Cout) {
+    // (priced for RN_BREF episodes per chunk whatever the chunk holds: the split, and with it an episode's summation order, must not
+    // depend on the chunk size; a chunk of 2 RN_BREF episodes has twice the workgroups and the same fill of its rounds)
+    (void)B_chunk;
+    const int B = RN_BREF;
     const int Ci32 = (Cin + 31) / 32 * 32;
     const long tiles = (long)((Cout + 63) / 64) * ((Ci32 + 63) / 64) * B;
     const long chunks = (npix + WG_PK - 1) / WG_PK;

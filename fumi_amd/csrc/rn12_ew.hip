@@ -539,9 +539,11 @@ __global__ __launch_bounds__(256) void rn_img_prep_kernel(long BM, int Cin, RnGe
 }  // namespace
 size_t rn_coef_scratch_floats(int B, int nt, int K, int C) { return (size_t)B * ((nt + PR_GRP - 1) / PR_GRP) * K * C; }
 namespace {
+// pixels per workgroup of the reductions: from PER-EPISODE quantities only, so that an episode's summation order (and with bf16
+// storage everything downstream of it) does not depend on how many episodes share the chunk -- chunks and lanes are bit-neutral
 inline int red_rb(const RnMap& m) {
     const long npix = (long)m.M * m.g.Pp;
-    long rb = npix * m.B / 2048;
+    long rb = npix / 512;
     rb = rb < 64 ? 64 : (rb > 1024 ? 1024 : rb);
     return (int)rb;
 }

@@ -29,7 +29,7 @@ SYMBOLS = [
     "fumi_hip_conv4_feature_dim", "fumi_hip_fumi_conv4_step", "fumi_hip_maml_conv4_step", "fumi_hip_conv4_probe", "fumi_hip_conv4_features", "fumi_hip_conv4_set_option",
     "fumi_hip_conv4_encode", "fumi_hip_conv4_encode_bwd", "fumi_hip_am3_step_dx",
     "fumi_hip_resnet12_set_budget", "fumi_hip_fumi_resnet12_step", "fumi_hip_maml_resnet12_step", "fumi_hip_resnet12_features",
-    "fumi_hip_rn12_conv", "fumi_hip_rn12_wgrad",
+    "fumi_hip_rn12_conv", "fumi_hip_rn12_wgrad", "fumi_hip_resnet12_set_option", "fumi_hip_rn12_probe",
     "fumi_hip_conv3x3_fwd", "fumi_hip_conv3x3_bwd_data", "fumi_hip_conv3x3_bwd_weight",
     "fumi_hip_sgd_axpy", "fumi_hip_ce_fwd_bwd", "fumi_hip_proto_reduce", "fumi_hip_clip_step", "fumi_hip_lstm_bidir",
 ]
@@ -163,6 +163,9 @@ def lib():
         L.fumi_hip_resnet12_features.argtypes = [c_void_p, c_void_p] + [c_int] * 6 + [PI, c_void_p, PP, c_void_p]
         L.fumi_hip_rn12_conv.argtypes = [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p] * 4
         L.fumi_hip_rn12_wgrad.argtypes = [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p] * 3
+        L.fumi_hip_resnet12_set_option.argtypes = [c_int, c_int]
+        L.fumi_hip_rn12_probe.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, POINTER(c_size_t),
+                                          POINTER(c_int)]
         L.fumi_hip_conv4_features.argtypes = [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, PP, c_void_p]
         L.fumi_hip_conv4_encode.argtypes = [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p, PP, c_void_p, c_void_p, c_int]
         L.fumi_hip_conv4_encode_bwd.argtypes = [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p] * 4 + [c_float, PP]
@@ -941,6 +944,23 @@ def rn12_wgrad(ws, x, dy, H, W, k):
     _check(lib().fumi_hip_rn12_wgrad(ws.handle, _stream(dev), B, M, H, W, Cin, Cout, k * k, _bf16ptr(x, "x"), _bf16ptr(dy, "dy"),
                                      _f32(dW, "dW")), "fumi_hip_rn12_wgrad")
     return dW
+
+
+def resnet12_set_option(key, value):
+    """fumi_hip_resnet12_set_option: key 0 = probe mode (test hook), key 1 = the reverse sweep stops after inner step `value`."""
+    _check(lib().fumi_hip_resnet12_set_option(int(key), int(value)), "fumi_hip_resnet12_set_option")
+
+
+def rn12_probe(ws, device, pass_, kind, block=0, idx=0):
+    """Test hook: one stored intermediate of the last single-chunk ResNet-12 step run in probe mode, flat (bf16 maps as
+    torch.bfloat16, everything else fp32) -- fumi_hip_rn12_probe."""
+    n, bf = c_size_t(0), c_int(0)
+    dummy = torch.empty(4, device=device, dtype=torch.float32)
+    args = (ws.handle, _stream(device), int(pass_), int(kind), int(block), int(idx))
+    _check(lib().fumi_hip_rn12_probe(*args, c_void_p(dummy.data_ptr()), 0, ctypes.byref(n), ctypes.byref(bf)), "fumi_hip_rn12_probe")
+    out = torch.empty(n.value // (2 if bf.value else 4), device=device, dtype=torch.bfloat16 if bf.value else torch.float32)
+    _check(lib().fumi_hip_rn12_probe(*args, c_void_p(out.data_ptr()), n.value, ctypes.byref(n), ctypes.byref(bf)), "fumi_hip_rn12_probe")
+    return out
 
 
 def conv4_set_option(key, value):

@@ -258,6 +258,20 @@ int fumi_hip_conv4_probe(fumi_ws_t* ws, fumi_stream_t stream, int pass, int kind
  * `chunk`: episodes processed per pass over the tape (0 = derived from the workspace budget, fumi_hip_resnet12_set_budget /
  * FUMI_RN12_BUDGET_GB, default 200 GB): the meta-gradient is the sum over chunks. */
 int fumi_hip_resnet12_set_budget(double gigabytes);
+/* Test hooks of the ResNet-12 steps (no reference counterpart: the reference keeps every intermediate in autograd's graph).
+ * set_option key 0: probe mode on / off -- one lane; a step whose meta-batch is a single chunk keeps its buffer table, the gradient
+ * of every inner step and the direction of the last Hessian-vector product;  key 1: the reverse sweep stops after inner step `value`
+ * (0 = whole sweep), so that the tangent maps of that step can be read.
+ * fumi_hip_rn12_probe copies one stored intermediate of the last such step (tests/test_resnet12_probe.py compares every stage of the
+ * sweep with oracle/resnet12_manual.py on the engine's own upstream maps).  pass 0..T-1: tape of support step `pass`; T: query pass;
+ * T+1: tangent maps of the last Hessian-vector product; -1: parameter space.  kind, pass >= 0: 0 u[block][idx], 1 a[block][idx],
+ * 2 out[block], 3 du[block][idx], 4 da[block][idx], 5 dout[block] (bf16 padded channels-last [B][M (H+2)(W+2)][C]), 6 coef[block][idx]
+ * fp32 [B][13][C] (mu, r, A, C0, D1, D2, TB, TC, M1, M2, K0, DD1, E12), 7 f, 8 df [B][M][F], 9 z, 10 p, 11 dz [B][M][N] fp32.
+ * kind, pass -1: 0 parameter slot idx [B][PSZ], 1 head slot idx, 2 G / 3 dh of inner step idx, 4 bar, 5 bar_h, 6 HV, 7 HV_h, 8 V, 9 V_h,
+ * 10 / 11 prepared support / query images (bf16, 16 channels).  *n_bytes: size; *is_bf16: element type; copies min(size, max_bytes). */
+int fumi_hip_resnet12_set_option(int key, int value);
+int fumi_hip_rn12_probe(fumi_ws_t* ws, fumi_stream_t stream, int pass, int kind, int block, int idx, void* out, size_t max_bytes,
+        size_t* n_bytes, int* is_bf16);
 int fumi_hip_fumi_resnet12_step(fumi_ws_t* ws, fumi_stream_t stream,
         int B, int N, int S, int Qn, int Cin, int H, int W, int nblk, const int* channels, int Dt, int Ht,
         int T, float alpha, int tanh_head, int need_grad, float grad_scale, int chunk,

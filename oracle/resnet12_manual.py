@@ -234,7 +234,9 @@ def net_hvp(tape, vth, vh, scale, rnd):
     dzd = p * (zd - (p * zd).sum(-1, keepdim=True)) * scale
     dhd = torch.cat([dzd.t() @ f + dz.t() @ fd, dzd.sum(0)[:, None]], 1)
     M, C, Ho, Wo = tape["oshape"]
-    dxd = rnd(((dzd @ h[:, :-1] + dz @ vh[:, :-1]) / (Ho * Wo))[:, :, None, None].expand(M, C, Ho, Wo))
+    dfd = dzd @ h[:, :-1] + dz @ vh[:, :-1]
+    dxd = rnd((dfd / (Ho * Wo))[:, :, None, None].expand(M, C, Ho, Wo))
+    tape.update(fd=fd, dzd=dzd, dfd=dfd)
     out = []
     for i in reversed(range(len(tape["blocks"]))):
         dxd, gb = block_tan_bwd(dxd, tape["blocks"][i], rnd, need_dx=i > 0)
@@ -246,22 +248,26 @@ def episode_grads(theta, h0, x_s, y_s, x_q, y_q, T, alpha, first_order=False, rn
     """(query logits, query loss, d loss / d theta, d loss / d h0) of one episode, no autograd anywhere."""
     th, h, tapes = [t for t in theta], h0, []
     S = x_s.shape[0]
+    steps = []                                             # (theta_t, head_t, g_t, dh_t) of every inner step, for `trace`
     for _ in range(T):
         z, tape = net_fwd(x_s, th, h, rnd)
         g, dh = net_bwd(z, y_s, tape, 1.0 / S, rnd)
         tapes.append(tape)
+        steps.append((list(th), h, list(g), dh))
         th = [p - alpha * gi for p, gi in zip(th, g)]
         h = h - alpha * dh
     zq, tq = net_fwd(x_q, th, h, rnd)
     loss = F.cross_entropy(zq, y_q)
     bar_th, bar_h = net_bwd(zq, y_q, tq, 1.0 / x_q.shape[0], rnd)
     if trace is not None:
-        trace.update(tapes=tapes, query=tq, bar_T=(list(bar_th), bar_h), theta_T=list(th), head_T=h, hv=[])
+        trace.update(tapes=tapes, query=tq, bar_T=(list(bar_th), bar_h), theta_T=list(th), head_T=h, hv=[], steps=steps, zq=zq, bars=[])
     if not first_order:
-        for tape in reversed(tapes):
-            hv_th, hv_h = net_hvp(tape, bar_th, bar_h, 1.0 / S, rnd)
+        stop = 0 if trace is None else trace.get("hvp_stop", 0)
+        for t in reversed(range(stop, len(tapes))):
+            hv_th, hv_h = net_hvp(tapes[t], bar_th, bar_h, 1.0 / S, rnd)
             if trace is not None:
                 trace["hv"].append((hv_th, hv_h))
+                trace["V"] = (list(bar_th), bar_h)              # direction of the LAST Hessian-vector product
             bar_th = [b - alpha * v for b, v in zip(bar_th, hv_th)]
             bar_h = bar_h - alpha * hv_h
     return zq, loss, bar_th, bar_h

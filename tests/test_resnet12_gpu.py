@@ -236,12 +236,14 @@ def test_episode_chunks_sum_to_the_whole_meta_batch(dev, ws):
     parts = run_maml(ws, dev, ep, theta, Wf, bfin, 0, 0.05, False, chunk=2)          # chunks of 2, 2, 1 episodes
     assert torch.equal(whole["logits"], parts["logits"]) and torch.equal(whole["preds"], parts["preds"])
     assert torch.equal(whole["loss_b"], parts["loss_b"])
-    assert rel_l2(parts["g_params"], [t.cpu() for t in whole["g_params"]]) <= 2e-2
+    # an episode's launch geometry (reduction slabs, tile shapes, weight-gradient splits) depends on per-episode quantities only, so
+    # chunking changes nothing but the order of the final sum over episodes
+    assert rel_l2(parts["g_params"], [t.cpu() for t in whole["g_params"]]) <= 1e-5
     whole1 = run_maml(ws, dev, ep, theta, Wf, bfin, 1, 0.05, False, chunk=5)
     whole1 = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in whole1.items() if v is not None}
     parts1 = run_maml(ws, dev, ep, theta, Wf, bfin, 1, 0.05, False, chunk=3)
-    assert rel(parts1["logits"].cpu(), whole1["logits"].cpu()) <= 0.05
-    assert rel_l2(parts1["g_params"], [t.cpu() for t in whole1["g_params"]]) <= 0.25
+    assert torch.equal(parts1["logits"], whole1["logits"]) and torch.equal(parts1["loss_b"], whole1["loss_b"])
+    assert rel_l2(parts1["g_params"], [t.cpu() for t in whole1["g_params"]]) <= 1e-5
 
 
 def test_gradient_is_linear_in_grad_scale_and_eval_equals_train_forward(dev, ws):
