@@ -194,10 +194,12 @@ def test_hessian_vector_product_extracted_from_the_steps(channels, H, tol, dev, 
 
 
 @pytest.mark.parametrize("channels,H,T,first_order,tol", [
-    ((32,), 8, 1, True, 0.08), ((32,), 8, 1, False, 0.08), ((32,), 8, 2, False, 0.16),
-    ((32, 64), 16, 1, False, 0.4), ((32, 64, 64, 128), 32, 1, False, 0.95)])
+    ((32,), 8, 1, True, 0.08), ((32,), 8, 1, False, 0.08), ((32,), 8, 2, False, 0.16)])
 def test_whole_steps_against_the_bf16_sweep(channels, H, T, first_order, tol, dev, ws):
-    """Inner steps included (first and second order): logits and meta-gradients stay within the measured drift of a bf16 chain."""
+    """Inner steps included (first and second order): logits and meta-gradients stay within the measured drift of a bf16 chain.  One
+    block only: deeper nets decorrelate (0.4 rel-L2 at two blocks, 0.95 at four -- bounds that could not fail), so depth, the true
+    channel widths and T up to 5 are covered STAGE BY STAGE on the engine's own stored maps instead, where nothing accumulates
+    (tests/test_resnet12_probe.py, tests/rn12_stages.py: 2^-7 / 2e-3 per map, 2e-4 per sum)."""
     N = 3
     ep, theta, _ = case(7, 2, N, 3, 2, H, channels)
     Wf, bfin = head_of(N, channels[-1])
@@ -262,7 +264,9 @@ def test_gradient_is_linear_in_grad_scale_and_eval_equals_train_forward(dev, ws)
 def test_full_size_20way_episode_pair_against_the_stored_sweep(dev, ws):
     """BASELINE.json configs[4]'s episode shape at full size: 20-way 5-shot, 3 x 84 x 84 images, channels 64 / 160 / 320 / 640, one
     inner step, second-order FuMI meta-gradient, two episodes.  The expected values were produced by oracle/gen_resnet12_golden.py
-    (minutes of host time); inputs are regenerated from its seeds."""
+    (minutes of host time); inputs are regenerated from its seeds.  A COARSE net (a bf16 chain this deep decorrelates: the bounds are
+    the measured drift); the sharp checks of the same kernels at the same widths are the teacher-forced stage checks of
+    tests/test_resnet12_probe.py, and the true T = 5 / Q = 15 shape runs there through size-independent properties."""
     from fumi_amd import hip
     from oracle import gen_resnet12_golden as G
     path = os.path.join(GOLDEN, "resnet12_20way.npz")
