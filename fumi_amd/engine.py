@@ -122,11 +122,6 @@ def get_engine():
     return _ENGINE
 
 
-def is_test_engine():
-    """True when a test installed a checker engine (``set_engine``); product code never does."""
-    return _ENGINE is not None and not isinstance(_ENGINE, HipEngine)
-
-
 def set_engine(engine):
     """Test hook (tests/ only)."""
     global _ENGINE

@@ -68,6 +68,7 @@ def _restore(args, model, optimizer):
 
 
 def main(args):
+    check_supported(args)
     family = args.model if args.model in ("maml", "fumi", "clip") else "am3"      # unknown names are AM3, like utils.init_model
     mod = {"maml": maml, "fumi": fumi, "am3": am3, "clip": clip}[family]
     results_path = f"{args.log_dir}/results"
@@ -120,24 +121,36 @@ def main(args):
 
 
 def parse_args(argv=None):
+    """Flags -> args (+ args.device, fumi/main.py:141-149).  Pure: nothing here touches the engine, so host-only users of the parser
+    (tools, tests, a dry run on a login node) get the same namespace the reference builds."""
     args = utils.parser().parse_args(sys.argv[1:] if argv is None else argv)
     use_gpu = (not args.disable_cuda) and torch.cuda.is_available()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     args.device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
-    if not use_gpu and not _engine.is_test_engine():
-        # the reference falls back to the CPU here (fumi/main.py:145-146); this engine is MI355X-only and says so NOW rather
-        # than from inside the first meta-step
+    print(f"running on device {args.device}")
+    return args
+
+
+def check_supported(args):
+    """What the reference runs and this engine does not, refused where the engine is first needed (the top of ``main``) instead
+    of from inside the first meta-step -- with the reference's exception types where it has one."""
+    eng = _engine.get_engine()                  # (raises FumiHipError when the shared object has not been built)
+    if args.device.type != "cuda" and not getattr(eng, "runs_on_host", False):
+        # the reference falls back to the CPU here (fumi/main.py:145-146); this engine is MI355X-only
         raise hip.FumiHipError(
             ("--disable_cuda was given" if args.disable_cuda else "no GPU is visible (torch.cuda.is_available() is False)")
             + ": fumi_amd has no CPU execution path -- every step runs on the MI355X library "
               "(fumi_amd/lib/libfumi_hip.so).  Run the reference itself for a CPU run.")
-    if getattr(args, "fine_tune", False) and args.text_encoder in ("RNN", "RNNhid") and args.model in ("fumi", "am3"):
-        # the reference trains the bi-LSTM here (fumi/models/fumi.py:65-67, common.py:44-161); the engine's LSTM op is forward
-        # only, so this combination is refused when the flags are parsed instead of at the first training step
+    family = args.model if args.model in ("maml", "fumi", "clip") else "am3"      # unknown names are AM3, like utils.init_model
+    if getattr(args, "fine_tune", False) and args.text_encoder in ("RNN", "RNNhid") and family in ("fumi", "am3"):
+        # the reference trains the bi-LSTM here (fumi/models/fumi.py:65-67, common.py:44-161); the engine's LSTM op is forward only
         raise NotImplementedError("--fine_tune with --text_encoder RNN / RNNhid: the engine's bi-LSTM text encoder is forward only "
                                   "(frozen LSTM weights are supported: drop --fine_tune)")
-    print(f"running on device {args.device}")
-    return args
+    if family == "am3" and args.text_encoder == "rand" and args.dropout > 0 and not args.evaluate:
+        # fumi/models/am3.py:118-126 applies dropout inside h only; the engine's AM3 step draws the masks of g and h together and
+        # `rand` replaces g by an identity, so training this combination needs --dropout 0 (the CLI default is 0.25)
+        raise NotImplementedError("--model am3 --text_encoder rand trains only with --dropout 0 on this engine "
+                                  "(the step's dropout would also hit the identity that stands in for g)")
 
 
 def _maybe_init_distributed(args):

@@ -9,6 +9,7 @@ from oracle import fumi_ref as R
 
 class OracleEngine:
     name = "oracle-cpu (tests only)"
+    runs_on_host = True                 # (a capability the product engine does not have: fumi_amd.main.check_supported)
 
     def glove_bag_select(self, tokens_s, y_s, n_way, table, pad_id, mode):
         rows = torch.stack([R.class_text_select(tokens_s[b], y_s[b], n_way) for b in range(tokens_s.shape[0])])

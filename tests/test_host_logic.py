@@ -271,26 +271,37 @@ def test_cli_maml_synthetic_cpu_plumbing(oracle_engine, tmp_path, monkeypatch):
     assert runs and os.path.exists(tmp_path / "res" / "runs" / runs[0] / "ckpt.pth.tar")
 
 
-def test_disable_cuda_is_refused_at_parse_args():
-    """The reference falls back to the CPU (fumi/main.py:145-146); this engine has no CPU path and says so when the flags
-    are parsed, not from inside the first meta-step."""
+def test_disable_cuda_is_refused_where_the_engine_is_first_needed(tmp_path):
+    """The reference falls back to the CPU (fumi/main.py:145-146); this engine has no CPU path and says so at the top of `main`,
+    before anything is built -- `parse_args` itself stays pure (host-only users of the parser get the reference's namespace)."""
     from fumi_amd import engine, hip, main as cli
     old = engine.set_engine(None)
     try:
+        args = cli.parse_args(["--model", "maml", "--disable_cuda", "--log_dir", str(tmp_path)])
+        assert args.device.type == "cpu"
         with pytest.raises(hip.FumiHipError, match="no CPU execution path"):
-            cli.parse_args(["--model", "maml", "--disable_cuda"])
+            cli.main(args)
+        assert not os.listdir(tmp_path)                                  # refused before any side effect
     finally:
         engine.set_engine(old)
 
 
-def test_fine_tuning_the_lstm_is_refused_at_parse_args(oracle_engine):
-    """--fine_tune with RNN / RNNhid trains the bi-LSTM in the reference (fumi.py:65-67); the engine's LSTM op is forward only and
-    says so when the flags are parsed (frozen LSTM text encoders work: test_rnn_text_encoders_keep_the_reference_surface)."""
+def test_unsupported_flag_combinations_are_refused_up_front(oracle_engine):
+    """--fine_tune with RNN / RNNhid trains the bi-LSTM in the reference (fumi.py:65-67); the engine's LSTM op is forward only (frozen
+    LSTM text encoders work: test_rnn_text_encoders_keep_the_reference_surface).  `--model am3 --text_encoder rand` trains only
+    with --dropout 0 (am3.py:118-126 applies dropout inside h only).  Both are refused by `check_supported`, for every model name
+    that builds the model in question (unknown names are AM3, like utils.init_model)."""
     from fumi_amd import main as cli
-    for enc in ("RNN", "RNNhid"):
-        with pytest.raises(NotImplementedError, match="forward only"):
-            cli.parse_args(["--model", "fumi", "--disable_cuda", "--text_encoder", enc, "--fine_tune"])
-    cli.parse_args(["--model", "fumi", "--disable_cuda", "--text_encoder", "RNN"])          # frozen: accepted
+    for model in ("fumi", "am3", "some-unknown-name"):
+        for enc in ("RNN", "RNNhid"):
+            with pytest.raises(NotImplementedError, match="forward only"):
+                cli.check_supported(cli.parse_args(["--model", model, "--disable_cuda", "--text_encoder", enc, "--fine_tune"]))
+    cli.check_supported(cli.parse_args(["--model", "fumi", "--disable_cuda", "--text_encoder", "RNN"]))          # frozen: accepted
+    cli.check_supported(cli.parse_args(["--model", "maml", "--disable_cuda", "--text_encoder", "RNN", "--fine_tune"]))   # no text path
+    with pytest.raises(NotImplementedError, match="--dropout 0"):
+        cli.check_supported(cli.parse_args(["--model", "am3", "--disable_cuda", "--text_encoder", "rand"]))      # CLI default 0.25
+    cli.check_supported(cli.parse_args(["--model", "am3", "--disable_cuda", "--text_encoder", "rand", "--dropout", "0"]))
+    cli.check_supported(cli.parse_args(["--model", "am3", "--disable_cuda", "--text_encoder", "rand", "--evaluate"]))
 
 
 def test_cli_flag_validation_raises_value_error(oracle_engine, tmp_path, monkeypatch):
