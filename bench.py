@@ -532,7 +532,10 @@ def main():
     ap.add_argument("--as-worded-steps", type=int, default=10)
     ap.add_argument("--no-configs4", action="store_true", help="skip the ResNet-12 / bf16 leg (BASELINE.json configs[4], N = 1 only)")
     ap.add_argument("--configs4-episodes", type=int, default=C4["B_per_gpu"], help="episodes of the ResNet-12 leg (one GPU's share: 64)")
-    ap.add_argument("--configs4-steps", type=int, default=1)
+    ap.add_argument("--configs4-steps", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (EXACTLY --steps steps between two barriers) is repeated this many times back to back; "
+                         "`value` / `ms_per_step` are the MEDIAN repeat's, min / max are reported beside it")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-rank lines of BASELINE.json configs[0], [2], [3] (N = 1 only)")
     ap.add_argument("--no-phase-timing", action="store_true", help="do not record HIP events around the library's phases")
     ap.add_argument("--all-phases", action="store_true",
@@ -593,19 +596,33 @@ def main():
         # an event record is a ~6 us bubble on the stream: the roofline kernel is timed at every 8th step of the timed region
         prof_every = 1 if a.all_phases else max(1, min(PROF_EVERY, a.steps // 16))     # >= 16 samples from a short run too
         ws.set_profiling(True, None if a.all_phases else ["xpanel_bwd", "query"], every=prof_every)
-    barrier()
-    t0 = time.perf_counter()
+    # the timed region: EXACTLY a.steps steps bracketed by barrier + synchronize on both sides -- repeated a.repeats times back to
+    # back (a short region on a freshly started process sees clock and queue jitter of several per cent: the median repeat is the
+    # measurement, min and max say how far the repeats spread)
+    reps = max(1, a.repeats)
+    times = []
     last = None
-    for i in range(a.steps):
-        last = model.evaluate(args, batches[i % NBATCH], opt, "train")
-    barrier()
-    el = time.perf_counter() - t0
+    for r_ in range(reps):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            last = model.evaluate(args, batches[i % NBATCH], opt, "train")
+        barrier()
+        times.append(time.perf_counter() - t0)
     prof = ws.profile() if not a.no_phase_timing else {}
     ws.set_profiling(False)
-    t = torch.tensor([el], device="cpu" if rehearsal else dev, dtype=torch.float64)
+    t = torch.tensor(times, device="cpu" if rehearsal else dev, dtype=torch.float64)
     allreduce = None
+    ranks_info = None
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                              # every repeat: the slowest rank's time
+        # who took part: (rank, device index, episodes of the global meta-batch it owns), gathered so that the line proves N ranks
+        from fumi_amd import dist as fdist
+        lo, hi = fdist.shard(Bg)
+        mine = torch.tensor([rank, dev.index if dev.index is not None else 0, hi - lo], device="cpu" if rehearsal else dev, dtype=torch.int64)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        ranks_info = [{"rank": int(g_[0]), "device": int(g_[1]), "episodes": int(g_[2])} for g_ in gathered]
         # the step's one collective, timed on its own after the timed region: the flat [grads | loss | acc] buffer
         flat = model._flat_grads().flat
         buf = flat.clone() if not rehearsal else flat.cpu()
@@ -616,12 +633,18 @@ def main():
         for _ in range(20):
             dist.all_reduce(buf)
         barrier()
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if not rehearsal else None
+        except Exception:                                                     # (version query is informational only)
+            rccl = None
         allreduce = {"bytes": int(flat.numel() * 4), "avg_us": round((time.perf_counter() - t1) / 20 * 1e6, 1),
-                     "backend": "gloo (rehearsal)" if rehearsal else "nccl (RCCL)", "per_step": 1, "overlapped": False,
+                     "backend": "gloo (rehearsal)" if rehearsal else "nccl (RCCL)", "torch_backend": dist.get_backend(),
+                     "rccl_version": rccl, "per_step": 1, "overlapped": False,
                      "why_not_overlapped": "the gradient is final only after the step's last reduction (gW0's split-K slabs and the "
                                            "hypernetwork slabs leave the last matrix launch); what is ready earlier is 70 KB of the "
                                            "3 MB, and a 3 MB ring all-reduce is latency-bound (DESIGN.md section 6)"}
-    el = float(t.item())
+    times = sorted(float(x) for x in t.tolist())
+    el = times[len(times) // 2]                                               # the median repeat
 
     if rank == 0:
         print(f"[bench] timed region done: {el / a.steps * 1e3:.4f} ms/step", file=sys.stderr, flush=True)
@@ -629,6 +652,10 @@ def main():
         out = {
             "metric": "episodes/sec (5-way 5-shot FuMI)", "value": round(Bg * a.steps / el, 2), "unit": "episodes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "settle_steps_untimed": settle, "ms_per_step": round(ms, 4),
+            "repeats": {"n": len(times), "of_steps": a.steps, "reported": "median",
+                        "ms_per_step_min": round(times[0] / a.steps * 1e3, 4), "ms_per_step_median": round(ms, 4),
+                        "ms_per_step_max": round(times[-1] / a.steps * 1e3, 4)},
+            "world_size": world, "ranks": ranks_info if ranks_info else [{"rank": 0, "device": dev.index or 0, "episodes": Bg}],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo, not a measurement)",
             "config": {"workload": "FuMI 5-way 5-shot, 32 query/class, ResNet-152-style 2048-d embeddings, im_hid [256,64], "
                                    "GloVe-300 token text (L=128, V=20000, mean pool), text_hid 256, 1 inner step, "

@@ -118,3 +118,7 @@ def test_bench_rehearsal_runs_the_two_rank_code_path():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_meta_batch"] == 64 and out["value"] > 0
     assert out["allreduce"]["bytes"] > 2_000_000 and out["allreduce"]["avg_us"] > 0 and "REHEARSAL" in out["data"]
+    # the line itself proves N ranks took part: world size, the collective's backend, every rank's device and episode share
+    assert out["world_size"] == 2 and out["allreduce"]["torch_backend"] == "gloo"
+    assert sorted(r_["rank"] for r_ in out["ranks"]) == [0, 1] and all(r_["episodes"] == 32 for r_ in out["ranks"])
+    assert out["repeats"]["n"] >= 3 and out["repeats"]["ms_per_step_min"] <= out["ms_per_step"] <= out["repeats"]["ms_per_step_max"]
