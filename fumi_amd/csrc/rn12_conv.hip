@@ -87,9 +87,17 @@ struct ConvCfg {
 // three-buffer ring with requests two tiles ahead and a COUNTED wait -- vmcnt(NBL): the newest tile may still be in flight -- was
 // built and measured: the wait for the loads halves (9.9 -> 5.3 % of a wave's time) and the barrier takes it over (3.6 -> 8.8 %):
 // 884 vs 889 us per launch, 558.6 vs 557.1 ms per step.)
-template <int NF, int MW, int BKS>
+// S16: the same tile on v_mfma_f32_16x16x32_bf16 (four times as many instructions of half the cycles and twice the depth: equal
+// cycles per flop, equal LDS bytes per flop).  Why: under this kernel's load the chip holds its clock well below 2.4 GHz, and the
+// clock it holds depends on the MFMA shape (MI355X_MICROARCH.md, DVFS give-back item 7: the 16x16x32 loop delivers 1.12-1.15 x the
+// FLOP/s of the 32x32x16 loop at equal cycles per FLOP on random data, operands read from LDS).  Fragment order of the weights in
+// memory (rn_wprep_kernel) is then [tap][Cin/32][Cout/16][64 lanes][8]: lane l = column l & 15, k = 8 (l >> 4) + j of a 32-deep step;
+// the A fragment of a lane is 16 bytes of pixel row l & 15 at channel 8 (l >> 4) of the step, and the slab's 16-byte chunks are XOR-ed
+// with (row & 7) instead of (row >> 1) & 7 (conflict-free for THIS read pattern: tools/lds_swizzle_check.py).
+template <int NF, int MW, int BKS, bool S16>
 __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
     typedef ConvCfg<NF, MW, BKS> C;
+    auto swz = [](int r) { return S16 ? (r & 7) : ((r >> 1) & 7); };
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ RnSrc s_src[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -120,20 +128,31 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
     if (tid == 0) { s_src[0] = a.src[0]; s_src[1] = a.src[1]; s_src[2] = a.src[2]; s_src[3] = a.src[3]; }
     unsigned char* const As = lds;
     unsigned char* const Bs = lds + a.slab_rows * 128;            // (slab_rows: a multiple of 8, the granule of the LDS-direct loads)
-    int prow[MW];                                                   // this lane's pixels as rows of a halo-less slab
+    constexpr int NPR = S16 ? 2 * MW : MW;                          // pixel sub-tiles per lane: 16 rows each (S16) or 32
+    int prow[NPR];                                                  // this lane's pixels as rows of a halo-less slab
 #pragma unroll
-    for (int m = 0; m < MW; ++m) {
-        long c = c0 + wave * 32 * MW + m * 32 + (lane & 31);
+    for (int m = 0; m < NPR; ++m) {
+        long c = c0 + wave * 32 * MW + (S16 ? m * 16 + (lane & 15) : m * 32 + (lane & 31));
         c = c > clast ? clast : c;                                  // (rows past the end compute a copy of the last pixel; never stored)
         prow[m] = (int)(rn_pix_of(c, a.g) - pfirst);
     }
-    f32x16 acc[MW][NF];
+    f32x16 acc[S16 ? 1 : MW][S16 ? 1 : NF];
+    f32x4 acc16[S16 ? 2 * MW : 1][S16 ? 2 * NF : 1];
+    if constexpr (!S16) {
 #pragma unroll
-    for (int m = 0; m < MW; ++m)
+        for (int m = 0; m < MW; ++m)
 #pragma unroll
-        for (int f = 0; f < NF; ++f)
+            for (int f = 0; f < NF; ++f)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][f][i] = 0.f;
+                for (int i = 0; i < 16; ++i) acc[m][f][i] = 0.f;
+    } else {
+#pragma unroll
+        for (int m = 0; m < 2 * MW; ++m)
+#pragma unroll
+            for (int f = 0; f < 2 * NF; ++f)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc16[m][f][i] = 0.f;
+    }
     __syncthreads();
     const int CF = a.Cout >> 5;
     const int srow = tid >> 3, schunk = tid & 7;
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                     const int r = r0 + (lane >> 3);
                     int p = pbase + r0;
                     p = p < 0 ? 0 : (p > plim ? plim : p);
-                    int chunk = (lane & 7) ^ ((r >> 1) & 7);
+                    int chunk = (lane & 7) ^ swz(r);
                     chunk = chunk * 8 < kc ? chunk : 0;
                     const unsigned off = ((unsigned)p * (unsigned)S.Cin + (unsigned)(chunk * 8)) * 2u;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(inb + off),
@@ -190,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                         const int r = r0 + 32 * i + srow;
                         const long p = p0 - hs + r;
                         const bool ok = chok && p >= 0 && p < a.npix;
-                        if (r < rows) *(u32x4*)(As + r * 128 + ((schunk ^ ((r >> 1) & 7)) << 4)) = ok ? v[i] : (u32x4){0u, 0u, 0u, 0u};
+                        if (r < rows) *(u32x4*)(As + r * 128 + ((schunk ^ swz(r)) << 4)) = ok ? v[i] : (u32x4){0u, 0u, 0u, 0u};
                     }
                 }
             }
@@ -202,14 +221,17 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
             const int ntile = S.ntaps * npt;
             constexpr int NBL = (BKS * NF + 3) / 4;                // KiB blocks per wave and tile (4 waves); clamped duplicates past the end
             const int nblk = min(BKS, nks) * NF;                   // KiB blocks of a tile (nks <= BKS, or a multiple of it)
-            const char* fragb = (const char*)(frag + ((long)(c0 >> 4) * CF + cg * NF) * 512) + lane * 16;
+            // (S16: a 32-deep step is 2 NF blocks of 16 columns; the same bytes per tap and per tile, another order)
+            const char* fragb = S16 ? (const char*)(frag + ((long)(c0 >> 5) * (2 * CF) + cg * 2 * NF) * 512) + lane * 16
+                                    : (const char*)(frag + ((long)(c0 >> 4) * CF + cg * NF) * 512) + lane * 16;
             const long tap_stride = (long)KS * CF * 1024, part_stride = (long)BKS * CF * 1024;
             // one KiB block of a weight tile: block wave + 4 j of the tile whose first block is at tbase (clamped duplicate past the end)
             auto bissue1 = [&](const char* tbase, int buf, int j) {
                 int blk = uni(wave) + 4 * j;
                 blk = blk < nblk ? blk : nblk - 1;
-                const int ks = blk / NF, f = blk - ks * NF;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + ((long)ks * CF + f) * 1024),
+                constexpr int PB = S16 ? 2 * NF : NF;               // blocks per step
+                const int ks = blk / PB, f = blk - ks * PB;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + ((long)ks * (S16 ? 2 * CF : CF) + f) * 1024),
                                                  (__attribute__((address_space(3))) void*)(Bs + buf * C::BT + blk * 1024), 16, 0, 0);
             };
             auto bissue = [&](const char* tbase, int buf) {
@@ -223,26 +245,49 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                 const int kn = min(BKS, nks - k0);
                 const int toff = S.ntaps == 9 ? (t / 3 - 1) * Wp + (t % 3 - 1) : 0;
                 const unsigned char* Bt = Bs + buf * C::BT;
-                int arow[MW];
+                int arow[NPR];
 #pragma unroll
-                for (int m = 0; m < MW; ++m) arow[m] = prow[m] + hs + toff;
+                for (int m = 0; m < NPR; ++m) arow[m] = prow[m] + hs + toff;
                 int slot = nxt ? 0 : NBL;
-                auto kstep = [&](int ks) {
-                    rbf16x8 bf[NF];
+                if constexpr (!S16) {
+                    auto kstep = [&](int ks) {
+                        rbf16x8 bf[NF];
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) bf[f] = *(const rbf16x8*)(Bt + ((ks * NF + f) * 64 + lane) * 16);
+                        for (int f = 0; f < NF; ++f) bf[f] = *(const rbf16x8*)(Bt + ((ks * NF + f) * 64 + lane) * 16);
 #pragma unroll
-                    for (int m = 0; m < MW; ++m) {
-                        const int ch = (k0 + ks) * 2 + (lane >> 5);
-                        const rbf16x8 af = *(const rbf16x8*)(As + arow[m] * 128 + ((ch ^ ((arow[m] >> 1) & 7)) << 4));
+                        for (int m = 0; m < MW; ++m) {
+                            const int ch = (k0 + ks) * 2 + (lane >> 5);
+                            const rbf16x8 af = *(const rbf16x8*)(As + arow[m] * 128 + ((ch ^ swz(arow[m])) << 4));
 #pragma unroll
-                        for (int f = 0; f < NF; ++f) acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[f], acc[m][f], 0, 0, 0);
-                        if (slot < NBL) { bissue1(nxt, nbuf, slot); ++slot; }
+                            for (int f = 0; f < NF; ++f) acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[f], acc[m][f], 0, 0, 0);
+                            if (slot < NBL) { bissue1(nxt, nbuf, slot); ++slot; }
+                        }
+                    };
+                    // (a runtime loop on purpose: fully unrolled, hipcc hoists the next k-steps' fragment reads and spills -- 576 bytes of
+                    //  scratch per lane at NF = 5, MW = 2 and 8.6x the time; at NF = 2 it fits, 200 VGPRs, and is no faster: 950 vs 910 us)
+                    for (int ks = 0; ks < kn; ++ks) kstep(ks);
+                } else {
+                    // 32-deep steps: the 2 MW A fragments of the step stay in registers, the B fragments come in two halves of NF
+                    for (int k2 = 0; k2 < (kn >> 1); ++k2) {
+                        rbf16x8 af[2 * MW];
+                        const int ch = ((k0 >> 1) + k2) * 4 + (lane >> 4);
+#pragma unroll
+                        for (int m = 0; m < 2 * MW; ++m) af[m] = *(const rbf16x8*)(As + arow[m] * 128 + ((ch ^ swz(arow[m])) << 4));
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            rbf16x8 bf[NF];
+#pragma unroll
+                            for (int f = 0; f < NF; ++f) bf[f] = *(const rbf16x8*)(Bt + (((k2 * 2 + h) * NF + f) * 64 + lane) * 16);
+#pragma unroll
+                            for (int m = 0; m < 2 * MW; ++m) {
+#pragma unroll
+                                for (int f = 0; f < NF; ++f)
+                                    acc16[m][h * NF + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[f], acc16[m][h * NF + f], 0, 0, 0);
+                                if ((m & 1) && slot < NBL) { bissue1(nxt, nbuf, slot); ++slot; }
+                            }
+                        }
                     }
-                };
-                // (a runtime loop on purpose: fully unrolled, hipcc hoists the next k-steps' fragment reads and spills -- 576 bytes of
-                //  scratch per lane at NF = 5, MW = 2 and 8.6x the time; at NF = 2 it fits, 200 VGPRs, and is no faster: 950 vs 910 us)
-                for (int ks = 0; ks < kn; ++ks) kstep(ks);
+                }
                 for (; slot < NBL; ++slot) bissue1(nxt, nbuf, slot);         // (a short tile: the rest after it)
             };
             RNSTAMP(0)                                              // (prologue / between chunks + slab loads issued)
@@ -292,15 +337,27 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
         // rows [128 hq, 128 hq + 128) of the tile belong to waves [2 hq / MW ...): with MW = 2 waves 2 hq, 2 hq + 1 (64 rows each)
         if (hq) __syncthreads();
         if (wave / (4 / MW) == hq || MW == 1) {
+            if constexpr (!S16) {
 #pragma unroll
-            for (int m = 0; m < MW; ++m)
+                for (int m = 0; m < MW; ++m)
 #pragma unroll
-                for (int f = 0; f < NF; ++f)
+                    for (int f = 0; f < NF; ++f)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int row = (wave * 32 * MW + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) - 128 * hq;
-                        Ot[row * C::NTP + f * 32 + (lane & 31)] = rn_f2bf(acc[m][f][i]);
-                    }
+                        for (int i = 0; i < 16; ++i) {
+                            const int row = (wave * 32 * MW + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) - 128 * hq;
+                            Ot[row * C::NTP + f * 32 + (lane & 31)] = rn_f2bf(acc[m][f][i]);
+                        }
+            } else {                                                // 16 x 16 tiles: column = lane & 15, row = 4 (lane >> 4) + register
+#pragma unroll
+                for (int m = 0; m < 2 * MW; ++m)
+#pragma unroll
+                    for (int f = 0; f < 2 * NF; ++f)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = (wave * 32 * MW + m * 16 + 4 * (lane >> 4) + i) - 128 * hq;
+                            Ot[row * C::NTP + f * 16 + (lane & 15)] = rn_f2bf(acc16[m][f][i]);
+                        }
+            }
         }
         __syncthreads();
         if (rg < C::NRG) {
@@ -354,12 +411,19 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
     }
 }
 
-template <int NF, int MW, int BKS>
-int conv_launch(hipStream_t st, const RnConvArgs& a, int* nt_out) {
+// the 16x16x32 form needs 32-deep steps: every source's channel count a multiple of 32 (FUMI_RN_S16=0: the 32x32x16 form everywhere).
+// rn_wprep_kernel lays a layer's fragments out for the form its channel count selects: both sides call this.
+bool rn_use_s16(int Cin) {
+    static const int on = getenv("FUMI_RN_S16") ? atoi(getenv("FUMI_RN_S16")) : 1;
+    return on && (Cin & 31) == 0;
+}
+
+template <int NF, int MW, int BKS, bool S16>
+int conv_launch2(hipStream_t st, const RnConvArgs& a, int* nt_out) {
     typedef ConvCfg<NF, MW, BKS> C;
     const int lds = C::lds_bytes(a.g);
     if (lds > 160 * 1024) return FUMI_ENOTSUP;
-    FUMI_SET_DYN_LDS((rn_conv_kernel<NF, MW, BKS>), lds);
+    FUMI_SET_DYN_LDS((rn_conv_kernel<NF, MW, BKS, S16>), lds);
     RnConvArgs k = a;
     const long NC = a.npix / a.g.Pp * ((long)a.g.H * a.g.W);
     k.tiles = (int)((NC + C::MT - 1) / C::MT); k.ncg = a.Cout / C::NT; k.slab_rows = C::slab_rows(a.g); k.tpi = 0;
@@ -373,10 +437,16 @@ int conv_launch(hipStream_t st, const RnConvArgs& a, int* nt_out) {
     static const int glds_env = getenv("FUMI_RN_GLDS") ? atoi(getenv("FUMI_RN_GLDS")) : 1;
     k.glds = glds_env; k.trace = g_rn_trace;
     const dim3 grid((unsigned)((long)k.tiles * groups));
-    hipLaunchKernelGGL((rn_conv_kernel<NF, MW, BKS>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((rn_conv_kernel<NF, MW, BKS, S16>), grid, dim3(256), lds, st, k);
     LAUNCH_CHECK();
     if (nt_out) *nt_out = k.tiles;
     return FUMI_OK;
+}
+template <int NF, int MW, int BKS>
+int conv_launch(hipStream_t st, const RnConvArgs& a, int* nt_out) {
+    bool s16 = true;
+    for (int s = 0; s < a.nsrc; ++s) s16 = s16 && rn_use_s16(a.src[s].Cin);
+    return s16 ? conv_launch2<NF, MW, BKS, true>(st, a, nt_out) : conv_launch2<NF, MW, BKS, false>(st, a, nt_out);
 }
 
 // tile shape for a layer: 256-pixel tiles (each wave 64 pixels: every weight fragment feeds two MFMAs, 0.7 KiB of LDS reads per MFMA
@@ -572,9 +642,10 @@ __global__ __launch_bounds__(256) void rn_wgrad_reduce_kernel(int nsplit, int nt
     }
 }
 
-// fp32 OIHW master -> bf16 fragment copies
+// fp32 OIHW master -> bf16 fragment copies.  sf / sb: the 16x16x32 fragment order (32-deep steps, 16-column blocks) for the forward /
+// the backward-data copy, else the 32x32x16 order (16-deep steps, 32-column blocks); a 1 KiB block is 64 lanes x 8 elements either way
 __global__ __launch_bounds__(256) void rn_wprep_kernel(int Cout, int Cin, int Cin_real, int ntaps, const float* W, long wstride,
-                                                       rbf16* fwd, rbf16* bwd, long fstride) {
+                                                       rbf16* fwd, rbf16* bwd, long fstride, int sf, int sb) {
     const int b = blockIdx.y;
     const long nel = (long)ntaps * Cin * Cout;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -582,17 +653,19 @@ __global__ __launch_bounds__(256) void rn_wprep_kernel(int Cout, int Cin, int Ci
     const float* w = W + (long)b * wstride;
     const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
     const long blk = i >> 9;
-    {   // forward: blk = (tap * KS + ks) * CF + cb
-        const int CF = Cout >> 5, KS = Cin >> 4;
+    {   // forward: blk = (tap * KS + ks) * CF + cb -- contraction over ci, columns co
+        const int CF = sf ? Cout >> 4 : Cout >> 5, KS = sf ? Cin >> 5 : Cin >> 4;
         const int cb = (int)(blk % CF), ks = (int)((blk / CF) % KS), tap = (int)(blk / ((long)CF * KS));
-        const int co = 32 * cb + (lane & 31), ci = 16 * ks + 8 * (lane >> 5) + j;
+        const int co = sf ? 16 * cb + (lane & 15) : 32 * cb + (lane & 31);
+        const int ci = sf ? 32 * ks + 8 * (lane >> 4) + j : 16 * ks + 8 * (lane >> 5) + j;
         const float v = ci < Cin_real ? w[((long)co * Cin_real + ci) * ntaps + tap] : 0.f;
         fwd[(long)b * fstride + i] = rn_f2bf(v);
     }
     if (bwd) {  // backward data: blk = (tap * KSo + ks) * CFi + cb, contraction over co, columns ci; tap flipped
-        const int CFi = Cin >> 5, KSo = Cout >> 4;
+        const int CFi = sb ? Cin >> 4 : Cin >> 5, KSo = sb ? Cout >> 5 : Cout >> 4;
         const int cb = (int)(blk % CFi), ks = (int)((blk / CFi) % KSo), tap = (int)(blk / ((long)CFi * KSo));
-        const int ci = 32 * cb + (lane & 31), co = 16 * ks + 8 * (lane >> 5) + j;
+        const int ci = sb ? 16 * cb + (lane & 15) : 32 * cb + (lane & 31);
+        const int co = sb ? 32 * ks + 8 * (lane >> 4) + j : 16 * ks + 8 * (lane >> 5) + j;
         bwd[(long)b * fstride + i] = rn_f2bf(w[((long)co * Cin_real + ci) * ntaps + (ntaps - 1 - tap)]);
     }
 }
@@ -714,7 +787,7 @@ int launch_rn_wprep(hipStream_t st, int B, int Cout, int Cin, int Cin_real, int 
     if ((Cout & 31) || (Cin & 15) || (bwd && (Cin & 31))) return FUMI_EINVAL;
     const long nel = (long)ntaps * Cin * Cout;
     hipLaunchKernelGGL(rn_wprep_kernel, dim3((unsigned)((nel + 255) / 256), B), dim3(256), 0, st, Cout, Cin, Cin_real, ntaps, W, wstride,
-                       fwd, bwd, fstride);
+                       fwd, bwd, fstride, rn_use_s16(Cin) ? 1 : 0, rn_use_s16(Cout) ? 1 : 0);
     LAUNCH_CHECK();
     return FUMI_OK;
 }
