@@ -82,7 +82,7 @@ int fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out) {
     if (device < 0 || device >= ndev) return FUMI_EINVAL;
     HIP_TRY(hipSetDevice(device));
     fumi_ws* ws = new fumi_ws();
-    ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr; ws->hcnt = nullptr; ws->acnt = nullptr; ws->w0p = nullptr; ws->w0p_cap = 0; ws->side_buf = nullptr; ws->side_cap = 0; ws->pub_src = nullptr; ws->pub_dst = nullptr; ws->pub_n = 0; ws->pub_seq = 0;
+    ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr; ws->hcnt = nullptr; ws->acnt = nullptr; ws->w0p = nullptr; ws->w0p_cap = 0; ws->side_buf = nullptr; ws->side_cap = 0; ws->pub_src = nullptr; ws->pub_dst = nullptr; ws->pub_n = 0; ws->pub_seq = 0; ws->adam = nullptr;
     ws->profiling = 0; ws->prof_every = 1; memset(ws->prof_seen, 0, sizeof(ws->prof_seen)); ws->recs = new std::vector<ProfRec>(); ws->pool = new std::vector<hipEvent_t>();
     ws->side = nullptr; ws->lane = nullptr;
     for (int i = 0; i < 3; ++i) { ws->lanes[i] = nullptr; ws->lane_ev[i] = nullptr; }
@@ -122,6 +122,7 @@ void fumi_hip_workspace_destroy(fumi_ws_t* ws) {
     if (ws->acnt) (void)hipFree(ws->acnt);
     if (ws->side_buf) (void)hipFree(ws->side_buf);
     if (ws->w0p) (void)hipFree(ws->w0p);
+    delete ws->adam;
     if (ws->status_host) (void)hipHostFree(ws->status_host);
     for (auto& r : *ws->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : *ws->pool) (void)hipEventDestroy(e);
@@ -354,7 +355,7 @@ static int fumi_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     }
     {
         ProfScope pr(ws, st, FUMI_PH_REDUCE);
-        if ((rc = launch_reduce_multi(st, fin))) return rc;
+        if ((rc = launch_reduce_multi_final(ws, st, fin))) return rc;      // (+ a deferred optimizer step and publication)
     }
     return FUMI_OK;
 }

@@ -23,6 +23,7 @@ struct fumi_ws {
     int* status;         // device status word (own small allocation)
     int* status_host;    // pinned
     const float* pub_src; float* pub_dst; int pub_n; unsigned long long pub_seq;   // deferred publication (api: publish_scalars_deferred)
+    struct AdamPending* adam;   // deferred optimizer step (fumi_hip_adam_step_deferred): folded into the step's final reduction launch
     int* acnt;           // [FUMI_ACNT] arrival counters of the split adapt kernel (reset by the query kernel of the same step)
     int* hcnt;           // [FUMI_HCNT] arrival counters of hyper_fwd_split_kernel, zero between launches
     float* side_buf; size_t side_cap;   // small allocation that survives slab rewinds (ResNet-12 chunk loop: heads of the whole meta-batch)
@@ -139,6 +140,33 @@ struct ReduceSegs {
     }
 };
 int launch_reduce_multi(hipStream_t st, ReduceSegs& sg);
+#ifdef __HIPCC__
+// torch.optim.Adam's update of one element (coupled L2 weight decay, bias correction folded into lr_over_bc1 / inv_sqrt_bc2), the
+// operation order of torch's _single_tensor_adam.  FMA contraction is switched off for this body (HIP's default is
+// -ffp-contract=fast, and __fmul_rn / __fadd_rn are plain operators that contract like any other): every operation rounds on its
+// own, so the stand-alone Adam kernel (adam.hip) and the fold into the final reduction (gemm.hip) give the same bits whatever code
+// surrounds the call.
+__device__ __forceinline__ void adam_update1(float g, float& p, float& m, float& v, float lr_over_bc1, float inv_sqrt_bc2, float b1,
+                                             float b2, float eps, float wd) {
+#pragma clang fp contract(off)
+    const float gr = g + wd * p;
+    m = m + (1.f - b1) * (gr - m);                                       // lerp form, as torch does
+    v = b2 * v + (1.f - b2) * gr * gr;
+    p = p - lr_over_bc1 * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+}
+#endif
+// A deferred Adam step (fumi_hip_adam_step_deferred): tensors by value, coefficients already folded (adam.hip)
+struct AdamPending {
+    int n, on;
+    float* p[32]; const float* g[32]; float* m[32]; float* v[32]; long numel[32];
+    float lr_over_bc1, inv_sqrt_bc2, b1, b2, eps, wd;
+};
+// The LAST launch of a training meta-step: the reduction `sg` (whose outputs are the gradients and the step's statistics) with,
+// when the workspace holds them and every gradient tensor of the pending optimizer step is one whole segment of `sg`, the Adam
+// update of each element right behind its gradient and the deferred publication of the statistics -- one launch instead of
+// three, same arithmetic in the same order (bit-identical parameters).  Falls back to the separate launches otherwise.
+int launch_reduce_multi_final(fumi_ws* ws, hipStream_t st, ReduceSegs& sg);
+int launch_adam_pending(fumi_ws* ws, hipStream_t st);       // the plain Adam launch of a still pending deferred step (adam.hip)
 // out[n] = scale * sum_m X[m*ld + n]
 int launch_colsum(hipStream_t st, const float* X, int M, int N, long ld, float scale, float* out);
 // several column sums (bias gradients) in TWO launches: partial sums of 128-row chunks for every job, then one

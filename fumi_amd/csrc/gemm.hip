@@ -14,6 +14,8 @@
 //                            k = 8c + 4*(lane>>5) + j  -- any partition of the slab's k works if A and B agree.
 //   m/n-contiguous operand-> T[k][BM]    : a lane reads T[k][col0 + (lane&31)] (consecutive lanes, consecutive banks).
 #include "common.h"
+#include <string.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -225,6 +227,71 @@ __global__ void reduce_multi_kernel(ReduceSegs sg) {
     }
 }
 
+// reduce_multi + the optimizer step + the publication of the statistics (launch_reduce_multi_final).  ap[k] != NULL: segment k's
+// outputs are the gradient of a parameter tensor: p / m / v at the same offsets get torch.optim.Adam's update (the expressions of
+// adam_kernel, adam.hip, in the same order: bit-identical).  An output that lies in [pub_src, pub_src + pub_n) is also stored to
+// the pinned host buffer; the lane whose store is the last one (a device counter) stores the sequence word behind it.
+struct AdamSegs { float* p[24]; float* m[24]; float* v[24]; float lr_over_bc1, inv_sqrt_bc2, b1, b2, eps, wd; };
+__device__ __forceinline__ void adam1(float g, float& p, float& m, float& v, const AdamSegs& a) {
+    adam_update1(g, p, m, v, a.lr_over_bc1, a.inv_sqrt_bc2, a.b1, a.b2, a.eps, a.wd);
+}
+__global__ void reduce_multi_adam_kernel(ReduceSegs sg, AdamSegs ad, const float* pub_src, int pub_n, float* pub_dst,
+                                         unsigned long long pub_seq, int* pub_cnt) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= sg.end[sg.n - 1]) return;
+    int k = 0;
+    while (k + 1 < sg.n && i >= sg.end[k]) ++k;
+    const long u = i - (k ? sg.end[k - 1] : 0);
+    const long st = sg.stride[k];
+    const int ns = sg.nslab[k];
+    if (sg.vec[k]) {
+        const float* src = sg.src[k] + 4 * u;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        int t = 0;
+        for (; t + 3 < ns; t += 4) {
+            const f32x4 a = *(const f32x4*)(src + t * st), b = *(const f32x4*)(src + (t + 1) * st);
+            const f32x4 c = *(const f32x4*)(src + (t + 2) * st), d = *(const f32x4*)(src + (t + 3) * st);
+            s0 += a; s1 += b; s0 += c; s1 += d;
+        }
+        for (; t + 1 < ns; t += 2) { s0 += *(const f32x4*)(src + t * st); s1 += *(const f32x4*)(src + (t + 1) * st); }
+        if (t < ns) s0 += *(const f32x4*)(src + t * st);
+        const f32x4 g = sg.scale * (s0 + s1);
+        *(f32x4*)(sg.dst[k] + 4 * u) = g;
+        if (ad.p[k]) {
+            f32x4 pp = *(f32x4*)(ad.p[k] + 4 * u), mm = *(f32x4*)(ad.m[k] + 4 * u), vv = *(f32x4*)(ad.v[k] + 4 * u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pe = pp[e], me = mm[e], ve = vv[e];
+                adam1(g[e], pe, me, ve, ad);
+                pp[e] = pe; mm[e] = me; vv[e] = ve;
+            }
+            *(f32x4*)(ad.p[k] + 4 * u) = pp; *(f32x4*)(ad.m[k] + 4 * u) = mm; *(f32x4*)(ad.v[k] + 4 * u) = vv;
+        }
+    } else {
+        const float* src = sg.src[k] + u;
+        float s0 = 0.f, s1 = 0.f;
+        int t = 0;
+        for (; t + 1 < ns; t += 2) { s0 += src[t * st]; s1 += src[(t + 1) * st]; }
+        if (t < ns) s0 += src[t * st];
+        const float g = sg.scale * (s0 + s1);
+        float* d = sg.dst[k] + u;
+        *d = g;
+        if (ad.p[k]) {
+            float pp = ad.p[k][u], mm = ad.m[k][u], vv = ad.v[k][u];
+            adam1(g, pp, mm, vv, ad);
+            ad.p[k][u] = pp; ad.m[k][u] = mm; ad.v[k][u] = vv;
+        }
+        if (pub_dst && d >= pub_src && d < pub_src + pub_n) {          // (the statistics are single-element segments)
+            __hip_atomic_store(pub_dst + (d - pub_src), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (__hip_atomic_fetch_add(pub_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pub_n - 1) {
+                __hip_atomic_store(pub_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (ready for the next step)
+                __hip_atomic_store((unsigned long long*)(pub_dst + 14), pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
 __global__ void colsum_kernel(const float* __restrict__ X, int M, int N, long ld, float scale, float* __restrict__ out) {
     // one wave-column-group per block: blockDim = (64, 4); each y-slice sums a strided subset of rows
     __shared__ float part[4][64];
@@ -303,6 +370,40 @@ int launch_reduce_multi(hipStream_t st, ReduceSegs& sg) {
     const long tot = sg.end[sg.n - 1];
     if (tot < 1) return FUMI_OK;
     hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sg);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+int launch_reduce_multi_final(fumi_ws* ws, hipStream_t st, ReduceSegs& sg) {
+    AdamPending* ap = ws ? ws->adam : nullptr;
+    if (!ap || !ap->on || sg.n < 1) return launch_reduce_multi(st, sg);
+    static const int fuse_env = getenv("FUMI_ADAM_FUSE") ? atoi(getenv("FUMI_ADAM_FUSE")) : 1;
+    // every gradient tensor of the pending step must be exactly one segment (whole tensor, from its first element); no other
+    // segment may write into a gradient tensor; a pending publication must read single-element segments of this reduction only
+    AdamSegs ad; memset(&ad, 0, sizeof(ad));
+    bool ok = fuse_env != 0;
+    int matched = 0, pub_found = 0;
+    for (int k = 0; k < sg.n && ok; ++k) {
+        const long cnt = (sg.end[k] - (k ? sg.end[k - 1] : 0)) * (sg.vec[k] ? 4 : 1);
+        const float* d = sg.dst[k];
+        for (int j = 0; j < ap->n; ++j) {
+            if (d == ap->g[j] && cnt == ap->numel[j]) { ad.p[k] = ap->p[j]; ad.m[k] = ap->m[j]; ad.v[k] = ap->v[j]; ++matched; break; }
+            if (d + cnt > ap->g[j] && d < ap->g[j] + ap->numel[j]) { ok = false; break; }            // partial cover: not this way
+        }
+        if (ad.p[k] && sg.vec[k] && ((((uintptr_t)ad.p[k] | (uintptr_t)ad.m[k] | (uintptr_t)ad.v[k]) & 15) != 0)) ok = false;
+        if (ws->pub_dst && d >= ws->pub_src && d < ws->pub_src + ws->pub_n) { if (cnt == 1 && !sg.vec[k]) ++pub_found; else ok = false; }
+    }
+    ok = ok && matched == ap->n && (!ws->pub_dst || pub_found == ws->pub_n);
+    if (!ok) {                                             // separate launches, same results
+        int rc = launch_reduce_multi(st, sg);
+        return rc ? rc : launch_adam_pending(ws, st);
+    }
+    ad.lr_over_bc1 = ap->lr_over_bc1; ad.inv_sqrt_bc2 = ap->inv_sqrt_bc2; ad.b1 = ap->b1; ad.b2 = ap->b2; ad.eps = ap->eps; ad.wd = ap->wd;
+    const long tot = sg.end[sg.n - 1];
+    hipLaunchKernelGGL(reduce_multi_adam_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sg, ad, ws->pub_src, ws->pub_n,
+                       ws->pub_dst, ws->pub_seq, ws->status + 48);
+    ap->on = 0;
+    ws->pub_dst = nullptr; ws->pub_src = nullptr;          // (the publication rode along)
     LAUNCH_CHECK();
     return FUMI_OK;
 }

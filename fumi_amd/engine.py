@@ -11,6 +11,7 @@ _ENGINE = None
 
 class HipEngine:
     name = "hip-gfx950"
+    folds_optimizer_step = True        # fumi_step consumes a deferred Adam step / publication (fumi_hip_adam_step_deferred)
 
     def _ws(self, t):
         return hip.Workspace.get(t.device if isinstance(t, torch.Tensor) and t.is_cuda else hip._dev(t))

@@ -22,7 +22,7 @@ SYMBOLS = [
     "fumi_hip_set_profiling", "fumi_hip_set_profiling_every", "fumi_hip_get_profile", "fumi_hip_phase_name",
     "fumi_hip_fumi_step", "fumi_hip_fumi_step_indexed", "fumi_hip_maml_step", "fumi_hip_am3_step",
     "fumi_hip_glove_bag", "fumi_hip_glove_bag_select", "fumi_hip_class_text_select", "fumi_hip_xpanel_fwd", "fumi_hip_xpanel_bwd",
-    "fumi_hip_adam_step",
+    "fumi_hip_adam_step", "fumi_hip_adam_step_deferred", "fumi_hip_adam_flush",
     "fumi_hip_linear_fwd", "fumi_hip_linear_bwd_data", "fumi_hip_linear_bwd_weight",
     "fumi_hip_sample_episodes", "fumi_hip_sample_episodes_tm", "fumi_hip_gather_rows", "fumi_hip_publish_scalars",
     "fumi_hip_publish_scalars_deferred", "fumi_hip_publish_flush", "fumi_hip_am3_metrics",
@@ -134,6 +134,8 @@ def lib():
         L.fumi_hip_xpanel_fwd.argtypes = [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 5
         L.fumi_hip_xpanel_bwd.argtypes = [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 3 + [c_float, c_void_p]
         L.fumi_hip_adam_step.argtypes = [c_void_p, c_void_p, c_int, PP, PP, PP, PP, POINTER(ctypes.c_long)] + [c_float] * 5 + [c_int]
+        L.fumi_hip_adam_step_deferred.argtypes = [c_void_p, c_int, PP, PP, PP, PP, POINTER(ctypes.c_long)] + [c_float] * 5 + [c_int]
+        L.fumi_hip_adam_flush.argtypes = [c_void_p, c_void_p, POINTER(c_int)]
         L.fumi_hip_linear_fwd.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 3 + [c_int, c_void_p]
         L.fumi_hip_linear_bwd_data.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 3
         L.fumi_hip_linear_bwd_weight.argtypes = [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p] * 4
@@ -641,6 +643,20 @@ def adam_step(ws, args, lr, beta1, beta2, eps, weight_decay, step, device):
     rc = lib().fumi_hip_adam_step(ws.handle, _stream(device), args.n, args.p, args.g, args.m, args.v, args.numel,
                                   float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step))
     _check(rc, "fumi_hip_adam_step")
+
+
+def adam_step_deferred(ws, args, lr, beta1, beta2, eps, weight_decay, step):
+    """The same update, folded into the last launch of the next training meta-step of ``ws`` (fumi_hip_adam_step_deferred)."""
+    rc = lib().fumi_hip_adam_step_deferred(ws.handle, args.n, args.p, args.g, args.m, args.v, args.numel,
+                                           float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step))
+    _check(rc, "fumi_hip_adam_step_deferred")
+
+
+def adam_flush(ws, device):
+    """Launches a deferred Adam step no meta-step has folded; True when it had to."""
+    launched = c_int(0)
+    _check(lib().fumi_hip_adam_flush(ws.handle, _stream(device), ctypes.byref(launched)), "fumi_hip_adam_flush")
+    return bool(launched.value)
 
 
 def linear_fwd(ws, x, W, b=None, act=0):

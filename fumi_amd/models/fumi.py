@@ -238,6 +238,14 @@ class FUMI(nn.Module):
         g_th, g_ph = fg.split(nth) if train else (None, None)
         # [.. grads .. | sum loss / B | sum acc / B], written by the engine -> one all-reduce(sum) -> global means everywhere
         tail = fg.tail if train else torch.empty(2, device=x_s.device, dtype=torch.float32)
+        # One process: optimizer.step() (fumi.py:193) needs no launch of its own -- the step's last launch (the final reduction that
+        # produces every gradient element) applies Adam's update right behind each element and publishes the two statistics; the
+        # update and the publication are registered with the workspace BEFORE the step (csrc/gemm.hip: launch_reduce_multi_final).
+        fold = (train and self.im_encoder not in ("conv4", "resnet12") and fdist.world()[1] == 1 and x_s.is_cuda
+                and getattr(eng, "folds_optimizer_step", False) and hasattr(optimizer, "defer_step") and not lazy.SYNC
+                and not lazy.USE_EVENT and optimizer.defer_step(x_s.device))
+        if fold:
+            loss, acc = lazy.scalars(tail, 2, defer=True)
         if self.im_encoder in ("conv4", "resnet12"):
             step = eng.fumi_conv4_step if self.im_encoder == "conv4" else eng.fumi_resnet12_step
             out = step(self.n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, args.step_size, self.norm_hypernet,
@@ -248,10 +256,14 @@ class FUMI(nn.Module):
                                 g_theta=g_th, g_phi=g_ph, cls_text=cls_text, stats=tail, dropout_p=drop_p, seed=drop_seed)
         fdist.all_reduce_sum_(fg.flat if train else tail)
         # read back asynchronously (fumi.py:195 blocks here); in training the two stores ride on the optimizer's launch
-        loss, acc = lazy.scalars(tail, 2, defer=train)
+        if not fold:
+            loss, acc = lazy.scalars(tail, 2, defer=train)
         if train:
             fg.attach()                          # .grad of every parameter IS a view of the buffer the engine just filled
-            getattr(optimizer, "step_fused", optimizer.step)()     # (nothing is left for zero_grad() to clear, fumi.py:190-193)
+            if fold:
+                optimizer.finish_deferred(x_s.device)              # (launches the update only if the step could not fold it)
+            else:
+                getattr(optimizer, "step_fused", optimizer.step)()     # (nothing is left for zero_grad() to clear, fumi.py:190-193)
             lazy.flush(x_s.device)
         preds = out["preds_f"]                                   # float, like the reference's test_preds (fumi.py:180-183)
         if fdist.world()[1] > 1 and not train:

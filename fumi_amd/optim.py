@@ -43,6 +43,32 @@ class Adam(torch.optim.Adam):
                 return torch.optim.Adam.step(self)
         return None
 
+    def defer_step(self, device):
+        """Registers this step with the device's workspace instead of launching it: the engine folds the update into the last
+        launch of the training meta-step that follows (``fumi_hip_adam_step_deferred``; single process only -- the caller checks).
+        True when registered; the caller then runs the meta-step and ``finish_deferred``.  False (nothing done) when the step
+        has to go the ordinary way: first step (no gradient views yet), several groups, hooks, a non-fusable configuration."""
+        if self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks or len(self.param_groups) != 1:
+            return False
+        group = self.param_groups[0]
+        cached = self._fused_args.get(0)
+        params = [p for p in group["params"] if p.grad is not None]
+        if cached is None or not params or len(params) > 24:
+            return False
+        ident = tuple(p.data_ptr() for p in params) + tuple(p.grad.data_ptr() for p in params)
+        if cached.ident != ident or isinstance(group["lr"], torch.Tensor) or group.get("amsgrad") or group.get("maximize"):
+            return False
+        if hasattr(self.step, "_wrapped_by_lr_sched"):
+            self._opt_called = True
+        cached.count += 1
+        b1, b2 = group["betas"]
+        hip.adam_step_deferred(hip.Workspace.get(device), cached, group["lr"], b1, b2, group["eps"], group["weight_decay"], cached.count)
+        return True
+
+    def finish_deferred(self, device):
+        """After the meta-step: launches the registered update on its own if the step could not fold it."""
+        return hip.adam_flush(hip.Workspace.get(device), device)
+
     def state_dict(self):
         self._sync_steps()
         return super().state_dict()

@@ -189,6 +189,15 @@ int fumi_hip_xpanel_bwd(fumi_ws_t* ws, fumi_stream_t stream, int B, int S, int Q
 int fumi_hip_adam_step(fumi_ws_t* ws, fumi_stream_t stream, int n_tensors, float* const* params,
         const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const long* numel,
         float lr, float beta1, float beta2, float eps, float weight_decay, int step);
+/* Deferred form: nothing is launched -- the update (same arithmetic, same order: bit-identical parameters) is folded into the
+ * LAST launch of the next fumi_hip_fumi_step / _indexed of this workspace, whose final reduction produces every gradient element:
+ * `optimizer.step()` (fumi/models/fumi.py:193) costs no launch of its own.  Single GPU only (with several ranks the all-reduce
+ * lies between gradient and update).  fumi_hip_adam_flush launches a still pending step as the ordinary kernel (*launched = 1)
+ * or reports that a meta-step had folded it (*launched = 0). */
+int fumi_hip_adam_step_deferred(fumi_ws_t* ws, int n_tensors, float* const* params,
+        const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const long* numel,
+        float lr, float beta1, float beta2, float eps, float weight_decay, int step);
+int fumi_hip_adam_flush(fumi_ws_t* ws, fumi_stream_t stream, int* launched);
 /* y[M,N] = act(x[M,K] W[N,K]^T + b[N]);  act: 0 none, 1 relu, 2 tanh.  b may be NULL. */
 int fumi_hip_linear_fwd(fumi_ws_t* ws, fumi_stream_t stream, int M, int N, int K,
         const float* x, const float* W, const float* b, int act, float* y);
