@@ -82,7 +82,7 @@ int fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out) {
     if (device < 0 || device >= ndev) return FUMI_EINVAL;
     HIP_TRY(hipSetDevice(device));
     fumi_ws* ws = new fumi_ws();
-    ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr; ws->hcnt = nullptr; ws->acnt = nullptr; ws->w0p = nullptr; ws->w0p_cap = 0; ws->side_buf = nullptr; ws->side_cap = 0; ws->pub_src = nullptr; ws->pub_dst = nullptr; ws->pub_n = 0; ws->pub_seq = 0; ws->adam = nullptr;
+    ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr; ws->hcnt = nullptr; ws->acnt = nullptr; ws->w0p = nullptr; ws->w0p_cap = 0; ws->side_buf = nullptr; ws->side_cap = 0; ws->pub_src = nullptr; ws->pub_dst = nullptr; ws->pub_n = 0; ws->pub_seq = 0; ws->adam = nullptr; ws->glove = nullptr;
     ws->profiling = 0; ws->prof_every = 1; memset(ws->prof_seen, 0, sizeof(ws->prof_seen)); ws->recs = new std::vector<ProfRec>(); ws->pool = new std::vector<hipEvent_t>();
     ws->side = nullptr; ws->lane = nullptr;
     for (int i = 0; i < 3; ++i) { ws->lanes[i] = nullptr; ws->lane_ev[i] = nullptr; }
@@ -123,6 +123,7 @@ void fumi_hip_workspace_destroy(fumi_ws_t* ws) {
     if (ws->side_buf) (void)hipFree(ws->side_buf);
     if (ws->w0p) (void)hipFree(ws->w0p);
     delete ws->adam;
+    delete ws->glove;
     if (ws->status_host) (void)hipHostFree(ws->status_host);
     for (auto& r : *ws->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : *ws->pool) (void)hipEventDestroy(e);
@@ -248,6 +249,20 @@ static int fumi_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     float* hfp = hyper_lds ? ws_f(ws, hfp_n) : nullptr;
     float* hbf = hbf_n ? ws_f(ws, hbf_n) : nullptr;
 
+    // A deferred embedding bag (fumi_hip_glove_bag_select_deferred) produces cls_text: it rides in the first launch of the forward
+    // X-panel pass when that pass pre-splits its column operands AND the hypernetwork forward (the reader of cls_text) runs as that
+    // pass's rider, i.e. behind it; in every other configuration it is launched here, before anything can read its output.
+    GlovePending* glove = (ws->glove && ws->glove->on) ? ws->glove : nullptr;
+    static const int glove_ride = getenv("FUMI_GLOVE_RIDE") ? atoi(getenv("FUMI_GLOVE_RIDE")) : 1;
+    if (glove) {
+        static const int overlap0 = getenv("FUMI_OVERLAP") ? atoi(getenv("FUMI_OVERLAP")) : 0;
+        HyperFwdArgs probe_rider;
+        const bool rides = glove_ride && cls_text && glove->a.out == cls_text && !(ws->side && (overlap0 & 1)) && hyper_lds &&
+            hyper_fwd_split_args(R, Dt, Ht, H1, tanh_head, cls_text, phi[0], phi[1], phi[2], phi[3], u, h, hfp, ws->hcnt, &probe_rider) &&
+            xpanel_fwd_presplits(B, S, Qn, D, hid[0], x_s, x_q, theta[0], true, rows, xpanel_planes(ws, B, S, D, hid[0]));
+        if (!rides) { if ((rc = glove_flush(ws, st))) return rc; glove = nullptr; }
+    }
+    p.glove = glove;
     // class text rows (fumi.py:207-210), then the hypernetwork (fumi.py:70-86,104-113)
     const float* ctext = cls_text;
     if (!ctext) {

@@ -24,6 +24,7 @@ struct fumi_ws {
     int* status_host;    // pinned
     const float* pub_src; float* pub_dst; int pub_n; unsigned long long pub_seq;   // deferred publication (api: publish_scalars_deferred)
     struct AdamPending* adam;   // deferred optimizer step (fumi_hip_adam_step_deferred): folded into the step's final reduction launch
+    struct GlovePending* glove; // deferred embedding bag (fumi_hip_glove_bag_select_deferred): rider workgroups of the step's first launch
     int* acnt;           // [FUMI_ACNT] arrival counters of the split adapt kernel (reset by the query kernel of the same step)
     int* hcnt;           // [FUMI_HCNT] arrival counters of hyper_fwd_split_kernel, zero between launches
     float* side_buf; size_t side_cap;   // small allocation that survives slab rewinds (ResNet-12 chunk loop: heads of the whole meta-batch)
@@ -155,6 +156,15 @@ __device__ __forceinline__ void adam_update1(float g, float& p, float& m, float&
     p = p - lr_over_bc1 * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
 }
 #endif
+// One embedding-bag request (glove.hip / glove_bag.h): out[r, :] = pool over the L tokens of row r (select form: of the first support
+// row of class r % N of episode r / N) of table rows; a deferred one waits in the workspace for the next FuMI step (glove_flush
+// launches it on its own)
+struct GloveArgs {
+    const int64_t* tok; int R, L; int64_t pad_id; const float* table; int V, E, mode; float* out; int* status;
+    const int64_t* y_s; int N, S;
+};
+struct GlovePending { GloveArgs a; int on, vec; size_t lds; };
+int glove_flush(fumi_ws* ws, hipStream_t st);
 // A deferred Adam step (fumi_hip_adam_step_deferred): tensors by value, coefficients already folded (adam.hip)
 struct AdamPending {
     int n, on;
@@ -195,7 +205,11 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
                       const HyperFwdArgs* rider = nullptr, int* rider_done = nullptr /* set to 1 when the rider was launched */,
                       float* parts = nullptr /* [xpanel_fwd_ksplit(), B, S+Qn, h0] partial products of a split contraction */,
                       int* parts_unreduced = nullptr /* not NULL: the parts are NOT summed into A0; receives their number (0: A0 is final) */,
-                      unsigned short* planes = nullptr /* xpanel_planes(): room for the column operand split once per launch (the fast forward needs it) */);
+                      unsigned short* planes = nullptr /* xpanel_planes(): room for the column operand split once per launch (the fast forward needs it) */,
+                      struct GlovePending* glove = nullptr /* a pending embedding bag: rides in the pre-split launch (or is launched first) */);
+// true when launch_xpanel_fwd with these arguments takes the pre-split path (the launch that can carry a pending embedding bag)
+bool xpanel_fwd_presplits(int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q, const float* W0, bool gram,
+                          const struct XRows* rows, unsigned short* planes);
 // room for W0 [h0, D] and the support rows [B, S, D] split into three bf16 planes each (grown on demand, owned by the workspace);
 // NULL when the fast forward does not apply
 unsigned short* xpanel_planes(fumi_ws* ws, int B, int S, int D, int h0);
@@ -239,6 +253,7 @@ struct EpisodeProblem {
     const HyperBwdArgs* bwd_rider;              // not NULL: the consumer of `head_bar` as rider workgroups of xpanel_bwd (hyper_bwd.h);
     int (*bwd_rider_fallback)(void*);           // called (with hook_ctx2) right after xpanel_bwd when that launch could not carry it
     void* hook_ctx2;
+    struct GlovePending* glove;                 // a pending embedding bag whose output the forward rider reads: carried by xpanel_fwd's first launch
     int (*after_xpanel_fwd)(void*); void* hook_ctx;   // host callback right after xpanel_fwd is enqueued: the producer of `head`
                                                 // is launched there, so its host-side preparation does not delay the matrix pass
 };

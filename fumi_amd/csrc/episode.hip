@@ -1619,7 +1619,7 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
         ProfScope ps(ws, st, FUMI_PH_XPANEL_FWD);
         int rider_done = 0;
         if ((rc = launch_xpanel_fwd(st, p.B, p.S, p.Qn, p.D, h0, p.x_s, p.x_q, p.W[0], w.A0, w.G, p.rows.table ? &p.rows : nullptr,
-                                    p.fwd_rider, &rider_done, nullptr, nullptr, xpanel_planes(ws, p.B, p.S, p.D, h0)))) return rc;
+                                    p.fwd_rider, &rider_done, nullptr, nullptr, xpanel_planes(ws, p.B, p.S, p.D, h0), p.glove))) return rc;
         if (p.fwd_rider && !rider_done && p.fwd_rider_fallback && (rc = p.fwd_rider_fallback(p.hook_ctx))) return rc;
     }
     if (p.after_xpanel_fwd && (rc = p.after_xpanel_fwd(p.hook_ctx))) return rc;

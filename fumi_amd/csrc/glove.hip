@@ -13,99 +13,38 @@
 
 namespace {
 
-// one 512-thread workgroup per output row: the row's L tokens are split over the 8 waves (8x the gathers in flight per
-// row; the whole launch is only B*N = 160 rows at the bench shape, so a wave per row left most CUs idle)
-constexpr int GW = 8;        // waves per output row
-constexpr int GU = 16;       // row gathers in flight per wave
+}  // namespace
+#include "glove_bag.h"
+namespace {
+
 template <bool VEC>
-__global__ __launch_bounds__(512) void glove_bag_kernel(const int64_t* __restrict__ tok, int R, int L, int64_t pad_id,
-                                                        const float* __restrict__ table, int V, int E, int mode,
-                                                        float* __restrict__ out, int* status,
-                                                        const int64_t* __restrict__ y_s, int N, int S) {
-    extern __shared__ __attribute__((aligned(16))) float part[];      // [GW][Ep] partial sums / maxima, then [GW] counts
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = blockIdx.x;
-    constexpr int W = VEC ? 4 : 1;
-    const int nchunk = (E / W + 63) / 64;        // chunks of 64 lanes x W floats
-    const int Ep = nchunk * 64 * W;
-    float* cnts = part + GW * Ep;
-    long src_row = r;
-    if (y_s) {                                   // select form: output row r = (episode, class); source = first support row of the class
-        const int b = r / N, c = r - b * N;
-        const int64_t* ys = y_s + (long)b * S;
-        int first = S;
-        for (int s0 = 0; s0 < S && first == S; s0 += 64) {
-            const int s_ = s0 + lane;
-            const unsigned long long m = __ballot(s_ < S && ys[s_] == c);
-            if (m) first = s0 + __ffsll((long long)m) - 1;
-        }
-        if (first == S) {                        // the reference raises IndexError here (fumi.py:209)
-            if (threadIdx.x == 0) atomicOr(status, FUMI_ST_CLASS_MISSING);
-            for (int j = threadIdx.x; j < E; j += blockDim.x) out[(long)r * E + j] = __builtin_nanf("");
-            return;
-        }
-        src_row = (long)b * S + first;
-    }
-    const int64_t* t = tok + src_row * L;
-    const int lw = (L + GW - 1) / GW;            // tokens per wave
-    const int lbeg = wave * lw, lend = min(L, lbeg + lw);
-    for (int c = 0; c < nchunk; ++c) {
-        const int j = (c * 64 + lane) * W;
-        const int jc = j < E ? j : 0;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (mode == 1) acc = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        int cnt = 0;
-        for (int l0 = lbeg; l0 < lend; l0 += 64) {
-            const int nl = min(64, lend - l0);
-            long my = lane < nl ? t[l0 + lane] : pad_id;
-            cnt += __popcll(__ballot(lane < nl && my != pad_id));
-            if (my < 0 || my >= V) { if (lane < nl) atomicOr(status, FUMI_ST_LABEL_RANGE); my = 0; }
-            const int mylo = (int)my;
-            for (int u0 = 0; u0 < nl; u0 += GU) {
-                f32x4 v[GU];
-#pragma unroll
-                for (int u = 0; u < GU; ++u) {
-                    const int id = __shfl(mylo, min(u0 + u, nl - 1), 64);
-                    const float* row = table + (long)id * E + jc;
-                    if (VEC) v[u] = *(const f32x4*)row; else { v[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; v[u][0] = row[0]; }
-                }
-#pragma unroll
-                for (int u = 0; u < GU; ++u) {
-                    if (u0 + u < nl) {
-                        if (mode == 0) acc += v[u];
-                        else { acc[0] = fmaxf(acc[0], v[u][0]); acc[1] = fmaxf(acc[1], v[u][1]); acc[2] = fmaxf(acc[2], v[u][2]); acc[3] = fmaxf(acc[3], v[u][3]); }
-                    }
-                }
-            }
-        }
-        float* pp = part + wave * Ep + (c * 64 + lane) * W;
-        if (VEC) *(f32x4*)pp = acc; else pp[0] = acc[0];
-        if (lane == 0 && c == 0) cnts[wave] = (float)cnt;
-    }
-    __syncthreads();
-    float dn = 0.f;
-#pragma unroll
-    for (int w_ = 0; w_ < GW; ++w_) dn += cnts[w_];
-    for (int j = threadIdx.x; j < E; j += blockDim.x) {
-        float a = part[j];
-#pragma unroll
-        for (int w_ = 1; w_ < GW; ++w_) a = mode == 0 ? a + part[w_ * Ep + j] : fmaxf(a, part[w_ * Ep + j]);
-        out[(long)r * E + j] = mode == 0 ? a / dn : a;
-    }
+__global__ __launch_bounds__(512) void glove_bag_kernel(GloveArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) float part[];
+    glove_bag_row<VEC>(ga, blockIdx.x, part);
 }
 
-int launch_bag(fumi_ws_t* ws, hipStream_t st, const int64_t* tok, int R, int L, int64_t pad_id, const float* table, int V,
-               int E, int mode, float* out, const int64_t* y_s, int N, int S) {
-    const bool vec = E % 4 == 0 && ((uintptr_t)table & 15) == 0 && ((uintptr_t)out & 15) == 0;
-    dim3 grid(R), block(64 * GW);
-    const int W = vec ? 4 : 1;
-    const int Ep = ((E / W + 63) / 64) * 64 * W;
-    const size_t lds = (size_t)(GW * Ep + GW) * sizeof(float);
-    if (lds > 64 * 1024) return FUMI_ENOTSUP;
-    if (vec) hipLaunchKernelGGL(glove_bag_kernel<true>, grid, block, lds, st, tok, R, L, pad_id, table, V, E, mode, out, ws->status, y_s, N, S);
-    else hipLaunchKernelGGL(glove_bag_kernel<false>, grid, block, lds, st, tok, R, L, pad_id, table, V, E, mode, out, ws->status, y_s, N, S);
+// vec / lds of a request (FUMI_ENOTSUP when a row's partial sums do not fit)
+int bag_geometry(const GloveArgs& ga, bool* vec, size_t* lds) {
+    *vec = ga.E % 4 == 0 && ((uintptr_t)ga.table & 15) == 0 && ((uintptr_t)ga.out & 15) == 0;
+    const int W = *vec ? 4 : 1;
+    const int Ep = ((ga.E / W + 63) / 64) * 64 * W;
+    *lds = (size_t)(GW * Ep + GW) * sizeof(float);
+    return *lds > 64 * 1024 ? FUMI_ENOTSUP : FUMI_OK;
+}
+int launch_bag_args(hipStream_t st, const GloveArgs& ga) {
+    bool vec; size_t lds;
+    int rc = bag_geometry(ga, &vec, &lds);
+    if (rc) return rc;
+    dim3 grid(ga.R), block(64 * GW);
+    if (vec) hipLaunchKernelGGL(glove_bag_kernel<true>, grid, block, lds, st, ga);
+    else hipLaunchKernelGGL(glove_bag_kernel<false>, grid, block, lds, st, ga);
     LAUNCH_CHECK();
     return FUMI_OK;
+}
+int launch_bag(fumi_ws_t* ws, hipStream_t st, const int64_t* tok, int R, int L, int64_t pad_id, const float* table, int V,
+               int E, int mode, float* out, const int64_t* y_s, int N, int S) {
+    GloveArgs ga{tok, R, L, pad_id, table, V, E, mode, out, ws->status, y_s, N, S};
+    return launch_bag_args(st, ga);
 }
 
 }  // namespace
@@ -123,4 +62,33 @@ extern "C" int fumi_hip_glove_bag_select(fumi_ws_t* ws, fumi_stream_t stream, co
         return FUMI_EINVAL;
     HIP_TRY(hipSetDevice(ws->device));
     return launch_bag(ws, (hipStream_t)stream, tok_s, B * N, L, pad_id, table, V, E, mode, out, y_s, N, S);
+}
+
+// Deferred form of fumi_hip_glove_bag_select: nothing is launched -- the request rides as extra workgroups of the FIRST launch of
+// the next fumi_hip_fumi_step / _indexed of this workspace (the pre-split of the layer-0 column operands, xpanel.hip: both are short,
+// latency-bound and independent), or is launched on its own at the start of that step when its shapes take another path.
+// `out` [B, N, E] must be the cls_text handed to that step.
+extern "C" int fumi_hip_glove_bag_select_deferred(fumi_ws_t* ws, const int64_t* tok_s, const int64_t* y_s,
+        int B, int N, int S, int L, int64_t pad_id, const float* table, int V, int E, int mode, float* out) {
+    if (!ws || !tok_s || !y_s || !table || !out || B < 1 || N < 1 || S < 1 || L < 1 || V < 1 || E < 1 || mode < 0 || mode > 1)
+        return FUMI_EINVAL;
+    if (!ws->glove) { ws->glove = new GlovePending(); ws->glove->on = 0; }
+    GloveArgs ga{tok_s, B * N, L, pad_id, table, V, E, mode, out, ws->status, y_s, N, S};
+    bool vec; size_t lds;
+    int rc = bag_geometry(ga, &vec, &lds);
+    if (rc) return rc;
+    ws->glove->a = ga; ws->glove->vec = vec ? 1 : 0; ws->glove->lds = lds; ws->glove->on = 1;
+    return FUMI_OK;
+}
+
+int glove_flush(fumi_ws* ws, hipStream_t st) {
+    if (!ws || !ws->glove || !ws->glove->on) return FUMI_OK;
+    ws->glove->on = 0;
+    return launch_bag_args(st, ws->glove->a);
+}
+
+extern "C" int fumi_hip_glove_flush(fumi_ws_t* ws, fumi_stream_t stream) {
+    if (!ws) return FUMI_EINVAL;
+    HIP_TRY(hipSetDevice(ws->device));
+    return glove_flush(ws, (hipStream_t)stream);
 }

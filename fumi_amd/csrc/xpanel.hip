@@ -555,6 +555,44 @@ __global__ __launch_bounds__(256) void xpanel_presplit_kernel(XPanel p, int cbg,
     dst[2 * plane] = (u32x4){l0_[0], l0_[1], l1_[0], l1_[1]};
 }
 
+// The pre-split with a pending embedding bag (glove_bag.h) as its first `nglove` workgroups: two short, latency-bound, independent
+// launches (6-7 us and 10 us) become one.  512 threads: a bag workgroup handles one output row, a pre-split workgroup 8 fragments.
+}  // namespace
+#include "glove_bag.h"
+namespace {
+template <bool VEC>
+__global__ __launch_bounds__(512) void xpanel_presplit_glove_kernel(XPanel p, int cbg, unsigned short* __restrict__ Wp, unsigned short* __restrict__ Xp,
+                                                                    GloveArgs ga, int nglove) {
+    extern __shared__ __attribute__((aligned(16))) float gpart[];
+    if ((int)blockIdx.x < nglove) { glove_bag_row<VEC>(ga, blockIdx.x, gpart); return; }
+    const int bid = blockIdx.x - nglove;
+    const int K = p.D, nks = K >> 4, CB = p.h0 >> 5;
+    const long gw = (long)bid * 8 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, c = lane & 31, k8 = (lane >> 5) * 8;
+    const long blk = gw / nks; const int ks = (int)(gw - blk * nks);
+    const float* src; u32x4* dst; long plane;
+    if (blk < CB) {
+        src = p.W0 + ((long)blk * 32 + c) * K + ks * 16 + k8;
+        plane = (long)p.h0 * (K >> 3);
+        dst = (u32x4*)Wp + ((long)ks * CB + blk) * 64 + lane;
+    } else {
+        const long xb = blk - CB;
+        if (xb >= (long)p.B * cbg) return;
+        const int b = (int)(xb / cbg), g = (int)(xb - (long)b * cbg), col = g * 32 + c;
+        src = col < p.S ? xrow(p, b, col) + ks * 16 + k8 : nullptr;
+        plane = (long)cbg * 32 * (K >> 3);
+        dst = (u32x4*)Xp + (long)b * 3 * plane + ((long)ks * cbg + g) * 64 + lane;
+    }
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 v0 = src ? *(const f32x4*)src : z4, v1 = src ? *(const f32x4*)(src + 4) : z4;
+    u32x2 h0_, m0_, l0_, h1_, m1_, l1_;
+    split3(v0, h0_, m0_, l0_);
+    split3(v1, h1_, m1_, l1_);
+    dst[0] = (u32x4){h0_[0], h0_[1], h1_[0], h1_[1]};
+    dst[plane] = (u32x4){m0_[0], m0_[1], m1_[0], m1_[1]};
+    dst[2 * plane] = (u32x4){l0_[0], l0_[1], l1_[0], l1_[1]};
+}
+
 // One tile of xpanel_fwd_ps_kernel: 256 threads stage SR x 32 rows of X (from row m0) per slab; every wave owns RB 32-row blocks
 // (from tile row `wrow`) of ONE 32-column block whose fragments it reads at `bq` (+ plane per piece, + kstride per 16-deep step).
 // W0 tiles: RB = SR = 2, the four waves sit side by side on the same 64 rows.  Gram tiles: RB = 1, SR = 4, the four waves sit
@@ -1241,11 +1279,21 @@ unsigned short* xpanel_planes(fumi_ws* ws, int B, int S, int D, int h0) {
     return ws->w0p;
 }
 
+bool xpanel_fwd_presplits(int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q, const float* W0, bool gram,
+                          const XRows* rows, unsigned short* planes) {
+    if (rows && rows->table) x_s = x_q = rows->table;
+    const bool aligned = al16(x_s) && al16(x_q) && al16(W0);
+    // (a split contraction -- narrow outputs with a `parts` buffer, AM3's encoder -- takes the 64 x 64 kernel; callers that pass no
+    // `parts` never split)
+    return aligned && planes && xpanel_fwd_ps_ok(D, h0) && D / SBK >= PS_MIN_SLABS;
+}
+
 int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
                       const float* W0, float* A0, float* G, const XRows* rows, const HyperFwdArgs* rider, int* rider_done,
-                      float* parts, int* parts_unreduced, unsigned short* planes) {
+                      float* parts, int* parts_unreduced, unsigned short* planes, GlovePending* glove) {
     if (parts_unreduced) *parts_unreduced = 0;
     if (rider_done) *rider_done = 0;
+    if (glove && !glove->on) glove = nullptr;
     float* const A0_final = A0;
     XPanel p{x_s, x_q, W0, B, S, Qn, D, h0, nullptr, nullptr, nullptr, 0, G ? S : 0, 1, 0};
     if (rows && rows->table) { p.table = rows->table; p.idx_s = rows->idx_s; p.idx_q = rows->idx_q; p.n_rows = rows->n_rows; p.x_s = p.x_q = rows->table; }
@@ -1259,13 +1307,26 @@ int launch_xpanel_fwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const
     static const int nst = getenv("FUMI_XP_NST") ? atoi(getenv("FUMI_XP_NST")) : 2;      // staging ring depth (tuning knob)
     // Default: split-bf16 (error against fp64 at the fp32 MFMA kernel's level: DESIGN.md) -- with the column operand split once per
     // step where the shape allows (50 + 6 us at the bench shapes), else per tile (70 us).  FUMI_XP_SB=0: the fp32 MFMA kernel (78 us).
-    if (aligned && planes && p.ksplit == 1 && xpanel_fwd_ps_ok(D, h0) && D / SBK >= PS_MIN_SLABS) {      // (split contractions: the 64 x 64 kernel)
+    const bool presplit = aligned && planes && p.ksplit == 1 && xpanel_fwd_ps_ok(D, h0) && D / SBK >= PS_MIN_SLABS;
+    if (glove && !presplit) {                                   // (callers check xpanel_fwd_presplits first: not expected)
+        glove->on = 0;
+        if (glove->vec) hipLaunchKernelGGL(xpanel_presplit_glove_kernel<true>, dim3((unsigned)glove->a.R), dim3(512), glove->lds, st, p, 0, nullptr, nullptr, glove->a, glove->a.R);
+        else hipLaunchKernelGGL(xpanel_presplit_glove_kernel<false>, dim3((unsigned)glove->a.R), dim3(512), glove->lds, st, p, 0, nullptr, nullptr, glove->a, glove->a.R);
+        glove = nullptr;
+    }
+    if (presplit) {      // (split contractions: the 64 x 64 kernel)
         // column operands split once (bf16 planes in fragment order), then tiles that only split X: 64 x 128 against W0, 128 x 32
         // against the support rows
         static const int ride = getenv("FUMI_XP_RIDER") ? atoi(getenv("FUMI_XP_RIDER")) : 1;
         const int cbg = (p.gcols + 31) / 32;
         unsigned short* Wp = planes; unsigned short* Xp = planes + ps_w0_bytes(D, h0) / sizeof(unsigned short);
         const long nfrag = ((long)h0 / 32 + (long)B * cbg) * (D / 16);      // one wave per fragment
+        if (glove) {                                                        // the pending embedding bag rides in front (its rows first)
+            const unsigned ng = (unsigned)glove->a.R, nb = (unsigned)((nfrag + 7) / 8);
+            if (glove->vec) hipLaunchKernelGGL(xpanel_presplit_glove_kernel<true>, dim3(ng + nb), dim3(512), glove->lds, st, p, cbg, Wp, Xp, glove->a, (int)ng);
+            else hipLaunchKernelGGL(xpanel_presplit_glove_kernel<false>, dim3(ng + nb), dim3(512), glove->lds, st, p, cbg, Wp, Xp, glove->a, (int)ng);
+            glove->on = 0; glove = nullptr;
+        } else
         hipLaunchKernelGGL(xpanel_presplit_kernel, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, st, p, cbg, Wp, Xp);
         const int tm = (S + Qn + 63) / 64, tg = (S + Qn + 127) / 128;
         const unsigned nwg = 8u * nper * (tm * (h0 / 128) * p.ksplit + tg * cbg);

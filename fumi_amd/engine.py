@@ -28,8 +28,9 @@ class HipEngine:
                                     need_grad=need_grad, grad_scale=grad_scale, g_theta=g_theta, g_phi=g_phi, stats=stats,
                                     dropout_p=dropout_p, seed=seed)
 
-    def glove_bag_select(self, tokens_s, y_s, n_way, table, pad_id, mode):
-        return hip.glove_bag_select(self._ws(tokens_s), tokens_s, y_s, n_way, table, pad_id, mode)
+    def glove_bag_select(self, tokens_s, y_s, n_way, table, pad_id, mode, defer=False):
+        """defer: the bag rides in the first launch of the ``fumi_step`` that must follow with the result as ``cls_text``"""
+        return hip.glove_bag_select(self._ws(tokens_s), tokens_s, y_s, n_way, table, pad_id, mode, defer=defer)
 
     def maml_step(self, x_s, y_s, x_q, y_q, params, T, alpha, first_order, need_grad, grad_scale, g_params=None,
                   stats=None):

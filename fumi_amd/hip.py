@@ -21,7 +21,7 @@ SYMBOLS = [
     "fumi_hip_set_spin_limit", "fumi_hip_set_trace_buffer",
     "fumi_hip_set_profiling", "fumi_hip_set_profiling_every", "fumi_hip_get_profile", "fumi_hip_phase_name",
     "fumi_hip_fumi_step", "fumi_hip_fumi_step_indexed", "fumi_hip_maml_step", "fumi_hip_am3_step",
-    "fumi_hip_glove_bag", "fumi_hip_glove_bag_select", "fumi_hip_class_text_select", "fumi_hip_xpanel_fwd", "fumi_hip_xpanel_bwd",
+    "fumi_hip_glove_bag", "fumi_hip_glove_bag_select", "fumi_hip_glove_bag_select_deferred", "fumi_hip_glove_flush", "fumi_hip_class_text_select", "fumi_hip_xpanel_fwd", "fumi_hip_xpanel_bwd",
     "fumi_hip_adam_step", "fumi_hip_adam_step_deferred", "fumi_hip_adam_flush",
     "fumi_hip_linear_fwd", "fumi_hip_linear_bwd_data", "fumi_hip_linear_bwd_weight",
     "fumi_hip_sample_episodes", "fumi_hip_sample_episodes_tm", "fumi_hip_gather_rows", "fumi_hip_publish_scalars",
@@ -130,6 +130,9 @@ def lib():
                                          c_int, c_void_p]
         L.fumi_hip_glove_bag_select.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64,
                                                 c_void_p, c_int, c_int, c_int, c_void_p]
+        L.fumi_hip_glove_bag_select_deferred.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64,
+                                                         c_void_p, c_int, c_int, c_int, c_void_p]
+        L.fumi_hip_glove_flush.argtypes = [c_void_p, c_void_p]
         L.fumi_hip_class_text_select.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p] * 3
         L.fumi_hip_xpanel_fwd.argtypes = [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 5
         L.fumi_hip_xpanel_bwd.argtypes = [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 3 + [c_float, c_void_p]
@@ -581,19 +584,33 @@ def glove_bag(ws, tokens, table, pad_id, mode="mean"):
     return out
 
 
-def glove_bag_select(ws, tokens_s, y_s, n_way, table, pad_id, mode="mean"):
-    """[B,N,E] pooled text of the first support row of each class (fumi.py:207-210 + common.py:23-41 in one kernel)."""
+def glove_bag_select(ws, tokens_s, y_s, n_way, table, pad_id, mode="mean", defer=False):
+    """[B,N,E] pooled text of the first support row of each class (fumi.py:207-210 + common.py:23-41 in one kernel).
+    defer: nothing is launched; the request rides in the first launch of the FuMI step that MUST follow on ``ws`` with the
+    returned tensor as its ``cls_text`` (fumi_hip_glove_bag_select_deferred)."""
     if mode not in ("mean", "max"):
         raise NameError(f"{mode} pooling strat not defined")
     dev = _dev(tokens_s)
     B, S, Lseq = tokens_s.shape
     V, E = table.shape
     out = torch.empty(B, n_way, E, device=dev, dtype=torch.float32)
+    if defer:
+        rc = lib().fumi_hip_glove_bag_select_deferred(ws.handle, _i64(tokens_s, "tokens"), _i64(y_s, "y_s"), B, n_way, S, Lseq,
+                                                      int(pad_id), _f32(table, "table"), V, E, 0 if mode == "mean" else 1,
+                                                      _f32(out, "out"))
+        _check(rc, "fumi_hip_glove_bag_select_deferred")
+        ws._glove_keep = (tokens_s, y_s, table)       # (the request holds raw pointers until the step has launched it)
+        return out
     rc = lib().fumi_hip_glove_bag_select(ws.handle, _stream(dev), _i64(tokens_s, "tokens"), _i64(y_s, "y_s"), B, n_way, S,
                                          Lseq, int(pad_id), _f32(table, "table"), V, E, 0 if mode == "mean" else 1,
                                          _f32(out, "out"))
     _check(rc, "fumi_hip_glove_bag_select")
     return out
+
+
+def glove_flush(ws, device):
+    """Launches a deferred embedding bag that no step has carried."""
+    _check(lib().fumi_hip_glove_flush(ws.handle, _stream(device)), "fumi_hip_glove_flush")
 
 
 def class_text_select(ws, text_s, y_s, n_way):

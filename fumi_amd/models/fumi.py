@@ -228,8 +228,10 @@ class FUMI(nn.Module):
             # kernel instead of pooling all S support rows first
             if self.pooling_strat not in ("mean", "max"):
                 raise NameError(f"{self.pooling_strat} pooling strat not defined")
+            # (with the MLP encoder the bag rides in the first launch of the step below instead of being a launch of its own)
+            ride = {"defer": True} if (self.im_encoder not in ("conv4", "resnet12") and getattr(eng, "folds_optimizer_step", False)) else {}
             cls_text = eng.glove_bag_select(to(s_text), y_s, self.n_way, self.text_encoder.embed.weight.detach(),
-                                            self.text_encoder.padding_token, self.pooling_strat)
+                                            self.text_encoder.padding_token, self.pooling_strat, **ride)
         else:
             text_s = self._encode_text(to(s_text), dev)
 

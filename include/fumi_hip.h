@@ -174,6 +174,12 @@ int fumi_hip_glove_bag(fumi_ws_t* ws, fumi_stream_t stream, const int64_t* tok, 
  * the N class rows that fumi.py:207-210 selects). */
 int fumi_hip_glove_bag_select(fumi_ws_t* ws, fumi_stream_t stream, const int64_t* tok_s, const int64_t* y_s,
         int B, int N, int S, int L, int64_t pad_id, const float* table, int V, int E, int mode, float* out);
+/* Deferred form: nothing is launched -- the request rides as extra workgroups of the first launch of the next fumi_hip_fumi_step /
+ * _indexed of this workspace (or is launched at its start when that step's shapes take another path); `out` [B,N,E] must be the
+ * cls_text handed to that step.  fumi_hip_glove_flush launches a pending request on its own. */
+int fumi_hip_glove_bag_select_deferred(fumi_ws_t* ws, const int64_t* tok_s, const int64_t* y_s,
+        int B, int N, int S, int L, int64_t pad_id, const float* table, int V, int E, int mode, float* out);
+int fumi_hip_glove_flush(fumi_ws_t* ws, fumi_stream_t stream);
 /* out[b,n,:] = text_s[b, first s with y_s[b,s]==n, :] */
 int fumi_hip_class_text_select(fumi_ws_t* ws, fumi_stream_t stream, int B, int N, int S, int Dt,
         const float* text_s, const int64_t* y_s, float* out);
