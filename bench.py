@@ -645,6 +645,20 @@ def main():
                                            "3 MB, and a 3 MB ring all-reduce is latency-bound (DESIGN.md section 6)"}
     times = sorted(float(x) for x in t.tolist())
     el = times[len(times) // 2]                                               # the median repeat
+    # what the HOST costs per step (Python + ctypes + launches), measured where it cannot be confused with waiting for the device:
+    # bursts of 4 steps enqueued into an EMPTY queue, median of 15
+    host_ms = None
+    if world == 1:
+        burst = []
+        for r_ in range(15):
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for i in range(4):
+                model.evaluate(args, batches[i % NBATCH], opt, "train")
+            burst.append((time.perf_counter() - tb) / 4)
+        torch.cuda.synchronize()
+        burst.sort()
+        host_ms = round(burst[len(burst) // 2] * 1e3, 4)
 
     if rank == 0:
         print(f"[bench] timed region done: {el / a.steps * 1e3:.4f} ms/step", file=sys.stderr, flush=True)
@@ -655,6 +669,7 @@ def main():
             "repeats": {"n": len(times), "of_steps": a.steps, "reported": "median",
                         "ms_per_step_min": round(times[0] / a.steps * 1e3, 4), "ms_per_step_median": round(ms, 4),
                         "ms_per_step_max": round(times[-1] / a.steps * 1e3, 4)},
+            "host_ms_per_step": host_ms,
             "world_size": world, "ranks": ranks_info if ranks_info else [{"rank": 0, "device": dev.index or 0, "episodes": Bg}],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo, not a measurement)",
             "config": {"workload": "FuMI 5-way 5-shot, 32 query/class, ResNet-152-style 2048-d embeddings, im_hid [256,64], "

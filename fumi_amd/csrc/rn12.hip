@@ -484,7 +484,11 @@ int run_rn12_episodes(fumi_ws* ws, hipStream_t st, const Rn12Problem& p) {
     }
     int Bc = p.chunk > 0 ? (p.chunk < p.B ? p.chunk : p.B) : (p.B + lanes - 1) / lanes;
     if (p.chunk <= 0) {
-        while (Bc > 1 && lanes * chunk_bytes(n, Bc, p, c.sc) > budget) Bc = (Bc + 1) / 2;
+        // the largest chunk whose lanes fit (chunk_bytes is close to linear in Bc: start from the estimate, then step down)
+        const size_t one = chunk_bytes(n, 1, p, c.sc);
+        const long est = (long)(budget / ((size_t)lanes * (one ? one : 1))) + 1;
+        if (Bc > est) Bc = (int)(est < 1 ? 1 : est);
+        while (Bc > 1 && lanes * chunk_bytes(n, Bc, p, c.sc) > budget) --Bc;
     }
     if (Bc >= p.B) lanes = 1;                                             // a single chunk
     const size_t region = ws_align(chunk_bytes(n, Bc, p, c.sc));
