@@ -346,11 +346,12 @@ static int hvp_pass(StepCtx& c, int M, const float* img, const float* frags, Pas
     return FUMI_OK;
 }
 
+constexpr int CV_MAXTAPE = 32;                   // taped inner steps of a second-order step
 // last step's buffer table, for fumi_hip_conv4_probe (tests compare every intermediate with oracle/conv4_manual.py)
 struct ProbeTab {
     bool valid; fumi_ws* ws; char* base;            // the workspace (and its slab) the pointers below were carved from
     Net n; int T, S, Qn; int ntape;
-    PassBufs tape[8]; PassBufs query; TanBufs tan;
+    PassBufs tape[CV_MAXTAPE]; PassBufs query; TanBufs tan;
     float* params; float* heads; float* G; float* dh; float* bar; float* barh; float* HV; float* HVh;
 };
 static ProbeTab g_probe;
@@ -431,7 +432,9 @@ int run_conv4_episodes(fumi_ws* ws, hipStream_t st, Conv4Problem p, const Conv4H
     if (rc) return rc;
     if (p.T < 0 || p.S < 1 || p.Qn < 1) return FUMI_EINVAL;
     const bool grad = p.need_grad != 0, second = grad && p.second_order && p.T > 0;
-    if (second && p.T > 8) return FUMI_ENOTSUP;                      // taped inner steps (the probe table holds 8)
+    // taped inner steps: the tape of every step stays resident (2 GiB per step at 32 episodes x 25 support images), so the cap is
+    // the table's size, not memory; the reference's defaults are 5 (train) and 100 (test: no tape), fumi/utils/utils.py:171-179
+    if (second && p.T > CV_MAXTAPE) return FUMI_ENOTSUP;             // (the host wrappers say so in words before they call)
     const int ntape = second ? p.T : 1;
     const int nslot = second ? p.T + 1 : 2;
     const size_t F1 = (size_t)cx[0].n.N * (cx[0].n.F + 1);
@@ -477,7 +480,7 @@ int run_conv4_episodes(fumi_ws* ws, hipStream_t st, Conv4Problem p, const Conv4H
         c.S = p.S; c.Qn = p.Qn; c.img_s = x_s; c.img_q = x_q; c.y_s = y_s; c.y_q = y_q;
         c.sc.cpart = ws_f(ws, c.sc.cpart_n); c.sc.wpart = ws_f(ws, c.sc.wpart_n); c.sc.rpart = ws_f(ws, c.sc.rpart_n);
         c.sc.dsum = (double*)ws_f(ws, c.sc.dsum_n * 2); c.sc.rowl = ws_f(ws, c.sc.rowl_n);
-        PassBufs tape_l[8]; PassBufs query_l; TanBufs tan_l;
+        PassBufs tape_l[CV_MAXTAPE]; PassBufs query_l; TanBufs tan_l;
         PassBufs* tape = lanes == 1 ? pt.tape : tape_l; PassBufs& query = lanes == 1 ? pt.query : query_l; TanBufs& tan = lanes == 1 ? pt.tan : tan_l;
         for (int t = 0; t < ntape; ++t) pass_carve(ws, n, p.S, true, tape[t]);
         pass_carve(ws, n, p.Qn, grad, query);

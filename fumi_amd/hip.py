@@ -798,6 +798,17 @@ def _conv4_shapes(x_s, y_s, x_q, y_q, theta):
     return B, S, Qn, Cin, H, W, nblk, F
 
 
+CONV4_MAX_TAPED_STEPS = 32
+
+
+def _conv4_tape_limit(T, need_grad, second_order):
+    """A second-order Conv4 step keeps the tape of every inner step resident: at most 32 (csrc/conv4.hip CV_MAXTAPE); evaluation
+    (no gradient) and first-order steps reuse one tape and take any T (the reference's test default is 100 steps)."""
+    if need_grad and second_order and int(T) > CONV4_MAX_TAPED_STEPS:
+        raise FumiHipError(f"conv4: {T} taped inner steps requested, at most {CONV4_MAX_TAPED_STEPS} are supported for a second-order "
+                           f"meta-gradient (first-order steps and evaluation take any number)")
+
+
 def _step_outputs(dev, B, Qn, N):
     return (torch.empty(B, Qn, N, device=dev, dtype=torch.float32), torch.empty(B, Qn, device=dev, dtype=torch.int64),
             torch.empty(B, Qn, device=dev, dtype=torch.float32), torch.empty(B, device=dev, dtype=torch.float32),
@@ -807,6 +818,7 @@ def _step_outputs(dev, B, Qn, N):
 def fumi_conv4_step(ws, n_way, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_head, *, cls_text=None, text_s=None,
                     need_grad=True, grad_scale=None, g_theta=None, g_phi=None, stats=None):
     """FuMI meta-step with the Conv4 encoder (fumi/models/fumi.py:146-192 with im_net = Conv4)."""
+    _conv4_tape_limit(T, need_grad, True)
     dev = _dev(x_s)
     B, S, Qn, Cin, H, W, nblk, F = _conv4_shapes(x_s, y_s, x_q, y_q, theta)
     N = int(n_way)
@@ -836,6 +848,7 @@ def fumi_conv4_step(ws, n_way, x_s, y_s, x_q, y_q, theta, phi, T, alpha, tanh_he
 def maml_conv4_step(ws, x_s, y_s, x_q, y_q, params, T, alpha, first_order=False, *, need_grad=True, grad_scale=None,
                     g_params=None, stats=None):
     """MAML meta-step with the Conv4 encoder: params = theta (3 per block) + [lin_final W [N,F], b [N]]."""
+    _conv4_tape_limit(T, need_grad, not first_order)
     dev = _dev(x_s)
     B, S, Qn, Cin, H, W, nblk, F = _conv4_shapes(x_s, y_s, x_q, y_q, params[:-2])
     N = int(params[-2].shape[0])
