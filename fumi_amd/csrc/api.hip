@@ -87,6 +87,7 @@ int fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out) {
     ws->side = nullptr; ws->lane = nullptr;
     for (int i = 0; i < 3; ++i) { ws->lanes[i] = nullptr; ws->lane_ev[i] = nullptr; }
     for (auto& e : ws->ev) e = nullptr;
+    for (auto& e : ws->evx) e = nullptr;
     // small persistent device buffers: status word, arrival counters (kept zero between launches by the kernels that use them)
     auto fail = [&](int code) { fumi_hip_workspace_destroy(ws); return code; };
     if (hipMalloc((void**)&ws->status, 256) != hipSuccess) return fail(FUMI_ENOMEM);
@@ -102,6 +103,9 @@ int fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out) {
         if (hipStreamCreateWithPriority(&ws->side, hipStreamNonBlocking, hi ? greatest : least) != hipSuccess) ws->side = nullptr;   // overlap is optional
     }
     for (auto& e : ws->ev) if (ws->side && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(ws->side); ws->side = nullptr;
+    }
+    for (auto& e : ws->evx) if (ws->side && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
         (void)hipStreamDestroy(ws->side); ws->side = nullptr;
     }
     if (bytes_hint) {
@@ -128,6 +132,7 @@ void fumi_hip_workspace_destroy(fumi_ws_t* ws) {
     for (auto& r : *ws->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : *ws->pool) (void)hipEventDestroy(e);
     for (auto e : ws->ev) if (e) (void)hipEventDestroy(e);
+    for (auto e : ws->evx) if (e) (void)hipEventDestroy(e);
     if (ws->side) (void)hipStreamDestroy(ws->side);
     for (int i = 0; i < 3; ++i) {
         if (ws->lanes[i]) (void)hipStreamDestroy(ws->lanes[i]);

@@ -36,6 +36,7 @@ struct fumi_ws {
     hipStream_t lane;    // ResNet-12 / Conv4: the stream of the second lane of episodes (created on first use); = lanes[0]
     hipStream_t lanes[3]; hipEvent_t lane_ev[3];   // streams of lanes 1..3 and their join events (ws_lane_stream)
     hipEvent_t ev[4];    // fork / join points (timing disabled)
+    hipEvent_t evx[2];   // fork / join of the query-row half of the backward X-panel pass beside the reverse sweep (episode.hip)
     std::vector<ProfRec>* recs;
     std::vector<hipEvent_t>* pool;
 };
@@ -259,6 +260,9 @@ struct EpisodeProblem {
 };
 size_t episode_workspace_bytes(const EpisodeProblem& p);
 int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p);
+// the two-launch form of the backward X-panel pass (query rows beside the reverse sweep, support rows behind it): slabs of each part
+bool xpanel_bwd_two_part_ok(int D, int h0);
+void xpanel_bwd_two_part_split(int B, int S, int Qn, int D, int h0, int* nsq, int* kcq, int* nss, int* kcs);
 
 // MAML with a bare linear head (linhead.hip)
 size_t linhead_lds_floats(int N, int S, int Qn, int T, int taped);

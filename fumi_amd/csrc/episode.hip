@@ -38,7 +38,10 @@ struct EpiBuf {
     float *pW[MAXL], *pb[MAXL], *pWh, *pbh, *pb0, *pD, *ploss, *pcorr;   // per-tile partial slabs
     float *Wb[MAXL], *bb[MAXL], *Whb, *bhb, *b0b, *Db;                   // adjoint state per episode
     float *abar[MAXL], *X0, *X1, *eb, *lb;     // reverse scratch
-    float *A0bar;                              // [B,R,h0] adjoint of A0 (support rows: sum over inner steps)
+    float *A0bar;                              // adjoint of A0 (support rows: sum over inner steps): episode b's support rows at
+    float *A0bar_q; int ldsr, ldq;             //   A0bar + b ldsr h0, its query rows at A0bar_q + b ldq h0 -- interleaved [B,R,h0] (ldsr = ldq =
+                                               //   R, A0bar_q = A0bar + S h0) or split [B,S,h0] | [B,Qn,h0] (ldsr = S, ldq = Qn: the two halves
+                                               //   of the backward X-panel pass run as two launches, run_episodes)
     float *apart; int *acnt;                   // adapt_lds split over column parts: [B,2,8,S*h_1] layer-1 partial sums; [B] arrival counters (persistent, zero between steps)
     float *xpart; int *xcnt;                   // reverse_lds: [B,2,8,S*h_1] partial sums exchanged between the column parts; [B] arrival counters
     int *status; int spin_limit;               // status word (FUMI_ST_SYNC_TIMEOUT when a wait for the sibling parts expires); polls per wait
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(512) void query_kernel(EpiDims d, EpiBuf w, const f
         __syncthreads();
     }
     // layer 0: Abar0 rows of the query set, b0bar, and the adjoint of the low-rank factor D_T
-    float* A0bq = w.A0bar + ((long)b * (S + Qn) + S + r0) * h0;
+    float* A0bq = w.A0bar_q + ((long)b * w.ldq + r0) * h0;
     wg_copy(A0bq, z(0), (long)nr * h0);
     float* pb0 = w.pb0 + pt * h0;
     wg_colsum(sm, sm_cap, nr, h0, z(0), h0, [&](int n, float s) { pb0[n] = s; });
@@ -978,7 +981,7 @@ __global__ __launch_bounds__(512) void query_lds_kernel(StageTab stg, StageTab s
     }
     // layer 0: Abar0 rows of the query set, b0bar, and the adjoint of the low-rank factor D_T
     const float* z0 = a(0);
-    float* A0bq = w.A0bar + ((long)b * (S + Qn) + S + r0) * h0;
+    float* A0bq = w.A0bar_q + ((long)b * w.ldq + r0) * h0;
     {
         const int c4n = (h0 + 3) >> 2;
         for (int i = tid; i < nr * c4n; i += nt) {
@@ -1023,7 +1026,7 @@ __global__ __launch_bounds__(512) void reverse_kernel(EpiDims d, EpiBuf w, float
     float* bhb = w.bhb + (long)b * N;
     float* b0b = w.b0b + (long)b * h0;
     float* Db = w.Db + (long)b * S * h0;
-    float* A0bs = w.A0bar + (long)b * (S + d.Qn) * h0;
+    float* A0bs = w.A0bar + (long)b * w.ldsr * h0;
     auto sum_tiles = [&](float* dst, const float* src, long sz) {
         wg_sum_slabs(dst, src + (long)b * ntile * sz, ntile, sz, sz);
     };
@@ -1424,7 +1427,7 @@ __global__ __launch_bounds__(512) void reverse_lds_kernel(StageTab stg_init, Sta
     }
     // ---- outputs: this part's columns of the layer-0 / layer-1 adjoints; part 0 also the unsplit ones
     store_img(w.Wb[1] + (long)b * h1 * h0 + c0, h0, Wb1, ldc, h1, h0c);
-    store_img(w.A0bar + (long)b * (S + d.Qn) * h0 + c0, h0, A0bs, ldc, S, h0c);
+    store_img(w.A0bar + (long)b * w.ldsr * h0 + c0, h0, A0bs, ldc, S, h0c);
     for (int n = tid; n < h0c; n += nt) w.b0b[(long)b * h0 + c0 + n] = b0b[n];
     if (c == 0) {
         for (int i = 1; i < L; ++i) {
@@ -1583,7 +1586,12 @@ size_t episode_workspace_bytes(const EpisodeProblem& p) {
     carve(c, p, w);
     if (p.need_grad) {
         int kc;
-        const size_t ns = (size_t)xpanel_bwd_nsplit(p.B, p.S, p.Qn, p.D, p.h[0], &kc);
+        size_t ns = (size_t)xpanel_bwd_nsplit(p.B, p.S, p.Qn, p.D, p.h[0], &kc);
+        if (xpanel_bwd_two_part_ok(p.D, p.h[0])) {       // (the two-launch form has more, shorter slabs)
+            int nsq, kcq, nss, kcs;
+            xpanel_bwd_two_part_split(p.B, p.S, p.Qn, p.D, p.h[0], &nsq, &kcq, &nss, &kcs);
+            ns = std::max(ns, (size_t)(nsq + nss));
+        }
         c.bytes += ws_align(ns * p.h[0] * (size_t)p.D * sizeof(float));
     }
     return c.bytes;
@@ -1612,6 +1620,20 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     }
     const int h0 = p.h[0];
     int rc;
+    // The backward X-panel pass in two launches (T >= 2): its query-row part beside the reverse sweep on the workspace's second
+    // stream (the sweep is a chain of T x ~30 us on P workgroups per episode -- 128 of the 256 CUs at the reference sizes --, the pass
+    // fills the others and is done before the sweep), its support-row part behind the sweep.  The adjoint array is then laid out
+    // split ([B,S,h0] | [B,Qn,h0]) so that each part reads one contiguous panel.  FUMI_EPI_OVERLAP=0: one launch behind the sweep.
+    static const int ovl_env = getenv("FUMI_EPI_OVERLAP") ? atoi(getenv("FUMI_EPI_OVERLAP")) : 1;
+    // (measured: FuMI BERT T = 5, 32 episodes 0.436 -> 0.420 ms per step; a 4-episode MAML step, whose pass is 23 us, LOSES 18 us to
+    // the fork / join and the extra launch -- only meta-batches whose pass is long enough to be worth hiding: >= 2048 query rows)
+    const bool two_part = ovl_env && p.need_grad && p.T >= 2 && ws->side && ws->evx[0] && ws->evx[1] && !ws->profiling && !p.after_reverse &&
+                          xpanel_bwd_two_part_ok(p.D, h0) && p.second_order && (long)p.B * p.Qn >= 2048;
+    if (p.need_grad) {
+        w.ldsr = two_part ? p.S : p.S + p.Qn; w.ldq = two_part ? p.Qn : p.S + p.Qn;
+        w.A0bar_q = two_part ? w.A0bar + (size_t)p.B * p.S * h0 : w.A0bar + (size_t)p.S * h0;
+    } else { w.A0bar_q = nullptr; w.ldsr = w.ldq = 0; }
+    float* bwd_slabs = nullptr; int nsq = 0, kcq = 0, nss = 0, kcs = 0;
 
     // ---- shared pass 1 over X: [A0 | G] = [Xs;Xq] [W0;Xs]^T for every episode, one launch (xpanel.hip)
     if (p.inputs_ready) HIP_TRY(hipEventRecord(p.inputs_ready, st));
@@ -1736,6 +1758,17 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
         }
         LAUNCH_CHECK();
     }
+    if (two_part) {
+        // query-row part of gW0 = Abar0^T X on the second stream, behind the query pass (whose adjoint rows it reads)
+        xpanel_bwd_two_part_split(p.B, p.S, p.Qn, p.D, h0, &nsq, &kcq, &nss, &kcs);
+        const long slab = (long)h0 * p.D;
+        bwd_slabs = ws_f(ws, (size_t)(nsq + nss) * slab);
+        HIP_TRY(hipEventRecord(ws->evx[0], st));
+        HIP_TRY(hipStreamWaitEvent(ws->side, ws->evx[0], 0));
+        if ((rc = launch_xpanel_bwd(ws->side, p.B, 0, p.Qn, p.D, h0, nullptr, p.x_q, w.A0bar_q, bwd_slabs, kcq, nsq,
+                                    p.rows.table ? &p.rows : nullptr, nullptr, nullptr))) return rc;
+        HIP_TRY(hipEventRecord(ws->evx[1], ws->side));
+    }
     {
         ProfScope ps(ws, st, FUMI_PH_REVERSE);
         static const bool force_global_r = getenv("FUMI_EPI_GLOBAL") != nullptr;   // dev/test: take the generic kernels
@@ -1812,10 +1845,17 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     {
         ProfScope pg(ws, st, FUMI_PH_XPANEL_BWD);
         int kc;
-        const int ns = xpanel_bwd_nsplit(p.B, p.S, p.Qn, p.D, h0, &kc);
+        int ns = xpanel_bwd_nsplit(p.B, p.S, p.Qn, p.D, h0, &kc);
         const long slab = (long)h0 * p.D;
-        float* slabs = ws_f(ws, (size_t)ns * slab);
+        float* slabs = two_part ? bwd_slabs : ws_f(ws, (size_t)ns * slab);
         int rider_done = 0;
+        if (two_part) {
+            // support-row part behind the sweep (with the hypernetwork backward as its rider), then the second stream's part joins
+            if ((rc = launch_xpanel_bwd(st, p.B, p.S, 0, p.D, h0, p.x_s, nullptr, w.A0bar, bwd_slabs + (size_t)nsq * slab, kcs, nss,
+                                        p.rows.table ? &p.rows : nullptr, p.bwd_rider, &rider_done))) return rc;
+            HIP_TRY(hipStreamWaitEvent(st, ws->evx[1], 0));
+            ns = nsq + nss;
+        } else
         if ((rc = launch_xpanel_bwd(st, p.B, p.S, p.Qn, p.D, h0, p.x_s, p.x_q, w.A0bar, slabs, kc, ns, p.rows.table ? &p.rows : nullptr,
                                     p.bwd_rider, &rider_done))) return rc;
         if (p.bwd_rider && !rider_done && p.bwd_rider_fallback && (rc = p.bwd_rider_fallback(p.hook_ctx2))) return rc;

@@ -1398,6 +1398,22 @@ int xpanel_bwd_nsplit(int B, int S, int Qn, int D, int h0, int* kchunk_out) {
     return (int)((Ktot + kc - 1) / kc);
 }
 
+// Two-launch form (run_episodes, T >= 2): the contraction over the B Qn query rows needs only the query pass's adjoints, so it runs
+// on a second stream BESIDE the reverse sweep (a latency chain on half of the CUs); the B S support rows follow the sweep as a short
+// launch of 64-row slabs.  Each part is this same kernel family on a panel with S = 0 (query rows) or Qn = 0 (support rows) and the
+// matching half of the split adjoint array.
+bool xpanel_bwd_two_part_ok(int D, int h0) {
+    static const int bsb = getenv("FUMI_XPB_SB") ? atoi(getenv("FUMI_XPB_SB")) : 1;
+    return bsb && xpanel_bwd_wide(D, h0) && D % 128 == 0;
+}
+void xpanel_bwd_two_part_split(int B, int S, int Qn, int D, int h0, int* nsq, int* kcq, int* nss, int* kcs) {
+    *nsq = xpanel_bwd_nsplit(B, 0, Qn, D, h0, kcq);
+    long kc = 64;                                       // short slabs: the launch is as long as one slab's chain
+    const long K = (long)B * S;
+    if ((K + kc - 1) / kc > 32) kc = ((K + 31) / 32 + BK - 1) / BK * BK;
+    *kcs = (int)kc; *nss = (int)((K + kc - 1) / kc);
+}
+
 int launch_xpanel_bwd(hipStream_t st, int B, int S, int Qn, int D, int h0, const float* x_s, const float* x_q,
                       const float* Abar, float* slabs, int kchunk, int nsplit, const XRows* rows, const HyperBwdArgs* rider,
                       int* rider_done) {

@@ -615,6 +615,23 @@ def test_generic_episode_kernels_in_subprocess(dev):
     assert " passed" in r.stdout
 
 
+def test_one_launch_backward_xpanel_pass_in_subprocess(dev):
+    """With two or more inner steps the backward X-panel pass runs as two launches (its query-row part on a second stream beside the
+    reverse sweep, FUMI_EPI_OVERLAP, the default).  Re-run the reference-parity cases with FUMI_EPI_OVERLAP=0 (one launch behind the
+    sweep; read once per process, hence the child process) so both forms stay covered -- the goldens with T = 5 take the two-launch
+    form in THIS process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, FUMI_EPI_OVERLAP="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-q", "-m", "gpu",
+                        "-p", "no:cacheprovider", "-k", "fumi_step_matches_reference or maml_step_matches_reference"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 _SB_SCRIPT = r"""
 import sys, json, torch
 sys.path.insert(0, %r)
