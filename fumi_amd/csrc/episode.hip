@@ -1623,12 +1623,12 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     // The backward X-panel pass in two launches (T >= 2): its query-row part beside the reverse sweep on the workspace's second
     // stream (the sweep is a chain of T x ~30 us on P workgroups per episode -- 128 of the 256 CUs at the reference sizes --, the pass
     // fills the others and is done before the sweep), its support-row part behind the sweep.  The adjoint array is then laid out
-    // split ([B,S,h0] | [B,Qn,h0]) so that each part reads one contiguous panel.  FUMI_EPI_OVERLAP=0: one launch behind the sweep.
+    // split ([B,S,h0] | [B,Qn,h0]) so that each part reads one contiguous panel.  FUMI_EPI_OVERLAP=0: one launch behind the sweep (2: the two-launch form at any size, for tests).
     static const int ovl_env = getenv("FUMI_EPI_OVERLAP") ? atoi(getenv("FUMI_EPI_OVERLAP")) : 1;
     // (measured: FuMI BERT T = 5, 32 episodes 0.436 -> 0.420 ms per step; a 4-episode MAML step, whose pass is 23 us, LOSES 18 us to
     // the fork / join and the extra launch -- only meta-batches whose pass is long enough to be worth hiding: >= 2048 query rows)
     const bool two_part = ovl_env && p.need_grad && p.T >= 2 && ws->side && ws->evx[0] && ws->evx[1] && !ws->profiling && !p.after_reverse &&
-                          xpanel_bwd_two_part_ok(p.D, h0) && p.second_order && (long)p.B * p.Qn >= 2048;
+                          xpanel_bwd_two_part_ok(p.D, h0) && p.second_order && ((long)p.B * p.Qn >= 2048 || ovl_env == 2);      // (2: tests)
     if (p.need_grad) {
         w.ldsr = two_part ? p.S : p.S + p.Qn; w.ldq = two_part ? p.Qn : p.S + p.Qn;
         w.A0bar_q = two_part ? w.A0bar + (size_t)p.B * p.S * h0 : w.A0bar + (size_t)p.S * h0;

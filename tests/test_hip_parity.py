@@ -263,6 +263,33 @@ def test_fumi_configs1_full_meta_batch_against_oracle(dev, ws):
     _check_grads([str(i) for i in range(8)], out["g_theta"] + out["g_phi"], None, ref["g_theta"] + ref["g_phi"])
 
 
+def test_fumi_configs2_per_rank_meta_batch_against_oracle(dev, ws):
+    """BASELINE.json configs[2]'s per-rank shape (32 episodes, 5-way 5-shot, 32 query / class, D = 2048, [256, 64], 768-d BERT text
+    rows, T = 5 -- the reference's default number of training adaptation steps, fumi/utils/utils.py:171-175) against the oracle.  At
+    this size the backward X-panel pass takes its two-launch form (query rows on the second stream beside the reverse sweep,
+    csrc/episode.hip run_episodes): this is the in-process parity check of that form."""
+    from fumi_amd import hip
+    B, N, K, Q, D, hid, Dt, Ht, T = 32, 5, 5, 32, 2048, [256, 64], 768, 256, 5
+    ep = cg.make_episodes(2025, B, N, K, Q, D, Dt)
+    theta, phi = cg.make_fumi_params(2025, D, hid, Dt, Ht)
+    out = hip.fumi_step_select(ws, N, _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev),
+                               _g(ep["text_s"], dev), [_g(t, dev) for t in theta], [_g(t, dev) for t in phi], T, cg.ALPHA, False)
+    assert ws.read_status() == 0
+    th = [t.clone().requires_grad_(True) for t in theta]
+    ph = [t.clone().requires_grad_(True) for t in phi]
+    ref = R.fumi_meta_step(th, ph, ep["text_s"], ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], N, T, cg.ALPHA, False)
+    assert rel_to_max(out["logits"].cpu(), ref["logits"]) <= LOGIT_TOL
+    assert rel_to_max(out["loss_b"].cpu(), ref["loss_b"]) <= LOGIT_TOL
+    mask = safe_margin_mask(ref["logits"], MARGIN)
+    assert float(mask.float().mean()) > 0.99 and torch.equal(out["preds"].cpu()[mask], ref["preds"][mask])
+    _check_grads([str(i) for i in range(8)], out["g_theta"] + out["g_phi"], None, ref["g_theta"] + ref["g_phi"])
+    # the same inputs again: the two streams leave no run-to-run difference (fixed summation order in every part)
+    out2 = hip.fumi_step_select(ws, N, _g(ep["x_s"], dev), _g(ep["y_s"], dev), _g(ep["x_q"], dev), _g(ep["y_q"], dev),
+                                _g(ep["text_s"], dev), [_g(t, dev) for t in theta], [_g(t, dev) for t in phi], T, cg.ALPHA, False)
+    for a, b in zip(out["g_theta"] + out["g_phi"], out2["g_theta"] + out2["g_phi"]):
+        assert torch.equal(a, b)
+
+
 def test_expired_sibling_wait_sets_the_status_bit(dev, ws):
     """The split reverse sweep waits for its sibling workgroups with a bounded spin; an expired wait must be reported
     (FUMI_ST_SYNC_TIMEOUT -> RuntimeError), not carried on from silently.  With a limit of 0 polls every wait that is not
@@ -615,15 +642,15 @@ def test_generic_episode_kernels_in_subprocess(dev):
     assert " passed" in r.stdout
 
 
-def test_one_launch_backward_xpanel_pass_in_subprocess(dev):
-    """With two or more inner steps the backward X-panel pass runs as two launches (its query-row part on a second stream beside the
-    reverse sweep, FUMI_EPI_OVERLAP, the default).  Re-run the reference-parity cases with FUMI_EPI_OVERLAP=0 (one launch behind the
-    sweep; read once per process, hence the child process) so both forms stay covered -- the goldens with T = 5 take the two-launch
-    form in THIS process."""
+def test_two_launch_backward_xpanel_pass_in_subprocess(dev):
+    """With two or more inner steps and a meta-batch of at least 2048 query rows the backward X-panel pass runs as two launches (its
+    query-row part on a second stream beside the reverse sweep, FUMI_EPI_OVERLAP).  The reference-generated goldens are small
+    meta-batches and take the one-launch form in this process; re-run them with FUMI_EPI_OVERLAP=2 (the two-launch form whatever
+    the size; read once per process, hence the child process) so that every T >= 2 golden pins both forms."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, FUMI_EPI_OVERLAP="0")
+    env = dict(os.environ, FUMI_EPI_OVERLAP="2")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-q", "-m", "gpu",
                         "-p", "no:cacheprovider", "-k", "fumi_step_matches_reference or maml_step_matches_reference"],
