@@ -445,7 +445,7 @@ def configs4_leg(dev, steps, warmup, with_cpu, episodes):
                            "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
                            "algorithmic_bytes": int(alg),
                            "kernel": "rn_conv_kernel: forward / input-gradient convolutions and their tangent forms as implicit GEMMs "
-                                     "over shifted pixel slabs on v_mfma_f32_32x32x16_bf16 (csrc/rn12_conv.hip)",
+                                     "over shifted pixel slabs on v_mfma_f32_16x16x32_bf16 (32x32x16 for the two 3-channel image layers; csrc/rn12_conv.hip)",
                            "flops_per_step": conv_flops, "ms_per_step": round(per_step * 1e3, 2), "launches_per_step": n // psteps,
                            "timed": "HIP events around every launch of one extra step after the timed region (single stream)"}
         if "rn_wgrad" in prof:
