@@ -39,36 +39,74 @@ __device__ __forceinline__ bool interior_of(long p, const RnGeom& g, int& y, int
 }
 
 // ---- BN + LeakyReLU ----------------------------------------------------------------------------------------------------------------
-template <bool TAN>
-__global__ __launch_bounds__(256) void rn_act_kernel(RnMap m, const rbf16* u, const rbf16* ud, const float* coef, rbf16* out) {
+// Map passes: a thread owns ONE 8-channel chunk and walks pixels (thread = (row group rg, chunk ch), pixels pbeg + rg, + nrg, ..), so
+// the per-channel coefficient vectors are loaded once per thread instead of once per pixel -- the one-pixel-per-thread form moved
+// 4.5 TB/s where the reductions, which always had this shape, move 5.6-6.6 (a tangent pass reads 6-11 coefficient vectors = 12-22
+// 16-byte loads through the vector L1 per 2-5 16-byte loads of map data).  UNR pixels per iteration keep several loads in flight.
+__device__ __forceinline__ bool interior32(unsigned p, const RnGeom& g) {
+    const unsigned q = p % (unsigned)g.Pp, y = q / (unsigned)g.Wp, x = q - y * (unsigned)g.Wp;
+    return y >= 1 && y <= (unsigned)g.H && x >= 1 && x <= (unsigned)g.W;
+}
+// (the plain pass has two coefficient vectors and one load per pixel: one pixel per thread moves 6.1 TB/s, the walking form 5.7)
+__global__ __launch_bounds__(256) void rn_act1_kernel(RnMap m, const rbf16* u, const float* coef, rbf16* out) {
     const int b = blockIdx.y, nch = m.C >> 3;
     const long npix = (long)m.M * m.g.Pp;
     const long unit = (long)blockIdx.x * 256 + threadIdx.x;
     if (unit >= npix * nch) return;
     const long p = unit / nch; const int c = (int)(unit - p * nch) * 8;
     const long off = ((long)b * npix + p) * m.C + c;
-    int y, x;
-    F8 o;
-    if (!interior_of(p, m.g, y, x)) {
-        *(u32x4*)(out + off) = (u32x4){0u, 0u, 0u, 0u};
-        return;
-    }
+    if (!interior32((unsigned)p, m.g)) { *(u32x4*)(out + off) = (u32x4){0u, 0u, 0u, 0u}; return; }
     const float* cf = coef + (long)b * RCF_N * m.C;
     const F8 uv = ldbf(u + off), A = ldcf(cf, RCF_A, m.C, c), C0 = ldcf(cf, RCF_C0, m.C, c);
-    if (!TAN) {
+    F8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float v = A.v[j] * uv.v[j] + C0.v[j]; o.v[j] = v > 0.f ? v : RN_SLOPE * v; }
-    } else {
-        const F8 udv = ldbf(ud + off), MU = ldcf(cf, RCF_MU, m.C, c), R = ldcf(cf, RCF_R, m.C, c), TB = ldcf(cf, RCF_TB, m.C, c),
-                 TC = ldcf(cf, RCF_TC, m.C, c);
+    for (int j = 0; j < 8; ++j) { const float v = A.v[j] * uv.v[j] + C0.v[j]; o.v[j] = v > 0.f ? v : RN_SLOPE * v; }
+    *(u32x4*)(out + off) = pack8(o);
+}
+template <bool TAN>
+__global__ __launch_bounds__(256) void rn_act_kernel(RnMap m, const rbf16* u, const rbf16* ud, const float* coef, rbf16* out, int RB) {
+    constexpr int UNR = TAN ? 2 : 4;
+    const int b = blockIdx.y, nch = m.C >> 3, nrg = 256 / nch;
+    const unsigned npix = (unsigned)m.M * (unsigned)m.g.Pp;
+    const int ch = threadIdx.x % nch, rg = threadIdx.x / nch, c = ch * 8;
+    if (rg >= nrg) return;
+    const float* cf = coef + (long)b * RCF_N * m.C;
+    const F8 A = ldcf(cf, RCF_A, m.C, c), C0 = ldcf(cf, RCF_C0, m.C, c);
+    F8 MU, R, TB, TC;
+    if (TAN) { MU = ldcf(cf, RCF_MU, m.C, c); R = ldcf(cf, RCF_R, m.C, c); TB = ldcf(cf, RCF_TB, m.C, c); TC = ldcf(cf, RCF_TC, m.C, c); }
+    const unsigned pbeg = blockIdx.x * (unsigned)RB, pend = min(npix, pbeg + (unsigned)RB);
+    const long base = (long)b * npix * m.C + c;
+    for (unsigned p0 = pbeg + rg; p0 < pend; p0 += UNR * nrg) {
+        u32x4 uv[UNR], udv[UNR]; bool in[UNR], ok[UNR];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = A.v[j] * uv.v[j] + C0.v[j];
-            const float xh = (uv.v[j] - MU.v[j]) * R.v[j];
-            o.v[j] = lmask(v) * (A.v[j] * udv.v[j] + TB.v[j] * xh + TC.v[j]);
+        for (int k = 0; k < UNR; ++k) {
+            const unsigned p = p0 + k * nrg;
+            ok[k] = p < pend; in[k] = ok[k] && interior32(p, m.g);
+            const long off = base + (long)(ok[k] ? p : pbeg) * m.C;
+            uv[k] = *(const u32x4*)(u + off);
+            if (TAN) udv[k] = *(const u32x4*)(ud + off);
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            if (!ok[k]) continue;
+            const unsigned p = p0 + k * nrg;
+            F8 o;
+            const F8 uf = unpack8(uv[k]);
+            if (!TAN) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float v = A.v[j] * uf.v[j] + C0.v[j]; o.v[j] = v > 0.f ? v : RN_SLOPE * v; }
+            } else {
+                const F8 udf = unpack8(udv[k]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = A.v[j] * uf.v[j] + C0.v[j];
+                    const float xh = (uf.v[j] - MU.v[j]) * R.v[j];
+                    o.v[j] = lmask(v) * (A.v[j] * udf.v[j] + TB.v[j] * xh + TC.v[j]);
+                }
+            }
+            *(u32x4*)(out + base + (long)p * m.C) = in[k] ? pack8(o) : (u32x4){0u, 0u, 0u, 0u};
         }
     }
-    *(u32x4*)(out + off) = pack8(o);
 }
 
 // partial sums over RB consecutive pixels per workgroup: thread (row group rg, chunk ch)
@@ -127,41 +165,59 @@ __global__ __launch_bounds__(256) void rn_bwd_reduce_kernel(RnMap m, const rbf16
 
 template <bool TAN>
 __global__ __launch_bounds__(256) void rn_bwd_apply_kernel(RnMap m, const rbf16* u, const rbf16* ud, const rbf16* da, const rbf16* dad,
-                                                           const float* coef, rbf16* du) {
-    const int b = blockIdx.y, nch = m.C >> 3;
-    const long npix = (long)m.M * m.g.Pp;
-    const long unit = (long)blockIdx.x * 256 + threadIdx.x;
-    if (unit >= npix * nch) return;
-    const long p = unit / nch; const int c = (int)(unit - p * nch) * 8;
-    const long off = ((long)b * npix + p) * m.C + c;
-    int y, x;
-    if (!interior_of(p, m.g, y, x)) { *(u32x4*)(du + off) = (u32x4){0u, 0u, 0u, 0u}; return; }
+                                                           const float* coef, rbf16* du, int RB) {
+    constexpr int UNR = 2;
+    const int b = blockIdx.y, nch = m.C >> 3, nrg = 256 / nch;
+    const unsigned npix = (unsigned)m.M * (unsigned)m.g.Pp;
+    const int ch = threadIdx.x % nch, rg = threadIdx.x / nch, c = ch * 8;
+    if (rg >= nrg) return;
     const float* cf = coef + (long)b * RCF_N * m.C;
-    const F8 uv = ldbf(u + off), dav = ldbf(da + off);
     const F8 A = ldcf(cf, RCF_A, m.C, c), C0 = ldcf(cf, RCF_C0, m.C, c), MU = ldcf(cf, RCF_MU, m.C, c), R = ldcf(cf, RCF_R, m.C, c),
              D1 = ldcf(cf, RCF_D1, m.C, c), D2 = ldcf(cf, RCF_D2, m.C, c);
-    F8 o;
-    if (!TAN) {
+    F8 M1, M2, K0, DD1, E12;
+    if (TAN) {
+        M1 = ldcf(cf, RCF_M1, m.C, c); M2 = ldcf(cf, RCF_M2, m.C, c); K0 = ldcf(cf, RCF_K0, m.C, c);
+        DD1 = ldcf(cf, RCF_DD1, m.C, c); E12 = ldcf(cf, RCF_E12, m.C, c);
+    }
+    const unsigned pbeg = blockIdx.x * (unsigned)RB, pend = min(npix, pbeg + (unsigned)RB);
+    const long base = (long)b * npix * m.C + c;
+    for (unsigned p0 = pbeg + rg; p0 < pend; p0 += UNR * nrg) {
+        u32x4 uv[UNR], dav[UNR], udv[UNR], dadv[UNR]; bool in[UNR], ok[UNR];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = A.v[j] * uv.v[j] + C0.v[j];
-            const float xh = (uv.v[j] - MU.v[j]) * R.v[j];
-            o.v[j] = A.v[j] * (dav.v[j] * lmask(v) - D1.v[j] - xh * D2.v[j]);
+        for (int k = 0; k < UNR; ++k) {
+            const unsigned p = p0 + k * nrg;
+            ok[k] = p < pend; in[k] = ok[k] && interior32(p, m.g);
+            const long off = base + (long)(ok[k] ? p : pbeg) * m.C;
+            uv[k] = *(const u32x4*)(u + off); dav[k] = *(const u32x4*)(da + off);
+            if (TAN) { udv[k] = *(const u32x4*)(ud + off); dadv[k] = *(const u32x4*)(dad + off); }
         }
-    } else {
-        const F8 udv = ldbf(ud + off), dadv = ldbf(dad + off);
-        const F8 M1 = ldcf(cf, RCF_M1, m.C, c), M2 = ldcf(cf, RCF_M2, m.C, c), K0 = ldcf(cf, RCF_K0, m.C, c),
-                 DD1 = ldcf(cf, RCF_DD1, m.C, c), E12 = ldcf(cf, RCF_E12, m.C, c);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = A.v[j] * uv.v[j] + C0.v[j], mk = lmask(v);
-            const float xh = (uv.v[j] - MU.v[j]) * R.v[j];
-            const float xhd = R.v[j] * (udv.v[j] - M1.v[j] - xh * M2.v[j]);
-            const float dv = dav.v[j] * mk, dvd = dadv.v[j] * mk;
-            o.v[j] = K0.v[j] * (dv - D1.v[j] - xh * D2.v[j]) + A.v[j] * (dvd - DD1.v[j] - xhd * D2.v[j] - xh * E12.v[j]);
+        for (int k = 0; k < UNR; ++k) {
+            if (!ok[k]) continue;
+            const unsigned p = p0 + k * nrg;
+            const F8 uf = unpack8(uv[k]), daf = unpack8(dav[k]);
+            F8 o;
+            if (!TAN) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = A.v[j] * uf.v[j] + C0.v[j];
+                    const float xh = (uf.v[j] - MU.v[j]) * R.v[j];
+                    o.v[j] = A.v[j] * (daf.v[j] * lmask(v) - D1.v[j] - xh * D2.v[j]);
+                }
+            } else {
+                const F8 udf = unpack8(udv[k]), dadf = unpack8(dadv[k]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = A.v[j] * uf.v[j] + C0.v[j], mk = lmask(v);
+                    const float xh = (uf.v[j] - MU.v[j]) * R.v[j];
+                    const float xhd = R.v[j] * (udf.v[j] - M1.v[j] - xh * M2.v[j]);
+                    const float dv = daf.v[j] * mk, dvd = dadf.v[j] * mk;
+                    o.v[j] = K0.v[j] * (dv - D1.v[j] - xh * D2.v[j]) + A.v[j] * (dvd - DD1.v[j] - xhd * D2.v[j] - xh * E12.v[j]);
+                }
+            }
+            *(u32x4*)(du + base + (long)p * m.C) = in[k] ? pack8(o) : (u32x4){0u, 0u, 0u, 0u};
         }
     }
-    *(u32x4*)(du + off) = pack8(o);
 }
 
 // ---- residual join: s = BN3(u3) + BNs(us), o = maxpool2(lrelu(s)) ----------------------------------------------------------------------
@@ -351,9 +407,10 @@ __global__ __launch_bounds__(256) void rn_join_reduce_kernel(RnJoin J, const rbf
     }
 }
 
-// du3 / dus of ONE pixel from its ds (ds' in the tangent pass)
+// (one-cell-per-thread form, kept for the TANGENT pass: with its 22 coefficient vectors the cell-walking form below spills)
+// du3 / dus of ONE pixel from its ds (ds' in the tangent pass), coefficients loaded per pixel
 template <bool TAN>
-__device__ __forceinline__ void join_apply_pixel(const RnJoin& J, const float* c3, const float* cs, const JoinCoef& k, long off, int c,
+__device__ __forceinline__ void join_apply_pixel_ld(const RnJoin& J, const float* c3, const float* cs, const JoinCoef& k, long off, int c,
                                                  const F8& u3, const F8& us, const float ds[8], const float dsd[8], rbf16* du3, rbf16* dus) {
     const int C = J.m.C;
     const F8 MU3 = ldcf(c3, RCF_MU, C, c), R3 = ldcf(c3, RCF_R, C, c), MUs = ldcf(cs, RCF_MU, C, c), Rs = ldcf(cs, RCF_R, C, c);
@@ -388,7 +445,7 @@ __device__ __forceinline__ void join_apply_pixel(const RnJoin& J, const float* c
 // y in {2 cy - 1, 2 cy}, x in {2 cx - 1, 2 cx}), so a cell is either a whole pooling window (1 <= cy <= Ho, 1 <= cx <= Wo) or lies
 // on the rim: border pixels (zeros) and interior pixels no window covers (odd H / W: ds = 0).
 template <bool TAN>
-__global__ __launch_bounds__(256) void rn_join_apply_kernel(RnJoin J, const rbf16* dout, const rbf16* doutd, rbf16* du3, rbf16* dus,
+__global__ __launch_bounds__(256) void rn_join_apply_cell_kernel(RnJoin J, const rbf16* dout, const rbf16* doutd, rbf16* du3, rbf16* dus,
                                                             int ncy, int ncx) {
     const int b = blockIdx.y, C = J.m.C, nch = C >> 3;
     const unsigned nci = (unsigned)ncy * ncx, ncell = (unsigned)J.m.M * nci;
@@ -419,7 +476,7 @@ __global__ __launch_bounds__(256) void rn_join_apply_kernel(RnJoin J, const rbf1
                 const float mk = w.am[j] == q ? w.lm[j] : 0.f;
                 ds[j] = dov.v[j] * mk; dsd[j] = TAN ? dodv.v[j] * mk : 0.f;
             }
-            join_apply_pixel<TAN>(J, c3 + z, cs + z, k, off[q], c, unpack8(w.u3[q]), unpack8(w.us[q]), ds, dsd, du3, dus);
+            join_apply_pixel_ld<TAN>(J, c3 + z, cs + z, k, off[q], c, unpack8(w.u3[q]), unpack8(w.us[q]), ds, dsd, du3, dus);
         }
         return;
     }
@@ -434,7 +491,114 @@ __global__ __launch_bounds__(256) void rn_join_apply_kernel(RnJoin J, const rbf1
             *(u32x4*)(du3 + off) = (u32x4){0u, 0u, 0u, 0u}; *(u32x4*)(dus + off) = (u32x4){0u, 0u, 0u, 0u};
             continue;
         }
-        join_apply_pixel<TAN>(J, c3, cs, k, off, c, ldbf(J.u3 + off), ldbf(J.us + off), ds, dsd, du3, dus);
+        join_apply_pixel_ld<TAN>(J, c3, cs, k, off, c, ldbf(J.u3 + off), ldbf(J.us + off), ds, dsd, du3, dus);
+    }
+}
+
+// du3 / dus of ONE pixel from its ds (ds' in the tangent pass); the coefficient vectors of the thread's channel chunk are loaded
+// once per thread (JoinApplyCoef) -- the thread walks cells
+template <bool TAN>
+struct JoinApplyCoef {
+    F8 MU3, R3, MUs, Rs, D13, D23, D1s, D2s;                    // (the ten tangent-only vectors are re-loaded per pixel: with all 22 in
+    __device__ __forceinline__ void load(const float* c3, const float* cs, int C, int c) {       //  registers the kernel spills)
+        MU3 = ldcf(c3, RCF_MU, C, c); R3 = ldcf(c3, RCF_R, C, c); MUs = ldcf(cs, RCF_MU, C, c); Rs = ldcf(cs, RCF_R, C, c);
+        D13 = ldcf(c3, RCF_D1, C, c); D23 = ldcf(c3, RCF_D2, C, c); D1s = ldcf(cs, RCF_D1, C, c); D2s = ldcf(cs, RCF_D2, C, c);
+    }
+};
+template <bool TAN>
+__device__ __forceinline__ void join_apply_pixel(const JoinCoef& k, const JoinApplyCoef<TAN>& q, const float* c3, const float* cs, int C, int c,
+                                                 const F8& u3, const F8& us, const F8& u3d, const F8& usd, const float ds[8],
+                                                 const float dsd[8], rbf16* du3, rbf16* dus, long off) {
+    F8 o3, os;
+    if (!TAN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh3 = (u3.v[j] - q.MU3.v[j]) * q.R3.v[j], xhs = (us.v[j] - q.MUs.v[j]) * q.Rs.v[j];
+            o3.v[j] = k.A3.v[j] * (ds[j] - q.D13.v[j] - xh3 * q.D23.v[j]);
+            os.v[j] = k.As.v[j] * (ds[j] - q.D1s.v[j] - xhs * q.D2s.v[j]);
+        }
+    } else {
+        {
+            const F8 M13 = ldcf(c3, RCF_M1, C, c), M23 = ldcf(c3, RCF_M2, C, c), K03 = ldcf(c3, RCF_K0, C, c), DD13 = ldcf(c3, RCF_DD1, C, c),
+                     E3 = ldcf(c3, RCF_E12, C, c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh3 = (u3.v[j] - q.MU3.v[j]) * q.R3.v[j];
+                const float xh3d = q.R3.v[j] * (u3d.v[j] - M13.v[j] - xh3 * M23.v[j]);
+                o3.v[j] = K03.v[j] * (ds[j] - q.D13.v[j] - xh3 * q.D23.v[j]) + k.A3.v[j] * (dsd[j] - DD13.v[j] - xh3d * q.D23.v[j] - xh3 * E3.v[j]);
+            }
+        }
+        {
+            const F8 M1s = ldcf(cs, RCF_M1, C, c), M2s = ldcf(cs, RCF_M2, C, c), K0s = ldcf(cs, RCF_K0, C, c), DD1s = ldcf(cs, RCF_DD1, C, c),
+                     Es = ldcf(cs, RCF_E12, C, c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xhs = (us.v[j] - q.MUs.v[j]) * q.Rs.v[j];
+                const float xhsd = q.Rs.v[j] * (usd.v[j] - M1s.v[j] - xhs * M2s.v[j]);
+                os.v[j] = K0s.v[j] * (ds[j] - q.D1s.v[j] - xhs * q.D2s.v[j]) + k.As.v[j] * (dsd[j] - DD1s.v[j] - xhsd * q.D2s.v[j] - xhs * Es.v[j]);
+            }
+        }
+    }
+    *(u32x4*)(du3 + off) = pack8(o3);
+    *(u32x4*)(dus + off) = pack8(os);
+}
+
+// thread = (row group rg, 8-channel chunk ch) walking 2 x 2 CELLS of the padded grid: cell (cy, cx) = padded pixels y in {2 cy - 1,
+// 2 cy}, x in {2 cx - 1, 2 cx}, so a cell is either a whole pooling window (1 <= cy <= Ho, 1 <= cx <= Wo) or lies on the rim: border
+// pixels (zeros) and interior pixels no window covers (odd H / W: ds = 0).  (One cell per thread re-loaded the 10 / 22 coefficient
+// vectors of its chunk for every pixel: 3.2-3.4 TB/s; the reductions, which walk with their coefficients in registers, move 6.)
+template <bool TAN>
+__global__ __launch_bounds__(256) void rn_join_apply_kernel(RnJoin J, const rbf16* dout, const rbf16* doutd, rbf16* du3, rbf16* dus,
+                                                            int ncy, int ncx, unsigned CB) {
+    const int b = blockIdx.y, C = J.m.C, nch = C >> 3, nrg = 256 / nch;
+    const unsigned nci = (unsigned)ncy * ncx, ncell = (unsigned)J.m.M * nci;
+    const int ch = threadIdx.x % nch, rg = threadIdx.x / nch, c = ch * 8;
+    if (rg >= nrg) return;
+    const float* c3 = J.coef3 + (long)b * RCF_N * C; const float* cs = J.coefs + (long)b * RCF_N * C;
+    const JoinCoef k = join_coef(c3, cs, C, c);
+    JoinApplyCoef<TAN> q; q.load(c3, cs, C, c);
+    const unsigned cbeg = blockIdx.x * CB, cend = min(ncell, cbeg + CB);
+    float ds[8], dsd[8];
+    const F8 zf = unpack8((u32x4){0u, 0u, 0u, 0u});
+    for (unsigned cell = cbeg + rg; cell < cend; cell += nrg) {
+        const unsigned img = cell / nci, q0 = cell - img * nci;
+        const int cy = (int)(q0 / (unsigned)ncx), cx = (int)(q0 - (unsigned)cy * ncx);
+        if (cy >= 1 && cy <= J.Ho && cx >= 1 && cx <= J.Wo) {
+            long off[4];
+            const long doff = join_offsets(J, b, img, cy - 1, cx - 1, c, off);
+            JoinWin w;
+            join_window(J, k, off, c, w);
+            const F8 dov = ldbf(dout + doff);
+            F8 dodv;
+            if (TAN) dodv = ldbf(doutd + doff);
+#pragma unroll
+            for (int p_ = 0; p_ < 4; ++p_) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float mk = w.am[j] == p_ ? w.lm[j] : 0.f;
+                    ds[j] = dov.v[j] * mk; dsd[j] = TAN ? dodv.v[j] * mk : 0.f;
+                }
+                int z = 0;
+                if (TAN) asm volatile("s_mov_b32 %0, 0" : "=s"(z));       // (opaque: keeps the per-pixel coefficient loads per pixel)
+                join_apply_pixel<TAN>(k, q, c3 + z, cs + z, C, c, unpack8(w.u3[p_]), unpack8(w.us[p_]), TAN ? ldbf(J.u3d + off[p_] + z) : zf,
+                                      TAN ? ldbf(J.usd + off[p_] + z) : zf, ds, dsd, du3, dus, off[p_]);
+            }
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ds[j] = 0.f; dsd[j] = 0.f; }
+        const long imgbase = ((long)b * J.m.M + img) * J.m.g.Pp;
+        for (int p_ = 0; p_ < 4; ++p_) {
+            const int y = 2 * cy - 1 + (p_ >> 1), x = 2 * cx - 1 + (p_ & 1);
+            if (y < 0 || y >= J.m.g.Hp || x < 0 || x >= J.m.g.Wp) continue;
+            const long off = (imgbase + (long)y * J.m.g.Wp + x) * C + c;
+            if (y < 1 || y > J.m.g.H || x < 1 || x > J.m.g.W) {
+                *(u32x4*)(du3 + off) = (u32x4){0u, 0u, 0u, 0u}; *(u32x4*)(dus + off) = (u32x4){0u, 0u, 0u, 0u};
+                continue;
+            }
+            join_apply_pixel<TAN>(k, q, c3, cs, C, c, ldbf(J.u3 + off), ldbf(J.us + off), TAN ? ldbf(J.u3d + off) : zf,
+                                  TAN ? ldbf(J.usd + off) : zf, ds, dsd, du3, dus, off);
+        }
     }
 }
 
@@ -565,11 +729,16 @@ int launch_rn_coef(hipStream_t st, const RnCoefArgs& a0, float* scratch) {
 }
 
 static inline dim3 unit_grid(const RnMap& m, long npix) { return dim3((unsigned)((npix * (m.C >> 3) + 255) / 256), m.B); }
+// pixels per workgroup of the pixel-looped map passes: every thread walks ~8 pixels (per-episode quantities only)
+static inline int map_rb(const RnMap& m) { return (256 / (m.C >> 3)) * 8; }
 
 int launch_rn_act(hipStream_t st, const RnMap& m, const rbf16* u, const rbf16* ud, const float* coef, rbf16* out) {
     const long npix = (long)m.M * m.g.Pp;
-    if (ud) hipLaunchKernelGGL(rn_act_kernel<true>, unit_grid(m, npix), dim3(256), 0, st, m, u, ud, coef, out);
-    else hipLaunchKernelGGL(rn_act_kernel<false>, unit_grid(m, npix), dim3(256), 0, st, m, u, ud, coef, out);
+    if ((m.C >> 3) > 256 || npix >= (1L << 31)) return FUMI_ENOTSUP;
+    const int rb = map_rb(m);
+    const dim3 grid((unsigned)((npix + rb - 1) / rb), m.B);
+    if (ud) hipLaunchKernelGGL(rn_act_kernel<true>, grid, dim3(256), 0, st, m, u, ud, coef, out, rb);
+    else hipLaunchKernelGGL(rn_act1_kernel, unit_grid(m, npix), dim3(256), 0, st, m, u, coef, out);
     LAUNCH_CHECK();
     return FUMI_OK;
 }
@@ -600,8 +769,11 @@ int launch_rn_bwd_reduce(hipStream_t st, const RnMap& m, const rbf16* u, const r
 int launch_rn_bwd_apply(hipStream_t st, const RnMap& m, const rbf16* u, const rbf16* ud, const rbf16* da, const rbf16* dad,
                         const float* coef, rbf16* du, int tangent) {
     const long npix = (long)m.M * m.g.Pp;
-    if (tangent) hipLaunchKernelGGL(rn_bwd_apply_kernel<true>, unit_grid(m, npix), dim3(256), 0, st, m, u, ud, da, dad, coef, du);
-    else hipLaunchKernelGGL(rn_bwd_apply_kernel<false>, unit_grid(m, npix), dim3(256), 0, st, m, u, ud, da, dad, coef, du);
+    if ((m.C >> 3) > 256 || npix >= (1L << 31)) return FUMI_ENOTSUP;
+    const int rb = map_rb(m);
+    const dim3 grid((unsigned)((npix + rb - 1) / rb), m.B);
+    if (tangent) hipLaunchKernelGGL(rn_bwd_apply_kernel<true>, grid, dim3(256), 0, st, m, u, ud, da, dad, coef, du, rb);
+    else hipLaunchKernelGGL(rn_bwd_apply_kernel<false>, grid, dim3(256), 0, st, m, u, ud, da, dad, coef, du, rb);
     LAUNCH_CHECK();
     return FUMI_OK;
 }
@@ -637,9 +809,15 @@ int launch_rn_join_reduce(hipStream_t st, const RnJoin& j, const rbf16* dout, co
 int launch_rn_join_apply(hipStream_t st, const RnJoin& j, const rbf16* dout, const rbf16* doutd, rbf16* du3, rbf16* dus, int tangent) {
     const int ncy = j.m.g.Hp / 2 + 1, ncx = j.m.g.Wp / 2 + 1;          // cells (2 cy - 1 .. 2 cy) cover padded rows 0 .. Hp - 1
     const long ncell = (long)j.m.M * ncy * ncx;
-    if (ncell * (j.m.C >> 3) >= (1L << 32) - 256) return FUMI_ENOTSUP;
-    if (tangent) hipLaunchKernelGGL(rn_join_apply_kernel<true>, unit_grid(j.m, ncell), dim3(256), 0, st, j, dout, doutd, du3, dus, ncy, ncx);
-    else hipLaunchKernelGGL(rn_join_apply_kernel<false>, unit_grid(j.m, ncell), dim3(256), 0, st, j, dout, doutd, du3, dus, ncy, ncx);
+    if ((j.m.C >> 3) > 256 || ncell * (j.m.C >> 3) >= (1L << 32) - 256) return FUMI_ENOTSUP;
+    if (tangent) {                                                       // one cell per thread (see rn_join_apply_cell_kernel)
+        hipLaunchKernelGGL(rn_join_apply_cell_kernel<true>, unit_grid(j.m, ncell), dim3(256), 0, st, j, dout, doutd, du3, dus, ncy, ncx);
+        LAUNCH_CHECK();
+        return FUMI_OK;
+    }
+    const unsigned cb = (unsigned)(256 / (j.m.C >> 3)) * 4;              // cells per workgroup: every thread walks ~4 cells (16 pixels)
+    const dim3 grid((unsigned)((ncell + cb - 1) / cb), j.m.B);
+    hipLaunchKernelGGL(rn_join_apply_kernel<false>, grid, dim3(256), 0, st, j, dout, doutd, du3, dus, ncy, ncx, cb);
     LAUNCH_CHECK();
     return FUMI_OK;
 }
