@@ -381,3 +381,39 @@ def check_step(hip, ws, dev, run, ep, theta, head0, channels, T, alpha, hvp_step
         hip.resnet12_set_option(1, 0)
         hip.resnet12_set_option(0, 0)
     return chk, lay, final
+
+
+def check_first_order(hip, ws, dev, run, ep, theta, head0, channels, T, alpha):
+    """First-order step (MAML `--first_order`, maml.py:173-177) or T = 0: one tape reused by every inner step, two alternating
+    parameter slots, no Hessian-vector products -- the last support pass, the query pass and `bar` = the query pass's gradient."""
+    B, S = ep["x_s"].shape[:2]
+    Qn, Cimg, H = ep["x_q"].shape[1], ep["x_s"].shape[2], ep["x_s"].shape[3]
+    N, Fd = head0.shape[1], channels[-1]
+    lay = Layout(channels, Cimg, H)
+    chk = Checker()
+    hip.resnet12_set_option(0, 1)
+    try:
+        out = run()
+        assert ws.read_status() == 0
+        E = Engine(hip, ws, dev, lay, B, N, S, Qn, T, Cimg)
+        slots = [E.f32(-1, 0, (B, lay.PSZ), idx=i) for i in range(2)]
+        heads = [E.f32(-1, 1, (B, N, Fd + 1), idx=i) for i in range(2)]
+        bar, barh = E.f32(-1, 4, (B, lay.PSZ)), E.f32(-1, 5, (B, N, Fd + 1))
+        zq = out["logits"].cpu().double()
+        cur = T % 2                                                    # the slot the query pass reads
+        for b in range(B):
+            tg = f"fo e{b}"
+            if T > 0:                                                  # the tape holds the LAST inner step (slot (T - 1) % 2 -> slot T % 2)
+                prev = (T - 1) % 2
+                Gl, dhl = E.f32(-1, 2, (B, lay.PSZ), idx=0), E.f32(-1, 3, (B, N, Fd + 1), idx=0)
+                E.T = T
+                check_pass(E, chk, f"{tg} t{T - 1}", 0, b, slots[prev][b], heads[prev][b], ep["y_s"][b], 1.0 / S, Gl[b], dhl[b])
+                chk.vec(f"{tg} slot", slots[cur][b], slots[prev][b] - alpha * Gl[b], 1e-6)
+                chk.vec(f"{tg} head", heads[cur][b], heads[prev][b] - alpha * dhl[b], 1e-6)
+            else:
+                th0 = torch.cat([t.reshape(-1).double() for t in theta])
+                chk.vec(f"{tg} slot0", slots[0][b][:th0.numel()], th0, 1e-7)
+            check_pass(E, chk, f"{tg} q", T, b, slots[cur][b], heads[cur][b], ep["y_q"][b], 1.0 / Qn, bar[b], barh[b], z_ext=zq[b])
+    finally:
+        hip.resnet12_set_option(0, 0)
+    return chk, lay, (out, bar, barh)

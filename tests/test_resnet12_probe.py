@@ -153,6 +153,22 @@ def test_fumi_form_hypernetwork_gradients_from_the_engines_head_adjoints(dev, ws
         chk.assert_ok()
 
 
+@pytest.mark.parametrize("T", [0, 2, 3])
+def test_first_order_and_zero_step_forms(T, dev, ws):
+    """MAML `--first_order` (maml.py:173-177) and T = 0: one reused tape and two alternating parameter slots instead of a tape per
+    step -- the last support pass, the query pass with the slot it must read, and the meta-gradient = the query pass's own gradient."""
+    from fumi_amd import hip
+    channels, H, B, N, alpha = (32, 64, 96), 8, 2, 3, 0.05
+    ep, theta, Wf, bfin = _case(36 + T, B, N, 2, 2, H, channels)
+    head0 = torch.cat([Wf, bfin[:, None]], 1).double()[None].expand(B, -1, -1)
+    d = {k: ep[k].to(dev) for k in ("x_s", "y_s", "x_q", "y_q")}
+    params = [t.to(dev) for t in theta + [Wf, bfin]]
+    run = lambda: hip.maml_resnet12_step(ws, d["x_s"], d["y_s"], d["x_q"], d["y_q"], params, T, alpha, True)
+    chk, lay, final = ST.check_first_order(hip, ws, dev, run, ep, theta, head0, channels, T, alpha)
+    _check_meta_gradient(chk, lay, final, B, len(theta))
+    chk.assert_ok()
+
+
 def test_probe_refuses_without_a_probe_mode_step(dev, ws):
     from fumi_amd import hip
     channels, H, B, N = (32,), 8, 2, 3
