@@ -82,7 +82,7 @@ int fumi_hip_workspace_create(int device, size_t bytes_hint, fumi_ws_t** out) {
     if (device < 0 || device >= ndev) return FUMI_EINVAL;
     HIP_TRY(hipSetDevice(device));
     fumi_ws* ws = new fumi_ws();
-    ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr; ws->hcnt = nullptr; ws->acnt = nullptr; ws->w0p = nullptr; ws->w0p_cap = 0; ws->side_buf = nullptr; ws->side_cap = 0; ws->pub_src = nullptr; ws->pub_dst = nullptr; ws->pub_n = 0; ws->pub_seq = 0; ws->adam = nullptr; ws->glove = nullptr;
+    ws->device = device; ws->base = nullptr; ws->cap = 0; ws->off = 0; ws->status = nullptr; ws->status_host = nullptr; ws->hcnt = nullptr; ws->acnt = nullptr; ws->w0p = nullptr; ws->w0p_cap = 0; ws->side_buf = nullptr; ws->side_cap = 0; ws->pub_src = nullptr; ws->pub_dst = nullptr; ws->pub_n = 0; ws->pub_seq = 0; ws->adam = nullptr; ws->glove = nullptr; ws->text_grad = nullptr;
     ws->profiling = 0; ws->prof_every = 1; memset(ws->prof_seen, 0, sizeof(ws->prof_seen)); ws->recs = new std::vector<ProfRec>(); ws->pool = new std::vector<hipEvent_t>();
     ws->side = nullptr; ws->lane = nullptr;
     for (int i = 0; i < 3; ++i) { ws->lanes[i] = nullptr; ws->lane_ev[i] = nullptr; }
@@ -331,9 +331,12 @@ static int fumi_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     HyperBwdArgs brider;
     struct BwdCtx { hipStream_t st; const HyperBwdArgs* a; } bctx{st, &brider};
     bool fused_bwd = false;
+    // an armed text gradient (fumi_hip_fumi_want_text_grad) needs ubar [R,Ht] in memory: every form of the backward leaves it in ub
+    float* text_grad = need_grad ? ws->text_grad : nullptr;
+    if (need_grad) ws->text_grad = nullptr;
     if (need_grad && !fork_bwd && hbf &&
         hyper_bwd_fused_args(R, Dt, Ht, H1, tanh_head, 1.f, ctext, u, h, hbar, phi[2], hbf, g_phi[0], g_phi[1], g_phi[2], g_phi[3],
-                             &fin, &brider)) {
+                             &fin, &brider, text_grad ? ub : nullptr)) {
         fused_bwd = true;
         p.bwd_rider = &brider;
         p.bwd_rider_fallback = [](void* c) -> int { BwdCtx* x = (BwdCtx*)c; return launch_hyper_bwd_fused(x->st, *x->a); };
@@ -369,6 +372,11 @@ static int fumi_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     return FUMI_OK;
     }();
     if (rc) return rc;
+    if (text_grad) {                                                 // d(scale * sum_b loss_b) / d ctext = scale * ubar A0   [R,Dt]
+        g = gemm_args(R, Dt, Ht, ub, Ht, phi[0], Dt, text_grad, Dt);
+        g.alpha = grad_scale;
+        if ((rc = launch_gemm(sh, g, 0, 1))) return rc;
+    }
     if (fork_bwd) {                                                  // join: the caller's stream owns every result again
         HIP_TRY(hipEventRecord(ws->ev[3], sh));
         HIP_TRY(hipStreamWaitEvent(st, ws->ev[3], 0));
@@ -377,6 +385,12 @@ static int fumi_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
         ProfScope pr(ws, st, FUMI_PH_REDUCE);
         if ((rc = launch_reduce_multi_final(ws, st, fin))) return rc;      // (+ a deferred optimizer step and publication)
     }
+    return FUMI_OK;
+}
+
+int fumi_hip_fumi_want_text_grad(fumi_ws_t* ws, float* g_cls_text) {
+    if (!ws) return FUMI_EINVAL;
+    ws->text_grad = g_cls_text;
     return FUMI_OK;
 }
 

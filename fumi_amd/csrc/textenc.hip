@@ -2,8 +2,9 @@
 //   * CLIP baseline (fumi/models/clip.py:11-41 forward, :96-108 training step): two Linear.ReLU.Linear towers, cosine
 //     similarity of every (text, image) pair, symmetric cross-entropy against the diagonal.  Linears on the GEMM family
 //     (gemm.hip); the normalisation, the two soft-maxes and their backward through the norms are the kernels here.
-//   * bi-LSTM text encoders RNN / RnnHid (fumi/models/common.py:44-161), forward only (the encoder is frozen unless
-//     --fine_tune): input projections of all tokens as one GEMM per direction, then L dependent steps of [R,H] x [H,4H] + gates.
+//   * bi-LSTM text encoders RNN / RnnHid (fumi/models/common.py:44-161): input projections of all tokens as one GEMM per
+//     direction, then L dependent steps of [R,H] x [H,4H] + gates.  Frozen encoders (the default, fumi.py:65-67) use the
+//     forward-only entry; --fine_tune uses the tape-keeping forward and back-propagation through time below it.
 #include "common.h"
 #include <string.h>
 
@@ -92,6 +93,57 @@ __global__ void lstm_gate_kernel(int R, int H, int L, int t, const int64_t* tok,
     const float cn = sigm(gf) * c[id] + sigm(gi) * tanhf(gg);
     c[id] = cn;
     h[id] = sigm(go) * tanhf(cn);
+}
+
+// the same step keeping what back-propagation needs, all indexed [r][t]: the four gate activations, the incoming h and c, tanh(c_t)
+__global__ void lstm_gate_tape_kernel(int R, int H, int L, int t, const int64_t* tok, int64_t pad, const float* pre, const float* rec,
+                                      const float* b_hh, float* c, float* h, float* gates, float* hprev, float* cprev, float* tcs) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long)R * H) return;
+    const int r = (int)(id / H), j = (int)(id - (long)r * H);
+    int len = 0;
+    for (int k = 0; k < L; ++k) len += tok[(long)r * L + k] != pad;
+    if (t >= len) return;                                                  // (hprev of such steps stays at the memset's zeros)
+    const long rt = (long)r * L + t;
+    const float* p = pre + rt * 4 * H;
+    const float* q = rec + (long)r * 4 * H;
+    const float gi = sigm(p[j] + q[j] + b_hh[j]), gf = sigm(p[H + j] + q[H + j] + b_hh[H + j]);
+    const float gg = tanhf(p[2 * H + j] + q[2 * H + j] + b_hh[2 * H + j]), go = sigm(p[3 * H + j] + q[3 * H + j] + b_hh[3 * H + j]);
+    const float cp = c[id], cn = gf * cp + gi * gg, tc = tanhf(cn);
+    float* gt = gates + rt * 4 * H;
+    gt[j] = gi; gt[H + j] = gf; gt[2 * H + j] = gg; gt[3 * H + j] = go;
+    hprev[rt * H + j] = h[id]; cprev[rt * H + j] = cp; tcs[rt * H + j] = tc;
+    c[id] = cn;
+    h[id] = go * tc;
+}
+
+// one step of back-propagation through time for one direction (dir 0 walks t = L-1..0, dir 1 walks t = 0..L-1).  A row is active
+// at t < len; the adjoint of its state comes from the step processed just before (rec = dgates W_hh, and dc) or, at the row's
+// first step of this walk, from the encoder's output adjoint d_out[r][dir*H + j] (on h for RNN, on c for RnnHid).
+__global__ void lstm_gate_bwd_kernel(int R, int H, int L, int t, int dir, const int64_t* tok, int64_t pad, const float* gates,
+                                     const float* cprev, const float* tcs, const float* d_out, int use_cell, const float* rec,
+                                     float* dc, float* dgates) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long)R * H) return;
+    const int r = (int)(id / H), j = (int)(id - (long)r * H);
+    int len = 0;
+    for (int k = 0; k < L; ++k) len += tok[(long)r * L + k] != pad;
+    const long rt = (long)r * L + t;
+    float* dg = dgates + rt * 4 * H;
+    if (t >= len) { dg[j] = 0.f; dg[H + j] = 0.f; dg[2 * H + j] = 0.f; dg[3 * H + j] = 0.f; return; }
+    const bool chained = dir == 0 ? (t + 1 < len) : (t >= 1);
+    const float seed = d_out[(long)r * 2 * H + dir * H + j];
+    const float dh = chained ? rec[id] : (use_cell ? 0.f : seed);
+    const float dcin = chained ? dc[id] : (use_cell ? seed : 0.f);
+    const float* gt = gates + rt * 4 * H;
+    const float gi = gt[j], gf = gt[H + j], gg = gt[2 * H + j], go = gt[3 * H + j];
+    const float tc = tcs[rt * H + j], cp = cprev[rt * H + j];
+    const float dct = dcin + dh * go * (1.f - tc * tc);
+    dg[j] = dct * gg * gi * (1.f - gi);
+    dg[H + j] = dct * cp * gf * (1.f - gf);
+    dg[2 * H + j] = dct * gi * (1.f - gg * gg);
+    dg[3 * H + j] = dh * tc * go * (1.f - go);
+    dc[id] = dct * gf;
 }
 
 // out[r][d*H + j] = state_d[r][j]
@@ -207,6 +259,102 @@ int fumi_hip_lstm_bidir(fumi_ws_t* ws, fumi_stream_t stream, int R, int L, int E
     float** fin = use_cell ? cs : hs;
     hipLaunchKernelGGL(lstm_out_kernel, dim3(nblk((long)R * 2 * H)), dim3(256), 0, st, R, H, fin[0], fin[1], out);
     LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+// tape of a training-mode forward, floats: x [R,L,E] | per direction: gates [R,L,4H], hprev [R,L,H], cprev [R,L,H], tanh_c [R,L,H]
+int64_t fumi_hip_lstm_tape_floats(int R, int L, int E, int H) {
+    if (R < 1 || L < 1 || E < 1 || H < 1) return 0;
+    return (int64_t)R * L * E + 2 * (int64_t)R * L * 7 * H;
+}
+
+namespace {
+struct LstmTape { float* x; float* gates[2]; float* hprev[2]; float* cprev[2]; float* tc[2]; };
+LstmTape lstm_tape(float* tape, size_t RL, int E, int H) {
+    LstmTape t;
+    t.x = tape; tape += RL * E;
+    for (int d = 0; d < 2; ++d) {
+        t.gates[d] = tape; tape += RL * 4 * H;
+        t.hprev[d] = tape; tape += RL * H;
+        t.cprev[d] = tape; tape += RL * H;
+        t.tc[d] = tape; tape += RL * H;
+    }
+    return t;
+}
+}  // namespace
+
+int fumi_hip_lstm_bidir_train(fumi_ws_t* ws, fumi_stream_t stream, int R, int L, int E, int H,
+        const int64_t* tokens, int64_t pad_id, const float* table, int64_t V, const float* const* w, int use_cell, float* out,
+        float* tape) {
+    if (!ws || !tokens || !table || !w || !out || !tape || R < 1 || L < 1 || E < 1 || H < 1 || V < 1) return FUMI_EINVAL;
+    for (int i = 0; i < 8; ++i) if (!w[i]) return FUMI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ws->device));
+    const size_t RL = (size_t)R * L;
+    size_t bytes = 2 * ws_align(RL * 4 * H * 4) + ws_align((size_t)R * 4 * H * 4) + 4 * ws_align((size_t)R * H * 4);
+    int rc = ws_reserve(ws, bytes);
+    if (rc) return rc;
+    LstmTape tp = lstm_tape(tape, RL, E, H);
+    float* pre[2] = {ws_f(ws, RL * 4 * H), ws_f(ws, RL * 4 * H)};
+    float* rec = ws_f(ws, (size_t)R * 4 * H);
+    float* hs[2] = {ws_f(ws, (size_t)R * H), ws_f(ws, (size_t)R * H)};
+    float* cs[2] = {ws_f(ws, (size_t)R * H), ws_f(ws, (size_t)R * H)};
+    TRY(fumi_hip_gather_rows(ws, stream, table, V, (int64_t)E * 4, tokens, (int64_t)RL, tp.x));
+    for (int d = 0; d < 2; ++d) {
+        GemmArgs g = gemm_args((int)RL, 4 * H, E, tp.x, E, w[4 * d], E, pre[d], 4 * H);
+        g.bias = w[4 * d + 2];
+        TRY(launch_gemm(st, g, 0, 0));
+        HIP_TRY(hipMemsetAsync(hs[d], 0, (size_t)R * H * 4, st));
+        HIP_TRY(hipMemsetAsync(cs[d], 0, (size_t)R * H * 4, st));
+        HIP_TRY(hipMemsetAsync(tp.hprev[d], 0, RL * H * 4, st));          // steps past a row's length: a finite factor of their zero dgates
+    }
+    for (int d = 0; d < 2; ++d)
+        for (int s = 0; s < L; ++s) {
+            const int t = d == 0 ? s : L - 1 - s;
+            GemmArgs g = gemm_args(R, 4 * H, H, hs[d], H, w[4 * d + 1], H, rec, 4 * H);
+            TRY(launch_gemm(st, g, 0, 0));
+            hipLaunchKernelGGL(lstm_gate_tape_kernel, dim3(nblk((long)R * H)), dim3(256), 0, st, R, H, L, t, tokens, pad_id, pre[d], rec,
+                               w[4 * d + 3], cs[d], hs[d], tp.gates[d], tp.hprev[d], tp.cprev[d], tp.tc[d]);
+            LAUNCH_CHECK();
+        }
+    float** fin = use_cell ? cs : hs;
+    hipLaunchKernelGGL(lstm_out_kernel, dim3(nblk((long)R * 2 * H)), dim3(256), 0, st, R, H, fin[0], fin[1], out);
+    LAUNCH_CHECK();
+    return FUMI_OK;
+}
+
+int fumi_hip_lstm_bidir_bwd(fumi_ws_t* ws, fumi_stream_t stream, int R, int L, int E, int H,
+        const int64_t* tokens, int64_t pad_id, const float* const* w, int use_cell, const float* tape, const float* d_out,
+        float* const* g_w) {
+    if (!ws || !tokens || !w || !tape || !d_out || !g_w || R < 1 || L < 1 || E < 1 || H < 1) return FUMI_EINVAL;
+    for (int i = 0; i < 8; ++i) if (!w[i] || !g_w[i]) return FUMI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(ws->device));
+    const size_t RL = (size_t)R * L;
+    size_t bytes = ws_align(RL * 4 * H * 4) + 2 * ws_align((size_t)R * H * 4);
+    int rc = ws_reserve(ws, bytes);
+    if (rc) return rc;
+    LstmTape tp = lstm_tape(const_cast<float*>(tape), RL, E, H);
+    float* dg = ws_f(ws, RL * 4 * H);
+    float* rec = ws_f(ws, (size_t)R * H);
+    float* dc = ws_f(ws, (size_t)R * H);
+    for (int d = 0; d < 2; ++d) {
+        for (int s = 0; s < L; ++s) {
+            const int t = d == 0 ? L - 1 - s : s;
+            hipLaunchKernelGGL(lstm_gate_bwd_kernel, dim3(nblk((long)R * H)), dim3(256), 0, st, R, H, L, t, d, tokens, pad_id, tp.gates[d],
+                               tp.cprev[d], tp.tc[d], d_out, use_cell, rec, dc, dg);
+            LAUNCH_CHECK();
+            if (s + 1 == L) break;
+            GemmArgs g = gemm_args(R, H, 4 * H, dg + (size_t)t * 4 * H, L * 4 * H, w[4 * d + 1], H, rec, H);   // dh_prev = dgates_t W_hh
+            TRY(launch_gemm(st, g, 0, 1));
+        }
+        GemmArgs g = gemm_args(4 * H, E, (int)RL, dg, 4 * H, tp.x, E, g_w[4 * d], E);                  // dW_ih = dgates^T x
+        TRY(launch_gemm(st, g, 1, 1));
+        g = gemm_args(4 * H, H, (int)RL, dg, 4 * H, tp.hprev[d], H, g_w[4 * d + 1], H);                // dW_hh = dgates^T h_prev
+        TRY(launch_gemm(st, g, 1, 1));
+        TRY(launch_colsum(st, dg, (int)RL, 4 * H, 4 * H, 1.f, g_w[4 * d + 2]));                        // both biases add to the same gate
+        TRY(launch_colsum(st, dg, (int)RL, 4 * H, 4 * H, 1.f, g_w[4 * d + 3]));
+    }
     return FUMI_OK;
 }
 

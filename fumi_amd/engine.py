@@ -86,6 +86,25 @@ class HipEngine:
     def lstm_bidir(self, tokens, table, lstm_w, pad_id, use_cell):
         return hip.lstm_bidir(self._ws(tokens), tokens, table, lstm_w, pad_id, use_cell)
 
+    def lstm_bidir_train(self, tokens, table, lstm_w, pad_id, use_cell):
+        """(out, tape): the forward of a trainable bi-LSTM encoder (--fine_tune with RNN / RNNhid, fumi/models/fumi.py:65-67)."""
+        return hip.lstm_bidir_train(self._ws(tokens), tokens, table, lstm_w, pad_id, use_cell)
+
+    def lstm_bidir_bwd(self, tokens, table, lstm_w, pad_id, use_cell, tape, d_out):
+        return hip.lstm_bidir_bwd(self._ws(tokens), tokens, table, lstm_w, pad_id, use_cell, tape, d_out)
+
+    def class_rows_select(self, rows_s, y_s, n_way):
+        """[B,N,...] the first support row of every class (fumi.py:207-210) of float32 OR int64 rows [B,S,W]: a pure row copy, so
+        token rows go through the float kernel as pairs of 32-bit words."""
+        if rows_s.dtype == torch.int64:
+            out = hip.class_text_select(self._ws(rows_s), rows_s.contiguous().view(torch.float32), y_s, n_way)
+            return out.view(torch.int64)
+        return hip.class_text_select(self._ws(rows_s), rows_s.contiguous(), y_s, n_way)
+
+    def fumi_want_text_grad(self, device, g_cls_text):
+        """The next fumi_step(need_grad=True) on `device` also writes d loss / d class text rows into g_cls_text [B,N,Dt]."""
+        hip.fumi_want_text_grad(hip.Workspace.get(torch.device(device)), g_cls_text)
+
     def am3_metrics(self, n_way, stats):
         return hip.am3_metrics(self._ws(stats), n_way, stats)
 

@@ -31,7 +31,8 @@ SYMBOLS = [
     "fumi_hip_resnet12_set_budget", "fumi_hip_fumi_resnet12_step", "fumi_hip_maml_resnet12_step", "fumi_hip_resnet12_features",
     "fumi_hip_rn12_conv", "fumi_hip_rn12_wgrad", "fumi_hip_resnet12_set_option", "fumi_hip_rn12_probe",
     "fumi_hip_conv3x3_fwd", "fumi_hip_conv3x3_bwd_data", "fumi_hip_conv3x3_bwd_weight",
-    "fumi_hip_sgd_axpy", "fumi_hip_ce_fwd_bwd", "fumi_hip_proto_reduce", "fumi_hip_clip_step", "fumi_hip_lstm_bidir",
+    "fumi_hip_sgd_axpy", "fumi_hip_ce_fwd_bwd", "fumi_hip_proto_reduce", "fumi_hip_clip_step", "fumi_hip_lstm_bidir", "fumi_hip_lstm_tape_floats", "fumi_hip_lstm_bidir_train", "fumi_hip_lstm_bidir_bwd",
+    "fumi_hip_fumi_want_text_grad",
 ]
 
 ST_LABEL_RANGE, ST_CLASS_MISSING, ST_SYNC_TIMEOUT = 1, 2, 4
@@ -181,6 +182,12 @@ def lib():
         L.fumi_hip_ce_fwd_bwd.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.fumi_hip_clip_step.argtypes = [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, PP, c_int, c_void_p, c_void_p, PP]
         L.fumi_hip_lstm_bidir.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_int64, c_void_p, c_int64, PP, c_int, c_void_p]
+        L.fumi_hip_lstm_tape_floats.argtypes = [c_int] * 4
+        L.fumi_hip_lstm_tape_floats.restype = c_int64
+        L.fumi_hip_lstm_bidir_train.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_int64, c_void_p, c_int64, PP, c_int,
+                                                c_void_p, c_void_p]
+        L.fumi_hip_lstm_bidir_bwd.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_int64, PP, c_int, c_void_p, c_void_p, PP]
+        L.fumi_hip_fumi_want_text_grad.argtypes = [c_void_p, c_void_p]
         L.fumi_hip_proto_reduce.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p] * 3
         _lib = L
     return _lib
@@ -1168,3 +1175,47 @@ def lstm_bidir(ws, tokens, table, lstm_w, pad_id, use_cell):
     _check(lib().fumi_hip_lstm_bidir(ws.handle, _stream(dev), R, L, E, H, _i64(tokens, "tokens"), int(pad_id), _f32(table, "table"), V,
                                      _parr(lstm_w, "lstm_w"), int(bool(use_cell)), _f32(out, "out")), "fumi_hip_lstm_bidir")
     return out
+
+
+def _lstm_dims(tokens, table, lstm_w):
+    L = tokens.shape[-1]
+    R = tokens.numel() // L
+    V, E = table.shape
+    H = int(lstm_w[1].shape[1])
+    for d in range(2):
+        _shape(lstm_w[4 * d], (4 * H, E), "weight_ih"); _shape(lstm_w[4 * d + 1], (4 * H, H), "weight_hh")
+        _shape(lstm_w[4 * d + 2], (4 * H,), "bias_ih"); _shape(lstm_w[4 * d + 3], (4 * H,), "bias_hh")
+    return R, L, V, E, H
+
+
+def lstm_bidir_train(ws, tokens, table, lstm_w, pad_id, use_cell):
+    """(out [..., 2H], tape): lstm_bidir keeping what lstm_bidir_bwd needs (--fine_tune with RNN / RNNhid, fumi.py:65-67)."""
+    dev = _dev(tokens)
+    R, L, V, E, H = _lstm_dims(tokens, table, lstm_w)
+    out = torch.empty(*tokens.shape[:-1], 2 * H, device=dev, dtype=torch.float32)
+    tape = torch.empty(int(lib().fumi_hip_lstm_tape_floats(R, L, E, H)), device=dev, dtype=torch.float32)
+    _check(lib().fumi_hip_lstm_bidir_train(ws.handle, _stream(dev), R, L, E, H, _i64(tokens, "tokens"), int(pad_id), _f32(table, "table"),
+                                           V, _parr(lstm_w, "lstm_w"), int(bool(use_cell)), _f32(out, "out"), _f32(tape, "tape")),
+           "fumi_hip_lstm_bidir_train")
+    return out, tape
+
+
+def lstm_bidir_bwd(ws, tokens, table, lstm_w, pad_id, use_cell, tape, d_out):
+    """Gradients of the 8 LSTM tensors for the output adjoint d_out [..., 2H] of the lstm_bidir_train call that wrote `tape`."""
+    dev = _dev(tokens)
+    R, L, V, E, H = _lstm_dims(tokens, table, lstm_w)
+    if tape.numel() != int(lib().fumi_hip_lstm_tape_floats(R, L, E, H)):
+        raise ValueError("tape: not the tape of a lstm_bidir_train call of these shapes")
+    if d_out.numel() != R * 2 * H:
+        raise ValueError(f"d_out: expected {R * 2 * H} elements, got {d_out.numel()}")
+    g_w = [torch.empty_like(t) for t in lstm_w]
+    _check(lib().fumi_hip_lstm_bidir_bwd(ws.handle, _stream(dev), R, L, E, H, _i64(tokens, "tokens"), int(pad_id), _parr(lstm_w, "lstm_w"),
+                                         int(bool(use_cell)), _f32(tape, "tape"), _f32(d_out, "d_out"), _parr(g_w, "g_w")),
+           "fumi_hip_lstm_bidir_bwd")
+    return g_w
+
+
+def fumi_want_text_grad(ws, g_cls_text):
+    """Arm the next fumi_step(need_grad=True) on ws to write d loss / d class text rows into g_cls_text [B*N, Dt] (None disarms)."""
+    _check(lib().fumi_hip_fumi_want_text_grad(ws.handle, None if g_cls_text is None else _f32(g_cls_text, "g_cls_text")),
+           "fumi_hip_fumi_want_text_grad")

@@ -3,9 +3,10 @@
 ``WordEmbedding`` (common.py:8-41) keeps its constructor, attributes (``embed``, ``embedding_dim``, ``padding_token``)
 and ``state_dict`` key (``embed.weight``); its forward is the HIP embedding-bag kernel (csrc/glove.hip).
 The bi-LSTM encoders ``RNN`` / ``RnnHid`` (common.py:44-161) keep their constructors, attributes and ``state_dict`` keys
-(``embed.weight``, ``rnn.weight_ih_l0`` ...); their forward is the engine's bidirectional-LSTM op (csrc/textenc.hip), forward
-only: like every text encoder they are frozen unless ``--fine_tune`` (fumi.py:65-67), and fine-tuning an LSTM is not
-supported by the engine.
+(``embed.weight``, ``rnn.weight_ih_l0`` ...); their forward is the engine's bidirectional-LSTM op (csrc/textenc.hip).  Like
+every text encoder they are frozen unless ``--fine_tune`` (fumi.py:65-67); under ``--fine_tune`` the LSTM is trained through
+``forward_train`` / ``backward`` (the engine's tape-keeping forward and back-propagation through time), which FUMI.evaluate
+drives with the text adjoint its meta-step returns.
 """
 import numpy as np
 import torch
@@ -104,12 +105,36 @@ class _BiLstmEncoder(nn.Module):
     def forward(self, x):
         """x: int64 tokens (b, N*K, L) -> (b, N*K, rnn_hid_dim): the forward direction's state at the last real token and the
         backward direction's at token 0 (common.py:98-107 / :154-161), i.e. each direction's final state."""
-        if any(p.requires_grad for p in self.parameters()) and torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("fine-tuning the bi-LSTM text encoder (--fine_tune with RNN / RNNhid) is not supported by "
-                                      "the engine: its LSTM op is forward only")
+        if self.trainable() and torch.is_grad_enabled() and self.training:
+            raise NotImplementedError("a trainable bi-LSTM text encoder (--fine_tune with RNN / RNNhid) is trained through "
+                                      "forward_train / backward (FUMI.evaluate does); this forward is the frozen encoder's")
         return _engine.get_engine().lstm_bidir(x.contiguous(), self.embed.weight.detach(),
                                                [w.detach().contiguous() for w in self.lstm_weights()], self.padding_token,
                                                self.use_cell)
+
+    def trainable(self):
+        """--fine_tune leaves the LSTM's parameters trainable (fumi.py:65-67); the pretrained word table stays frozen
+        (nn.Embedding.from_pretrained, common.py:60-63)."""
+        return any(p.requires_grad for p in self.rnn.parameters())
+
+    def forward_train(self, x):
+        """(out, tape): forward that keeps what `backward` needs (the engine's tape, csrc/textenc.hip)."""
+        if self.embed.weight.requires_grad:
+            raise NotImplementedError("embedding_type='rand' with a trainable word table is not supported by the engine "
+                                      "(the models build RNN / RnnHid on the frozen pretrained table)")
+        return _engine.get_engine().lstm_bidir_train(x.contiguous(), self.embed.weight.detach(),
+                                                     [w.detach().contiguous() for w in self.lstm_weights()], self.padding_token,
+                                                     self.use_cell)
+
+    def backward(self, x, tape, d_out):
+        """Back-propagation through time: leaves d_out's pull-back in .grad of the eight LSTM tensors (what loss.backward() does
+        for the reference's trainable encoder).  Returns the gradient tensors."""
+        ws = self.lstm_weights()
+        gs = _engine.get_engine().lstm_bidir_bwd(x.contiguous(), self.embed.weight.detach(), [w.detach().contiguous() for w in ws],
+                                                 self.padding_token, self.use_cell, tape, d_out.contiguous())
+        for w, g in zip(ws, gs):
+            w.grad = g
+        return gs
 
 
 class RNN(_BiLstmEncoder):

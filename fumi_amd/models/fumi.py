@@ -22,7 +22,7 @@ from ..utils import utils as utils
 from ..utils.average_meter import AverageMeter
 from ..utils.hypernet_init import hyper_weight_layer_init
 from ..utils.wandb_compat import wandb
-from .common import RNN, RnnHid, WordEmbedding
+from .common import RNN, RnnHid, WordEmbedding, _BiLstmEncoder
 
 try:
     from tqdm import tqdm
@@ -223,6 +223,7 @@ class FUMI(nn.Module):
         T = args.num_train_adapt_steps if train else args.num_test_adapt_steps
         eng = _engine.get_engine()
         text_s = cls_text = None
+        lstm_ft = train and isinstance(self.text_encoder, _BiLstmEncoder) and self.text_encoder.trainable()
         if isinstance(self.text_encoder, WordEmbedding):
             # only the N class rows of an episode are ever used (fumi.py:207-210): select, gather and pool them in one
             # kernel instead of pooling all S support rows first
@@ -232,6 +233,16 @@ class FUMI(nn.Module):
             ride = {"defer": True} if (self.im_encoder not in ("conv4", "resnet12") and getattr(eng, "folds_optimizer_step", False)) else {}
             cls_text = eng.glove_bag_select(to(s_text), y_s, self.n_way, self.text_encoder.embed.weight.detach(),
                                             self.text_encoder.padding_token, self.pooling_strat, **ride)
+        elif lstm_ft:
+            # trainable bi-LSTM (--fine_tune, fumi.py:65-67): only the class rows carry a text adjoint (fumi.py:207-210), so only
+            # they are encoded with a tape; the meta-step below returns d loss / d cls_text for the LSTM's backward
+            if self.im_encoder in ("conv4", "resnet12"):
+                raise NotImplementedError("--fine_tune with RNN / RNNhid and a convolutional image encoder: the text adjoint is "
+                                          "only produced by the step on precomputed image features")
+            tok_cls = eng.class_rows_select(to(s_text), y_s, self.n_way)
+            cls_text, lstm_tape = self.text_encoder.forward_train(tok_cls)
+            g_cls_text = torch.empty_like(cls_text)
+            eng.fumi_want_text_grad(x_s.device, g_cls_text)
         else:
             text_s = self._encode_text(to(s_text), dev)
 
@@ -243,7 +254,7 @@ class FUMI(nn.Module):
         # One process: optimizer.step() (fumi.py:193) needs no launch of its own -- the step's last launch (the final reduction that
         # produces every gradient element) applies Adam's update right behind each element and publishes the two statistics; the
         # update and the publication are registered with the workspace BEFORE the step (csrc/gemm.hip: launch_reduce_multi_final).
-        fold = (train and self.im_encoder not in ("conv4", "resnet12") and fdist.world()[1] == 1 and x_s.is_cuda
+        fold = (train and not lstm_ft and self.im_encoder not in ("conv4", "resnet12") and fdist.world()[1] == 1 and x_s.is_cuda
                 and getattr(eng, "folds_optimizer_step", False) and hasattr(optimizer, "defer_step") and not lazy.SYNC
                 and not lazy.USE_EVENT and optimizer.defer_step(x_s.device))
         if fold:
@@ -257,6 +268,9 @@ class FUMI(nn.Module):
                                 need_grad=train, grad_scale=1.0 / B,
                                 g_theta=g_th, g_phi=g_ph, cls_text=cls_text, stats=tail, dropout_p=drop_p, seed=drop_seed)
         fdist.all_reduce_sum_(fg.flat if train else tail)
+        if lstm_ft:                              # the encoder's .grad (this rank's episodes, then summed like every other gradient)
+            for g in self.text_encoder.backward(tok_cls, lstm_tape, g_cls_text):
+                fdist.all_reduce_sum_(g)
         # read back asynchronously (fumi.py:195 blocks here); in training the two stores ride on the optimizer's launch
         if not fold:
             loss, acc = lazy.scalars(tail, 2, defer=train)

@@ -343,6 +343,22 @@ int fumi_hip_clip_step(fumi_ws_t* ws, fumi_stream_t stream, int nt, int ni, int 
  * the four *_reverse tensors. */
 int fumi_hip_lstm_bidir(fumi_ws_t* ws, fumi_stream_t stream, int R, int L, int E, int H,
         const int64_t* tokens, int64_t pad_id, const float* table, int64_t V, const float* const* w, int use_cell, float* out);
+/* The same encoders under --fine_tune (fumi/models/fumi.py:65-67 leaves text_encoder.parameters() trainable; the word table is
+ * nn.Embedding.from_pretrained, frozen either way, common.py:60-63).  The training-mode forward writes, besides out, the tape the
+ * backward needs into caller memory of fumi_hip_lstm_tape_floats(R, L, E, H) floats; the backward is back-propagation through time
+ * over the same packed prefixes: d_out [R,2H] (adjoint of out) -> g_w, 8 tensors shaped like w (written, not accumulated;
+ * bias_ih and bias_hh receive the same sums).  Rows whose d_out is zero contribute nothing. */
+int64_t fumi_hip_lstm_tape_floats(int R, int L, int E, int H);
+int fumi_hip_lstm_bidir_train(fumi_ws_t* ws, fumi_stream_t stream, int R, int L, int E, int H,
+        const int64_t* tokens, int64_t pad_id, const float* table, int64_t V, const float* const* w, int use_cell, float* out,
+        float* tape);
+int fumi_hip_lstm_bidir_bwd(fumi_ws_t* ws, fumi_stream_t stream, int R, int L, int E, int H,
+        const int64_t* tokens, int64_t pad_id, const float* const* w, int use_cell, const float* tape, const float* d_out,
+        float* const* g_w);
+/* Arms the NEXT fumi_hip_fumi_step / _indexed call with need_grad != 0 on this workspace to also write
+ * g_cls_text [B*N, Dt] = d(grad_scale * sum_b loss_b) / d(class text rows): what autograd hands a trainable text encoder through
+ * get_hyper_params (fumi.py:196-215).  One-shot: the step clears it.  NULL disarms. */
+int fumi_hip_fumi_want_text_grad(fumi_ws_t* ws, float* g_cls_text);
 
 /* FuMI meta-step on ZERO-COPY episodes: identical to fumi_hip_fumi_step except that the image rows are not handed over as
  * x_s [B,S,D] / x_q [B,Qn,D] but addressed in an HBM-resident table [n_rows, D] through idx_s [B,S] / idx_q [B,Qn] (what

@@ -106,11 +106,13 @@ def fumi_episode(theta, phi, text_s, x_s, y_s, x_q, n_way, T, alpha, tanh_head, 
 
 
 def fumi_meta_step(theta, phi, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha, tanh_head,
-                   need_grad=True, first_order=False, dropout=None):
+                   need_grad=True, first_order=False, dropout=None, extra=None):
     """fumi.py:115-196.  theta/phi: lists of leaf tensors (requires_grad set by the caller when need_grad).
     text_s [B,S,Dt] (already text-encoded), x_s [B,S,D], y_s [B,S], x_q [B,Qn,D], y_q [B,Qn].
     Returns dict(logits [B,Qn,N], preds [B,Qn] int64, loss_b [B], acc_b [B], loss, acc,
-                 g_theta, g_phi = gradients of the MEAN loss (what ``outer_loss.backward()`` leaves in .grad))."""
+                 g_theta, g_phi = gradients of the MEAN loss (what ``outer_loss.backward()`` leaves in .grad)).
+    extra: further tensors text_s depends on (a trainable text encoder's weights under --fine_tune, fumi.py:65-67, or text_s
+    itself): their gradients of the same loss come back as g_extra."""
     B = x_s.shape[0]
     logits, loss_b = [], []
     for b in range(B):
@@ -123,9 +125,11 @@ def fumi_meta_step(theta, phi, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha, tanh
     out = _pack(logits, loss_b, y_q)
     out["loss"] = loss.detach()
     if need_grad:
-        g = torch.autograd.grad(loss, list(theta) + list(phi), allow_unused=True)
-        g = [torch.zeros_like(p) if gi is None else gi for gi, p in zip(g, list(theta) + list(phi))]
-        out["g_theta"], out["g_phi"] = g[:len(theta)], g[len(theta):]
+        leaves = list(theta) + list(phi) + list(extra or [])
+        g = torch.autograd.grad(loss, leaves, allow_unused=True)
+        g = [torch.zeros_like(p) if gi is None else gi for gi, p in zip(g, leaves)]
+        out["g_theta"], out["g_phi"] = g[:len(theta)], g[len(theta):len(theta) + len(phi)]
+        out["g_extra"] = g[len(theta) + len(phi):]
     return out
 
 

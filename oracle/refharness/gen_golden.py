@@ -219,6 +219,62 @@ def gen_rnn(ref_common):
     print("rnn:", out["rnn"].shape)
 
 
+def gen_fumi_rnn_finetune(ref_fumi, ref_common):
+    """FUMI(text_encoder="RNN" / "RNNhid", fine_tune=True) (fumi.py:46-67): one training meta-batch through the unmodified
+    ``evaluate`` -- the loss reaches the bi-LSTM through get_hyper_params (fumi.py:196-212), so .grad of rnn.* is the fixture
+    the engine's LSTM backward is held to.  Token rows are distinct per support SAMPLE (the class text is the class's first
+    support row), ragged, incl. a one-token and a full-length row; the word table is the stub KeyedVectors' (frozen)."""
+    B, N, K, Q, D, hid, Dt, Ht, T, L, E = 3, 4, 2, 3, 40, [24], 16, 32, 2, 7, 12
+    known = [f"w{i}" for i in range(30)]
+    dictionary = {"PAD": 0, **{f"w{i}": i + 1 for i in range(30)}}
+    kv = _FakeKV(known, E, 9)
+    stubs.install()
+    import gensim.downloader as api
+    api.load = lambda name: kv
+    ref_common.api = api
+    seed = 4242
+    ep = cg.make_episodes(seed, B, N, K, Q, D, Dt, blocked=False)
+    rs = np.random.RandomState(seed + 1)
+    S, Qn = N * K, N * Q
+
+    def rows(n):
+        t = np.zeros((B, n, L), dtype=np.int64)
+        for b in range(B):
+            for s_ in range(n):
+                ln = 1 if s_ == 0 else (L if s_ == 1 else rs.randint(1, L + 1))
+                t[b, s_, :ln] = rs.randint(1, 31, size=ln)
+        return torch.from_numpy(t)
+    ep["text_s"], ep["text_q"] = rows(S), rows(Qn)
+    theta, phi = cg.make_fumi_params(seed, D, hid, Dt, Ht)
+    out = dict(seed=np.int64(seed), text_s=ep["text_s"].numpy(), text_q=ep["text_q"].numpy(),
+               dims=np.asarray([B, N, K, Q, D, hid[0], Dt, Ht, T, L, E], dtype=np.int64))
+    rnn_sd = None
+    for enc in ("RNN", "RNNhid"):
+        torch.manual_seed(21)
+        model = ref_fumi.FUMI(n_way=N, im_emb_dim=D, im_hid_dim=hid, text_encoder=enc, text_emb_dim=Dt, text_hid_dim=Ht,
+                              dropout_rate=0.0, dictionary=dictionary, pooling_strat="mean", norm_hypernet=True, fine_tune=True)
+        sd = cg.fumi_state_dict(theta, phi)
+        if rnn_sd is None:
+            rnn_sd = {k: v.detach().clone() for k, v in model.state_dict().items() if k.startswith("text_encoder.")}
+            out.update({k: v.numpy().copy() for k, v in rnn_sd.items()})
+        sd.update(rnn_sd)
+        model.load_state_dict(sd)
+        assert [n for n, p_ in model.named_parameters() if p_.requires_grad and n.startswith("text_encoder.")] == \
+            [f"text_encoder.rnn.{n}" for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse",
+                                              "weight_hh_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse")]
+        opt = torch.optim.Adam(model.parameters(), lr=3e-5, weight_decay=5e-4)
+        with torch.autograd.graph.allow_mutation_on_saved_tensors():
+            loss, acc, preds, _ = model.evaluate(_args(T, n_way=N), cg.to_batch(ep), opt, "train")
+        out[f"{enc}.loss"], out[f"{enc}.acc"] = np.float64(loss), np.float64(acc)
+        out[f"{enc}.preds"] = preds.numpy().astype(np.int64)
+        for n, p_ in model.named_parameters():
+            if p_.requires_grad:
+                out[f"{enc}.grad.{n}"] = p_.grad.detach().numpy().copy()
+                out[f"{enc}.post.{n}.digest"] = cg.digest(p_)
+        print(f"fumi_rnn_finetune[{enc}]: loss={float(loss):.6f} acc={float(acc):.4f}")
+    np.savez(os.path.join(OUT, "fumi_rnn_finetune.npz"), **out)
+
+
 def gen_surface(ref_fumi, ref_maml, ref_am3, ref_utils):
     """The drop-in surface: every CLI flag's default/type (utils.py:19-229) and the state_dict keys/shapes of the three
     models at the CLI defaults -> tests/golden/surface.json."""
@@ -265,6 +321,8 @@ def main():
         gen_clip()
     if not only or "rnn" in only:
         gen_rnn(ref_common)
+    if not only or "fumi_rnn_finetune" in only:
+        gen_fumi_rnn_finetune(ref_fumi, ref_common)
     if not only or "surface" in only:
         gen_surface(ref_fumi, ref_maml, ref_am3, ref_utils)
 

@@ -96,3 +96,22 @@ def dropout_mask_flat(seed, p, tag, rows, width):
     u = _mix((np.uint64(int(key)) ^ np.arange(rows * width, dtype=np.uint64)) & 0xFFFFFFFF)
     keep = (u >= max(1, int(p * 4294967296.0))).reshape(rows, width)
     return torch.from_numpy(keep.astype(np.float32) / np.float32(1.0 - p))
+
+
+# ---- the FUMI + trainable bi-LSTM fixture (tests/golden/fumi_rnn_finetune.npz, oracle/refharness/gen_golden.py) ----------------
+RNN_KEYS = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse",
+            "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+
+
+def rnn_finetune_case():
+    """(gold, dims dict, episodes with the fixture's token rows, theta, phi, word table, the 8 LSTM tensors in nn.LSTM's order)."""
+    gold = load_golden("fumi_rnn_finetune")
+    B, N, K, Q, D, h0, Dt, Ht, T, L, E = [int(v) for v in gold["dims"]]
+    seed = int(gold["seed"])
+    ep = cg.make_episodes(seed, B, N, K, Q, D, Dt, blocked=False)
+    ep["text_s"], ep["text_q"] = torch.from_numpy(gold["text_s"]), torch.from_numpy(gold["text_q"])
+    theta, phi = cg.make_fumi_params(seed, D, [h0], Dt, Ht)
+    table = torch.from_numpy(gold["text_encoder.embed.weight"])
+    lstm_w = [torch.from_numpy(gold["text_encoder.rnn." + k]) for k in RNN_KEYS]
+    dims = dict(B=B, N=N, K=K, Q=Q, D=D, hid=[h0], Dt=Dt, Ht=Ht, T=T, L=L, E=E)
+    return gold, dims, ep, theta, phi, table, lstm_w

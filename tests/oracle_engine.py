@@ -18,7 +18,14 @@ class OracleEngine:
     def fumi_step(self, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head, need_grad, grad_scale,
                   g_theta=None, g_phi=None, cls_text=None, stats=None, dropout_p=0.0, seed=0):
         B = x_s.shape[0]
+        want = getattr(self, "_text_grad", None) if need_grad else None
+        if need_grad:
+            self._text_grad = None
+        extra = None
         if cls_text is not None:                # expand the per-class rows back to per-sample rows for the oracle
+            if want is not None:
+                cls_text = cls_text.detach().clone().requires_grad_(True)
+                extra = [cls_text]
             text_s = torch.gather(cls_text, 1, y_s[..., None].expand(-1, -1, cls_text.shape[-1]))
         th = [t.detach().clone().requires_grad_(True) for t in theta]
         ph = [t.detach().clone().requires_grad_(True) for t in phi]
@@ -26,10 +33,13 @@ class OracleEngine:
         if dropout_p > 0:
             from helpers import dropout_mask
             drop = lambda b, call, layer, rows, width: dropout_mask(seed, dropout_p, b, call, layer, rows, width)
-        out = R.fumi_meta_step(th, ph, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha, tanh_head, need_grad=need_grad, dropout=drop)
+        out = R.fumi_meta_step(th, ph, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha, tanh_head, need_grad=need_grad, dropout=drop,
+                               extra=extra)
         if need_grad:
             for dst, g in zip(list(g_theta) + list(g_phi), out["g_theta"] + out["g_phi"]):
                 dst.copy_(g * (B * grad_scale))               # oracle returns mean-loss grads = (1/B) sum_b
+            if want is not None:
+                want.copy_((out["g_extra"][0] * (B * grad_scale)).reshape(want.shape))
         if stats is not None:
             stats.copy_(torch.stack([out["loss_b"].sum(), out["acc_b"].sum()]) * grad_scale)
         return dict(logits=out["logits"], preds=out["preds"], preds_f=out["preds"].float(), loss_b=out["loss_b"], acc_b=out["acc_b"])
@@ -186,6 +196,20 @@ class OracleEngine:
         lead = tokens.shape[:-1]
         out = R.lstm_encode(tokens.reshape(1, -1, tokens.shape[-1]), table, lstm_w, pad_id, use_cell)
         return out.reshape(*lead, -1)
+
+    def lstm_bidir_train(self, tokens, table, lstm_w, pad_id, use_cell):
+        return self.lstm_bidir(tokens, table, lstm_w, pad_id, use_cell), None         # (the checker re-runs the forward under autograd)
+
+    def lstm_bidir_bwd(self, tokens, table, lstm_w, pad_id, use_cell, tape, d_out):
+        w = [t.detach().clone().requires_grad_(True) for t in lstm_w]
+        out = R.lstm_encode(tokens.reshape(1, -1, tokens.shape[-1]), table, w, pad_id, use_cell)
+        return list(torch.autograd.grad((out.reshape(d_out.shape) * d_out).sum(), w))
+
+    def class_rows_select(self, rows_s, y_s, n_way):
+        return torch.stack([R.class_text_select(rows_s[b], y_s[b], n_way) for b in range(rows_s.shape[0])])
+
+    def fumi_want_text_grad(self, device, g_cls_text):
+        self._text_grad = g_cls_text
 
     def glove_bag(self, tokens, table, pad_id, mode):
         return R.word_embedding_pool(tokens, table, pad_id, mode)

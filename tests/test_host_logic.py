@@ -287,15 +287,21 @@ def test_disable_cuda_is_refused_where_the_engine_is_first_needed(tmp_path):
 
 
 def test_unsupported_flag_combinations_are_refused_up_front(oracle_engine):
-    """--fine_tune with RNN / RNNhid trains the bi-LSTM in the reference (fumi.py:65-67); the engine's LSTM op is forward only (frozen
-    LSTM text encoders work: test_rnn_text_encoders_keep_the_reference_surface).  `--model am3 --text_encoder rand` trains only
-    with --dropout 0 (am3.py:118-126 applies dropout inside h only).  Both are refused by `check_supported`, for every model name
-    that builds the model in question (unknown names are AM3, like utils.init_model)."""
+    """--fine_tune with RNN / RNNhid trains the bi-LSTM in the reference (fumi.py:65-67); the engine does for FuMI on precomputed
+    image features (test_fumi_trains_the_bilstm_under_fine_tune) and refuses it for AM3 and for the convolutional encoders (frozen
+    LSTM text encoders work everywhere: test_rnn_text_encoders_keep_the_reference_surface).  `--model am3 --text_encoder rand`
+    trains only with --dropout 0 (am3.py:118-126 applies dropout inside h only).  Both are refused by `check_supported`, for
+    every model name that builds the model in question (unknown names are AM3, like utils.init_model)."""
     from fumi_amd import main as cli
-    for model in ("fumi", "am3", "some-unknown-name"):
-        for enc in ("RNN", "RNNhid"):
+    for enc in ("RNN", "RNNhid"):
+        for model in ("am3", "some-unknown-name"):
             with pytest.raises(NotImplementedError, match="forward only"):
                 cli.check_supported(cli.parse_args(["--model", model, "--disable_cuda", "--text_encoder", enc, "--fine_tune"]))
+        for im in ("conv4", "resnet12"):
+            with pytest.raises(NotImplementedError, match="forward only"):
+                cli.check_supported(cli.parse_args(["--model", "fumi", "--disable_cuda", "--text_encoder", enc, "--fine_tune",
+                                                    "--im_encoder", im]))
+        cli.check_supported(cli.parse_args(["--model", "fumi", "--disable_cuda", "--text_encoder", enc, "--fine_tune"]))
     cli.check_supported(cli.parse_args(["--model", "fumi", "--disable_cuda", "--text_encoder", "RNN"]))          # frozen: accepted
     cli.check_supported(cli.parse_args(["--model", "maml", "--disable_cuda", "--text_encoder", "RNN", "--fine_tune"]))   # no text path
     with pytest.raises(NotImplementedError, match="--dropout 0"):
@@ -347,6 +353,42 @@ def test_fumi_glove_path_uses_class_rows_only(oracle_engine):
     ph = [p.detach().clone().requires_grad_(True) for p in m._phi()]
     ref = R.fumi_meta_step(th, ph, text, ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], c["N"], 2, cg.ALPHA, False, need_grad=False)
     assert abs(float(loss) - float(ref["loss"])) < 1e-5 and np.array_equal(preds.numpy().astype(np.int64), ref["preds"].numpy())
+
+
+@pytest.mark.parametrize("enc", ["RNN", "RNNhid"])
+def test_fumi_trains_the_bilstm_under_fine_tune(enc, oracle_engine):
+    """FUMI(text_encoder=RNN / RNNhid, fine_tune=True).evaluate(train) (fumi.py:46-67,115-196): class token rows -> taped LSTM
+    forward -> meta-step with the text adjoint -> LSTM backward -> Adam over every trainable tensor.  Gradients and post-step
+    parameters against the reference's own (host plumbing on the checker engine; the kernels: test_hip_parity.py)."""
+    from helpers import rnn_finetune_case, RNN_KEYS
+    from fumi_amd.models.fumi import FUMI
+    from fumi_amd.models import common
+    gold, c, ep, theta, phi, table, lstm_w = rnn_finetune_case()
+    words = [f"w{i}" for i in range(30)]
+    common.register_word_vectors("glove", common.ArrayKeyedVectors(words, table[1:].numpy()))
+    dictionary = {"PAD": 0, **{w: i + 1 for i, w in enumerate(words)}}
+    m = FUMI(n_way=c["N"], im_emb_dim=c["D"], im_hid_dim=c["hid"], text_encoder=enc, text_emb_dim=c["Dt"], text_hid_dim=c["Ht"],
+             dropout_rate=0.0, dictionary=dictionary, fine_tune=True)
+    sd = cg.fumi_state_dict(theta, phi)
+    sd.update({k: torch.from_numpy(gold[k]) for k in gold if k.startswith("text_encoder.")})
+    m.load_state_dict(sd)
+    trainable = [n for n, p in m.named_parameters() if p.requires_grad]
+    assert [n for n in trainable if n.startswith("text_encoder.")] == ["text_encoder.rnn." + k for k in RNN_KEYS]
+    opt = torch.optim.Adam(m.parameters(), lr=3e-5, weight_decay=5e-4)
+    loss, acc, preds, _ = m.evaluate(_args(c["T"]), cg.to_batch(ep), opt, "train")
+    assert abs(float(loss) - float(gold[f"{enc}.loss"])) < 2e-5 and abs(float(acc) - float(gold[f"{enc}.acc"])) < 1e-6
+    assert np.array_equal(preds.numpy().astype(np.int64), gold[f"{enc}.preds"])
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            g = gold[f"{enc}.grad.{n}"]
+            assert float((p.grad - torch.from_numpy(g)).abs().max()) <= 5e-5 * max(float(np.abs(g).max()), 1e-6), n
+            np.testing.assert_allclose(cg.digest(p)[3:], gold[f"{enc}.post.{n}.digest"][3:], rtol=0, atol=2e-7)
+    # a frozen encoder (no --fine_tune) keeps the LSTM out of the step
+    m2 = FUMI(n_way=c["N"], im_emb_dim=c["D"], im_hid_dim=c["hid"], text_encoder=enc, text_emb_dim=c["Dt"], text_hid_dim=c["Ht"],
+              dropout_rate=0.0, dictionary=dictionary)
+    m2.load_state_dict(sd)
+    l2, _, _, _ = m2.evaluate(_args(c["T"]), cg.to_batch(ep), torch.optim.Adam([p for p in m2.parameters() if p.requires_grad]), "train")
+    assert abs(float(l2) - float(gold[f"{enc}.loss"])) < 2e-5 and all(p.grad is None for p in m2.text_encoder.parameters())
 
 
 def test_bench_self_launches_one_process_per_gpu(monkeypatch, capsys):

@@ -1,0 +1,167 @@
+"""GPU parity of the trainable bi-LSTM text encoder (--fine_tune with --text_encoder RNN / RNNhid, fumi/models/fumi.py:46-67):
+the tape-keeping forward and back-propagation through time of csrc/textenc.hip, the text adjoint the FuMI meta-step hands back
+(fumi_hip_fumi_want_text_grad), and FUMI.evaluate(train) end to end against the reference's own gradients
+(tests/golden/fumi_rnn_finetune.npz, oracle/refharness/gen_golden.py)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import casegen as cg
+from oracle import fumi_ref as R
+from helpers import rel_to_max, rnn_finetune_case, RNN_KEYS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def ws(dev):
+    from fumi_amd import hip
+    return hip.Workspace.get(dev)
+
+
+def _g(t, dev):
+    return t.to(dev).contiguous()
+
+
+def _lstm_weights(g, E, H):
+    w = []
+    for _ in range(2):
+        w += [torch.randn(4 * H, E, generator=g) / E ** 0.5, torch.randn(4 * H, H, generator=g) / H ** 0.5,
+              torch.randn(4 * H, generator=g) * 0.1, torch.randn(4 * H, generator=g) * 0.1]
+    return w
+
+
+def _oracle_lstm_grads(tok, table, w, use_cell, d_out):
+    ww = [t.clone().requires_grad_(True) for t in w]
+    out = R.lstm_encode(tok, table, ww, 0, use_cell)
+    return out.detach(), torch.autograd.grad((out * d_out).sum(), ww)
+
+
+@pytest.mark.parametrize("use_cell", [False, True])
+def test_lstm_backward_matches_oracle(dev, ws, use_cell):
+    """fumi_hip_lstm_bidir_train / _bwd against autograd through the oracle's lstm_encode: the fixture's small rows (ragged, a
+    one-token and a full-length row) and GloVe-sized rows (E = 300, H = 150) with every length from 1 to L, incl. rows whose
+    output adjoint is zero (support rows that are not a class's first, fumi.py:207-210)."""
+    from fumi_amd import hip
+    gold, c, ep, _, _, table, w = rnn_finetune_case()
+    g = torch.Generator().manual_seed(11)
+    cases = [(ep["text_s"], table, w)]
+    V, E, H, L = 400, 300, 150, 24
+    tb = torch.rand(V, E, generator=g) * 2 - 1
+    tb[0] = 0
+    tok = torch.randint(1, V, (2, 15, L), generator=g)
+    for r in range(15):
+        tok[:, r, 1 + (r * 23) // 14:] = 0
+    cases.append((tok, tb, _lstm_weights(g, E, H)))
+    for tok, tb, w in cases:
+        H2 = 2 * w[1].shape[1]
+        d_out = torch.randn(*tok.shape[:2], H2, generator=g)
+        d_out[:, 1::3] = 0
+        ref_out, ref_g = _oracle_lstm_grads(tok, tb, w, use_cell, d_out)
+        wd = [_g(t, dev) for t in w]
+        out, tape = hip.lstm_bidir_train(ws, _g(tok, dev), _g(tb, dev), wd, 0, use_cell)
+        assert torch.equal(out, hip.lstm_bidir(ws, _g(tok, dev), _g(tb, dev), wd, 0, use_cell))     # same arithmetic as the frozen forward
+        assert rel_to_max(out.cpu(), ref_out) <= 2e-5
+        gs = hip.lstm_bidir_bwd(ws, _g(tok, dev), _g(tb, dev), wd, 0, use_cell, tape, _g(d_out, dev))
+        for k, a, b in zip(RNN_KEYS, gs, ref_g):
+            assert float(b.abs().max()) > 1e-4, k
+            assert rel_to_max(a.cpu(), b) <= 1e-4, (k, rel_to_max(a.cpu(), b))
+        assert torch.equal(gs[2], gs[3]) and torch.equal(gs[6], gs[7])               # the two biases add into the same gates
+    with pytest.raises(ValueError):
+        hip.lstm_bidir_bwd(ws, _g(tok, dev), _g(tb, dev), wd, 0, use_cell, tape[:-1], _g(d_out, dev))
+    assert ws.read_status() == 0
+
+
+@pytest.mark.parametrize("shape", ["golden", "gemm_fallback", "bench"])
+def test_fumi_step_text_gradient_matches_oracle(dev, ws, shape):
+    """fumi_hip_fumi_want_text_grad: d(grad_scale * sum_b loss_b) / d cls_text of the very next FuMI step against autograd through
+    the oracle's meta-step, in the three forms of the hypernetwork backward (fused rider; plain GEMMs for a text width the
+    LDS-resident kernels do not take; the bench's widths) -- and the step's other outputs are unchanged by the request."""
+    from fumi_amd import hip
+    B, N, K, Q, D, hid, Dt, Ht, T, tanh = {
+        "golden": (3, 4, 2, 3, 40, [24], 16, 32, 2, True),
+        "gemm_fallback": (2, 5, 1, 2, 64, [32, 16], 18, 20, 1, False),
+        "bench": (4, 5, 5, 15, 512, [256, 128], 768, 256, 2, True)}[shape]
+    ep = cg.make_episodes(77, B, N, K, Q, D, Dt)
+    theta, phi = cg.make_fumi_params(77, D, hid, Dt, Ht)
+    g = torch.Generator().manual_seed(3)
+    cls_text = torch.randn(B, N, Dt, generator=g)
+    th, ph = [t.clone().requires_grad_(True) for t in theta], [t.clone().requires_grad_(True) for t in phi]
+    ct = cls_text.clone().requires_grad_(True)
+    text_s = torch.gather(ct, 1, ep["y_s"][..., None].expand(-1, -1, Dt))
+    ref = R.fumi_meta_step(th, ph, text_s, ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], N, T, cg.ALPHA, tanh, extra=[ct])
+    args = [_g(ep[k], dev) for k in ("x_s", "y_s", "x_q", "y_q")]
+    thd, phd = [_g(t, dev) for t in theta], [_g(t, dev) for t in phi]
+    plain = hip.fumi_step(ws, *args, thd, phd, T, cg.ALPHA, tanh, cls_text=_g(cls_text, dev), grad_scale=1.0 / B)
+    g_ct = torch.full((B, N, Dt), float("nan"), device=dev)
+    hip.fumi_want_text_grad(ws, g_ct)
+    out = hip.fumi_step(ws, *args, thd, phd, T, cg.ALPHA, tanh, cls_text=_g(cls_text, dev), grad_scale=1.0 / B)
+    assert rel_to_max(g_ct.cpu(), ref["g_extra"][0]) <= 1e-4
+    for a, b in zip(out["g_theta"] + out["g_phi"], plain["g_theta"] + plain["g_phi"]):
+        assert rel_to_max(a.cpu(), b.cpu()) <= 1e-6
+    for a, b in zip(out["g_theta"] + out["g_phi"], ref["g_theta"] + ref["g_phi"]):
+        assert rel_to_max(a.cpu(), b) <= 1e-4
+    # one-shot: the next step does not write it again
+    g_ct.fill_(7.0)
+    hip.fumi_step(ws, *args, thd, phd, T, cg.ALPHA, tanh, cls_text=_g(cls_text, dev), grad_scale=1.0 / B)
+    torch.cuda.synchronize()
+    assert float(g_ct.min()) == 7.0 and float(g_ct.max()) == 7.0
+    # an evaluation step (need_grad = 0) leaves the request armed for the training step that follows
+    hip.fumi_want_text_grad(ws, g_ct)
+    hip.fumi_step(ws, *args, thd, phd, T, cg.ALPHA, tanh, cls_text=_g(cls_text, dev), need_grad=False)
+    torch.cuda.synchronize()
+    assert float(g_ct.min()) == 7.0
+    hip.fumi_want_text_grad(ws, None)
+    assert ws.read_status() == 0
+
+
+@pytest.mark.parametrize("enc", ["RNN", "RNNhid"])
+def test_fumi_finetunes_the_bilstm_like_the_reference(dev, enc):
+    """FUMI(text_encoder=RNN / RNNhid, fine_tune=True).evaluate(train) on the GPU against the reference's own run of the same
+    meta-batch: loss, predictions, .grad of all fourteen trainable tensors (eight of them the LSTM's) and the parameters after
+    the Adam step."""
+    from fumi_amd.models.fumi import FUMI
+    from fumi_amd.models import common
+    from fumi_amd.optim import Adam
+    gold, c, ep, theta, phi, table, lstm_w = rnn_finetune_case()
+    words = [f"w{i}" for i in range(30)]
+    common.register_word_vectors("glove", common.ArrayKeyedVectors(words, table[1:].numpy()))
+    dictionary = {"PAD": 0, **{w: i + 1 for i, w in enumerate(words)}}
+    m = FUMI(n_way=c["N"], im_emb_dim=c["D"], im_hid_dim=c["hid"], text_encoder=enc, text_emb_dim=c["Dt"], text_hid_dim=c["Ht"],
+             dropout_rate=0.0, dictionary=dictionary, fine_tune=True)
+    sd = cg.fumi_state_dict(theta, phi)
+    sd.update({k: torch.from_numpy(gold[k]) for k in gold if k.startswith("text_encoder.")})
+    m.load_state_dict(sd)
+    m.to(dev)
+    opt = Adam(m.parameters(), lr=3e-5, weight_decay=5e-4)
+    args = SimpleNamespace(device=dev, num_train_adapt_steps=c["T"], num_test_adapt_steps=c["T"], step_size=cg.ALPHA,
+                           first_order=False, num_ways=c["N"], batch_size=c["B"])
+    loss, acc, preds, _ = m.evaluate(args, cg.to_batch(ep), opt, "train")
+    assert abs(float(loss) - float(gold[f"{enc}.loss"])) < 2e-5 and abs(float(acc) - float(gold[f"{enc}.acc"])) < 1e-6
+    assert np.array_equal(preds.cpu().numpy().astype(np.int64), gold[f"{enc}.preds"])
+    n_checked = 0
+    for n, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        g = gold[f"{enc}.grad.{n}"]
+        assert rel_to_max(p.grad.cpu(), g) <= 1e-4, (n, rel_to_max(p.grad.cpu(), g))
+        np.testing.assert_allclose(cg.digest(p.detach().cpu())[3:], gold[f"{enc}.post.{n}.digest"][3:], rtol=0, atol=3e-7)
+        n_checked += 1
+    assert n_checked == 14
+    # second step: the optimizer now knows the LSTM's gradients -- the step must not fold Adam in front of the LSTM's backward
+    before = [p.detach().clone() for p in m.text_encoder.rnn.parameters()]
+    m.evaluate(args, cg.to_batch(ep), opt, "train")
+    torch.cuda.synchronize()
+    assert all(not torch.equal(a, b) for a, b in zip(before, m.text_encoder.rnn.parameters()))
+    # evaluation with the trained encoder: the frozen forward
+    l2, _, p2, _ = m.evaluate(args, cg.to_batch(ep), None, "test")
+    assert np.isfinite(float(l2)) and p2.shape == (c["B"], c["N"] * c["Q"])

@@ -102,6 +102,28 @@ def test_clip_restatement_matches_reference():
     assert_close_max(zs, gold["zero_shot"], 1e-6, "zero-shot call")
 
 
+@pytest.mark.parametrize("enc", ["RNN", "RNNhid"])
+def test_fumi_with_trainable_lstm_oracle_matches_reference(enc):
+    """--fine_tune with RNN / RNNhid (fumi.py:46-67): the loss reaches the bi-LSTM through get_hyper_params (fumi.py:196-212).
+    The oracle's lstm_encode inside fumi_meta_step's graph against the reference's own .grad of rnn.* (and of every other
+    parameter) after one unmodified evaluate(train)."""
+    from helpers import rnn_finetune_case, RNN_KEYS
+    gold, c, ep, theta, phi, table, lstm_w = rnn_finetune_case()
+    theta, phi, lstm_w = _leaf(theta), _leaf(phi), _leaf(lstm_w)
+    text = R.lstm_encode(ep["text_s"], table, lstm_w, 0, enc == "RNNhid")
+    out = R.fumi_meta_step(theta, phi, text, ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], c["N"], c["T"], cg.ALPHA, True,
+                           extra=lstm_w)
+    assert abs(float(out["loss"]) - float(gold[f"{enc}.loss"])) <= TOL and abs(float(out["acc"]) - float(gold[f"{enc}.acc"])) < 1e-6
+    assert np.array_equal(out["preds"].numpy(), gold[f"{enc}.preds"])
+    for k, g in zip(RNN_KEYS, out["g_extra"]):
+        assert_close_max(g, gold[f"{enc}.grad.text_encoder.rnn.{k}"], 5e-5, k)
+        assert float(np.abs(gold[f"{enc}.grad.text_encoder.rnn.{k}"]).max()) > 1e-6          # the fixture is not a zero gradient
+    names = ["im_net.linear0.weight", "im_net.linear0.bias", "hyper_net.0.weight", "hyper_net.0.bias", "hyper_net.2.weight",
+             "hyper_net.2.bias"]
+    for n, g in zip(names, out["g_theta"] + out["g_phi"]):
+        assert_close_max(g, gold[f"{enc}.grad.{n}"], 5e-5, n)
+
+
 def test_lstm_encoder_restatement_matches_reference():
     """oracle/fumi_ref.py lstm_encode against the reference's RNN (output states) and RnnHid (cell states), common.py:44-161."""
     gold = load_golden("rnn")
