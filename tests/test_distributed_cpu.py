@@ -35,6 +35,21 @@ def _build(kind):
         m = FUMI(n_way=c["N"], im_encoder="resnet12", image_size=16, text_encoder="BERT", text_emb_dim=c["Dt"], text_hid_dim=c["Ht"],
                  norm_hypernet=False)
         return c, ep, m
+    if kind == "fumi_rnn":
+        # --fine_tune with a bi-LSTM text encoder (fumi.py:46-67): the LSTM's eight gradients are summed over the ranks like the rest
+        from fumi_amd.models import common
+        V, L, E = 30, 6, 10
+        rs = np.random.RandomState(2)
+        words = [f"w{i}" for i in range(V)]
+        common.register_word_vectors("glove", common.ArrayKeyedVectors(words, rs.standard_normal((V, E)).astype(np.float32)))
+        dictionary = {"PAD": 0, **{w: i + 1 for i, w in enumerate(words)}}
+        ep = cg.make_episodes(11, c["B"], c["N"], c["K"], c["Q"], c["D"], 1, tokens=(V + 1, L, 0))
+        theta, phi = cg.make_fumi_params(11, c["D"], c["hid"], c["Dt"], c["Ht"])
+        torch.manual_seed(9)
+        m = FUMI(n_way=c["N"], im_emb_dim=c["D"], im_hid_dim=c["hid"], text_encoder="RNN", text_emb_dim=c["Dt"], text_hid_dim=c["Ht"],
+                 dictionary=dictionary, fine_tune=True)
+        m.load_state_dict(cg.fumi_state_dict(theta, phi), strict=False)
+        return c, ep, m
     ep = cg.make_episodes(11, c["B"], c["N"], c["K"], c["Q"], c["D"], c["Dt"])
     if kind == "fumi":
         theta, phi = cg.make_fumi_params(11, c["D"], c["hid"], c["Dt"], c["Ht"])
@@ -61,7 +76,7 @@ def _step(kind, c, ep, m):
         # (Adam's first step is lr * sign(g): among 12 M encoder weights some gradients are zero to fp32 noise, and the sharded sum
         # may land on the other side of zero -- SGD keeps the update linear in the gradient)
         opt = torch.optim.SGD(m.parameters(), lr=1e-3)
-    if kind in ("fumi", "fumi_resnet12"):
+    if kind in ("fumi", "fumi_resnet12", "fumi_rnn"):
         tr = m.evaluate(args, cg.to_batch(ep), opt, "train")[:2]
         te = m.evaluate(args, cg.to_batch(ep), None, "test")
         extra = te[2].numpy()
@@ -93,7 +108,7 @@ def _worker(rank, world, port, kind, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["fumi", "maml", "am3", "fumi_resnet12"])
+@pytest.mark.parametrize("kind", ["fumi", "maml", "am3", "fumi_resnet12", "fumi_rnn"])
 def test_two_rank_sharded_step_equals_single_process(kind, tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from fumi_amd import engine
