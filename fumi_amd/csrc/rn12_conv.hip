@@ -336,10 +336,12 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
     for (int hq = 0; hq < MW; ++hq) {
         // rows [128 hq, 128 hq + 128) of the tile belong to waves [2 hq / MW ...): with MW = 2 waves 2 hq, 2 hq + 1 (64 rows each)
         if (hq) __syncthreads();
-        if (wave / (4 / MW) == hq || MW == 1) {
+        // (a wave's 32-row blocks each lie inside one 128-row pass: block m of wave w belongs to pass (32 MW w + 32 m) / 128)
+        {
             if constexpr (!S16) {
 #pragma unroll
                 for (int m = 0; m < MW; ++m)
+                    if ((wave * MW + m) >> 2 == hq) {
 #pragma unroll
                     for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -347,9 +349,11 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                             const int row = (wave * 32 * MW + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) - 128 * hq;
                             Ot[row * C::NTP + f * 32 + (lane & 31)] = rn_f2bf(acc[m][f][i]);
                         }
+                    }
             } else {                                                // 16 x 16 tiles: column = lane & 15, row = 4 (lane >> 4) + register
 #pragma unroll
                 for (int m = 0; m < 2 * MW; ++m)
+                    if ((wave * MW + (m >> 1)) >> 2 == hq) {
 #pragma unroll
                     for (int f = 0; f < 2 * NF; ++f)
 #pragma unroll
@@ -357,6 +361,7 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                             const int row = (wave * 32 * MW + m * 16 + 4 * (lane >> 4) + i) - 128 * hq;
                             Ot[row * C::NTP + f * 16 + (lane & 15)] = rn_f2bf(acc16[m][f][i]);
                         }
+                    }
             }
         }
         __syncthreads();
@@ -461,6 +466,11 @@ int conv_dispatch(hipStream_t st, const RnConvArgs& a, int* nt_out) {
     // episode's results do not depend on how many episodes share its chunk)
     const long tiles256 = (a.npix + 255) / 256 * (a.Cout / (32 * NF)) * RN_BREF;
     const int two = 80 * 1024 - 256;                                  // two workgroups per CU
+    // (Measured in round 4 and not kept: 96 or 128 pixels per wave -- MW = 3 | 4, accumulators in AGPRs, one workgroup per CU, 0.53 /
+    // 0.45 KiB of LDS reads per MFMA instead of 0.7: 551 vs 420 us at 160 -> 160 42 x 42, 424 vs 354 at 320 -> 320 21 x 21, equal at
+    // 640 -> 640 10 x 10; MW = 4 with NF = 5 needs 320 accumulators and spills.  NF = 4 on the 640-channel layers is 8-9 % faster on
+    // one stream (800 instead of 640 workgroups on 512 slots) and changes nothing in the two-lane step: 15.78 vs 15.78 episodes/s.
+    // The epilogue below is written for any MW; only MW = 1 | 2 are instantiated.)
     if (force != 1 && (tiles256 >= 256 || force == 2)) {
         if (fbks == 4 && ConvCfg<NF, 2, 4>::lds_bytes(a.g) <= 160 * 1024) return conv_launch<NF, 2, 4>(st, a, nt_out);
         if (fbks == 2 && ConvCfg<NF, 2, 2>::lds_bytes(a.g) <= 160 * 1024) return conv_launch<NF, 2, 2>(st, a, nt_out);

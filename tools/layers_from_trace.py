@@ -34,10 +34,13 @@ for (ci, co, H, k) in SHAPES:
         tot["bwd"] += bd; w_fl["bwd"] += fl
     else:
         line += "         -      -"
-    w = wg[wi_:wi_ + 7]; wi_ += 7
-    wd = sum(x[0] for x in w[2:]) / 5
-    line += f"  {wd:8.0f} {fl / wd / 1e6:6.0f}"
-    tot["wgrad"] += wd; w_fl["wgrad"] += fl
+    if wg:
+        w = wg[wi_:wi_ + 7]; wi_ += 7
+        wd = sum(x[0] for x in w[2:]) / 5
+        line += f"  {wd:8.0f} {fl / wd / 1e6:6.0f}"
+        tot["wgrad"] += wd; w_fl["wgrad"] += fl
     print(line)
 for k_ in tot:
+    if tot[k_] == 0.0:
+        continue
     print(f"{k_}: {tot[k_] / 1e3:.2f} ms, {w_fl[k_] / tot[k_] / 1e6:.0f} TFLOP/s over the listed layers")
