@@ -470,7 +470,9 @@ int conv_dispatch(hipStream_t st, const RnConvArgs& a, int* nt_out) {
     // 0.45 KiB of LDS reads per MFMA instead of 0.7: 551 vs 420 us at 160 -> 160 42 x 42, 424 vs 354 at 320 -> 320 21 x 21, equal at
     // 640 -> 640 10 x 10; MW = 4 with NF = 5 needs 320 accumulators and spills.  NF = 4 on the 640-channel layers is 8-9 % faster on
     // one stream (800 instead of 640 workgroups on 512 slots) and changes nothing in the two-lane step: 15.78 vs 15.78 episodes/s.
-    // The epilogue below is written for any MW; only MW = 1 | 2 are instantiated.)
+    // The epilogue below is written for any MW; only MW = 1 | 2 are instantiated.  Unequal s_setprio for the two waves that share a
+    // SIMD -- by the parity of their wave slot, HW_ID[3:0] -- against the two falling into step: no change in any layer, 15.95 vs
+    // 15.98 episodes/s.)
     if (force != 1 && (tiles256 >= 256 || force == 2)) {
         if (fbks == 4 && ConvCfg<NF, 2, 4>::lds_bytes(a.g) <= 160 * 1024) return conv_launch<NF, 2, 4>(st, a, nt_out);
         if (fbks == 2 && ConvCfg<NF, 2, 2>::lds_bytes(a.g) <= 160 * 1024) return conv_launch<NF, 2, 2>(st, a, nt_out);

@@ -1,4 +1,9 @@
-# dev scratch: A/B of the ResNet-12 step's knobs at 16 episodes of configs[4]'s per-rank shape (two lanes of 2 chunks of 4)
-for cfg in "FUMI_RN_X=0" "FUMI_RN_NF640=4" "FUMI_RN_X=0" "FUMI_RN_NF640=4"; do
-  echo "== $cfg"; env $cfg timeout -k 10 300 python tools/bench_resnet12.py 16 2 5 15 2>&1 | tail -1
+# dev scratch: A/B of the wave-slot priorities (FUMI_RN_PRIO: bits 0-1 convolution mode, bits 2-3 weight-gradient mode; mode 1 = odd slot high, 2 = even slot high)
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+for cfg in "FUMI_RN_PRIO=0" "FUMI_RN_PRIO=1" "FUMI_RN_PRIO=2" "FUMI_RN_PRIO=5"; do
+  echo "== layers $cfg"
+  ( export $cfg; cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/prof_ab; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_ab -o lay -- python3 $R/tools/bench_rn12_layers.py 4 100 > /tmp/ab_events.txt 2>&1; cd $R; f=$(find /tmp/prof_ab -name "*kernel_trace.csv" | head -1); python tools/layers_from_trace.py $f 4 100 | tail -16 )
+done
+for cfg in "FUMI_RN_PRIO=0" "FUMI_RN_PRIO=1" "FUMI_RN_PRIO=5" "FUMI_RN_PRIO=0" "FUMI_RN_PRIO=5"; do
+  echo "== step $cfg"; env $cfg timeout -k 10 300 python tools/bench_resnet12.py 16 2 5 15 2>&1 | tail -1
 done
