@@ -707,6 +707,11 @@ static int am3_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
         cj.add(t1b, (int)Rs, Ht, Ht, g_w[3]);
     }
     if ((rc = wgrad(Ht, Dt, t1b, Ht, text_s, Dt, g_w[2]))) return rc;                  // gG0 = t1bar^T text (800 x 768: 128-row slabs)
+    if (float* tg = ws->text_grad) {                  // armed by fumi_hip_want_text_grad: d loss / d text_s = t1bar G0  [B*S,Dt]
+        ws->text_grad = nullptr;                      // (t1bar carries grad_scale and the dropout scale already)
+        g = gemm_args((int)Rs, Dt, Ht, t1b, Ht, G0, Dt, tg, Dt);
+        if ((rc = launch_gemm(st, g, 0, 1))) return rc;
+    }
     pb.reset();
     // image encoder: gWi = imbar_s^T Xs + imbar_q^T Xq (split over the contraction), gbi = colsum(imbar)
     {

@@ -331,7 +331,7 @@ static int fumi_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     HyperBwdArgs brider;
     struct BwdCtx { hipStream_t st; const HyperBwdArgs* a; } bctx{st, &brider};
     bool fused_bwd = false;
-    // an armed text gradient (fumi_hip_fumi_want_text_grad) needs ubar [R,Ht] in memory: every form of the backward leaves it in ub
+    // an armed text gradient (fumi_hip_want_text_grad) needs ubar [R,Ht] in memory: every form of the backward leaves it in ub
     float* text_grad = need_grad ? ws->text_grad : nullptr;
     if (need_grad) ws->text_grad = nullptr;
     if (need_grad && !fork_bwd && hbf &&
@@ -388,7 +388,7 @@ static int fumi_step_impl(fumi_ws_t* ws, fumi_stream_t stream,
     return FUMI_OK;
 }
 
-int fumi_hip_fumi_want_text_grad(fumi_ws_t* ws, float* g_cls_text) {
+int fumi_hip_want_text_grad(fumi_ws_t* ws, float* g_cls_text) {
     if (!ws) return FUMI_EINVAL;
     ws->text_grad = g_cls_text;
     return FUMI_OK;

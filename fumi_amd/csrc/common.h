@@ -25,7 +25,7 @@ struct fumi_ws {
     const float* pub_src; float* pub_dst; int pub_n; unsigned long long pub_seq;   // deferred publication (api: publish_scalars_deferred)
     struct AdamPending* adam;   // deferred optimizer step (fumi_hip_adam_step_deferred): folded into the step's final reduction launch
     struct GlovePending* glove; // deferred embedding bag (fumi_hip_glove_bag_select_deferred): rider workgroups of the step's first launch
-    float* text_grad;    // armed by fumi_hip_fumi_want_text_grad: the next FuMI step with need_grad also writes d loss / d class text rows here
+    float* text_grad;    // armed by fumi_hip_want_text_grad: the next FuMI step with need_grad also writes d loss / d class text rows here
     int* acnt;           // [FUMI_ACNT] arrival counters of the split adapt kernel (reset by the query kernel of the same step)
     int* hcnt;           // [FUMI_HCNT] arrival counters of hyper_fwd_split_kernel, zero between launches
     float* side_buf; size_t side_cap;   // small allocation that survives slab rewinds (ResNet-12 chunk loop: heads of the whole meta-batch)

@@ -854,6 +854,12 @@ int fumi_hip_fumi_resnet12_step(fumi_ws_t* ws, fumi_stream_t stream,
     g = gemm_args(Ht, Dt, R, ub, Ht, ctext, Dt, g_phi[0], Dt);           // gA0 = ubar^T c
     g.alpha = grad_scale;
     if ((rc = launch_gemm(st, g, 1, 1))) return rc;
+    if (float* tg = ws->text_grad) {                                     // armed by fumi_hip_want_text_grad: scale * ubar A0  [R,Dt]
+        ws->text_grad = nullptr;
+        g = gemm_args(R, Dt, Ht, ub, Ht, phi[0], Dt, tg, Dt);
+        g.alpha = grad_scale;
+        if ((rc = launch_gemm(st, g, 0, 1))) return rc;
+    }
     return launch_colsum(st, ub, R, Ht, Ht, grad_scale, g_phi[1]);
 }
 

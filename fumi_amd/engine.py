@@ -101,9 +101,9 @@ class HipEngine:
             return out.view(torch.int64)
         return hip.class_text_select(self._ws(rows_s), rows_s.contiguous(), y_s, n_way)
 
-    def fumi_want_text_grad(self, device, g_cls_text):
+    def want_text_grad(self, device, g_cls_text):
         """The next fumi_step(need_grad=True) on `device` also writes d loss / d class text rows into g_cls_text [B,N,Dt]."""
-        hip.fumi_want_text_grad(hip.Workspace.get(torch.device(device)), g_cls_text)
+        hip.want_text_grad(hip.Workspace.get(torch.device(device)), g_cls_text)
 
     def am3_metrics(self, n_way, stats):
         return hip.am3_metrics(self._ws(stats), n_way, stats)

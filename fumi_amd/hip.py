@@ -32,7 +32,7 @@ SYMBOLS = [
     "fumi_hip_rn12_conv", "fumi_hip_rn12_wgrad", "fumi_hip_resnet12_set_option", "fumi_hip_rn12_probe",
     "fumi_hip_conv3x3_fwd", "fumi_hip_conv3x3_bwd_data", "fumi_hip_conv3x3_bwd_weight",
     "fumi_hip_sgd_axpy", "fumi_hip_ce_fwd_bwd", "fumi_hip_proto_reduce", "fumi_hip_clip_step", "fumi_hip_lstm_bidir", "fumi_hip_lstm_tape_floats", "fumi_hip_lstm_bidir_train", "fumi_hip_lstm_bidir_bwd",
-    "fumi_hip_fumi_want_text_grad",
+    "fumi_hip_want_text_grad",
 ]
 
 ST_LABEL_RANGE, ST_CLASS_MISSING, ST_SYNC_TIMEOUT = 1, 2, 4
@@ -187,7 +187,7 @@ def lib():
         L.fumi_hip_lstm_bidir_train.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_int64, c_void_p, c_int64, PP, c_int,
                                                 c_void_p, c_void_p]
         L.fumi_hip_lstm_bidir_bwd.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_int64, PP, c_int, c_void_p, c_void_p, PP]
-        L.fumi_hip_fumi_want_text_grad.argtypes = [c_void_p, c_void_p]
+        L.fumi_hip_want_text_grad.argtypes = [c_void_p, c_void_p]
         L.fumi_hip_proto_reduce.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p] * 3
         _lib = L
     return _lib
@@ -1215,7 +1215,7 @@ def lstm_bidir_bwd(ws, tokens, table, lstm_w, pad_id, use_cell, tape, d_out):
     return g_w
 
 
-def fumi_want_text_grad(ws, g_cls_text):
+def want_text_grad(ws, g_cls_text):
     """Arm the next fumi_step(need_grad=True) on ws to write d loss / d class text rows into g_cls_text [B*N, Dt] (None disarms)."""
-    _check(lib().fumi_hip_fumi_want_text_grad(ws.handle, None if g_cls_text is None else _f32(g_cls_text, "g_cls_text")),
-           "fumi_hip_fumi_want_text_grad")
+    _check(lib().fumi_hip_want_text_grad(ws.handle, None if g_cls_text is None else _f32(g_cls_text, "g_cls_text")),
+           "fumi_hip_want_text_grad")

@@ -142,14 +142,8 @@ def check_supported(args):
             + ": fumi_amd has no CPU execution path -- every step runs on the MI355X library "
               "(fumi_amd/lib/libfumi_hip.so).  Run the reference itself for a CPU run.")
     family = args.model if args.model in ("maml", "fumi", "clip") else "am3"      # unknown names are AM3, like utils.init_model
-    if getattr(args, "fine_tune", False) and args.text_encoder in ("RNN", "RNNhid") and family in ("fumi", "am3"):
-        # the reference trains the bi-LSTM here (fumi/models/fumi.py:65-67, common.py:44-161).  The engine does so for FuMI on
-        # precomputed image features (the meta-step hands back the text adjoint, csrc/textenc.hip runs the LSTM's backward); the
-        # AM3 step and the steps with a convolutional encoder do not produce a text adjoint
-        if family == "am3" or args.im_encoder in ("conv4", "resnet12"):
-            raise NotImplementedError("--fine_tune with --text_encoder RNN / RNNhid is trained only for --model fumi on precomputed "
-                                      "image features: elsewhere the engine's bi-LSTM text encoder is forward only "
-                                      "(frozen LSTM weights are supported: drop --fine_tune)")
+    # (--fine_tune with --text_encoder RNN / RNNhid trains the bi-LSTM like the reference, fumi/models/fumi.py:65-67 / am3.py:74-76:
+    # every meta-step hands back the adjoint of its text input, csrc/textenc.hip runs the LSTM's backward)
     if family == "am3" and args.text_encoder == "rand" and args.dropout > 0 and not args.evaluate:
         # fumi/models/am3.py:118-126 applies dropout inside h only; the engine's AM3 step draws the masks of g and h together and
         # `rand` replaces g by an identity, so training this combination needs --dropout 0 (the CLI default is 0.25)

@@ -18,7 +18,7 @@ from ..flatgrad import FlatGrads, ParamWatch
 from ..utils import utils as utils
 from ..utils.average_meter import AverageMeter
 from ..utils.wandb_compat import wandb
-from .common import RNN, RnnHid, WordEmbedding
+from .common import RNN, RnnHid, WordEmbedding, _BiLstmEncoder
 
 
 class AM3(nn.Module):
@@ -171,8 +171,15 @@ class AM3(nn.Module):
         x_s, x_q, y_s, y_q = to(s_im), to(q_im), to(s_y), to(q_y)
         if x_s.dtype != torch.float32 or x_q.dtype != torch.float32:
             x_s, x_q = x_s.float(), x_q.float()
-        text = self._encode_text(to(s_text))
         need_grad = train and torch.is_grad_enabled()
+        # a trainable bi-LSTM (--fine_tune with RNN / RNNhid, am3.py:61-76): taped forward here, the step below hands back the
+        # adjoint of every support row's text encoding, the LSTM's backward follows the step
+        lstm_ft = need_grad and isinstance(self.text_encoder, _BiLstmEncoder) and self.text_encoder.trainable()
+        if lstm_ft:
+            tok = to(s_text)
+            text, lstm_tape = self.text_encoder.forward_train(tok)
+        else:
+            text = self._encode_text(to(s_text))
         w_det, th_det, fg = self._step_params(need_grad, num_ways)
         eng = _engine.get_engine()
         # train / val on the GPU: the step also leaves [loss, correct, mean lamda, confusion counts] in the buffer's tail, one
@@ -194,6 +201,9 @@ class AM3(nn.Module):
             w_det = w_det[:2] + self._rand_g(x_s.device) + w_det[6:]
             if need_grad:
                 g_w = list(g_w[:2]) + self._rand_g_scratch + list(g_w[6:])
+        if lstm_ft:
+            g_text = torch.empty_like(text)
+            eng.want_text_grad(x_s.device, g_text)
         out = eng.am3_step(x_s, y_s, x_q, y_q, text, w_det, num_ways,
                            self.lamda_fixed, need_grad=need_grad, grad_scale=1.0 / B,
                            g_w=g_w, dropout_p=drop_p, seed=drop_seed,
@@ -217,6 +227,9 @@ class AM3(nn.Module):
             if rand_text:                        # g is not part of the graph (am3.py:118-121): its .grad stays None
                 for p in self.g.parameters():
                     p.grad = None
+            if lstm_ft:                          # the encoder's .grad (this rank's episodes, then summed like every other gradient)
+                for g in self.text_encoder.backward(tok, lstm_tape, g_text):
+                    fdist.all_reduce_sum_(g)
             getattr(optimizer, "step_fused", optimizer.step)()
             if scheduler:
                 scheduler.step()

@@ -236,13 +236,10 @@ class FUMI(nn.Module):
         elif lstm_ft:
             # trainable bi-LSTM (--fine_tune, fumi.py:65-67): only the class rows carry a text adjoint (fumi.py:207-210), so only
             # they are encoded with a tape; the meta-step below returns d loss / d cls_text for the LSTM's backward
-            if self.im_encoder in ("conv4", "resnet12"):
-                raise NotImplementedError("--fine_tune with RNN / RNNhid and a convolutional image encoder: the text adjoint is "
-                                          "only produced by the step on precomputed image features")
             tok_cls = eng.class_rows_select(to(s_text), y_s, self.n_way)
             cls_text, lstm_tape = self.text_encoder.forward_train(tok_cls)
             g_cls_text = torch.empty_like(cls_text)
-            eng.fumi_want_text_grad(x_s.device, g_cls_text)
+            eng.want_text_grad(x_s.device, g_cls_text)
         else:
             text_s = self._encode_text(to(s_text), dev)
 

@@ -355,10 +355,12 @@ int fumi_hip_lstm_bidir_train(fumi_ws_t* ws, fumi_stream_t stream, int R, int L,
 int fumi_hip_lstm_bidir_bwd(fumi_ws_t* ws, fumi_stream_t stream, int R, int L, int E, int H,
         const int64_t* tokens, int64_t pad_id, const float* const* w, int use_cell, const float* tape, const float* d_out,
         float* const* g_w);
-/* Arms the NEXT fumi_hip_fumi_step / _indexed call with need_grad != 0 on this workspace to also write
- * g_cls_text [B*N, Dt] = d(grad_scale * sum_b loss_b) / d(class text rows): what autograd hands a trainable text encoder through
- * get_hyper_params (fumi.py:196-215).  One-shot: the step clears it.  NULL disarms. */
-int fumi_hip_fumi_want_text_grad(fumi_ws_t* ws, float* g_cls_text);
+/* Arms the NEXT meta-step with need_grad != 0 on this workspace to also write the adjoint of its text input, what autograd hands
+ * a trainable text encoder in the reference: fumi_hip_fumi_step / _indexed / fumi_hip_fumi_conv4_step / fumi_hip_fumi_resnet12_step
+ * write g_text [B*N, Dt] = d(grad_scale * sum_b loss_b) / d(class text rows) (get_hyper_params, fumi.py:196-215);
+ * fumi_hip_am3_step / _dx write g_text [B*S, Dt] = d loss / d text_s (every support row feeds its class prototype, am3.py:113-126).
+ * One-shot: the step clears it.  NULL disarms. */
+int fumi_hip_want_text_grad(fumi_ws_t* ws, float* g_text);
 
 /* FuMI meta-step on ZERO-COPY episodes: identical to fumi_hip_fumi_step except that the image rows are not handed over as
  * x_s [B,S,D] / x_q [B,Qn,D] but addressed in an HBM-resident table [n_rows, D] through idx_s [B,S] / idx_q [B,Qn] (what

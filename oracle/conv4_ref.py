@@ -59,7 +59,7 @@ def episode(theta, h, x_s, y_s, x_q, T, alpha, first_order=False):
 
 
 def fumi_conv4_meta_step(theta, phi, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha, tanh_head, need_grad=True,
-                         first_order=False):
+                         first_order=False, extra=None):
     """FuMI meta-step (fumi.py:115-196) with the Conv4 encoder: x_s [B,S,Cin,H,W], x_q [B,Qn,Cin,H,W]; the hypernetwork emits
     [N, F+1] head rows (F = Conv4 feature width).  Returns what fumi_ref.fumi_meta_step returns."""
     B = x_s.shape[0]
@@ -74,10 +74,11 @@ def fumi_conv4_meta_step(theta, phi, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha
     out = R._pack(logits, loss_b, y_q)
     out["loss"] = loss.detach()
     if need_grad:
-        ps = list(theta) + list(phi)
+        ps = list(theta) + list(phi) + list(extra or [])            # extra: tensors text_s depends on (fumi_ref.fumi_meta_step)
         g = torch.autograd.grad(loss, ps, allow_unused=True)
         g = [torch.zeros_like(p) if gi is None else gi for gi, p in zip(g, ps)]
-        out["g_theta"], out["g_phi"] = g[:len(theta)], g[len(theta):]
+        out["g_theta"], out["g_phi"] = g[:len(theta)], g[len(theta):len(theta) + len(phi)]
+        out["g_extra"] = g[len(theta) + len(phi):]
     return out
 
 

@@ -204,7 +204,7 @@ def prototypical_loss(prototypes, emb, targets):
     return F.cross_entropy(-sq_distances(prototypes, emb), targets)
 
 
-def am3_step(w, text_s, x_s, y_s, x_q, y_q, n_way, lamda_fixed=None, need_grad=True, masks=None):
+def am3_step(w, text_s, x_s, y_s, x_q, y_q, n_way, lamda_fixed=None, need_grad=True, masks=None, extra=None):
     """am3.py:128-212 with dropout 0.  w = dict(Wi,bi, G0,g0,G1,g1, H0,h0,H1,h1) (image_encoder, g, h).
     text_s [B,S,Dt] is the per-sample text encoding (identical within a class in the dataset, not required)."""
     im_s = F.linear(x_s, w["Wi"], w["bi"])
@@ -231,8 +231,10 @@ def am3_step(w, text_s, x_s, y_s, x_q, y_q, n_way, lamda_fixed=None, need_grad=T
                acc=preds.eq(y_q).float().mean())
     if need_grad:
         names = ["Wi", "bi", "G0", "g0", "G1", "g1", "H0", "h0", "H1", "h1"]
-        g = torch.autograd.grad(loss, [w[k] for k in names], allow_unused=True)
+        leaves = [w[k] for k in names] + list(extra or [])          # extra: tensors text_s depends on (a trainable text encoder)
+        g = torch.autograd.grad(loss, leaves, allow_unused=True)
         out["grads"] = OrderedDict((k, torch.zeros_like(w[k]) if gi is None else gi) for k, gi in zip(names, g))
+        out["g_extra"] = [torch.zeros_like(p) if gi is None else gi for gi, p in zip(g[len(names):], leaves[len(names):])]
     return out
 
 

@@ -219,7 +219,7 @@ def gen_rnn(ref_common):
     print("rnn:", out["rnn"].shape)
 
 
-def gen_fumi_rnn_finetune(ref_fumi, ref_common):
+def gen_fumi_rnn_finetune(ref_fumi, ref_common, ref_am3=None):
     """FUMI(text_encoder="RNN" / "RNNhid", fine_tune=True) (fumi.py:46-67): one training meta-batch through the unmodified
     ``evaluate`` -- the loss reaches the bi-LSTM through get_hyper_params (fumi.py:196-212), so .grad of rnn.* is the fixture
     the engine's LSTM backward is held to.  Token rows are distinct per support SAMPLE (the class text is the class's first
@@ -272,6 +272,27 @@ def gen_fumi_rnn_finetune(ref_fumi, ref_common):
                 out[f"{enc}.grad.{n}"] = p_.grad.detach().numpy().copy()
                 out[f"{enc}.post.{n}.digest"] = cg.digest(p_)
         print(f"fumi_rnn_finetune[{enc}]: loss={float(loss):.6f} acc={float(acc):.4f}")
+    # the same episodes and the same LSTM through AM3(text_encoder=RNN / RNNhid, fine_tune=True) (am3.py:61-76,113-126): there EVERY
+    # support row's encoding feeds its class prototype, so all B*S rows carry an adjoint
+    if ref_am3 is not None:
+        P = 20
+        w = cg.make_am3_params(seed, D, Dt, Ht, P)
+        out["am3_P"] = np.int64(P)
+        for enc in ("RNN", "RNNhid"):
+            torch.manual_seed(21)
+            model = ref_am3.AM3(im_encoder="precomputed", im_emb_dim=D, text_encoder=enc, text_emb_dim=Dt, text_hid_dim=Ht,
+                                prototype_dim=P, dropout=0.0, fine_tune=True, dictionary=dictionary, pooling_strat="mean")
+            sd = cg.am3_state_dict(w)
+            sd.update(rnn_sd)
+            model.load_state_dict(sd)
+            opt = torch.optim.Adam(model.parameters(), lr=3e-5, weight_decay=5e-4)
+            r = model.evaluate(cg.to_batch(ep), opt, None, N, torch.device("cpu"), "train")
+            out[f"am3.{enc}.loss"], out[f"am3.{enc}.acc"], out[f"am3.{enc}.avg_lamda"] = np.float64(r[0]), np.float64(r[1]), np.float64(r[5])
+            for n, p_ in model.named_parameters():
+                if p_.requires_grad:
+                    out[f"am3.{enc}.grad.{n}"] = p_.grad.detach().numpy().copy()
+                    out[f"am3.{enc}.post.{n}.digest"] = cg.digest(p_)
+            print(f"fumi_rnn_finetune[am3 {enc}]: loss={float(r[0]):.6f} acc={float(r[1]):.4f} lam={float(r[5]):.4f}")
     np.savez(os.path.join(OUT, "fumi_rnn_finetune.npz"), **out)
 
 
@@ -322,7 +343,7 @@ def main():
     if not only or "rnn" in only:
         gen_rnn(ref_common)
     if not only or "fumi_rnn_finetune" in only:
-        gen_fumi_rnn_finetune(ref_fumi, ref_common)
+        gen_fumi_rnn_finetune(ref_fumi, ref_common, ref_am3)
     if not only or "surface" in only:
         gen_surface(ref_fumi, ref_maml, ref_am3, ref_utils)
 

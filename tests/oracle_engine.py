@@ -18,10 +18,7 @@ class OracleEngine:
     def fumi_step(self, n_way, x_s, y_s, x_q, y_q, text_s, theta, phi, T, alpha, tanh_head, need_grad, grad_scale,
                   g_theta=None, g_phi=None, cls_text=None, stats=None, dropout_p=0.0, seed=0):
         B = x_s.shape[0]
-        want = getattr(self, "_text_grad", None) if need_grad else None
-        if need_grad:
-            self._text_grad = None
-        extra = None
+        want, extra = self._take_text_grad(need_grad), None
         if cls_text is not None:                # expand the per-class rows back to per-sample rows for the oracle
             if want is not None:
                 cls_text = cls_text.detach().clone().requires_grad_(True)
@@ -89,10 +86,16 @@ class OracleEngine:
             from helpers import dropout_mask_flat
             Rs, Ht = x_s.shape[0] * x_s.shape[1], w[2].shape[0]
             masks = (dropout_mask_flat(seed, dropout_p, 1, Rs, Ht), dropout_mask_flat(seed, dropout_p, 2, Rs, Ht))
-        out = R.am3_step(wd, text_s, x_s, y_s, x_q, y_q, n_way, lamda_fixed, need_grad=need_grad, masks=masks)
+        want, extra = self._take_text_grad(need_grad), None
+        if want is not None:
+            text_s = text_s.detach().clone().requires_grad_(True)
+            extra = [text_s]
+        out = R.am3_step(wd, text_s, x_s, y_s, x_q, y_q, n_way, lamda_fixed, need_grad=need_grad, masks=masks, extra=extra)
         if need_grad:
             for dst, k in zip(g_w, AM3_KEYS):
                 dst.copy_(out["grads"][k] * (B * grad_scale))
+            if want is not None:
+                want.copy_((out["g_extra"][0] * (B * grad_scale)).reshape(want.shape))
         correct = out["preds"].eq(y_q).float().sum().reshape(1)
         dx = getattr(self, "_dx", (None, None)) if (want_dx and need_grad) else (None, None)
         return dict(loss=(out["loss"] * (B * grad_scale)).reshape(1), preds=out["preds"], lamda_s=out["lamda_s"],
@@ -125,14 +128,20 @@ class OracleEngine:
                         g_theta=None, g_phi=None, cls_text=None, stats=None):
         from oracle import conv4_ref as C
         B = x_s.shape[0]
+        want, extra = self._take_text_grad(need_grad), None
         if cls_text is not None:
+            if want is not None:
+                cls_text = cls_text.detach().clone().requires_grad_(True)
+                extra = [cls_text]
             text_s = torch.gather(cls_text, 1, y_s[..., None].expand(-1, -1, cls_text.shape[-1]))
         th = [t.detach().clone().requires_grad_(True) for t in theta]
         ph = [t.detach().clone().requires_grad_(True) for t in phi]
-        out = C.fumi_conv4_meta_step(th, ph, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha, tanh_head, need_grad=need_grad)
+        out = C.fumi_conv4_meta_step(th, ph, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha, tanh_head, need_grad=need_grad, extra=extra)
         if need_grad:
             for dst, g in zip(list(g_theta) + list(g_phi), out["g_theta"] + out["g_phi"]):
                 dst.copy_(g * (B * grad_scale))
+            if want is not None:
+                want.copy_((out["g_extra"][0] * (B * grad_scale)).reshape(want.shape))
         if stats is not None:
             stats.copy_(torch.stack([out["loss_b"].sum(), out["acc_b"].sum()]) * grad_scale)
         return dict(logits=out["logits"], preds=out["preds"], preds_f=out["preds"].float(), loss_b=out["loss_b"], acc_b=out["acc_b"])
@@ -157,14 +166,20 @@ class OracleEngine:
                            g_theta=None, g_phi=None, cls_text=None, stats=None):
         from oracle import resnet12_ref as C
         B = x_s.shape[0]
+        want, extra = self._take_text_grad(need_grad), None
         if cls_text is not None:
+            if want is not None:
+                cls_text = cls_text.detach().clone().requires_grad_(True)
+                extra = [cls_text]
             text_s = torch.gather(cls_text, 1, y_s[..., None].expand(-1, -1, cls_text.shape[-1]))
         th = [t.detach().clone().requires_grad_(True) for t in theta]
         ph = [t.detach().clone().requires_grad_(True) for t in phi]
-        out = C.fumi_meta_step(th, ph, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha, tanh_head, need_grad=need_grad)
+        out = C.fumi_meta_step(th, ph, text_s, x_s, y_s, x_q, y_q, n_way, T, alpha, tanh_head, need_grad=need_grad, extra=extra)
         if need_grad:
             for dst, g in zip(list(g_theta) + list(g_phi), out["g_theta"] + out["g_phi"]):
                 dst.copy_(g * (B * grad_scale))
+            if want is not None:
+                want.copy_((out["g_extra"][0] * (B * grad_scale)).reshape(want.shape))
         if stats is not None:
             stats.copy_(torch.stack([out["loss_b"].sum(), out["acc_b"].sum()]) * grad_scale)
         return dict(logits=out["logits"], preds=out["preds"], preds_f=out["preds"].float(), loss_b=out["loss_b"], acc_b=out["acc_b"])
@@ -208,8 +223,15 @@ class OracleEngine:
     def class_rows_select(self, rows_s, y_s, n_way):
         return torch.stack([R.class_text_select(rows_s[b], y_s[b], n_way) for b in range(rows_s.shape[0])])
 
-    def fumi_want_text_grad(self, device, g_cls_text):
-        self._text_grad = g_cls_text
+    def want_text_grad(self, device, g_text):
+        self._text_grad = g_text
+
+    def _take_text_grad(self, need_grad):
+        """The armed text-adjoint buffer, consumed by the next step with need_grad (fumi_hip_want_text_grad's contract)."""
+        if not need_grad:
+            return None
+        want, self._text_grad = getattr(self, "_text_grad", None), None
+        return want
 
     def glove_bag(self, tokens, table, pad_id, mode):
         return R.word_embedding_pool(tokens, table, pad_id, mode)

@@ -287,23 +287,16 @@ def test_disable_cuda_is_refused_where_the_engine_is_first_needed(tmp_path):
 
 
 def test_unsupported_flag_combinations_are_refused_up_front(oracle_engine):
-    """--fine_tune with RNN / RNNhid trains the bi-LSTM in the reference (fumi.py:65-67); the engine does for FuMI on precomputed
-    image features (test_fumi_trains_the_bilstm_under_fine_tune) and refuses it for AM3 and for the convolutional encoders (frozen
-    LSTM text encoders work everywhere: test_rnn_text_encoders_keep_the_reference_surface).  `--model am3 --text_encoder rand`
-    trains only with --dropout 0 (am3.py:118-126 applies dropout inside h only).  Both are refused by `check_supported`, for
-    every model name that builds the model in question (unknown names are AM3, like utils.init_model)."""
+    """`--model am3 --text_encoder rand` trains only with --dropout 0 (am3.py:118-126 applies dropout inside h only): refused by
+    `check_supported` for every model name that builds AM3 (unknown names are AM3, like utils.init_model).  --fine_tune with RNN /
+    RNNhid trains the bi-LSTM like the reference (fumi.py:65-67) for every model and image encoder: accepted."""
     from fumi_amd import main as cli
     for enc in ("RNN", "RNNhid"):
-        for model in ("am3", "some-unknown-name"):
-            with pytest.raises(NotImplementedError, match="forward only"):
-                cli.check_supported(cli.parse_args(["--model", model, "--disable_cuda", "--text_encoder", enc, "--fine_tune"]))
+        for model in ("fumi", "am3", "some-unknown-name", "maml"):
+            cli.check_supported(cli.parse_args(["--model", model, "--disable_cuda", "--text_encoder", enc, "--fine_tune"]))
         for im in ("conv4", "resnet12"):
-            with pytest.raises(NotImplementedError, match="forward only"):
-                cli.check_supported(cli.parse_args(["--model", "fumi", "--disable_cuda", "--text_encoder", enc, "--fine_tune",
-                                                    "--im_encoder", im]))
-        cli.check_supported(cli.parse_args(["--model", "fumi", "--disable_cuda", "--text_encoder", enc, "--fine_tune"]))
-    cli.check_supported(cli.parse_args(["--model", "fumi", "--disable_cuda", "--text_encoder", "RNN"]))          # frozen: accepted
-    cli.check_supported(cli.parse_args(["--model", "maml", "--disable_cuda", "--text_encoder", "RNN", "--fine_tune"]))   # no text path
+            cli.check_supported(cli.parse_args(["--model", "fumi", "--disable_cuda", "--text_encoder", enc, "--fine_tune",
+                                                "--im_encoder", im]))
     with pytest.raises(NotImplementedError, match="--dropout 0"):
         cli.check_supported(cli.parse_args(["--model", "am3", "--disable_cuda", "--text_encoder", "rand"]))      # CLI default 0.25
     cli.check_supported(cli.parse_args(["--model", "am3", "--disable_cuda", "--text_encoder", "rand", "--dropout", "0"]))
@@ -389,6 +382,36 @@ def test_fumi_trains_the_bilstm_under_fine_tune(enc, oracle_engine):
     m2.load_state_dict(sd)
     l2, _, _, _ = m2.evaluate(_args(c["T"]), cg.to_batch(ep), torch.optim.Adam([p for p in m2.parameters() if p.requires_grad]), "train")
     assert abs(float(l2) - float(gold[f"{enc}.loss"])) < 2e-5 and all(p.grad is None for p in m2.text_encoder.parameters())
+
+
+@pytest.mark.parametrize("enc", ["RNN", "RNNhid"])
+def test_am3_trains_the_bilstm_under_fine_tune(enc, oracle_engine):
+    """AM3(text_encoder=RNN / RNNhid, fine_tune=True).evaluate(train) (am3.py:61-76,128-212): all B*S token rows -> taped LSTM forward
+    -> step with the text adjoint -> LSTM backward -> Adam.  Gradients and post-step parameters against the reference's own."""
+    from helpers import rnn_finetune_case, RNN_KEYS
+    from fumi_amd.models.am3 import AM3
+    from fumi_amd.models import common
+    gold, c, ep, _, _, table, lstm_w = rnn_finetune_case()
+    words = [f"w{i}" for i in range(30)]
+    common.register_word_vectors("glove", common.ArrayKeyedVectors(words, table[1:].numpy()))
+    dictionary = {"PAD": 0, **{w: i + 1 for i, w in enumerate(words)}}
+    P = int(gold["am3_P"])
+    m = AM3("precomputed", c["D"], enc, text_emb_dim=c["Dt"], text_hid_dim=c["Ht"], prototype_dim=P, dropout=0.0, fine_tune=True,
+            dictionary=dictionary)
+    sd = cg.am3_state_dict(cg.make_am3_params(int(gold["seed"]), c["D"], c["Dt"], c["Ht"], P))
+    sd.update({k: torch.from_numpy(gold[k]) for k in gold if k.startswith("text_encoder.")})
+    m.load_state_dict(sd)
+    opt = torch.optim.Adam(m.parameters(), lr=3e-5, weight_decay=5e-4)
+    r = m.evaluate(cg.to_batch(ep), opt, None, c["N"], torch.device("cpu"), "train")
+    assert abs(float(r[0]) - float(gold[f"am3.{enc}.loss"])) < 6e-5 and abs(float(r[1]) - float(gold[f"am3.{enc}.acc"])) < 1e-6
+    n_checked = 0
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            g = gold[f"am3.{enc}.grad.{n}"]
+            assert float((p.grad - torch.from_numpy(g)).abs().max()) <= 5e-5 * max(float(np.abs(g).max()), 1e-6), n
+            np.testing.assert_allclose(cg.digest(p)[3:], gold[f"am3.{enc}.post.{n}.digest"][3:], rtol=0, atol=2e-7)
+            n_checked += 1
+    assert n_checked == 18
 
 
 def test_bench_self_launches_one_process_per_gpu(monkeypatch, capsys):

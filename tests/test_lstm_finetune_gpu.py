@@ -1,6 +1,6 @@
 """GPU parity of the trainable bi-LSTM text encoder (--fine_tune with --text_encoder RNN / RNNhid, fumi/models/fumi.py:46-67):
 the tape-keeping forward and back-propagation through time of csrc/textenc.hip, the text adjoint the FuMI meta-step hands back
-(fumi_hip_fumi_want_text_grad), and FUMI.evaluate(train) end to end against the reference's own gradients
+(fumi_hip_want_text_grad), and FUMI.evaluate(train) end to end against the reference's own gradients
 (tests/golden/fumi_rnn_finetune.npz, oracle/refharness/gen_golden.py)."""
 from types import SimpleNamespace
 
@@ -84,7 +84,7 @@ def test_lstm_backward_matches_oracle(dev, ws, use_cell):
 
 @pytest.mark.parametrize("shape", ["golden", "gemm_fallback", "bench"])
 def test_fumi_step_text_gradient_matches_oracle(dev, ws, shape):
-    """fumi_hip_fumi_want_text_grad: d(grad_scale * sum_b loss_b) / d cls_text of the very next FuMI step against autograd through
+    """fumi_hip_want_text_grad: d(grad_scale * sum_b loss_b) / d cls_text of the very next FuMI step against autograd through
     the oracle's meta-step, in the three forms of the hypernetwork backward (fused rider; plain GEMMs for a text width the
     LDS-resident kernels do not take; the bench's widths) -- and the step's other outputs are unchanged by the request."""
     from fumi_amd import hip
@@ -104,7 +104,7 @@ def test_fumi_step_text_gradient_matches_oracle(dev, ws, shape):
     thd, phd = [_g(t, dev) for t in theta], [_g(t, dev) for t in phi]
     plain = hip.fumi_step(ws, *args, thd, phd, T, cg.ALPHA, tanh, cls_text=_g(cls_text, dev), grad_scale=1.0 / B)
     g_ct = torch.full((B, N, Dt), float("nan"), device=dev)
-    hip.fumi_want_text_grad(ws, g_ct)
+    hip.want_text_grad(ws, g_ct)
     out = hip.fumi_step(ws, *args, thd, phd, T, cg.ALPHA, tanh, cls_text=_g(cls_text, dev), grad_scale=1.0 / B)
     assert rel_to_max(g_ct.cpu(), ref["g_extra"][0]) <= 1e-4
     for a, b in zip(out["g_theta"] + out["g_phi"], plain["g_theta"] + plain["g_phi"]):
@@ -119,11 +119,11 @@ def test_fumi_step_text_gradient_matches_oracle(dev, ws, shape):
     torch.cuda.synchronize()
     assert float(g_ct.min()) == 7.0 and float(g_ct.max()) == 7.0
     # an evaluation step (need_grad = 0) leaves the request armed for the training step that follows
-    hip.fumi_want_text_grad(ws, g_ct)
+    hip.want_text_grad(ws, g_ct)
     hip.fumi_step(ws, *args, thd, phd, T, cg.ALPHA, tanh, cls_text=_g(cls_text, dev), need_grad=False)
     torch.cuda.synchronize()
     assert float(g_ct.min()) == 7.0
-    hip.fumi_want_text_grad(ws, None)
+    hip.want_text_grad(ws, None)
     assert ws.read_status() == 0
 
 
@@ -168,3 +168,161 @@ def test_fumi_finetunes_the_bilstm_like_the_reference(dev, enc):
     # evaluation with the trained encoder: the frozen forward
     l2, _, p2, _ = m.evaluate(args, cg.to_batch(ep), None, "test")
     assert np.isfinite(float(l2)) and p2.shape == (c["B"], c["N"] * c["Q"])
+
+
+def _text_adjoint_identity(g_text, cls_text, phi, g_phi):
+    """g_text = s ubar A0 and g_phi[0] = s ubar^T c share ubar: c^T g_text == g_phi[0]^T A0 exactly, and with R <= Dt rows of full
+    rank that determines g_text.  Returns (rel. error of g_text against the least-squares solution, rel. error of the row-sum identity
+    colsum(g_text) == g_phi[1] A0)."""
+    c = cls_text.reshape(-1, cls_text.shape[-1]).double().cpu()
+    M = g_text.reshape(c.shape).double().cpu()
+    A0, gA0, ga0 = phi[0].double().cpu(), g_phi[0].double().cpu(), g_phi[1].double().cpu()
+    assert c.shape[0] <= c.shape[1] and int(torch.linalg.matrix_rank(c)) == c.shape[0]
+    sol = torch.linalg.lstsq(c.t(), gA0.t() @ A0).solution
+    e1 = float((M - sol).abs().max() / sol.abs().max())
+    rs = ga0 @ A0
+    e2 = float((M.sum(0) - rs).abs().max() / rs.abs().max())
+    return e1, e2
+
+
+@pytest.mark.parametrize("encoder", ["conv4", "resnet12"])
+def test_conv_encoder_steps_hand_back_the_text_adjoint(dev, ws, encoder):
+    """fumi_hip_fumi_conv4_step / fumi_hip_fumi_resnet12_step with an armed fumi_hip_want_text_grad: the adjoint of the class text rows
+    is tied to the (separately verified) hypernetwork gradients by exact identities -- g_text = s ubar A0, g_phi[0] = s ubar^T c,
+    g_phi[1] = s colsum(ubar) -- which determine it when the B*N text rows are linearly independent."""
+    from fumi_amd import hip
+    from oracle import conv4_ref as CR
+    B, N, K, Q, H, Dt, Ht, T = 2, 3, 2, 2, 16, 8, 12, 2
+    ep = CR.make_image_episodes(5, B, N, K, Q, 3, H, H, Dt)
+    g = torch.Generator().manual_seed(1)
+    cls_text = torch.randn(B, N, Dt, generator=g)
+    if encoder == "conv4":
+        theta = CR.make_conv4_params(5, 3, 64, 4)
+        Fd = CR.feature_dim(H, H, 64, 4)
+        step = hip.fumi_conv4_step
+    else:
+        from oracle import resnet12_ref as RR
+        theta = RR.make_params(5, 3, (32, 64), torch.float32)
+        Fd = 64
+        step = hip.fumi_resnet12_step
+    _, phi = cg.make_fumi_params(5, 8, [Fd], Dt, Ht, head_scale=0.3)
+    args = [N] + [_g(ep[k], dev) for k in ("x_s", "y_s", "x_q", "y_q")] + [[_g(t, dev) for t in theta], [_g(t, dev) for t in phi], T, 0.05, True]
+    plain = step(ws, *args, cls_text=_g(cls_text, dev), grad_scale=1.0 / B)
+    g_ct = torch.full((B, N, Dt), float("nan"), device=dev)
+    hip.want_text_grad(ws, g_ct)
+    out = step(ws, *args, cls_text=_g(cls_text, dev), grad_scale=1.0 / B)
+    assert ws.read_status() == 0 and bool(torch.isfinite(g_ct).all()) and float(g_ct.abs().max()) > 0
+    for a, b in zip(out["g_theta"] + out["g_phi"], plain["g_theta"] + plain["g_phi"]):
+        assert torch.equal(a, b)                                  # the request changes nothing else
+    e1, e2 = _text_adjoint_identity(g_ct, cls_text, phi, out["g_phi"])
+    assert e1 <= 1e-4 and e2 <= 1e-4, (e1, e2)
+    g_ct.fill_(7.0)                                                # one-shot
+    step(ws, *args, cls_text=_g(cls_text, dev), grad_scale=1.0 / B)
+    torch.cuda.synchronize()
+    assert float(g_ct.min()) == 7.0 and float(g_ct.max()) == 7.0
+
+
+@pytest.mark.parametrize("lamda_fixed", [None, 1])
+def test_am3_step_text_gradient_matches_oracle(dev, ws, lamda_fixed):
+    """fumi_hip_am3_step with an armed text adjoint: d loss / d text_s of all B*S rows against autograd through the oracle's step
+    (am3.py:113-126: every support row's encoding feeds its class prototype), in the fused and the GEMM form of the text MLPs'
+    backward, and with lamda overridden (h out of the graph)."""
+    from fumi_amd import hip
+    for (B, N, K, Q, D, Dt, Ht, P) in [(3, 4, 2, 3, 40, 16, 32, 20), (4, 5, 5, 15, 512, 768, 256, 128)]:
+        ep = cg.make_episodes(9, B, N, K, Q, D, Dt)
+        w = cg.make_am3_params(9, D, Dt, Ht, P)
+        g = torch.Generator().manual_seed(2)
+        text = torch.randn(B, N * K, Dt, generator=g)
+        wl = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+        tx = text.clone().requires_grad_(True)
+        ref = R.am3_step(wl, tx, ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], N, lamda_fixed, extra=[tx])
+        wd = [_g(w[k], dev) for k in hip.AM3_KEYS]
+        args = [_g(ep[k], dev) for k in ("x_s", "y_s", "x_q", "y_q")] + [_g(text, dev), wd, N, lamda_fixed]
+        g_t = torch.full((B, N * K, Dt), float("nan"), device=dev)
+        hip.want_text_grad(ws, g_t)
+        out = hip.am3_step(ws, *args, grad_scale=1.0 / B)
+        assert abs(float(out["loss"]) - float(ref["loss"])) <= 1e-4 * max(1.0, float(ref["loss"]))
+        assert rel_to_max(g_t.cpu(), ref["g_extra"][0]) <= 2e-4, rel_to_max(g_t.cpu(), ref["g_extra"][0])
+        g_t.fill_(7.0)
+        hip.am3_step(ws, *args, grad_scale=1.0 / B)
+        torch.cuda.synchronize()
+        assert float(g_t.min()) == 7.0 and float(g_t.max()) == 7.0
+    assert ws.read_status() == 0
+
+
+@pytest.mark.parametrize("enc", ["RNN", "RNNhid"])
+def test_am3_finetunes_the_bilstm_like_the_reference(dev, enc):
+    """AM3(text_encoder=RNN / RNNhid, fine_tune=True).evaluate(train) on the GPU against the reference's own run: loss, .grad of all
+    eighteen trainable tensors (eight of them the LSTM's) and the parameters after the Adam step."""
+    from fumi_amd.models.am3 import AM3
+    from fumi_amd.models import common
+    from fumi_amd.optim import Adam
+    gold, c, ep, _, _, table, _ = rnn_finetune_case()
+    words = [f"w{i}" for i in range(30)]
+    common.register_word_vectors("glove", common.ArrayKeyedVectors(words, table[1:].numpy()))
+    dictionary = {"PAD": 0, **{w: i + 1 for i, w in enumerate(words)}}
+    P = int(gold["am3_P"])
+    m = AM3("precomputed", c["D"], enc, text_emb_dim=c["Dt"], text_hid_dim=c["Ht"], prototype_dim=P, dropout=0.0, fine_tune=True,
+            dictionary=dictionary)
+    sd = cg.am3_state_dict(cg.make_am3_params(int(gold["seed"]), c["D"], c["Dt"], c["Ht"], P))
+    sd.update({k: torch.from_numpy(gold[k]) for k in gold if k.startswith("text_encoder.")})
+    m.load_state_dict(sd)
+    m.to(dev)
+    opt = Adam(m.parameters(), lr=3e-5, weight_decay=5e-4)
+    r = m.evaluate(cg.to_batch(ep), opt, None, c["N"], dev, "train")
+    assert abs(float(r[0]) - float(gold[f"am3.{enc}.loss"])) < 1e-4 and abs(float(r[1]) - float(gold[f"am3.{enc}.acc"])) < 1e-6
+    n_checked = 0
+    for n, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        g = gold[f"am3.{enc}.grad.{n}"]
+        assert rel_to_max(p.grad.cpu(), g) <= 2e-4, (n, rel_to_max(p.grad.cpu(), g))
+        np.testing.assert_allclose(cg.digest(p.detach().cpu())[3:], gold[f"am3.{enc}.post.{n}.digest"][3:], rtol=0, atol=3e-7)
+        n_checked += 1
+    assert n_checked == 18
+
+
+def test_fumi_conv4_finetunes_the_bilstm(dev):
+    """FUMI(im_encoder='conv4', text_encoder='RNN', fine_tune=True).evaluate(train): the LSTM's .grad equals what its backward gives for
+    the text adjoint a direct call of the step returns, and every LSTM tensor moves."""
+    from fumi_amd import hip
+    from fumi_amd.models.fumi import FUMI
+    from fumi_amd.models import common
+    from fumi_amd.optim import Adam
+    from oracle import conv4_ref as CR
+    gold, c, _, _, _, table, _ = rnn_finetune_case()
+    words = [f"w{i}" for i in range(30)]
+    common.register_word_vectors("glove", common.ArrayKeyedVectors(words, table[1:].numpy()))
+    dictionary = {"PAD": 0, **{w: i + 1 for i, w in enumerate(words)}}
+    B, N, K, Q, H = c["B"], c["N"], c["K"], c["Q"], 16
+    ep = CR.make_image_episodes(3, B, N, K, Q, 3, H, H, c["Dt"])
+    ep["text_s"], ep["text_q"] = torch.from_numpy(gold["text_s"]), torch.from_numpy(gold["text_q"])
+    torch.manual_seed(4)
+    m = FUMI(n_way=N, im_encoder="conv4", image_size=H, text_encoder="RNN", text_emb_dim=c["Dt"], text_hid_dim=c["Ht"],
+             dictionary=dictionary, fine_tune=True)
+    m.text_encoder.load_state_dict({k[len("text_encoder."):]: torch.from_numpy(gold[k]) for k in gold if k.startswith("text_encoder.")})
+    m.to(dev)
+    ws = hip.Workspace.get(dev)
+    # what the step hands back for these parameters, then the LSTM's own backward of it
+    y_s = ep["y_s"].to(dev)
+    tok = m.text_encoder  # noqa: F841  (readability)
+    from fumi_amd import engine as _e
+    eng = _e.get_engine()
+    tok_cls = eng.class_rows_select(ep["text_s"].to(dev), y_s, N)
+    cls_text, tape = m.text_encoder.forward_train(tok_cls)
+    g_ct = torch.empty_like(cls_text)
+    hip.want_text_grad(ws, g_ct)
+    theta, phi = [p.detach() for p in m._theta()], [p.detach() for p in m._phi()]
+    hip.fumi_conv4_step(ws, N, ep["x_s"].to(dev), y_s, ep["x_q"].to(dev), ep["y_q"].to(dev), theta, phi, 1, 0.05, m.norm_hypernet,
+                        cls_text=cls_text, grad_scale=1.0 / B)
+    lw = [w.detach().contiguous() for w in m.text_encoder.lstm_weights()]
+    want = hip.lstm_bidir_bwd(ws, tok_cls, m.text_encoder.embed.weight.detach(), lw, 0, False, tape, g_ct)
+    before = [p.detach().clone() for p in m.text_encoder.rnn.parameters()]
+    opt = Adam(m.parameters(), lr=1e-3)
+    args = SimpleNamespace(device=dev, num_train_adapt_steps=1, num_test_adapt_steps=1, step_size=0.05, first_order=False, num_ways=N,
+                           batch_size=B)
+    m.evaluate(args, cg.to_batch(ep), opt, "train")
+    torch.cuda.synchronize()
+    for w_, g_ in zip(m.text_encoder.lstm_weights(), want):
+        assert float(g_.abs().max()) > 0 and rel_to_max(w_.grad.cpu(), g_.cpu()) <= 1e-5
+    assert all(not torch.equal(a, b) for a, b in zip(before, m.text_encoder.rnn.parameters()))

@@ -124,6 +124,25 @@ def test_fumi_with_trainable_lstm_oracle_matches_reference(enc):
         assert_close_max(g, gold[f"{enc}.grad.{n}"], 5e-5, n)
 
 
+@pytest.mark.parametrize("enc", ["RNN", "RNNhid"])
+def test_am3_with_trainable_lstm_oracle_matches_reference(enc):
+    """AM3(text_encoder=RNN / RNNhid, fine_tune=True) (am3.py:61-76,113-126): every support row's encoding feeds its class prototype.
+    The oracle's lstm_encode inside am3_step's graph against the reference's own .grad of rnn.* and of the ten AM3 tensors."""
+    from helpers import rnn_finetune_case, RNN_KEYS
+    gold, c, ep, _, _, table, lstm_w = rnn_finetune_case()
+    w = {k: v.clone().requires_grad_(True) for k, v in cg.make_am3_params(int(gold["seed"]), c["D"], c["Dt"], c["Ht"], int(gold["am3_P"])).items()}
+    lstm_w = _leaf(lstm_w)
+    text = R.lstm_encode(ep["text_s"], table, lstm_w, 0, enc == "RNNhid")
+    out = R.am3_step(w, text, ep["x_s"], ep["y_s"], ep["x_q"], ep["y_q"], c["N"], extra=lstm_w)
+    assert abs(float(out["loss"]) - float(gold[f"am3.{enc}.loss"])) <= TOL * 3 and abs(float(out["acc"]) - float(gold[f"am3.{enc}.acc"])) < 1e-6
+    assert abs(float(out["avg_lamda"]) - float(gold[f"am3.{enc}.avg_lamda"])) < 1e-6
+    for k, g in zip(RNN_KEYS, out["g_extra"]):
+        assert_close_max(g, gold[f"am3.{enc}.grad.text_encoder.rnn.{k}"], 5e-5, k)
+        assert float(np.abs(gold[f"am3.{enc}.grad.text_encoder.rnn.{k}"]).max()) > 1e-6
+    for n, g in zip(cg.am3_state_dict(w), out["grads"].values()):
+        assert_close_max(g, gold[f"am3.{enc}.grad.{n}"], 5e-5, n)
+
+
 def test_lstm_encoder_restatement_matches_reference():
     """oracle/fumi_ref.py lstm_encode against the reference's RNN (output states) and RnnHid (cell states), common.py:44-161."""
     gold = load_golden("rnn")
