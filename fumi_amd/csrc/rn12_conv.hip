@@ -472,7 +472,9 @@ int conv_dispatch(hipStream_t st, const RnConvArgs& a, int* nt_out) {
     // one stream (800 instead of 640 workgroups on 512 slots) and changes nothing in the two-lane step: 15.78 vs 15.78 episodes/s.
     // The epilogue below is written for any MW; only MW = 1 | 2 are instantiated.  Unequal s_setprio for the two waves that share a
     // SIMD -- by the parity of their wave slot, HW_ID[3:0] -- against the two falling into step: no change in any layer, 15.95 vs
-    // 15.98 episodes/s.)
+    // 15.98 episodes/s.  The 96-pixel form with two fragment sets in registers (reads of k-step ks + 1 under the MFMAs of ks, a full
+    // tile as straight-line code): hipcc waits with lgkmcnt(0) around every LDS-direct load and shuffles accumulators between AGPRs
+    // and VGPRs -- 1 685 us at 160 -> 160, four times the two-workgroup kernel.)
     if (force != 1 && (tiles256 >= 256 || force == 2)) {
         if (fbks == 4 && ConvCfg<NF, 2, 4>::lds_bytes(a.g) <= 160 * 1024) return conv_launch<NF, 2, 4>(st, a, nt_out);
         if (fbks == 2 && ConvCfg<NF, 2, 2>::lds_bytes(a.g) <= 160 * 1024) return conv_launch<NF, 2, 2>(st, a, nt_out);
