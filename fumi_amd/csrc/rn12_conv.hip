@@ -471,8 +471,9 @@ int conv_dispatch(hipStream_t st, const RnConvArgs& a, int* nt_out) {
     // 640 -> 640 10 x 10; MW = 4 with NF = 5 needs 320 accumulators and spills.  NF = 4 on the 640-channel layers is 8-9 % faster on
     // one stream (800 instead of 640 workgroups on 512 slots) and changes nothing in the two-lane step: 15.78 vs 15.78 episodes/s.
     // The epilogue below is written for any MW; only MW = 1 | 2 are instantiated.  Unequal s_setprio for the two waves that share a
-    // SIMD -- by the parity of their wave slot, HW_ID[3:0] -- against the two falling into step: no change in any layer, 15.95 vs
-    // 15.98 episodes/s.  The 96-pixel form with two fragment sets in registers (reads of k-step ks + 1 under the MFMAs of ks, a full
+    // CU -- exactly one workgroup per physical CU (XCC_ID, HW_ID.{se, sh, cu}; a flag taken with atomicCAS) at priority 3 -- against
+    // the two falling into step: no change in any layer, 15.39-15.41 vs 15.40-15.54 episodes/s on the same box.  (HW_ID[3:0] does
+    // not tell co-resident waves apart here: 474 of 480 sampled waves report slot 0.)  The 96-pixel form with two fragment sets in registers (reads of k-step ks + 1 under the MFMAs of ks, a full
     // tile as straight-line code): hipcc waits with lgkmcnt(0) around every LDS-direct load and shuffles accumulators between AGPRs
     // and VGPRs -- 1 685 us at 160 -> 160, four times the two-workgroup kernel.)
     if (force != 1 && (tiles256 >= 256 || force == 2)) {

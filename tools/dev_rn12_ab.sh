@@ -1,9 +1,9 @@
-# dev scratch: A/B of the wave-slot priorities (FUMI_RN_PRIO: bits 0-1 convolution mode, bits 2-3 weight-gradient mode; mode 1 = odd slot high, 2 = even slot high)
+# dev scratch: one high-priority workgroup per CU in the convolution (FUMI_RN_PRIO=1)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-for cfg in "FUMI_RN_PRIO=0" "FUMI_RN_PRIO=1" "FUMI_RN_PRIO=2" "FUMI_RN_PRIO=5"; do
+for cfg in "FUMI_RN_PRIO=0" "FUMI_RN_PRIO=1"; do
   echo "== layers $cfg"
-  ( export $cfg; cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/prof_ab; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_ab -o lay -- python3 $R/tools/bench_rn12_layers.py 4 100 > /tmp/ab_events.txt 2>&1; cd $R; f=$(find /tmp/prof_ab -name "*kernel_trace.csv" | head -1); python tools/layers_from_trace.py $f 4 100 | tail -16 )
+  ( export $cfg; cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/prof_ab; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_ab -o lay -- python3 $R/tools/bench_rn12_layers.py 4 100 fwd,bwd > /tmp/ab_events.txt 2>&1; cd $R; f=$(find /tmp/prof_ab -name "*kernel_trace.csv" | head -1); python tools/layers_from_trace.py $f 4 100 | tail -15 )
 done
-for cfg in "FUMI_RN_PRIO=0" "FUMI_RN_PRIO=1" "FUMI_RN_PRIO=5" "FUMI_RN_PRIO=0" "FUMI_RN_PRIO=5"; do
+for cfg in "FUMI_RN_PRIO=0" "FUMI_RN_PRIO=1" "FUMI_RN_PRIO=0" "FUMI_RN_PRIO=1"; do
   echo "== step $cfg"; env $cfg timeout -k 10 300 python tools/bench_resnet12.py 16 2 5 15 2>&1 | tail -1
 done
