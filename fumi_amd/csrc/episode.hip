@@ -1626,7 +1626,10 @@ int run_episodes(fumi_ws* ws, hipStream_t st, const EpisodeProblem& p) {
     // split ([B,S,h0] | [B,Qn,h0]) so that each part reads one contiguous panel.  FUMI_EPI_OVERLAP=0: one launch behind the sweep (2: the two-launch form at any size, for tests).
     static const int ovl_env = getenv("FUMI_EPI_OVERLAP") ? atoi(getenv("FUMI_EPI_OVERLAP")) : 1;
     // (measured: FuMI BERT T = 5, 32 episodes 0.436 -> 0.420 ms per step; a 4-episode MAML step, whose pass is 23 us, LOSES 18 us to
-    // the fork / join and the extra launch -- only meta-batches whose pass is long enough to be worth hiding: >= 2048 query rows)
+    // the fork / join and the extra launch -- only meta-batches whose pass is long enough to be worth hiding: >= 2048 query rows.
+    // At T = 1 the sweep is one 42 us launch on half of the CUs and the query-row part takes the other half for about as long: the
+    // headline step 0.2200 -> 0.2153 ms without phase timing; not adopted -- the pass is the bench's roofline kernel, timed as ONE
+    // launch on the caller's stream, and +2 % does not pay for a second population of that kernel in every profile)
     const bool two_part = ovl_env && p.need_grad && p.T >= 2 && ws->side && ws->evx[0] && ws->evx[1] && !ws->profiling && !p.after_reverse &&
                           xpanel_bwd_two_part_ok(p.D, h0) && p.second_order && ((long)p.B * p.Qn >= 2048 || ovl_env == 2);      // (2: tests)
     if (p.need_grad) {
