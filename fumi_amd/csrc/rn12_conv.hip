@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
     // dev tracing: cycles per phase summed in registers (a store inside the loop would join the vmcnt queue the waits count)
     const bool traced = a.trace && tid == 0 && blockIdx.x == gridDim.x / 2;
     unsigned long long t_prev = traced ? __builtin_amdgcn_s_memtime() : 0, t_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long clk0 = t_prev, real0 = traced ? __builtin_amdgcn_s_memrealtime() : 0;    // in-kernel clock (MI355X_MICROARCH.md, DVFS item 6)
 #define RNSTAMP(k) if (traced) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_sum[k] += t_now - t_prev; t_prev = t_now; }
     for (int s = 0; s < a.nsrc; ++s) {
         RnSrc S;                                                    // (wave-uniform: kept in scalar registers)
@@ -413,6 +414,7 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
     if (traced) {
         RNSTAMP(7)                                                  // (epilogue)
         for (int k = 0; k < 8; ++k) a.trace[k] = t_sum[k];
+        a.trace[8] = __builtin_amdgcn_s_memtime() - clk0; a.trace[9] = __builtin_amdgcn_s_memrealtime() - real0;
     }
 }
 
@@ -470,10 +472,14 @@ int conv_dispatch(hipStream_t st, const RnConvArgs& a, int* nt_out) {
     // 0.45 KiB of LDS reads per MFMA instead of 0.7: 551 vs 420 us at 160 -> 160 42 x 42, 424 vs 354 at 320 -> 320 21 x 21, equal at
     // 640 -> 640 10 x 10; MW = 4 with NF = 5 needs 320 accumulators and spills.  NF = 4 on the 640-channel layers is 8-9 % faster on
     // one stream (800 instead of 640 workgroups on 512 slots) and changes nothing in the two-lane step: 15.78 vs 15.78 episodes/s.
-    // The epilogue below is written for any MW; only MW = 1 | 2 are instantiated.  Unequal s_setprio for the two waves that share a
-    // CU -- exactly one workgroup per physical CU (XCC_ID, HW_ID.{se, sh, cu}; a flag taken with atomicCAS) at priority 3 -- against
-    // the two falling into step: no change in any layer, 15.39-15.41 vs 15.40-15.54 episodes/s on the same box.  (HW_ID[3:0] does
-    // not tell co-resident waves apart here: 474 of 480 sampled waves report slot 0.)  The 96-pixel form with two fragment sets in registers (reads of k-step ks + 1 under the MFMAs of ks, a full
+    // The epilogue below is written for any MW; only MW = 1 | 2 are instantiated.  Two attempts at unequal s_setprio for the two
+    // workgroups that share a CU (by HW_ID wave slot; by a per-CU flag taken with atomicCAS) changed nothing -- and could not: both
+    // guarded the s_setprio with a condition hipcc does not know to be wave-uniform, which lowers to an exec mask around an
+    // UNCONDITIONAL scalar s_setprio (cdna_hip_programming.md T5: the guard must go through readfirstlane).  Not repeated: the issue
+    // arbiter already prefers the older of two waves (MI355X_MICROARCH.md, Two waves per SIMD, items 2-4: static priority is worth
+    // 0-1 % there).  In-kernel clock under this kernel (s_memtime / s_memrealtime, tests/dev/trace_rn12_conv.py): 1.98 GHz at
+    // 160 -> 160, 2.30-2.33 at the other layers -- the distance to the peak is idle pipe, not a lowered clock.  The 96-pixel form
+    // with two fragment sets in registers (reads of k-step ks + 1 under the MFMAs of ks, a full
     // tile as straight-line code): hipcc waits with lgkmcnt(0) around every LDS-direct load and shuffles accumulators between AGPRs
     // and VGPRs -- 1 685 us at 160 -> 160, four times the two-workgroup kernel.)
     if (force != 1 && (tiles256 >= 256 || force == 2)) {

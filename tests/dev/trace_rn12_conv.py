@@ -23,12 +23,21 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
 fl = 2.0 * B * M * H * H * 9 * Cin * Cout
 print(f"{Cin}->{Cout} {H}x{H} B={B} M={M}: {ms * 1e3:.0f} us per call (incl. weight prep), {fl / ms / 1e9:.0f} TFLOP/s")
+import time
+t_end = time.time() + 2.5                                  # (the clock settles under a sustained load: >= 2 s of back-to-back launches)
+while time.time() < t_end:
+    for _ in range(20):
+        hip.rn12_conv(ws, x, Wt, H, H)
+    torch.cuda.synchronize()
 tr = torch.zeros(512, dtype=torch.int64, device=dev)
 L.fumi_hip_set_trace_buffer(2, ctypes.c_void_p(tr.data_ptr()))
 hip.rn12_conv(ws, x, Wt, H, H)
 torch.cuda.synchronize()
 L.fumi_hip_set_trace_buffer(2, None)
-t = tr.cpu().tolist()[:8]
+full = tr.cpu().tolist()
+t = full[:8]
+if full[9]:
+    print(f"in-kernel clock of the traced workgroup: {full[8] / full[9] * 0.1:.3f} GHz (s_memtime / s_memrealtime x 100 MHz)")
 names = ["between chunks + slab issue", "slab + first weight tile landed", "weight loads issued", "k-steps (MFMA)", "wait for the older weight set",
          "weight tile -> LDS", "barrier", "epilogue"]
 tot = sum(t)
