@@ -475,9 +475,10 @@ int conv_dispatch(hipStream_t st, const RnConvArgs& a, int* nt_out) {
     // The epilogue below is written for any MW; only MW = 1 | 2 are instantiated.  Two attempts at unequal s_setprio for the two
     // workgroups that share a CU (by HW_ID wave slot; by a per-CU flag taken with atomicCAS) changed nothing -- and could not: both
     // guarded the s_setprio with a condition hipcc does not know to be wave-uniform, which lowers to an exec mask around an
-    // UNCONDITIONAL scalar s_setprio (cdna_hip_programming.md T5: the guard must go through readfirstlane).  Not repeated: the issue
-    // arbiter already prefers the older of two waves (MI355X_MICROARCH.md, Two waves per SIMD, items 2-4: static priority is worth
-    // 0-1 % there).  In-kernel clock under this kernel (s_memtime / s_memrealtime, tests/dev/trace_rn12_conv.py): 1.98 GHz at
+    // UNCONDITIONAL scalar s_setprio (cdna_hip_programming.md T5: the guard must go through readfirstlane).  Repeated with that
+    // guard (a scalar branch around s_setprio 3 in the object), flag holder or the other workgroup high: 15.39-15.42 / 15.37 vs
+    // 15.45-15.47 episodes/s -- the issue arbiter already prefers the older of two waves (MI355X_MICROARCH.md, Two waves per SIMD,
+    // items 2-4).  In-kernel clock under this kernel (s_memtime / s_memrealtime, tests/dev/trace_rn12_conv.py): 1.98 GHz at
     // 160 -> 160, 2.30-2.33 at the other layers -- the distance to the peak is idle pipe, not a lowered clock.  The 96-pixel form
     // with two fragment sets in registers (reads of k-step ks + 1 under the MFMAs of ks, a full
     // tile as straight-line code): hipcc waits with lgkmcnt(0) around every LDS-direct load and shuffles accumulators between AGPRs
