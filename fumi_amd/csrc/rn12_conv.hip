@@ -3,6 +3,7 @@
 // fp32 accumulation.  Hand-written for gfx950 (wave64, 160 KiB LDS, ds_read_b64_tr_b16).
 #include "rn12.h"
 #include <stdlib.h>
+#include <type_traits>
 
 unsigned long long* g_rn_trace = nullptr;          // dev tracing only (tests/dev/trace_rn12_conv.py)
 void set_rn12_trace(void* p) { g_rn_trace = (unsigned long long*)p; }
@@ -12,6 +13,7 @@ namespace {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *(const u32x4*)p; }
 // wave-uniform values that reach the kernel through LDS or lane arithmetic live in VGPRs unless told otherwise: these move them to SGPRs
@@ -32,8 +34,10 @@ template <class T> __device__ __forceinline__ const T* uni(const T* p) { return 
 //   its 16-byte chunks XOR-ed by (pixel >> 1) & 7 (conflict-free ds_read_b128 for every tap shift); per tap the weight tile
 //   (4 k-steps x NF fragments x 1 KiB, already in MFMA B-fragment order in memory) is double-buffered through LDS -- the copy is linear,
 //   every wave reads each fragment with one ds_read_b128 -- while the matrix pipe works on the previous tap.
-//   epilogue: the fp32 tile is rounded to bf16 into LDS, then rows leave with 16-byte stores (border pixels as 0) and the batch-norm
-//   statistics (sum, sum of squares or of products with `dot`) of the STORED values are taken on the way.
+//   epilogue (interior pixels only; nothing reads the border of a convolution's output): the 16 x 16 x 32 form multiplies transposed and
+//   stores 16 bytes per lane straight from registers after one lane swap per dword; the 32 x 32 x 16 form (3-channel image layers) rounds
+//   the fp32 tile to bf16 into LDS and stores rows from there.  The batch-norm statistics (sum, sum of squares or of products with `dot`)
+//   are those of the STORED values in both.
 // =====================================================================================================================================
 constexpr int CV_KC = 64;                              // channels per staged chunk
 
@@ -96,6 +100,7 @@ struct ConvCfg {
 // with (row & 7) instead of (row >> 1) & 7 (conflict-free for THIS read pattern: tools/lds_swizzle_check.py).
 template <int NF, int MW, int BKS, bool S16>
 __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
+    constexpr bool DIRECT = S16;                    // the 16 x 16 x 32 form forms its products transposed and stores from registers
     typedef ConvCfg<NF, MW, BKS> C;
     auto swz = [](int r) { return S16 ? (r & 7) : ((r >> 1) & 7); };
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -125,6 +130,8 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
     }
     const long clast = min(c0 + C::MT, cend) - 1;
     const long pfirst = rn_pix_of(c0, a.g), plast = rn_pix_of(clast, a.g);
+    // (what the register epilogue needs of these, moved to scalar registers here: they are live across the whole main loop)
+    [[maybe_unused]] const unsigned epi_pbase = (unsigned)uni((int)((unsigned)pfirst * (unsigned)a.Cout)), epi_cmax = (unsigned)uni((int)(clast - c0));
     if (tid == 0) { s_src[0] = a.src[0]; s_src[1] = a.src[1]; s_src[2] = a.src[2]; s_src[3] = a.src[3]; }
     unsigned char* const As = lds;
     unsigned char* const Bs = lds + a.slab_rows * 128;            // (slab_rows: a multiple of 8, the granule of the LDS-direct loads)
@@ -159,7 +166,8 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
     // dev tracing: cycles per phase summed in registers (a store inside the loop would join the vmcnt queue the waits count)
     const bool traced = a.trace && tid == 0 && blockIdx.x == gridDim.x / 2;
     unsigned long long t_prev = traced ? __builtin_amdgcn_s_memtime() : 0, t_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long clk0 = t_prev, real0 = traced ? __builtin_amdgcn_s_memrealtime() : 0;    // in-kernel clock (MI355X_MICROARCH.md, DVFS item 6)
+    // in-kernel clock (MI355X_MICROARCH.md, DVFS item 6): start stamps to memory at once -- no registers held across the kernel
+    if (traced) { a.trace[10] = t_prev; a.trace[11] = __builtin_amdgcn_s_memrealtime(); }
 #define RNSTAMP(k) if (traced) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_sum[k] += t_now - t_prev; t_prev = t_now; }
     for (int s = 0; s < a.nsrc; ++s) {
         RnSrc S;                                                    // (wave-uniform: kept in scalar registers)
@@ -283,7 +291,8 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                             for (int m = 0; m < 2 * MW; ++m) {
 #pragma unroll
                                 for (int f = 0; f < NF; ++f)
-                                    acc16[m][h * NF + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[f], acc16[m][h * NF + f], 0, 0, 0);
+                                    // (transposed: weight fragment as the A operand -- rows = output channels, columns = pixels)
+                                    acc16[m][h * NF + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[f], af[m], acc16[m][h * NF + f], 0, 0, 0);
                                 if ((m & 1) && slot < NBL) { bissue1(nxt, nbuf, slot); ++slot; }
                             }
                         }
@@ -322,7 +331,92 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
         }
     }
     RNSTAMP(0)
-    // ---- epilogue, 128 rows at a time: fp32 accumulators -> bf16 image in LDS (rows of NTP elements: the two lane halves land 16
+    if constexpr (DIRECT) {
+        // ---- epilogue of the 16 x 16 x 32 form, without an LDS image: the products were formed TRANSPOSED (weight fragments as the A
+        //      operand), so a lane holds one pixel (its column of the tile) and, per 16-channel tile, four consecutive output
+        //      channels (4 (lane >> 4) ..); one v_permlane16_swap per packed dword between two neighbouring channel tiles leaves
+        //      every lane with EIGHT consecutive channels of its pixel: a 16-byte store straight from registers, the four lanes of a
+        //      pixel writing 64 contiguous bytes.  Statistics of the stored values: per lane over its pixels, over the 16 lanes that
+        //      share the channels (4 shuffle steps), over the waves through LDS.  (Round 4: 160 ds_write_b16 + two barriers + a read-
+        //      back per wave before; forward + input-gradient layer set 5.41 -> 5.19 ms, 1 x 1 layers -13..-17 %.)
+        float* red = (float*)lds;                                   // [4 waves][NT][2]
+        rbf16* outb = a.out + (long)b * a.out_stride + (long)cg * C::NT;
+        const rbf16* dotb = a.dot ? a.dot + (long)b * a.dot_stride + (long)cg * C::NT : nullptr;
+        const bool st = a.stats != nullptr;
+        if (st) __syncthreads();                                    // (As / Bs are dead in every wave before `red` is written)
+        auto pk = [](float x, float y) { return (unsigned)rn_f2bf(x) | ((unsigned)rn_f2bf(y) << 16); };
+        // (32-bit element offsets off the episode's base: the launcher checks that the output map has fewer than 2^31 elements)
+        const unsigned pbase = epi_pbase, cmax = epi_cmax;
+        const unsigned clane = (unsigned)(wave * 32 * MW + (lane & 15));
+        auto tile_out = [&](const u32x4& v, int m, int co, float (&s1)[8], float (&s2)[8], auto with_stats) {
+            if (clane + (unsigned)(m * 16) > cmax) return;        // (rows past the end computed a copy of the last pixel)
+            const unsigned off = pbase + (unsigned)prow[m] * (unsigned)a.Cout + (unsigned)co;
+            *(u32x4*)(outb + off) = v;
+            if constexpr (decltype(with_stats)::value) {
+                u32x4 d = v;
+                if (dotb) d = ld16(dotb + off);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = __uint_as_float(v[j] << 16), hi = __uint_as_float(v[j] & 0xffff0000u);
+                    const float dl = __uint_as_float(d[j] << 16), dh = __uint_as_float(d[j] & 0xffff0000u);
+                    s1[2 * j] += lo; s1[2 * j + 1] += hi;
+                    s2[2 * j] += lo * dl; s2[2 * j + 1] += hi * dh;
+                }
+            }
+        };
+        auto stats_out = [&](int co, float (&s1)[8], float (&s2)[8]) {
+            constexpr int W = 16;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int o = 1; o < W; o <<= 1) { s1[j] += __shfl_xor(s1[j], o); s2[j] += __shfl_xor(s2[j], o); }
+            }
+            if ((lane & (W - 1)) == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { red[((wave * C::NT) + co + j) * 2] = s1[j]; red[((wave * C::NT) + co + j) * 2 + 1] = s2[j]; }
+            }
+        };
+        auto body = [&](auto with_stats) {
+            constexpr bool WS = decltype(with_stats)::value;
+            {
+                const int g = lane >> 4;
+#pragma unroll
+                for (int fp = 0; fp < NF; ++fp) {                       // tiles 2 fp, 2 fp + 1: 32 channels
+                    const int co = (2 * fp + (g & 1)) * 16 + 8 * (g >> 1);
+                    float s1[8], s2[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+                    for (int m = 0; m < 2 * MW; ++m) {
+                        const f32x4& x = acc16[m][2 * fp]; const f32x4& y = acc16[m][2 * fp + 1];
+                        const u32x2 r0 = __builtin_amdgcn_permlane16_swap(pk(x[0], x[1]), pk(y[0], y[1]), false, false);
+                        const u32x2 r1 = __builtin_amdgcn_permlane16_swap(pk(x[2], x[3]), pk(y[2], y[3]), false, false);
+                        tile_out((u32x4){r0[0], r1[0], r0[1], r1[1]}, m, co, s1, s2, with_stats);
+                    }
+                    if constexpr (WS) stats_out(co, s1, s2);
+                }
+            }
+        };
+        if (st) body(std::true_type{}); else body(std::false_type{});
+        if (st) {
+            __syncthreads();
+            if (tid < C::NT) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { t1 += red[(w * C::NT + tid) * 2]; t2 += red[(w * C::NT + tid) * 2 + 1]; }
+                float* sp = a.stats + (((long)b * a.tiles + tile) * 2) * a.Cout + cg * C::NT + tid;
+                sp[0] = t1; sp[a.Cout] = t2;
+            }
+        }
+        if (traced) {
+            RNSTAMP(7)
+            for (int k = 0; k < 8; ++k) a.trace[k] = t_sum[k];
+            a.trace[8] = __builtin_amdgcn_s_memtime(); a.trace[9] = __builtin_amdgcn_s_memrealtime();
+        }
+        return;
+    }
+    // ---- epilogue of the 32 x 32 x 16 form (the two 3-channel image layers; FUMI_RN_S16=0: every layer), 128 rows at a time: fp32
+    //      accumulators -> bf16 image in LDS (rows of NTP elements: the two lane halves land 16
     //      banks apart), then rows leave with 16-byte stores and the statistics of the stored values are taken on the way
     rbf16* Ot = (rbf16*)lds;
     float* red = (float*)(lds + 128 * C::NTP * 2);
@@ -349,18 +443,6 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                         for (int i = 0; i < 16; ++i) {
                             const int row = (wave * 32 * MW + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) - 128 * hq;
                             Ot[row * C::NTP + f * 32 + (lane & 31)] = rn_f2bf(acc[m][f][i]);
-                        }
-                    }
-            } else {                                                // 16 x 16 tiles: column = lane & 15, row = 4 (lane >> 4) + register
-#pragma unroll
-                for (int m = 0; m < 2 * MW; ++m)
-                    if ((wave * MW + (m >> 1)) >> 2 == hq) {
-#pragma unroll
-                    for (int f = 0; f < 2 * NF; ++f)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int row = (wave * 32 * MW + m * 16 + 4 * (lane >> 4) + i) - 128 * hq;
-                            Ot[row * C::NTP + f * 16 + (lane & 15)] = rn_f2bf(acc16[m][f][i]);
                         }
                     }
             }
@@ -414,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
     if (traced) {
         RNSTAMP(7)                                                  // (epilogue)
         for (int k = 0; k < 8; ++k) a.trace[k] = t_sum[k];
-        a.trace[8] = __builtin_amdgcn_s_memtime() - clk0; a.trace[9] = __builtin_amdgcn_s_memrealtime() - real0;
+        a.trace[8] = __builtin_amdgcn_s_memtime(); a.trace[9] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -720,6 +802,7 @@ int launch_rn_conv(hipStream_t st, const RnConvArgs& a, int* nt_out) {
     for (int s = 0; s < a.nsrc; ++s)
         if (a.npix * a.src[s].Cin * 2 >= (1L << 32) - 65536) return FUMI_ENOTSUP;      // (byte offsets within an episode's map: 32-bit)
     if (a.B < 1 || a.nsrc < 1 || a.nsrc > 4 || a.Cout < 32 || (a.Cout & 31) || a.npix < 1) return FUMI_EINVAL;
+    if (a.npix * a.Cout >= (1L << 31) - 65536) return FUMI_ENOTSUP;                        // (element offsets within an episode's output map: 32-bit)
     for (int s = 0; s < a.nsrc; ++s)
         if (!a.src[s].in || !a.src[s].frag || a.src[s].Cin < 16 || (a.src[s].Cin & 15) || (a.src[s].ntaps != 9 && a.src[s].ntaps != 1))
             return FUMI_EINVAL;

