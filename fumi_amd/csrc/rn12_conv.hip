@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                                     : (const char*)(frag + ((long)(c0 >> 4) * CF + cg * NF) * 512) + lane * 16;
             const long tap_stride = (long)KS * CF * 1024, part_stride = (long)BKS * CF * 1024;
             // one KiB block of a weight tile: block wave + 4 j of the tile whose first block is at tbase (clamped duplicate past the end)
+            // one KiB block of a weight tile: block wave + 4 j of the tile whose first block is at tbase (clamped duplicate past the end)
             auto bissue1 = [&](const char* tbase, int buf, int j) {
                 int blk = uni(wave) + 4 * j;
                 blk = blk < nblk ? blk : nblk - 1;
@@ -242,6 +243,23 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                 const int ks = blk / PB, f = blk - ks * PB;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + ((long)ks * (S16 ? 2 * CF : CF) + f) * 1024),
                                                  (__attribute__((address_space(3))) void*)(Bs + buf * C::BT + blk * 1024), 16, 0, 0);
+            };
+            // (the same with the block's two offsets worked out ONCE per chunk, in scalar registers, for requests whose j is a compile-time
+            //  constant -- the 16 x 16 x 32 loop below: computed in place they were ~20 scalar / vector instructions in front of every
+            //  request, issued in order between two groups of MFMAs.  Indexed with run-time j the two tables would live in scratch.)
+            int b_src[NBL], b_dst[NBL];
+#pragma unroll
+            for (int j = 0; j < NBL; ++j) {
+                int blk = uni(wave) + 4 * j;
+                blk = blk < nblk ? blk : nblk - 1;
+                constexpr int PB = S16 ? 2 * NF : NF;
+                const int ks = blk / PB, f = blk - ks * PB;
+                b_src[j] = uni((ks * (S16 ? 2 * CF : CF) + f) * 1024);
+                b_dst[j] = uni(blk * 1024);
+            }
+            auto bissue_j = [&](const char* tbase, int buf, int J) {                // (J: a constant after unrolling at every call site)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + b_src[J]),
+                                                 (__attribute__((address_space(3))) void*)(Bs + buf * C::BT + b_dst[J]), 16, 0, 0);
             };
             auto bissue = [&](const char* tbase, int buf) {
 #pragma unroll
@@ -276,27 +294,43 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                     //  scratch per lane at NF = 5, MW = 2 and 8.6x the time; at NF = 2 it fits, 200 VGPRs, and is no faster: 950 vs 910 us)
                     for (int ks = 0; ks < kn; ++ks) kstep(ks);
                 } else {
-                    // 32-deep steps: the 2 MW A fragments of the step stay in registers, the B fragments come in two halves of NF
-                    for (int k2 = 0; k2 < (kn >> 1); ++k2) {
-                        rbf16x8 af[2 * MW];
-                        const int ch = ((k0 >> 1) + k2) * 4 + (lane >> 4);
+                    // 32-deep steps: the 2 MW A fragments of the step stay in registers, the B fragments come in two halves of NF.
+                    // (k2 is unrolled behind a run-time guard: every request's index is then a constant after unrolling)
+                    constexpr int PER = 2 * (NF >> 1);                 // requests placed per 32-deep step: behind every second fragment
 #pragma unroll
-                        for (int m = 0; m < 2 * MW; ++m) af[m] = *(const rbf16x8*)(As + arow[m] * 128 + ((ch ^ swz(arow[m])) << 4));
+                    for (int k2 = 0; k2 < BKS / 2; ++k2) {
+                        if (k2 < (kn >> 1)) {
+                            rbf16x8 af[2 * MW];
+                            const int ch = ((k0 >> 1) + k2) * 4 + (lane >> 4);
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
+                            for (int m = 0; m < 2 * MW; ++m) af[m] = *(const rbf16x8*)(As + arow[m] * 128 + ((ch ^ swz(arow[m])) << 4));
+                            // fragment-outer order: a weight fragment is dead after its 2 MW products, so the SAME registers take the
+                            // second half's fragment at once -- its LDS read runs under the first half's remaining products instead of
+                            // in front of the second half (where all five reads sat behind an lgkmcnt(0) in the middle of every tile)
                             rbf16x8 bf[NF];
 #pragma unroll
-                            for (int f = 0; f < NF; ++f) bf[f] = *(const rbf16x8*)(Bt + (((k2 * 2 + h) * NF + f) * 64 + lane) * 16);
+                            for (int f = 0; f < NF; ++f) bf[f] = *(const rbf16x8*)(Bt + (((k2 * 2) * NF + f) * 64 + lane) * 16);
 #pragma unroll
-                            for (int m = 0; m < 2 * MW; ++m) {
+                            for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                                for (int f = 0; f < NF; ++f)
-                                    // (transposed: weight fragment as the A operand -- rows = output channels, columns = pixels)
-                                    acc16[m][h * NF + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[f], af[m], acc16[m][h * NF + f], 0, 0, 0);
-                                if ((m & 1) && slot < NBL) { bissue1(nxt, nbuf, slot); ++slot; }
+                                for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                                    for (int m = 0; m < 2 * MW; ++m)
+                                        // (transposed: weight fragment as the A operand -- rows = output channels, columns = pixels)
+                                        acc16[m][h * NF + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[f], af[m], acc16[m][h * NF + f], 0, 0, 0);
+                                    if (h == 0) bf[f] = *(const rbf16x8*)(Bt + (((k2 * 2 + 1) * NF + f) * 64 + lane) * 16);
+                                    const int J = k2 * PER + h * (NF >> 1) + (f >> 1);
+                                    if ((f & 1) && J < NBL && nxt) bissue_j(nxt, nbuf, J);
+                                }
                             }
                         }
                     }
+                    if (nxt) {                                          // (a short tile, or more blocks than places: the rest after it)
+                        const int done = min(NBL, (kn >> 1) * PER);
+#pragma unroll
+                        for (int q = 0; q < NBL; ++q) if (q >= done) bissue_j(nxt, nbuf, q);
+                    }
+                    slot = NBL;
                 }
                 for (; slot < NBL; ++slot) bissue1(nxt, nbuf, slot);         // (a short tile: the rest after it)
             };
