@@ -715,15 +715,34 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(RnWgradArgs a, int ci_
                                              (__attribute__((address_space(3))) void*)(Xs + r0 * 128), 16, 0, 0);
         }
     };
+    // A lane's two byte offsets into a stage image for the fragment whose first row is r0 (tr_frag's address arithmetic).  A k-step adds
+    // 16 rows = 2 048 bytes and never touches bit 1 of the row, which is all the swizzle looks at: per tap the offsets are worked out ONCE
+    // and every read of the stage loop is base + constant (ten vector instructions per fragment used to sit between the MFMAs).
+    auto frag_off = [&](int r0, int cbase, int& o0, int& o1) {
+        const int grp = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
+        const int row = r0 + 8 * (grp >> 1) + fq;
+        const int colb = (cbase + 16 * (grp & 1) + 4 * fp) * 2;
+        o0 = row * 128 + (colb ^ (((row >> 1) & 1) << 6));
+        o1 = (row + 4) * 128 + (colb ^ ((((row + 4) >> 1) & 1) << 6));
+    };
+    int xo0[NTAP], xo1[NTAP], yo0, yo1;
+    frag_off(0, (wave >> 1) * 32, yo0, yo1);
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) frag_off(hs + (NTAP == 9 ? (t / 3 - 1) * Wp + (t % 3 - 1) : 0), (wave & 1) * 32, xo0[t], xo1[t]);
+    auto ld_frag = [&](const unsigned char* img, int o0, int o1, int kb) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + o0 + kb));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + o1 + kb));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(rbf16x8, v);
+    };
     auto compute = [&](int buf) {
         const unsigned char* Dy = lds + buf * stage_bytes; const unsigned char* Xs = Dy + WG_PK * 128;
 #pragma unroll 2
         for (int ks = 0; ks < WG_PK / 16; ++ks) {
-            const rbf16x8 af = tr_frag(Dy, ks * 16, (wave >> 1) * 32, lane);
+            const rbf16x8 af = ld_frag(Dy, yo0, yo1, ks * 2048);
 #pragma unroll
             for (int t = 0; t < NTAP; ++t) {
-                const int toff = NTAP == 9 ? (t / 3 - 1) * Wp + (t % 3 - 1) : 0;
-                const rbf16x8 bf = tr_frag(Xs, ks * 16 + hs + toff, (wave & 1) * 32, lane);
+                const rbf16x8 bf = ld_frag(Xs, xo0[t], xo1[t], ks * 2048);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
             }
         }
