@@ -737,13 +737,32 @@ __global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(RnWgradArgs a, int ci_
     };
     auto compute = [&](int buf) {
         const unsigned char* Dy = lds + buf * stage_bytes; const unsigned char* Xs = Dy + WG_PK * 128;
-#pragma unroll 2
-        for (int ks = 0; ks < WG_PK / 16; ++ks) {
-            const rbf16x8 af = ld_frag(Dy, yo0, yo1, ks * 2048);
+        if constexpr (NTAP == 9) {
+            // the 72 products of a stage as ONE sequence with a ring of RING x fragments read ahead (hipcc alone keeps one fragment in
+            // flight: every MFMA then waits out most of an LDS latency)
+            constexpr int KS = WG_PK / 16, NP = KS * NTAP, RING = 4;
+            rbf16x8 ring[RING], af[2];
+            af[0] = ld_frag(Dy, yo0, yo1, 0);
 #pragma unroll
-            for (int t = 0; t < NTAP; ++t) {
-                const rbf16x8 bf = ld_frag(Xs, xo0[t], xo1[t], ks * 2048);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+            for (int i = 0; i < RING; ++i) ring[i] = ld_frag(Xs, xo0[i % NTAP], xo1[i % NTAP], (i / NTAP) * 2048);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int ks = i / NTAP, t = i % NTAP;
+                if (t == 0 && ks + 1 < KS) af[(ks + 1) & 1] = ld_frag(Dy, yo0, yo1, (ks + 1) * 2048);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1], ring[i % RING], acc[t], 0, 0, 0);
+                const int n = i + RING;
+                if (n < NP) ring[i % RING] = ld_frag(Xs, xo0[n % NTAP], xo1[n % NTAP], (n / NTAP) * 2048);
+                __builtin_amdgcn_sched_barrier(0);                  // (pins this order: left alone the scheduler re-forms its one-ahead pattern)
+            }
+        } else {
+#pragma unroll 2
+            for (int ks = 0; ks < WG_PK / 16; ++ks) {
+                const rbf16x8 af = ld_frag(Dy, yo0, yo1, ks * 2048);
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t) {
+                    const rbf16x8 bf = ld_frag(Xs, xo0[t], xo1[t], ks * 2048);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+                }
             }
         }
     };
