@@ -822,6 +822,38 @@ __global__ __launch_bounds__(256) void rn_wgrad_reduce_kernel(int nsplit, int nt
     }
 }
 
+// The same sum for 3 x 3 layers with contiguous stores: torch's OIHW order puts the nine taps of one (co, ci) side by side, so a workgroup
+// that owns ONE (tap, co) row scatters its 64 results 36 bytes apart (PMC: 174 MB written per launch for ~15 MB of gradient).  Here a
+// workgroup owns all nine taps of (co, 64 ci): wave g adds slabs g, g + 4, .. of every tap, the four sums meet in LDS in fixed order, and
+// the 576 results leave as one contiguous run.
+__global__ __launch_bounds__(256) void rn_wgrad_reduce9_kernel(int nsplit, int Cout, int Ci32, int Cin_real, const float* part, float* G,
+                                                               long gstride) {
+    __shared__ float red[4][9][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cib = (Cin_real + 63) / 64;
+    const int co = blockIdx.x / cib, ci0 = (blockIdx.x % cib) * 64, ci = ci0 + lane;
+    const long rowst = (long)Ci32, tapst = (long)Cout * Ci32, slab = 9 * tapst;
+    float s[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] = 0.f;
+    if (ci < Cin_real) {
+        const float* p = part + (long)b * nsplit * slab + (long)co * rowst + ci;
+        for (int k = wv; k < nsplit; k += 4) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) s[t] += p[(long)k * slab + t * tapst];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[wv][t][lane] = s[t];
+    __syncthreads();
+    const int nci = min(64, Cin_real - ci0);
+    float* out = G + (long)b * gstride + ((long)co * Cin_real + ci0) * 9;
+    for (int i = threadIdx.x; i < nci * 9; i += 256) {
+        const int c = i / 9, t = i - c * 9;
+        out[i] = (red[0][t][c] + red[1][t][c]) + (red[2][t][c] + red[3][t][c]);
+    }
+}
+
 // fp32 OIHW master -> bf16 fragment copies.  sf / sb: the 16x16x32 fragment order (32-deep steps, 16-column blocks) for the forward /
 // the backward-data copy, else the 32x32x16 order (16-deep steps, 32-column blocks); a 1 KiB block is 64 lanes x 8 elements either way
 __global__ __launch_bounds__(256) void rn_wprep_kernel(int Cout, int Cin, int Cin_real, int ntaps, const float* W, long wstride,
@@ -953,7 +985,10 @@ int launch_rn_wgrad_reduce(hipStream_t st, int B, int nsplit, int ntaps, int Cou
                            float* G, long gstride) {
     const int Ci32 = (Cin + 31) / 32 * 32;
     const int cib = (Cin_real + 63) / 64, rows = ntaps * Cout;
-    if (nsplit >= 16)
+    if (ntaps == 9)
+        hipLaunchKernelGGL(rn_wgrad_reduce9_kernel, dim3((unsigned)(Cout * cib), B), dim3(256), 0, st, nsplit, Cout, Ci32, Cin_real, part, G,
+                           gstride);
+    else if (nsplit >= 16)
         hipLaunchKernelGGL(rn_wgrad_reduce_kernel<true>, dim3((unsigned)(rows * cib), B), dim3(256), 0, st, nsplit, ntaps, Cout, Ci32,
                            Cin_real, part, G, gstride);
     else
