@@ -584,6 +584,8 @@ int conv_dispatch(hipStream_t st, const RnConvArgs& a, int* nt_out) {
     // episode's results do not depend on how many episodes share its chunk)
     const long tiles256 = (a.npix + 255) / 256 * (a.Cout / (32 * NF)) * RN_BREF;
     const int two = 80 * 1024 - 256;                                  // two workgroups per CU
+    // (Round 4, the 10 x 10 maps on 128-pixel tiles -- three workgroups per CU at 42 KB / 166 registers: 640 -> 640 303 vs 341 us on one
+    // stream (972 TFLOP/s), nothing in the two-lane step (16.72-16.83 vs 16.73-16.76 episodes/s); 21 x 21 and above lose (354 vs 308).)
     // (Measured in round 4 and not kept: 96 or 128 pixels per wave -- MW = 3 | 4, accumulators in AGPRs, one workgroup per CU, 0.53 /
     // 0.45 KiB of LDS reads per MFMA instead of 0.7: 551 vs 420 us at 160 -> 160 42 x 42, 424 vs 354 at 320 -> 320 21 x 21, equal at
     // 640 -> 640 10 x 10; MW = 4 with NF = 5 needs 320 accumulators and spills.  NF = 4 on the 640-channel layers is 8-9 % faster on
