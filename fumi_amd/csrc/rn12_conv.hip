@@ -650,7 +650,8 @@ __device__ __forceinline__ rbf16x8 tr_frag(const unsigned char* img, int r0, int
 // three -- what deriving the dx = -1 / +1 fragments from the dx = 0 one with lane shifts would save at best -- 2.67 -> 2.43 ms per layer
 // set, one per k-step 2.27: the nine transposing LDS reads per k-step are not what holds this kernel at 0.29 of the peak.  64-pixel
 // stages in two buffers at two workgroups per CU (the next stage's loads under this stage's 36 MFMAs): 3.00 vs 2.86 ms per layer set,
-// 15.55 vs 15.84 episodes/s.)
+// 15.55 vs 15.84 episodes/s; 128-pixel stages in two buffers where both fit beside a second workgroup (21 x 21 and 10 x 10 maps, 2 x 38.5 KB),
+// after the fragment ring: 332 / 372 vs 333 / 372 us -- the partner workgroup already covers a stage's loads.)
 template <int NTAP>
 __global__ __launch_bounds__(256, 2) void rn_wgrad_kernel(RnWgradArgs a, int ci_tiles, int Ci32, int xcd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
