@@ -398,14 +398,22 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                 }
             }
         };
+        // sum over the 16 lanes of a row on the DPP path (quad swaps, then row shifts by 4 and 8 with zero fill): the total lands in
+        // lanes 12-15 of the row.  (__shfl_xor compiles to ds_bpermute_b32 here: 320 LDS round trips per wave in this epilogue.)
+        auto row16_sum = [](float v) {
+            auto dpp = [](float x, auto ctrl) {
+                return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true));
+            };
+            v += dpp(v, std::integral_constant<int, 0xB1>{});          // quad_perm [1,0,3,2]
+            v += dpp(v, std::integral_constant<int, 0x4E>{});          // quad_perm [2,3,0,1]
+            v += dpp(v, std::integral_constant<int, 0x114>{});         // row_shr:4
+            v += dpp(v, std::integral_constant<int, 0x118>{});         // row_shr:8
+            return v;
+        };
         auto stats_out = [&](int co, float (&s1)[8], float (&s2)[8]) {
-            constexpr int W = 16;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-#pragma unroll
-                for (int o = 1; o < W; o <<= 1) { s1[j] += __shfl_xor(s1[j], o); s2[j] += __shfl_xor(s2[j], o); }
-            }
-            if ((lane & (W - 1)) == 0) {
+            for (int j = 0; j < 8; ++j) { s1[j] = row16_sum(s1[j]); s2[j] = row16_sum(s2[j]); }
+            if ((lane & 15) == 15) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { red[((wave * C::NT) + co + j) * 2] = s1[j]; red[((wave * C::NT) + co + j) * 2 + 1] = s2[j]; }
             }
