@@ -20,10 +20,22 @@
 
 namespace {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave-wide reductions on the DPP path (quad swaps, row shifts by 4 and 8, row_bcast15 / 31: the total lands in lane 63 and is read
+// back as a scalar).  __shfl_xor compiles to ds_bpermute_b32 -- an LDS round trip per step; the head kernel runs ~70 of them per
+// query row.
+template <int CTRL, int ROWS = 0xf> __device__ __forceinline__ float dpp0(float x) {            // 0 where the pattern has no source
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROWS, 0xf, true));
+}
+template <int CTRL, int ROWS = 0xf> __device__ __forceinline__ float dpps(float x) {            // own value where it has none
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, ROWS, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum63(float v) {                                          // total in lane 63 only
+    v += dpp0<0xB1>(v); v += dpp0<0x4E>(v); v += dpp0<0x114>(v); v += dpp0<0x118>(v);
+    v += dpp0<0x142, 0xa>(v); v += dpp0<0x143, 0xc>(v);
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum63(v)), 63));
 }
 
 // LDS layout (floats): ip[N*P] tp[N*P] pr[N*P] pb[nw][N*P] lamc[N] cnt[N] lbar[N] wl[nw] wc[nw]
@@ -174,9 +186,9 @@ __global__ void am3_bias_rows_kernel(float* __restrict__ x, const float* __restr
 // LDS (floats): ip tp pr [N*P] | pb [nw][N*P] | ims txs [S*P] | lamc cnt lbar [N] | wl wc [nw] | ys [S] (ints) | lam [S]
 constexpr int HPJ = 8;                   // 64-lane chunks of the prototype dimension held in registers (P <= 512)
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpps<0xB1>(v)); v = fmaxf(v, dpps<0x4E>(v)); v = fmaxf(v, dpps<0x114>(v)); v = fmaxf(v, dpps<0x118>(v));
+    v = fmaxf(v, dpps<0x142, 0xa>(v)); v = fmaxf(v, dpps<0x143, 0xc>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, int P, int lamda_fixed, int need_grad,
                                                        float dscale,
@@ -300,9 +312,7 @@ __global__ __launch_bounds__(1024) void am3_head_kernel(int N, int S, int Qn, in
                 for (int k = 0; k < HPJ; ++k) { const int j = k * 64 + lane; if (k < npj && j < P) { const float df = pr[c * P + j] - x[k]; v[u] += df * df; } }
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] += __shfl_xor(v[u], o, 64);
+            for (int u = 0; u < 8; ++u) v[u] = wave_sum(v[u]);                    // (eight independent DPP chains: they interleave)
 #pragma unroll
             for (int u = 0; u < 8; ++u) if (c0 + u < N && lane == c0 + u) myd = v[u];
         }
