@@ -226,19 +226,24 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
             //      contiguous in memory AND in the order the LDS image has them: LDS-direct loads (one wave instruction per KiB block,
             //      no registers, no ds_write pass), double-buffered, requested one tile ahead, one barrier per tile.  Addresses: a
             //      scalar base per tile (advanced by constants) + lane * 16
-            const int npt = (nks + BKS - 1) / BKS;                 // tiles per tap
-            const int ntile = S.ntaps * npt;
+            // A 16-channel source (the 3-channel image layers) has ONE k-step per tap: a tile per tap would be 4 MFMAs between two barriers
+            // and eight weight requests of which six are clamped duplicates.  Its fragments of consecutive taps lie like consecutive
+            // k-steps (KS = 1), so the nine taps are walked as nine k-steps of one "tap" -- tiles of BKS taps, each k-step with its own
+            // pixel shift (TAPK).
+            const bool tapk = !S16 && S.ntaps == 9 && S.Cin == 16;
+            const int nksL = tapk ? 9 : nks, ntL = tapk ? 1 : S.ntaps;
+            const int npt = (nksL + BKS - 1) / BKS;                // tiles per tap
             constexpr int NBL = (BKS * NF + 3) / 4;                // KiB blocks per wave and tile (4 waves); clamped duplicates past the end
-            const int nblk = min(BKS, nks) * NF;                   // KiB blocks of a tile (nks <= BKS, or a multiple of it)
+            const int nblk = min(BKS, nksL) * NF;                  // KiB blocks of a full tile (a chunk's last tile may hold fewer: nb below)
             // (S16: a 32-deep step is 2 NF blocks of 16 columns; the same bytes per tap and per tile, another order)
             const char* fragb = S16 ? (const char*)(frag + ((long)(c0 >> 5) * (2 * CF) + cg * 2 * NF) * 512) + lane * 16
                                     : (const char*)(frag + ((long)(c0 >> 4) * CF + cg * NF) * 512) + lane * 16;
             const long tap_stride = (long)KS * CF * 1024, part_stride = (long)BKS * CF * 1024;
-            // one KiB block of a weight tile: block wave + 4 j of the tile whose first block is at tbase (clamped duplicate past the end)
-            // one KiB block of a weight tile: block wave + 4 j of the tile whose first block is at tbase (clamped duplicate past the end)
-            auto bissue1 = [&](const char* tbase, int buf, int j) {
+            // one KiB block of a weight tile of nb blocks: block wave + 4 j of the tile whose first block is at tbase (clamped duplicate past
+            // the end: never a read past the tile)
+            auto bissue1 = [&](const char* tbase, int buf, int j, int nb) {
                 int blk = uni(wave) + 4 * j;
-                blk = blk < nblk ? blk : nblk - 1;
+                blk = blk < nb ? blk : nb - 1;
                 constexpr int PB = S16 ? 2 * NF : NF;               // blocks per step
                 const int ks = blk / PB, f = blk - ks * PB;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + ((long)ks * (S16 ? 2 * CF : CF) + f) * 1024),
@@ -263,14 +268,14 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
             };
             auto bissue = [&](const char* tbase, int buf) {
 #pragma unroll
-                for (int j = 0; j < NBL; ++j) bissue1(tbase, buf, j);
+                for (int j = 0; j < NBL; ++j) bissue1(tbase, buf, j, nblk);
             };
             // the k-steps of one tile; `nxt` != NULL: the NEXT tile's NBL load requests are placed one by one BETWEEN the groups of MFMAs
             // (a wave issues in order: as a block in front of the k-steps they cost 880 cycles of a 2 300-cycle tile during which this
             // wave fed the matrix pipe nothing; behind an MFMA they issue while the pipe works)
-            auto compute = [&](int t, int k0, int buf, const char* nxt, int nbuf) {
-                const int kn = min(BKS, nks - k0);
-                const int toff = S.ntaps == 9 ? (t / 3 - 1) * Wp + (t % 3 - 1) : 0;
+            auto compute = [&](int t, int k0, int buf, const char* nxt, int nbuf, int nbn) {
+                const int kn = min(BKS, nksL - k0);
+                const int toff = (S.ntaps == 9 && !tapk) ? (t / 3 - 1) * Wp + (t % 3 - 1) : 0;
                 const unsigned char* Bt = Bs + buf * C::BT;
                 int arow[NPR];
 #pragma unroll
@@ -281,13 +286,15 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                         rbf16x8 bf[NF];
 #pragma unroll
                         for (int f = 0; f < NF; ++f) bf[f] = *(const rbf16x8*)(Bt + ((ks * NF + f) * 64 + lane) * 16);
+                        const int tt = k0 + ks;                     // TAPK: this k-step IS tap tt (channel chunk 0, its own pixel shift)
+                        const int tsh = tapk ? (tt / 3 - 1) * Wp + (tt % 3 - 1) : 0;
 #pragma unroll
                         for (int m = 0; m < MW; ++m) {
-                            const int ch = (k0 + ks) * 2 + (lane >> 5);
-                            const rbf16x8 af = *(const rbf16x8*)(As + arow[m] * 128 + ((ch ^ swz(arow[m])) << 4));
+                            const int ch = (tapk ? 0 : tt * 2) + (lane >> 5), ar = arow[m] + tsh;
+                            const rbf16x8 af = *(const rbf16x8*)(As + ar * 128 + ((ch ^ swz(ar)) << 4));
 #pragma unroll
                             for (int f = 0; f < NF; ++f) acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[f], acc[m][f], 0, 0, 0);
-                            if (slot < NBL) { bissue1(nxt, nbuf, slot); ++slot; }
+                            if (slot < NBL) { bissue1(nxt, nbuf, slot, nbn); ++slot; }
                         }
                     };
                     // (a runtime loop on purpose: fully unrolled, hipcc hoists the next k-steps' fragment reads and spills -- 576 bytes of
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                     }
                     slot = NBL;
                 }
-                for (; slot < NBL; ++slot) bissue1(nxt, nbuf, slot);         // (a short tile: the rest after it)
+                for (; slot < NBL; ++slot) bissue1(nxt, nbuf, slot, nbn);    // (a short tile: the rest after it)
             };
             RNSTAMP(0)                                              // (prologue / between chunks + slab loads issued)
             // the tile after the one being multiplied, walked in (tap, k-part) order: `ahead` is its address, (at, akp) its tap and
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
             const char* ahead = fragb;
             auto advance = [&]() {
                 if (++akp == npt) { akp = 0; ++at; }
-                ahead = at < S.ntaps ? fragb + at * tap_stride + akp * part_stride : nullptr;
+                ahead = at < ntL ? fragb + at * tap_stride + akp * part_stride : nullptr;
             };
             bissue(fragb, 0);
             advance();
@@ -349,11 +356,13 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
             __syncthreads();
             RNSTAMP(1)                                              // (slab and first weight tile in LDS)
             int gbuf = 0;
-            for (int t = 0; t < S.ntaps; ++t) {
+            for (int t = 0; t < ntL; ++t) {
                 for (int kp = 0; kp < npt; ++kp, gbuf ^= 1) {
                     const char* nxt = ahead;                        // requested into the other buffer while this tile is multiplied
+                    const int k0n = kp + 1 < npt ? (kp + 1) * BKS : 0;                     // the next tile's first k-step ...
+                    const int nbn = min(BKS, nksL - k0n) * NF;                             // ... and its blocks
                     RNSTAMP(2)
-                    compute(t, kp * BKS, gbuf, nxt, gbuf ^ 1);
+                    compute(t, kp * BKS, gbuf, nxt, gbuf ^ 1, nbn);
                     RNSTAMP(3)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     RNSTAMP(4)
