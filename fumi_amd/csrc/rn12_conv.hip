@@ -34,10 +34,10 @@ template <class T> __device__ __forceinline__ const T* uni(const T* p) { return 
 //   its 16-byte chunks XOR-ed by (pixel >> 1) & 7 (conflict-free ds_read_b128 for every tap shift); per tap the weight tile
 //   (4 k-steps x NF fragments x 1 KiB, already in MFMA B-fragment order in memory) is double-buffered through LDS -- the copy is linear,
 //   every wave reads each fragment with one ds_read_b128 -- while the matrix pipe works on the previous tap.
-//   epilogue (interior pixels only; nothing reads the border of a convolution's output): the 16 x 16 x 32 form multiplies transposed and
-//   stores 16 bytes per lane straight from registers after one lane swap per dword; the 32 x 32 x 16 form (3-channel image layers) rounds
-//   the fp32 tile to bf16 into LDS and stores rows from there.  The batch-norm statistics (sum, sum of squares or of products with `dot`)
-//   are those of the STORED values in both.
+//   epilogue (interior pixels only; nothing reads the border of a convolution's output): the products are formed transposed (weights as the
+//   A operand), so a lane holds one pixel; one lane swap per packed dword (v_permlane16_swap / 32) gives it eight consecutive channels =
+//   a 16-byte store straight from registers.  The batch-norm statistics (sum, sum of squares or of products with `dot`) are those of the
+//   STORED values, summed per lane, over the lanes of a pixel group on the DPP path, over the waves through LDS.
 // =====================================================================================================================================
 constexpr int CV_KC = 64;                              // channels per staged chunk
 
@@ -76,13 +76,12 @@ inline int rn_slab_span(const RnGeom& g, int mt) {
 
 template <int NF, int MW, int BKS>
 struct ConvCfg {
-    static constexpr int MT = 128 * MW, NT = 32 * NF, NTP = NT + 8;            // NTP: padded row of the epilogue image (bf16)
+    static constexpr int MT = 128 * MW, NT = 32 * NF;
     static constexpr int BT = BKS * NF * 1024;                                   // bytes of one weight tile (BKS k-steps of one tap)
-    static constexpr int NCH = NT / 8, NRG = 256 / NCH;                          // epilogue: 16-byte chunks per row, row groups
     static int slab_rows(const RnGeom& g) { return (rn_slab_span(g, MT) + 2 * g.halo + 7) / 8 * 8; }
     static int lds_bytes(const RnGeom& g) {
         const int main_ = slab_rows(g) * 128 + 2 * BT;
-        const int epi = 128 * NTP * 2 + NRG * NT * 2 * 4;                        // the epilogue goes through LDS 128 rows at a time
+        const int epi = 4 * NT * 2 * 4;                                          // the epilogue's statistics: [4 waves][NT][2] floats
         return (main_ > epi ? main_ : epi) + 16;
     }
 };
@@ -100,7 +99,6 @@ struct ConvCfg {
 // with (row & 7) instead of (row >> 1) & 7 (conflict-free for THIS read pattern: tools/lds_swizzle_check.py).
 template <int NF, int MW, int BKS, bool S16>
 __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
-    constexpr bool DIRECT = S16;                    // the 16 x 16 x 32 form forms its products transposed and stores from registers
     typedef ConvCfg<NF, MW, BKS> C;
     auto swz = [](int r) { return S16 ? (r & 7) : ((r >> 1) & 7); };
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -293,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
                             const int ch = (tapk ? 0 : tt * 2) + (lane >> 5), ar = arow[m] + tsh;
                             const rbf16x8 af = *(const rbf16x8*)(As + ar * 128 + ((ch ^ swz(ar)) << 4));
 #pragma unroll
-                            for (int f = 0; f < NF; ++f) acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[f], acc[m][f], 0, 0, 0);
+                            for (int f = 0; f < NF; ++f) acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[f], af, acc[m][f], 0, 0, 0);   // (transposed)
                             if (slot < NBL) { bissue1(nxt, nbuf, slot, nbn); ++slot; }
                         }
                     };
@@ -374,8 +372,8 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
         }
     }
     RNSTAMP(0)
-    if constexpr (DIRECT) {
-        // ---- epilogue of the 16 x 16 x 32 form, without an LDS image: the products were formed TRANSPOSED (weight fragments as the A
+    {
+        // ---- epilogue, without an LDS image (16 x 16 x 32 form; the 32 x 32 x 16 form of the 3-channel layers likewise with 32-lane swaps): the products were formed TRANSPOSED (weight fragments as the A
         //      operand), so a lane holds one pixel (its column of the tile) and, per 16-channel tile, four consecutive output
         //      channels (4 (lane >> 4) ..); one v_permlane16_swap per packed dword between two neighbouring channel tiles leaves
         //      every lane with EIGHT consecutive channels of its pixel: a 16-byte store straight from registers, the four lanes of a
@@ -390,9 +388,9 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
         auto pk = [](float x, float y) { return (unsigned)rn_f2bf(x) | ((unsigned)rn_f2bf(y) << 16); };
         // (32-bit element offsets off the episode's base: the launcher checks that the output map has fewer than 2^31 elements)
         const unsigned pbase = epi_pbase, cmax = epi_cmax;
-        const unsigned clane = (unsigned)(wave * 32 * MW + (lane & 15));
+        const unsigned clane = (unsigned)(wave * 32 * MW + (S16 ? (lane & 15) : (lane & 31)));
         auto tile_out = [&](const u32x4& v, int m, int co, float (&s1)[8], float (&s2)[8], auto with_stats) {
-            if (clane + (unsigned)(m * 16) > cmax) return;        // (rows past the end computed a copy of the last pixel)
+            if (clane + (unsigned)(m * (S16 ? 16 : 32)) > cmax) return;        // (rows past the end computed a copy of the last pixel)
             const unsigned off = pbase + (unsigned)prow[m] * (unsigned)a.Cout + (unsigned)co;
             *(u32x4*)(outb + off) = v;
             if constexpr (decltype(with_stats)::value) {
@@ -421,15 +419,43 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
         };
         auto stats_out = [&](int co, float (&s1)[8], float (&s2)[8]) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { s1[j] = row16_sum(s1[j]); s2[j] = row16_sum(s2[j]); }
-            if ((lane & 15) == 15) {
+            for (int j = 0; j < 8; ++j) {
+                s1[j] = row16_sum(s1[j]); s2[j] = row16_sum(s2[j]);
+                if constexpr (!S16) {                               // 32 lanes share the channels: rows 1 / 3 add lane 15 of rows 0 / 2
+                    s1[j] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1[j]), 0x142, 0xa, 0xf, false));
+                    s2[j] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2[j]), 0x142, 0xa, 0xf, false));
+                }
+            }
+            if ((lane & (S16 ? 15 : 31)) == (S16 ? 15 : 31)) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { red[((wave * C::NT) + co + j) * 2] = s1[j]; red[((wave * C::NT) + co + j) * 2 + 1] = s2[j]; }
             }
         };
         auto body = [&](auto with_stats) {
             constexpr bool WS = decltype(with_stats)::value;
-            {
+            if constexpr (!S16) {
+                // 32 x 32 tiles: a lane holds channels 8 q + 4 (lane >> 5) .. + 3 of its pixel for q = 0..3; v_permlane32_swap between the
+                // quads 2 qp and 2 qp + 1 leaves the lower half of the wave with channels 8 (2 qp) .. + 7, the upper half with the next eight
+                const int h = lane >> 5;
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int qp = 0; qp < 2; ++qp) {
+                        const int co = f * 32 + 8 * (2 * qp + h);
+                        float s1[8], s2[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+                        for (int m = 0; m < MW; ++m) {
+                            const f32x16& x = acc[m][f];
+                            const int i0 = 8 * qp, i1 = 8 * qp + 4;
+                            const u32x2 r0 = __builtin_amdgcn_permlane32_swap(pk(x[i0], x[i0 + 1]), pk(x[i1], x[i1 + 1]), false, false);
+                            const u32x2 r1 = __builtin_amdgcn_permlane32_swap(pk(x[i0 + 2], x[i0 + 3]), pk(x[i1 + 2], x[i1 + 3]), false, false);
+                            tile_out((u32x4){r0[0], r1[0], r0[1], r1[1]}, m, co, s1, s2, with_stats);
+                        }
+                        if constexpr (WS) stats_out(co, s1, s2);
+                    }
+            } else {
                 const int g = lane >> 4;
 #pragma unroll
                 for (int fp = 0; fp < NF; ++fp) {                       // tiles 2 fp, 2 fp + 1: 32 channels
@@ -465,89 +491,6 @@ __global__ __launch_bounds__(256, 2) void rn_conv_kernel(RnConvArgs a) {
             a.trace[8] = __builtin_amdgcn_s_memtime(); a.trace[9] = __builtin_amdgcn_s_memrealtime();
         }
         return;
-    }
-    // ---- epilogue of the 32 x 32 x 16 form (the two 3-channel image layers; FUMI_RN_S16=0: every layer), 128 rows at a time: fp32
-    //      accumulators -> bf16 image in LDS (rows of NTP elements: the two lane halves land 16
-    //      banks apart), then rows leave with 16-byte stores and the statistics of the stored values are taken on the way
-    rbf16* Ot = (rbf16*)lds;
-    float* red = (float*)(lds + 128 * C::NTP * 2);
-    const int ch = tid % C::NCH, rg = tid / C::NCH;
-    float s1[8], s2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    const long Pp = a.g.Pp;
-    rbf16* out = a.out + (long)b * a.out_stride + (long)cg * C::NT + ch * 8;
-    const rbf16* dot = a.dot ? a.dot + (long)b * a.dot_stride + (long)cg * C::NT + ch * 8 : nullptr;
-#pragma unroll
-    for (int hq = 0; hq < MW; ++hq) {
-        // rows [128 hq, 128 hq + 128) of the tile belong to waves [2 hq / MW ...): with MW = 2 waves 2 hq, 2 hq + 1 (64 rows each)
-        if (hq) __syncthreads();
-        // (a wave's 32-row blocks each lie inside one 128-row pass: block m of wave w belongs to pass (32 MW w + 32 m) / 128)
-        {
-            if constexpr (!S16) {
-#pragma unroll
-                for (int m = 0; m < MW; ++m)
-                    if ((wave * MW + m) >> 2 == hq) {
-#pragma unroll
-                    for (int f = 0; f < NF; ++f)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const int row = (wave * 32 * MW + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) - 128 * hq;
-                            Ot[row * C::NTP + f * 32 + (lane & 31)] = rn_f2bf(acc[m][f][i]);
-                        }
-                    }
-            }
-        }
-        __syncthreads();
-        if (rg < C::NRG) {
-            // row -> interior pixel (image, y, x), walked incrementally in steps of NRG rows
-            const long cb = c0 + 128 * hq + rg;
-            const int hw = a.g.H * a.g.W;
-            long img = (long)((unsigned)cb / (unsigned)hw); int rr = (int)(cb - img * hw);
-            int y = rr / a.g.W, x = rr - y * a.g.W;
-            for (int row = rg; row < 128; row += C::NRG) {
-                if (c0 + 128 * hq + row <= clast) {
-                    const long p = img * Pp + (long)(y + 1) * Wp + x + 1;
-                    const u32x4 v = *(const u32x4*)(Ot + row * C::NTP + ch * 8);
-                    *(u32x4*)(out + p * a.Cout) = v;
-                    if (a.stats) {
-                        u32x4 d = v;
-                        if (dot) d = ld16(dot + p * a.Cout);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float lo = __uint_as_float(v[j] << 16), hi = __uint_as_float(v[j] & 0xffff0000u);
-                            const float dl = __uint_as_float(d[j] << 16), dh = __uint_as_float(d[j] & 0xffff0000u);
-                            s1[2 * j] += lo; s1[2 * j + 1] += hi;
-                            s2[2 * j] += lo * dl; s2[2 * j + 1] += hi * dh;
-                        }
-                    }
-                }
-                x += C::NRG;
-                while (x >= a.g.W) { x -= a.g.W; ++y; }
-                while (y >= a.g.H) { y -= a.g.H; ++img; }
-            }
-        }
-    }
-    if (a.stats) {
-        if (rg < C::NRG) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                red[(rg * C::NT + ch * 8 + j) * 2] = s1[j];
-                red[(rg * C::NT + ch * 8 + j) * 2 + 1] = s2[j];
-            }
-        }
-        __syncthreads();
-        if (tid < C::NT) {
-            float t1 = 0.f, t2 = 0.f;
-            for (int g = 0; g < C::NRG; ++g) { t1 += red[(g * C::NT + tid) * 2]; t2 += red[(g * C::NT + tid) * 2 + 1]; }
-            float* st = a.stats + (((long)b * a.tiles + tile) * 2) * a.Cout + cg * C::NT + tid;
-            st[0] = t1; st[a.Cout] = t2;
-        }
-    }
-    if (traced) {
-        RNSTAMP(7)                                                  // (epilogue)
-        for (int k = 0; k < 8; ++k) a.trace[k] = t_sum[k];
-        a.trace[8] = __builtin_amdgcn_s_memtime(); a.trace[9] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
