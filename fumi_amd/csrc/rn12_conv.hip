@@ -901,7 +901,9 @@ int rn_wgrad_nsplit(int B_chunk, long npix, int Cin, int Cout) {
         ns = (1024 + tiles - 1) / tiles;
         ns = ns > nsmax ? nsmax : ns;
     } else {
-        const long slots = 512;
+        // (256, not the 512 slots of the chip: with two lanes of chunks in flight the other lane's kernels fill what a launch leaves,
+        //  and half the slabs are half the partial-sum traffic -- 17.36-17.42 -> 17.54-17.63 episodes/s; 128: the same)
+        static const long slots = getenv("FUMI_RN_WSLOTS") ? atol(getenv("FUMI_RN_WSLOTS")) : 256;
         auto eff = [&](long c) {
             const long w = tiles * c, rounds = (w + slots - 1) / slots;
             const double e = (double)w / (double)(rounds * slots);    // share of the rounds' slots that hold a workgroup
