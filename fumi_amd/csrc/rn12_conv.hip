@@ -89,7 +89,9 @@ struct ConvCfg {
 // (Weight tiles: two buffers, the next tile requested while this one is multiplied, s_waitcnt vmcnt(0) + one barrier per tile.  A
 // three-buffer ring with requests two tiles ahead and a COUNTED wait -- vmcnt(NBL): the newest tile may still be in flight -- was
 // built and measured: the wait for the loads halves (9.9 -> 5.3 % of a wave's time) and the barrier takes it over (3.6 -> 8.8 %):
-// 884 vs 889 us per launch, 558.6 vs 557.1 ms per step.)
+// 884 vs 889 us per launch, 558.6 vs 557.1 ms per step.  Repeated at the end of round 4, when the shorter k-steps had made the wait for
+// the next tile 22 % of a traced wave's time: layer set 2.57 / 2.05 vs 2.57 / 2.08 ms, 17.20-17.35 vs 17.23-17.33 episodes/s -- the partner
+// workgroup's products run under that wait either way.)
 // S16: the same tile on v_mfma_f32_16x16x32_bf16 (four times as many instructions of half the cycles and twice the depth: equal
 // cycles per flop, equal LDS bytes per flop).  Why: under this kernel's load the chip holds its clock well below 2.4 GHz, and the
 // clock it holds depends on the MFMA shape (MI355X_MICROARCH.md, DVFS give-back item 7: the 16x16x32 loop delivers 1.12-1.15 x the
